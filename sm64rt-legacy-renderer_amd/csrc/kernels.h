@@ -1,0 +1,47 @@
+// kernels.h -- host-callable launchers of the HIP kernels in librt64.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "rt64_gpu.h"
+
+// ---- lbvh.hip ---------------------------------------------------------------------------------------------------
+#define LBVH_SMALL_MAX 4096u          // leaves handled by the single-workgroup LDS builder
+enum { LBVH_MODE_TRIANGLES = 0, LBVH_MODE_INSTANCES = 1 };
+
+struct LbvhArgs {
+    int mode, refit;
+    uint32_t n;
+    // LBVH_MODE_TRIANGLES
+    const uint8_t *vertices; uint32_t vertexStride; const uint32_t *indices;
+    // LBVH_MODE_INSTANCES
+    const GpuInstance *instances;
+    // outputs
+    GpuNode *nodes;                   // max(n-1, 1)
+    GpuTri *tris;                     // n (triangles mode)
+    BlasHeader *header;
+    uint32_t *sortedIndex, *morton, *leafParent;   // n each
+    // scratch for the large path (allocated by the caller when n > LBVH_SMALL_MAX)
+    void *scratch; size_t scratchBytes;
+};
+
+size_t lbvh_small_lds_bytes(uint32_t n);
+size_t lbvh_large_scratch_bytes(uint32_t n);
+hipError_t lbvh_launch(const LbvhArgs &args, hipStream_t stream);
+hipError_t lbvh_launch_large(const LbvhArgs &args, hipStream_t stream);
+
+// ---- bc7.hip ------------------------------------------------------------------------------------------------------
+// Decode `blocksX * blocksY` BC7 blocks into an RGBA8 image of width x height texels.
+hipError_t bc7_decode_launch(const uint8_t *blocks, uint8_t *rgba, uint32_t width, uint32_t height, hipStream_t stream);
+
+// ---- passes.hip ---------------------------------------------------------------------------------------------------
+#define RT_GRID_BLOCKS 2048           // persistent grid of every ray kernel (8 workgroups of 256 per CU)
+size_t rt_stack_spill_bytes();        // bytes of FrameParams::traversalStack
+
+hipError_t launch_primary_trace(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, hipStream_t s);
+hipError_t launch_primary_shade(const FrameParams &P, const ViewImages &I, const int32_t *hitInstance, int cur, hipStream_t s);
+hipError_t launch_direct(const FrameParams &P, const ViewImages &I, int cur, hipStream_t s);
+hipError_t launch_indirect(const FrameParams &P, const ViewImages &I, int cur, hipStream_t s);
+hipError_t launch_refraction(const FrameParams &P, const ViewImages &I, hipStream_t s);
+hipError_t launch_reflection(const FrameParams &P, const ViewImages &I, hipStream_t s);
+hipError_t launch_gaussian(const uint16_t *in, uint16_t *out, int width, int height, int y0, int y1, hipStream_t s);
+hipError_t launch_compose_post(const FrameParams &P, const ViewImages &I, hipStream_t s);
+hipError_t launch_clear_final(const FrameParams &P, const ViewImages &I, hipStream_t s);

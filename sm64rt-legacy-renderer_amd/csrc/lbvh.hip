@@ -1,0 +1,279 @@
+// lbvh.hip -- LBVH construction / refit kernels (BLAS per mesh, TLAS per frame).
+//
+// Replaces the DXR driver's BuildRaytracingAccelerationStructure calls the reference issues from
+//   rt64_mesh.cpp:114-158 (BottomLevelASGenerator.cpp:245) and rt64_view.cpp:412-452 (TopLevelASGenerator.cpp:244).
+// Algorithm: Karras 2012 LBVH -- 30-bit Morton codes of the leaf-box centres, stable radix sort, binary radix tree by
+// longest common prefix of (code << 32 | leaf), bottom-up box fit.  The arithmetic follows the "Geometry spec" in
+// DESIGN.md operation by operation, so the node and triangle arrays are reproducible bit for bit.
+//
+// Small trees (n <= LBVH_SMALL_MAX leaves): ONE workgroup of 1024 threads does the whole build with the sort keys, the
+// parent links and the fit counters staged in LDS (1-bit split radix passes with wave-ballot-free prefix sums); only
+// the final GpuNode / GpuTri arrays touch HBM.  One launch per RT64_SetMesh and one per frame for the TLAS.
+// Large trees: multi-kernel path (global Morton pass, multi-block LSD radix sort, Karras pass, level-synchronous fit).
+#include "kernels.h"
+#include "device_math.h"
+
+#define LBVH_THREADS 1024
+
+namespace {
+
+DEV uint32_t float_to_ordered(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+DEV float ordered_to_float(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
+
+DEV uint32_t morton30(uint32_t x, uint32_t y, uint32_t z) {
+    uint32_t v[3] = { x & 1023u, y & 1023u, z & 1023u };
+    uint32_t code = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        uint32_t t = v[k];
+        t = (t | (t << 16)) & 0x030000FFu;
+        t = (t | (t << 8)) & 0x0300F00Fu;
+        t = (t | (t << 4)) & 0x030C30C3u;
+        t = (t | (t << 2)) & 0x09249249u;
+        code |= t << k;
+    }
+    return code;
+}
+
+struct Box { float mn[3], mx[3]; };
+
+DEV void load_positions(const LbvhArgs &a, uint32_t prim, float v[3][3]) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        uint32_t idx = a.indices[3 * prim + k];
+        const float *p = reinterpret_cast<const float *>(a.vertices + (size_t)idx * a.vertexStride);   // position = first 12 bytes (rt64_shader.cpp:88)
+        v[k][0] = p[0]; v[k][1] = p[1]; v[k][2] = p[2];
+    }
+}
+
+// G1: box of leaf i (leaf-index order).
+DEV Box leaf_box(const LbvhArgs &a, uint32_t i) {
+    Box b;
+    if (a.mode == LBVH_MODE_TRIANGLES) {
+        float v[3][3]; load_positions(a, i, v);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { b.mn[k] = fminf(fminf(v[0][k], v[1][k]), v[2][k]); b.mx[k] = fmaxf(fmaxf(v[0][k], v[1][k]), v[2][k]); }
+    }
+    else {   // LBVH_MODE_INSTANCES: the 8 corners of the mesh box through objectToWorld
+        const GpuInstance &in = a.instances[i];
+        const BlasHeader h = *in.header;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { b.mn[k] = INFINITY; b.mx[k] = -INFINITY; }
+        for (int c = 0; c < 8; c++) {
+            float p[3] = { (c & 1) ? h.bmax[0] : h.bmin[0], (c & 2) ? h.bmax[1] : h.bmin[1], (c & 4) ? h.bmax[2] : h.bmin[2] }, w[3];
+            g_xform_point(in.objectToWorld, p, w);
+#pragma unroll
+            for (int k = 0; k < 3; k++) { b.mn[k] = fminf(b.mn[k], w[k]); b.mx[k] = fmaxf(b.mx[k], w[k]); }
+        }
+    }
+    return b;
+}
+
+DEV uint32_t wave_inclusive_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(v, d, 64); if (lane >= d) v += o; }
+    return v;
+}
+
+DEV int delta64(const uint32_t *key, const uint32_t *val, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    unsigned long long a = ((unsigned long long)key[i] << 32) | val[i], b = ((unsigned long long)key[j] << 32) | val[j];
+    return __clzll((long long)(a ^ b));
+}
+
+// LDS carve (uint32 words): keyA[n] valA[n] keyB[n] valB[n] parentLeaf[n] parentNode[n] counters[n] scratch[64]
+__global__ __launch_bounds__(LBVH_THREADS) void lbvh_small_kernel(LbvhArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t n = a.n, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t *keyA = lds, *valA = lds + n, *keyB = lds + 2 * n, *valB = lds + 3 * n;
+    uint32_t *parentLeaf = lds + 4 * n, *parentNode = lds + 5 * n, *counters = lds + 6 * n, *scratch = lds + 7 * n;
+    // scratch[0..5] ordered bounds, [8..23] wave totals, [24] total, [25] flag
+
+    if (!a.refit) {
+        // ---- G2: scene box ------------------------------------------------------------------------------------
+        if (tid < 6) scratch[tid] = tid < 3 ? 0xFFFFFFFFu : 0u;
+        __syncthreads();
+        {
+            uint32_t mn[3] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu }, mx[3] = { 0, 0, 0 };
+            for (uint32_t i = tid; i < n; i += LBVH_THREADS) {
+                Box b = leaf_box(a, i);
+#pragma unroll
+                for (int k = 0; k < 3; k++) { mn[k] = min(mn[k], float_to_ordered(b.mn[k])); mx[k] = max(mx[k], float_to_ordered(b.mx[k])); }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) { atomicMin(&scratch[k], mn[k]); atomicMax(&scratch[3 + k], mx[k]); }
+        }
+        __syncthreads();
+        float bmin[3], scale[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            bmin[k] = ordered_to_float(scratch[k]);
+            float ext = ordered_to_float(scratch[3 + k]) - bmin[k];
+            scale[k] = ext > 0.0f ? 1024.0f / ext : 0.0f;
+        }
+        // ---- Morton keys ---------------------------------------------------------------------------------------
+        for (uint32_t i = tid; i < n; i += LBVH_THREADS) {
+            Box b = leaf_box(a, i);
+            uint32_t q[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                float c = (b.mn[k] + b.mx[k]) * 0.5f;
+                float f = (c - bmin[k]) * scale[k];
+                int qi = (int)f;
+                q[k] = (uint32_t)(qi < 0 ? 0 : (qi > 1023 ? 1023 : qi));
+            }
+            keyA[i] = morton30(q[0], q[1], q[2]);
+            valA[i] = i;
+        }
+        __syncthreads();
+        // ---- G3: stable LSD radix sort on the 30 code bits, one bit per pass, staged in LDS ---------------------
+        // Blocked arrangement: thread t owns items [t*ipt, (t+1)*ipt), so rank order == index order (stable).
+        const uint32_t ipt = (n + LBVH_THREADS - 1) / LBVH_THREADS;
+        const uint32_t first = min(tid * ipt, n), last = min(first + ipt, n);
+        uint32_t *ksrc = keyA, *vsrc = valA, *kdst = keyB, *vdst = valB;
+        for (int bit = 0; bit < 30; bit++) {
+            uint32_t c0 = 0;
+            for (uint32_t i = first; i < last; i++) c0 += ((ksrc[i] >> bit) & 1u) ^ 1u;
+            uint32_t incl = wave_inclusive_scan(c0, lane);
+            if (lane == 63) scratch[8 + wave] = incl;
+            __syncthreads();
+            if (wave == 0) {
+                uint32_t v = lane < (LBVH_THREADS / 64) ? scratch[8 + lane] : 0u;
+                uint32_t s = wave_inclusive_scan(v, lane);
+                if (lane < (LBVH_THREADS / 64)) scratch[8 + lane] = s - v;
+                if (lane == 63) scratch[24] = s;
+            }
+            __syncthreads();
+            const uint32_t zeros = scratch[24];
+            if (zeros != 0 && zeros != n) {
+                uint32_t r0 = scratch[8 + wave] + incl - c0;
+                uint32_t r1 = zeros + (first - r0);
+                for (uint32_t i = first; i < last; i++) {
+                    uint32_t k = ksrc[i], v = vsrc[i];
+                    uint32_t pos = ((k >> bit) & 1u) ? r1++ : r0++;
+                    kdst[pos] = k; vdst[pos] = v;
+                }
+                uint32_t *t = ksrc; ksrc = kdst; kdst = t; t = vsrc; vsrc = vdst; vdst = t;
+            }
+            __syncthreads();
+        }
+        if (ksrc != keyA) {   // uniform: every thread took the same branches
+            for (uint32_t i = tid; i < n; i += LBVH_THREADS) { keyA[i] = keyB[i]; valA[i] = valB[i]; }
+            __syncthreads();
+        }
+        for (uint32_t s = tid; s < n; s += LBVH_THREADS) { a.sortedIndex[s] = valA[s]; a.morton[s] = keyA[s]; }
+        // ---- G4: Karras radix tree -------------------------------------------------------------------------------
+        if (n == 1) {
+            if (tid == 0) { a.nodes[0].left = RT64_LEAF_BIT; a.nodes[0].right = RT64_NO_CHILD; a.nodes[0].parent = RT64_NO_CHILD; a.nodes[0].pad = 0; parentLeaf[0] = 0; a.leafParent[0] = 0; }
+        }
+        else {
+            if (tid == 0) { parentNode[0] = RT64_NO_CHILD; a.nodes[0].parent = RT64_NO_CHILD; }
+            const int N = (int)n;
+            for (int i = (int)tid; i < N - 1; i += LBVH_THREADS) {
+                int d = (delta64(keyA, valA, N, i, i + 1) - delta64(keyA, valA, N, i, i - 1)) >= 0 ? 1 : -1;
+                int dmin = delta64(keyA, valA, N, i, i - d);
+                int lmax = 2;
+                while (delta64(keyA, valA, N, i, i + lmax * d) > dmin) lmax *= 2;
+                int l = 0;
+                for (int t = lmax / 2; t >= 1; t /= 2)
+                    if (delta64(keyA, valA, N, i, i + (l + t) * d) > dmin) l += t;
+                int j = i + l * d;
+                int dnode = delta64(keyA, valA, N, i, j);
+                int s = 0;
+                for (int div = 2;; div *= 2) {
+                    int t = (l + div - 1) / div;
+                    if (delta64(keyA, valA, N, i, i + (s + t) * d) > dnode) s += t;
+                    if (t <= 1) break;
+                }
+                int g = i + s * d + (d < 0 ? -1 : 0);
+                int lo = i < j ? i : j, hi = i < j ? j : i;
+                uint32_t left, right;
+                if (lo == g) { left = RT64_LEAF_BIT | (uint32_t)g; parentLeaf[g] = (uint32_t)i; a.leafParent[g] = (uint32_t)i; }
+                else { left = (uint32_t)g; parentNode[g] = (uint32_t)i; a.nodes[g].parent = (uint32_t)i; }
+                if (hi == g + 1) { right = RT64_LEAF_BIT | (uint32_t)(g + 1); parentLeaf[g + 1] = (uint32_t)i; a.leafParent[g + 1] = (uint32_t)i; }
+                else { right = (uint32_t)(g + 1); parentNode[g + 1] = (uint32_t)i; a.nodes[g + 1].parent = (uint32_t)i; }
+                a.nodes[i].left = left; a.nodes[i].right = right; a.nodes[i].pad = 0;
+            }
+        }
+    }
+    else {
+        // G6 refit: topology from the previous build (written by an earlier launch).
+        for (uint32_t s = tid; s < n; s += LBVH_THREADS) parentLeaf[s] = a.leafParent[s];
+        for (uint32_t i = tid; i + 1 < n; i += LBVH_THREADS) parentNode[i] = a.nodes[i].parent;
+    }
+    for (uint32_t i = tid; i < n; i += LBVH_THREADS) counters[i] = 0;
+    __syncthreads();   // also orders this workgroup's global child-link stores before the loads below (one CU, shared L1)
+
+    // ---- G5: leaves in Morton order + bottom-up box fit ------------------------------------------------------------
+    for (uint32_t s = tid; s < n; s += LBVH_THREADS) {
+        const uint32_t leaf = a.sortedIndex[s];
+        Box b;
+        if (a.mode == LBVH_MODE_TRIANGLES) {
+            float v[3][3]; load_positions(a, leaf, v);
+            GpuTri t;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { t.v0[k] = v[0][k]; t.v1[k] = v[1][k]; t.v2[k] = v[2][k]; b.mn[k] = fminf(fminf(v[0][k], v[1][k]), v[2][k]); b.mx[k] = fmaxf(fmaxf(v[0][k], v[1][k]), v[2][k]); }
+            t.prim = leaf; t.pad1 = 0; t.pad2 = 0;
+            a.tris[s] = t;
+        }
+        else b = leaf_box(a, leaf);
+
+        if (n == 1) {
+            GpuNode &nd = a.nodes[0];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { nd.lmin[k] = b.mn[k]; nd.lmax[k] = b.mx[k]; nd.rmin[k] = INFINITY; nd.rmax[k] = -INFINITY; a.header->bmin[k] = b.mn[k]; a.header->bmax[k] = b.mx[k]; }
+            a.header->count = 1; a.header->pad = 0;
+            break;
+        }
+        uint32_t child = RT64_LEAF_BIT | s, p = parentLeaf[s];
+        for (;;) {
+            GpuNode &nd = a.nodes[p];
+            const bool isLeft = nd.left == child;
+            float *dmn = isLeft ? nd.lmin : nd.rmin, *dmx = isLeft ? nd.lmax : nd.rmax;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { dmn[k] = b.mn[k]; dmx[k] = b.mx[k]; }
+            __threadfence_block();
+            uint32_t arrived = atomicAdd(&counters[p], 1u);
+            if (arrived == 0) break;                        // the sibling subtree finishes this node
+            __threadfence_block();
+            const float *smn = isLeft ? nd.rmin : nd.lmin, *smx = isLeft ? nd.rmax : nd.lmax;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                float omn = *(volatile const float *)&smn[k], omx = *(volatile const float *)&smx[k];
+                b.mn[k] = fminf(b.mn[k], omn); b.mx[k] = fmaxf(b.mx[k], omx);
+            }
+            if (p == 0) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) { a.header->bmin[k] = b.mn[k]; a.header->bmax[k] = b.mx[k]; }
+                a.header->count = n; a.header->pad = 0;
+                break;
+            }
+            child = p; p = parentNode[p];
+        }
+    }
+}
+
+}  // namespace
+
+size_t lbvh_small_lds_bytes(uint32_t n) { return ((size_t)7 * n + 64) * sizeof(uint32_t); }
+
+hipError_t lbvh_launch(const LbvhArgs &args, hipStream_t stream) {
+    if (args.n == 0) return hipErrorInvalidValue;
+    if (args.n <= LBVH_SMALL_MAX) {
+        size_t lds = lbvh_small_lds_bytes(args.n);
+        static bool attrSet = false;
+        if (!attrSet) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lbvh_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lbvh_small_lds_bytes(LBVH_SMALL_MAX));
+            if (e != hipSuccess) return e;
+            attrSet = true;
+        }
+        hipLaunchKernelGGL(lbvh_small_kernel, dim3(1), dim3(LBVH_THREADS), lds, stream, args);
+        return hipGetLastError();
+    }
+    return lbvh_launch_large(args, stream);
+}
+
+// ---- large trees (n > LBVH_SMALL_MAX) ---------------------------------------------------------------------------------------
+size_t lbvh_large_scratch_bytes(uint32_t n) { return (size_t)n * 64; }
+hipError_t lbvh_launch_large(const LbvhArgs &, hipStream_t) { return hipErrorNotSupported; }

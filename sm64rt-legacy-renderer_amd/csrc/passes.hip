@@ -1,0 +1,571 @@
+// passes.hip -- the per-frame ray passes of the render path as HIP kernels (wave64, persistent workgroups).
+//
+// MI355X-side replacement of the DispatchRays / Dispatch / Draw sequence of View::render
+// (/root/reference/src/rt64lib/private/rt64_view.cpp:1321-1650) and of the HLSL entry points it runs:
+//   primary_trace + primary_shade  <- PrimaryRayGen (shaders/PrimaryRayGen.hlsl:31-198) + surface any-hit
+//   direct                         <- DirectRayGen (shaders/DirectRayGen.hlsl:14-65) + shadow any-hit
+//   indirect                       <- IndirectRayGen (shaders/IndirectRayGen.hlsl:31-137)
+//   refraction / reflection        <- RefractionRayGen.hlsl:19-117 / ReflectionRayGen.hlsl:25-143
+//   gaussian                       <- GaussianFilterRGB3x3CS.hlsl:21-82
+//   compose_post                   <- ComposePS.hlsl:18-37 + PostProcessPS.hlsl:13-36 (fused: one read of the G-buffer)
+// Differences in structure (not in results): primary visibility is a pure traversal kernel that writes a 16-byte hit
+// record per pixel, and shading runs as a second, traversal-free kernel over coherent hit records; images keep the
+// reference's storage formats so every quantisation point is preserved.
+//
+// Launch shape: RT_GRID_BLOCKS persistent workgroups of 256 threads walk 16x16-pixel tiles round-robin; a wave owns an
+// 8x8 pixel block (coherent rays, coalesced 8-row image stores).  Consecutive workgroup ids land on different XCDs, so
+// neighbouring tiles spread over all eight L2s while each tile's BVH nodes stay hot in its own.
+#include "kernels.h"
+#include "shade.h"
+
+namespace {
+
+struct Pixel { uint32_t x, y; bool valid; };
+
+DEV uint32_t tile_count(const FrameParams &P) {
+    return (uint32_t)((P.width + 15) / 16) * (uint32_t)((P.tileY1 - P.tileY0 + 15) / 16);
+}
+DEV Pixel tile_pixel(const FrameParams &P, uint32_t tile) {
+    const uint32_t tilesX = (uint32_t)(P.width + 15) / 16;
+    const uint32_t tx = tile % tilesX, ty = tile / tilesX;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    Pixel p;
+    p.x = tx * 16 + (wave & 1) * 8 + (lane & 7);
+    p.y = (uint32_t)P.tileY0 + ty * 16 + (wave >> 1) * 8 + (lane >> 3);
+    p.valid = p.x < (uint32_t)P.width && p.y < (uint32_t)P.tileY1;
+    return p;
+}
+
+DEV TraceStack make_stack(const FrameParams &P, uint32_t *ldsStack) {
+    TraceStack s;
+    s.lds = ldsStack + threadIdx.x;
+    s.spill = P.traversalStack + ((size_t)blockIdx.x * RT_BLOCK + threadIdx.x) * RT_STACK_SPILL;
+    return s;
+}
+
+DEV void flush_env(const FrameParams &P, const ShadeEnv &env, int rayCounter, uint32_t rays) {
+    flush_counts(P, env.cnt);
+    if (!P.countTraversal) return;
+    unsigned long long a = rays, b = env.shadowRays;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { a += __shfl_down(a, d, 64); b += __shfl_down(b, d, 64); }
+    if ((threadIdx.x & 63) == 0) { if (a) atomicAdd(&P.counters[rayCounter], a); if (b) atomicAdd(&P.counters[CTR_SHADOW], b); }
+}
+
+// ---- surface rays: closest hit over opaque instances ------------------------------------------------------------------
+// Hits on instances flagged opaque shorten tmax (R5): lim = (t - depthBias) + maxDepthBias.  Sort key = t - depthBias,
+// ties keep the first-come hit like the reference's strict '<' insertion (rt64_shader.cpp:557).
+struct SurfaceHit { float key, t, u, v; uint32_t instance, prim; bool hit; };
+
+DEV void trace_surface(const FrameParams &P, ShadeEnv &env, f3 o, f3 d, SurfaceHit &best) {
+    float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
+    best.hit = false; best.key = INFINITY;
+    trace_ray(P, oo, dd, RT_RAY_MIN_DISTANCE, RT_RAY_MAX_DISTANCE, true, env.stk,
+              [&](float t, float u, float v, uint32_t instance, uint32_t prim, float &tmax) -> bool {
+                  float key = t - P.instances[instance].material.depthBias;
+                  if (key < best.key) { best.key = key; best.t = t; best.u = u; best.v = v; best.instance = instance; best.prim = prim; best.hit = true; }
+                  float lim = key + P.maxDepthBias;
+                  if (lim < tmax) tmax = lim;
+                  return false;
+              }, env.cnt);
+}
+
+// ---- primary visibility --------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(RT_BLOCK) void primary_trace_kernel(FrameParams P, ViewImages I, int32_t *hitInstance) {
+    __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
+    ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
+    uint32_t rays = 0;
+    const uint32_t tiles = tile_count(P);
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        Pixel p = tile_pixel(P, tile);
+        if (!p.valid) continue;
+        f3 o, d; f2 ndc;
+        primary_ray(P, p.x, p.y, o, d, ndc);
+        SurfaceHit h;
+        trace_surface(P, env, o, d, h);
+        rays++;
+        const size_t i = (size_t)p.y * (size_t)P.width + p.x;
+        uint4 rec;
+        if (h.hit) { rec.x = __float_as_uint(h.t); rec.y = __float_as_uint(h.u); rec.z = __float_as_uint(h.v); rec.w = h.prim; hitInstance[i] = (int32_t)h.instance; }
+        else { rec.x = rec.y = rec.z = rec.w = 0xFFFFFFFFu; hitInstance[i] = -1; }
+        reinterpret_cast<uint4 *>(I.primaryHit)[i] = rec;
+    }
+    flush_env(P, env, CTR_PRIMARY, rays);
+}
+
+// ---- PrimaryRayGen resolve + G-buffer -------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(RT_BLOCK) void primary_shade_kernel(FrameParams P, ViewImages I, const int32_t *hitInstance, int cur) {
+    __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
+    ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
+    const uint32_t tiles = tile_count(P);
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        Pixel p = tile_pixel(P, tile);
+        if (!p.valid) continue;
+        const uint32_t px = p.x, py = p.y;
+        const size_t i = (size_t)py * (size_t)P.width + px;
+        f3 rayOrigin, rayDirection; f2 d;
+        primary_ray(P, px, py, rayOrigin, rayDirection, d);
+        f3 cU = mk3(P.cameraU[0], P.cameraU[1], P.cameraU[2]), cV = mk3(P.cameraV[0], P.cameraV[1], P.cameraV[2]), cW = mk3(P.cameraW[0], P.cameraW[1], P.cameraW[2]);
+        f3 nonNormRayDir = (cU * d.x + cV * d.y) + cW;
+        store_rgba16f(I.viewDirection, i, rayDirection.x, rayDirection.y, rayDirection.z, 0.0f);
+        float reflA = 0.0f, refrA = 0.0f;
+
+        f2 screenUV; screenUV.x = ((float)px + P.pixelJitter[0]) / (float)P.width; screenUV.y = ((float)py + P.pixelJitter[1]) / (float)P.height;
+        f3 bgColor = sample_background_2d(P, screenUV);
+        f4 skyColor = sample_sky_2d(P, screenUV);
+        f3 bgPosition = rayOrigin + rayDirection * RT_RAY_MAX_DISTANCE;
+        f2 prevBgPos = world_to_screen(P.prevViewProj, bgPosition), curBgPos = world_to_screen(P.viewProj, bgPosition);
+        bgColor = lerp3(bgColor, xyz(skyColor), skyColor.w);
+
+        RayDiff rayDiff;
+        rayDiff.dOdx = mk3s(0.0f); rayDiff.dOdy = mk3s(0.0f);
+        compute_ray_diffs(nonNormRayDir, cU, cV, P.resolution[2], P.resolution[3], rayDiff.dDdx, rayDiff.dDdy);
+
+        f3 resPosition = mk3s(0.0f), resNormal = -rayDirection, resSpecular = mk3s(0.0f), resTransparent = mk3s(0.0f), resTransparentLight = mk3s(0.0f);
+        bool resTransparentLightComputed = false;
+        f4 resColor = mk4(0, 0, 0, 1);
+        float resFlowX = (curBgPos.x - prevBgPos.x) * (float)P.width, resFlowY = (curBgPos.y - prevBgPos.y) * (float)P.height;
+        float resReactiveMask = 0.0f, resLockMask = 0.0f, resDepth = 1.0f;
+        int resInstanceId = -1;
+        const f3 ambient = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]) + mk3(P.ambientNoGIColor[0], P.ambientNoGIColor[1], P.ambientNoGIColor[2]);
+
+        const uint4 hrec = reinterpret_cast<const uint4 *>(I.primaryHit)[i];
+        const int hInst = hitInstance[i];
+        const uint32_t nhits = hInst >= 0 ? 1u : 0u;
+        for (uint32_t hit = 0; hit < nhits; hit++) {
+            HitRecord r;
+            if (!surface_anyhit(P, (uint32_t)hInst, hrec.w, __uint_as_float(hrec.x), __uint_as_float(hrec.y), __uint_as_float(hrec.z), rayDirection, rayDiff, px, py, r)) continue;
+            f4 hitColor = r.color;
+            float alphaContrib = resColor.w * hitColor.w;
+            if (alphaContrib >= RT_EPSILON) {
+                const uint32_t instanceId = r.instanceId;
+                const RT64_MATERIAL &m = P.instances[instanceId].material;
+                resLockMask += m.lockMask * alphaContrib;
+                bool usesLighting = m.lightGroupMaskBits > 0;
+                bool applyLighting = usesLighting && (hitColor.w > RT_APPLY_LIGHTS_MINIMUM_ALPHA);
+                f3 vertexPosition = rayOrigin + rayDirection * (r.dist + m.depthBias);
+                f3 vertexNormal = r.normal;
+                f3 specular = ld_v3(m.specularColor) * r.specular;
+                bool storeHit = false;
+                if (m.fogEnabled) {
+                    f4 fog = fog_from_camera(P, m, vertexPosition);
+                    resTransparent = resTransparent + xyz(fog) * (fog.w * alphaContrib);
+                    alphaContrib *= (1.0f - fog.w);
+                }
+                if (m.reflectionFactor > RT_EPSILON) {
+                    float fresnelAmount = fresnel_reflect_amount(vertexNormal, rayDirection, m.reflectionFactor, m.reflectionFresnelFactor);
+                    float reflectAmount = fresnelAmount * alphaContrib;
+                    reflA = reflectAmount;
+                    alphaContrib *= (1.0f - fresnelAmount);
+                    storeHit = true;
+                    resLockMask += reflectAmount;
+                }
+                f3 resColorAdd = xyz(hitColor) * alphaContrib;
+                if (applyLighting) {
+                    storeHit = true;
+                    resColor.x += resColorAdd.x; resColor.y += resColorAdd.y; resColor.z += resColorAdd.z;
+                }
+                else if (usesLighting) {
+                    if (!resTransparentLightComputed) {
+                        resTransparentLight = compute_lights_random(P, env, px, py, rayDirection, instanceId, vertexPosition, vertexNormal, specular, 1, true);
+                        resTransparentLightComputed = true;
+                    }
+                    resTransparent = resTransparent + resColorAdd * ((ambient + ld_v3(m.selfLight)) + resTransparentLight);
+                }
+                else resTransparent = resTransparent + resColorAdd * (ambient + ld_v3(m.selfLight));
+                resColor.w *= (1.0f - hitColor.w);
+                if (m.refractionFactor > RT_EPSILON) { storeHit = true; refrA = resColor.w; resColor.w = 0.0f; }
+                if (storeHit && resInstanceId < 0) {
+                    f2 prevPos = world_to_screen(P.prevViewProj, vertexPosition - r.flow);
+                    f2 curPos = world_to_screen(P.viewProj, vertexPosition);
+                    f4 projPos = mul4(P.viewProj, mk4(vertexPosition.x, vertexPosition.y, vertexPosition.z, 1.0f));
+                    resPosition = vertexPosition; resNormal = vertexNormal; resSpecular = specular; resInstanceId = (int)instanceId;
+                    resFlowX = (curPos.x - prevPos.x) * (float)P.width; resFlowY = (curPos.y - prevPos.y) * (float)P.height;
+                    resDepth = projPos.z / projPos.w;
+                }
+            }
+            if (resColor.w <= RT_EPSILON) break;
+        }
+        resReactiveMask += fmaxf(resTransparent.x, fmaxf(resTransparent.y, resTransparent.z));
+        resColor.x += bgColor.x * resColor.w; resColor.y += bgColor.y * resColor.w; resColor.z += bgColor.z * resColor.w;
+        resColor.w = 1.0f - resColor.w;
+
+        store_rgba16f(I.reflection, i, 0.0f, 0.0f, 0.0f, reflA);
+        store_rgba16f(I.refraction, i, 0.0f, 0.0f, 0.0f, refrA);
+        reinterpret_cast<float4 *>(I.shadingPosition)[i] = make_float4(resPosition.x, resPosition.y, resPosition.z, 0.0f);
+        store_rgba16f(I.shadingNormal, i, resNormal.x, resNormal.y, resNormal.z, 0.0f);
+        store_rgba16f(I.shadingSpecular, i, resSpecular.x, resSpecular.y, resSpecular.z, 0.0f);
+        store_rgba8(I.diffuse, i, resColor.x, resColor.y, resColor.z, resColor.w);
+        I.instanceId[i] = resInstanceId;
+        I.firstInstanceId[i] = resInstanceId;                       // CopyResource(rtFirstInstanceId, rtInstanceId), rt64_view.cpp:1383
+        store_rgba16f(I.transparent, i, resTransparent.x, resTransparent.y, resTransparent.z, 1.0f);
+        reinterpret_cast<uint32_t *>(I.flow)[i] = (uint32_t)f32_to_f16_bits(-resFlowX) | ((uint32_t)f32_to_f16_bits(resFlowY) << 16);
+        I.reactiveMask[i] = to_unorm8(fminf(resReactiveMask, 0.9f));
+        I.lockMask[i] = to_unorm8(P.binaryLockMask ? (resLockMask >= 0.5f ? 1.0f : 0.0f) : fminf(resLockMask, 1.0f));
+        store_rgba16f(I.normal[cur], i, resNormal.x, resNormal.y, resNormal.z, 0.0f);
+        I.depth[cur][i] = resDepth;
+    }
+    flush_env(P, env, CTR_PRIMARY, 0);
+}
+
+// ---- DirectRayGen ----------------------------------------------------------------------------------------------------------
+
+DEV float history_weight(const FrameParams &P, const ViewImages &I, size_t i, uint32_t px, uint32_t py, f3 normal, int cur, long &prevIndex) {
+    // DirectRayGen.hlsl:31-45 / IndirectRayGen.hlsl:43-56
+    uint32_t fl = reinterpret_cast<const uint32_t *>(I.flow)[i];
+    float fx = f16_bits_to_f32((uint16_t)(fl & 0xFFFFu)), fy = f16_bits_to_f32((uint16_t)(fl >> 16));
+    int ix = (int)((float)px + 0.5f + fx), iy = (int)((float)py + 0.5f + fy);
+    const int prev = cur ^ 1;
+    float prevDepth = 0.0f; f3 prevNormal = mk3s(0.0f);
+    prevIndex = -1;
+    if (ix >= 0 && iy >= 0 && ix < P.width && iy < P.height) {       // out-of-bounds image loads return 0
+        size_t j = (size_t)iy * (size_t)P.width + (size_t)ix;
+        prevDepth = I.depth[prev][j]; prevNormal = xyz(load_rgba16f(I.normal[prev], j));
+        prevIndex = (long)j;
+    }
+    float weightDepth = fabsf(I.depth[cur][i] - prevDepth) / 0.01f;
+    float weightNormal = powf(fmaxf(0.0f, dot3(prevNormal, normal)), 128.0f);
+    return expf(-weightDepth) * weightNormal;
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void direct_kernel(FrameParams P, ViewImages I, int cur) {
+    __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
+    ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
+    const uint32_t tiles = tile_count(P);
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        Pixel p = tile_pixel(P, tile);
+        if (!p.valid) continue;
+        const uint32_t px = p.x, py = p.y;
+        const size_t i = (size_t)py * (size_t)P.width + px;
+        const int instanceId = I.instanceId[i];
+        if (instanceId < 0) { store_rgba16f(I.directLight[cur], i, 1.0f, 1.0f, 1.0f, 0.0f); continue; }
+        f3 o, rayDirection; f2 ndc;
+        primary_ray(P, px, py, o, rayDirection, ndc);
+        const float4 pos4 = reinterpret_cast<const float4 *>(I.shadingPosition)[i];
+        f3 position = mk3(pos4.x, pos4.y, pos4.z), normal = xyz(load_rgba16f(I.shadingNormal, i)), specular = xyz(load_rgba16f(I.shadingSpecular, i));
+        f3 newDirect = mk3s(0.0f); float historyLength = 0.0f;
+        if (P.diReproject) {
+            long j; float w = history_weight(P, I, i, px, py, normal, cur, j);
+            f4 prevAccum = j >= 0 ? load_rgba16f(I.directLight[cur ^ 1], (size_t)j) : mk4(0, 0, 0, 0);
+            newDirect = xyz(prevAccum); historyLength = prevAccum.w * w;
+        }
+        const RT64_MATERIAL &m = P.instances[instanceId].material;
+        f3 resDirect = compute_lights_random(P, env, px, py, rayDirection, (uint32_t)instanceId, position, normal, specular, P.maxLights, true);
+        resDirect = resDirect + ld_v3(m.selfLight);
+        float eyeLambert = fmaxf(dot3(normal, -rayDirection), 0.0f);
+        f3 eyeReflected = reflect3(rayDirection, normal);
+        float eyeSpec = powf(fmaxf(saturatef(dot3(eyeReflected, -rayDirection)), 0.0f), m.specularExponent);
+        f3 eyeD = mk3(P.eyeLightDiffuseColor[0], P.eyeLightDiffuseColor[1], P.eyeLightDiffuseColor[2]), eyeS = mk3(P.eyeLightSpecularColor[0], P.eyeLightSpecularColor[1], P.eyeLightSpecularColor[2]);
+        resDirect = resDirect + (eyeD * eyeLambert + eyeS * (specular * eyeSpec));
+        historyLength = fminf(historyLength + 1.0f, 64.0f);
+        newDirect = lerp3(newDirect, resDirect, 1.0f / historyLength);
+        store_rgba16f(I.directLight[cur], i, newDirect.x, newDirect.y, newDirect.z, historyLength);
+    }
+    flush_env(P, env, CTR_PRIMARY, 0);
+}
+
+// ---- bounce-ray resolve shared by Indirect / Refraction / Reflection ------------------------------------------------------
+
+DEV bool bounce_record(const FrameParams &P, ShadeEnv &env, f3 origin, f3 dir, uint32_t px, uint32_t py, HitRecord &r) {
+    SurfaceHit h;
+    trace_surface(P, env, origin, dir, h);
+    if (!h.hit) return false;
+    RayDiff rd; rd.dOdx = rd.dOdy = rd.dDdx = rd.dDdy = mk3s(0.0f);
+    return surface_anyhit(P, h.instance, h.prim, h.t, h.u, h.v, dir, rd, px, py, r);
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void indirect_kernel(FrameParams P, ViewImages I, int cur) {
+    __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
+    ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
+    uint32_t rays = 0;
+    const f3 ambientBase = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]);
+    const f3 ambient = ambientBase + mk3(P.ambientNoGIColor[0], P.ambientNoGIColor[1], P.ambientNoGIColor[2]);
+    const uint32_t tiles = tile_count(P);
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        Pixel p = tile_pixel(P, tile);
+        if (!p.valid) continue;
+        const uint32_t px = p.x, py = p.y;
+        const size_t i = (size_t)py * (size_t)P.width + px;
+        const int instanceId = I.instanceId[i];
+        if (!(instanceId >= 0 && P.giSamples > 0)) { store_rgba16f(I.indirectLight[cur], i, ambient.x, ambient.y, ambient.z, 0.0f); continue; }
+        const float4 pos4 = reinterpret_cast<const float4 *>(I.shadingPosition)[i];
+        f3 rayOrigin = mk3(pos4.x, pos4.y, pos4.z), shadingNormal = xyz(load_rgba16f(I.shadingNormal, i));
+        f3 newIndirect = mk3s(0.0f); float historyLength = 0.0f;
+        if (P.giReproject) {
+            long j; float w = history_weight(P, I, i, px, py, shadingNormal, cur, j);
+            f4 prevAccum = j >= 0 ? load_rgba16f(I.indirectLight[cur ^ 1], (size_t)j) : mk4(0, 0, 0, 0);
+            newIndirect = xyz(prevAccum); historyLength = prevAccum.w * w;
+        }
+        uint32_t maxSamples = P.giSamples; const uint32_t blueNoiseMult = 64u / P.giSamples;
+        while (maxSamples > 0) {
+            f3 rayDirection = cos_hemisphere_blue_noise(P, px, py, P.frameCount + maxSamples * blueNoiseMult, shadingNormal);
+            HitRecord r;
+            bool have = bounce_record(P, env, rayOrigin, rayDirection, px, py, r);
+            rays++;
+            f3 bgColor = sample_background_envmap(P, rayDirection);
+            f4 sky = sample_sky_plane(P, rayDirection);
+            bgColor = lerp3(bgColor, xyz(sky), sky.w);
+            f3 resPosition = mk3s(0.0f), resNormal = mk3s(0.0f), resSpecular = mk3s(0.0f); f4 resColor = mk4(0, 0, 0, 1); int resInstanceId = -1;
+            if (have) {
+                f4 hitColor = r.color;
+                float alphaContrib = resColor.w * hitColor.w;
+                if (alphaContrib >= RT_EPSILON) {
+                    const RT64_MATERIAL &m = P.instances[r.instanceId].material;
+                    resPosition = rayOrigin + rayDirection * (r.dist + m.depthBias);
+                    resNormal = r.normal; resSpecular = ld_v3(m.specularColor) * r.specular;
+                    resColor.x += hitColor.x * alphaContrib; resColor.y += hitColor.y * alphaContrib; resColor.z += hitColor.z * alphaContrib;
+                    resColor.w *= (1.0f - hitColor.w);
+                    resInstanceId = (int)r.instanceId;
+                }
+            }
+            f3 resIndirect = ambientBase;
+            if (resInstanceId >= 0) {
+                f3 directLight = compute_lights_random(P, env, px, py, rayDirection, (uint32_t)resInstanceId, resPosition, resNormal, resSpecular, 1, true) + ld_v3(P.instances[resInstanceId].material.selfLight);
+                f3 indirectLight = ((xyz(resColor) * (1.0f - resColor.w)) * (ambient + directLight)) * P.giDiffuseStrength;
+                resIndirect = resIndirect + indirectLight;
+            }
+            resIndirect = resIndirect + bgColor * (P.giSkyStrength * resColor.w);
+            historyLength = fminf(historyLength + 1.0f, 64.0f);
+            newIndirect = lerp3(newIndirect, resIndirect, 1.0f / historyLength);
+            maxSamples--;
+        }
+        store_rgba16f(I.indirectLight[cur], i, newIndirect.x, newIndirect.y, newIndirect.z, historyLength);
+    }
+    flush_env(P, env, CTR_INDIRECT, rays);
+}
+
+DEV f3 hlsl_refract(f3 i, f3 n, float eta) {
+    float cosi = dot3(n, i);
+    float k = 1.0f - eta * eta * (1.0f - cosi * cosi);
+    if (k < 0.0f) return mk3s(0.0f);
+    return i * eta - n * (eta * cosi + sqrtf(k));
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void refraction_kernel(FrameParams P, ViewImages I) {
+    __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
+    ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
+    uint32_t rays = 0;
+    const f3 ambient = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]) + mk3(P.ambientNoGIColor[0], P.ambientNoGIColor[1], P.ambientNoGIColor[2]);
+    const uint32_t tiles = tile_count(P);
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        Pixel p = tile_pixel(P, tile);
+        if (!p.valid) continue;
+        const uint32_t px = p.x, py = p.y;
+        const size_t i = (size_t)py * (size_t)P.width + px;
+        const int instanceId = I.instanceId[i];
+        f4 refr = load_rgba16f(I.refraction, i);
+        const float refractionAlpha = refr.w;
+        if (instanceId < 0 || refractionAlpha <= RT_EPSILON) continue;
+        const float4 pos4 = reinterpret_cast<const float4 *>(I.shadingPosition)[i];
+        f3 rayOrigin = mk3(pos4.x, pos4.y, pos4.z), viewDirection = xyz(load_rgba16f(I.viewDirection, i)), shadingNormal = xyz(load_rgba16f(I.shadingNormal, i));
+        f3 rayDirection = hlsl_refract(viewDirection, shadingNormal, P.instances[instanceId].material.refractionFactor);
+        f2 screenUV; screenUV.x = ((float)px + P.pixelJitter[0]) / (float)P.width; screenUV.y = ((float)py + P.pixelJitter[1]) / (float)P.height;
+        f3 bgColor = sample_background_2d(P, screenUV);
+        f4 sky = sample_sky_2d(P, screenUV);
+        bgColor = lerp3(bgColor, xyz(sky), sky.w);
+        HitRecord r;
+        bool have = bounce_record(P, env, rayOrigin, rayDirection, px, py, r);
+        rays++;
+        f3 resPosition = mk3s(0.0f), resNormal = mk3s(0.0f), resSpecular = mk3s(0.0f), resTransparent = mk3s(0.0f); f4 resColor = mk4(0, 0, 0, 1); int resInstanceId = -1;
+        if (have) {
+            f4 hitColor = r.color;
+            float alphaContrib = resColor.w * hitColor.w;
+            if (alphaContrib >= RT_EPSILON) {
+                const RT64_MATERIAL &m = P.instances[r.instanceId].material;
+                bool usesLighting = m.lightGroupMaskBits > 0;
+                f3 vertexPosition = rayOrigin + rayDirection * (r.dist + m.depthBias);
+                if (m.fogEnabled) {
+                    f4 fog = fog_from_camera(P, m, vertexPosition);
+                    resTransparent = resTransparent + xyz(fog) * (fog.w * alphaContrib);
+                    alphaContrib *= (1.0f - fog.w);
+                }
+                if (usesLighting) {
+                    resColor.x += hitColor.x * alphaContrib; resColor.y += hitColor.y * alphaContrib; resColor.z += hitColor.z * alphaContrib;
+                    resPosition = vertexPosition; resNormal = r.normal; resSpecular = ld_v3(m.specularColor) * r.specular; resInstanceId = (int)r.instanceId;
+                }
+                else resTransparent = resTransparent + (xyz(hitColor) * alphaContrib) * (ambient + ld_v3(m.selfLight));
+                resColor.w *= (1.0f - hitColor.w);
+            }
+        }
+        f3 rgb = xyz(resColor);
+        if (resInstanceId >= 0) {
+            f3 directLight = compute_lights_random(P, env, px, py, rayDirection, (uint32_t)resInstanceId, resPosition, resNormal, resSpecular, 1, true) + ld_v3(P.instances[resInstanceId].material.selfLight);
+            rgb = rgb * (ambient + directLight);
+        }
+        rgb = rgb + (bgColor * resColor.w + resTransparent);
+        store_rgba16f(I.refraction, i, refr.x + rgb.x * refractionAlpha, refr.y + rgb.y * refractionAlpha, refr.z + rgb.z * refractionAlpha, refr.w);
+    }
+    flush_env(P, env, CTR_REFRACTION, rays);
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void reflection_kernel(FrameParams P, ViewImages I) {
+    __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
+    ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
+    uint32_t rays = 0;
+    const f3 ambient = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]) + mk3(P.ambientNoGIColor[0], P.ambientNoGIColor[1], P.ambientNoGIColor[2]);
+    const uint32_t tiles = tile_count(P);
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        Pixel p = tile_pixel(P, tile);
+        if (!p.valid) continue;
+        const uint32_t px = p.x, py = p.y;
+        const size_t i = (size_t)py * (size_t)P.width + px;
+        const int instanceId = I.instanceId[i];
+        f4 refl = load_rgba16f(I.reflection, i);
+        const float reflectionAlpha = refl.w;
+        if (instanceId < 0 || reflectionAlpha <= RT_EPSILON) continue;
+        const float4 pos4 = reinterpret_cast<const float4 *>(I.shadingPosition)[i];
+        f3 shadingPosition = mk3(pos4.x, pos4.y, pos4.z), viewDirection = xyz(load_rgba16f(I.viewDirection, i)), shadingNormal = xyz(load_rgba16f(I.shadingNormal, i));
+        f3 rayDirection = reflect3(viewDirection, shadingNormal);
+        float newReflectionAlpha = 0.0f;
+        f3 bgColor = sample_background_envmap(P, rayDirection);
+        f4 sky = sample_sky_plane(P, rayDirection);
+        bgColor = lerp3(bgColor, xyz(sky), sky.w);
+        HitRecord r;
+        bool have = bounce_record(P, env, shadingPosition, rayDirection, px, py, r);
+        rays++;
+        const RT64_MATERIAL &pm = P.instances[instanceId].material;
+        f3 resPosition = mk3s(0.0f), resNormal = mk3s(0.0f), resSpecular = mk3s(0.0f), resTransparent = mk3s(0.0f); f4 resColor = mk4(0, 0, 0, 1); int resInstanceId = -1;
+        if (have) {
+            f4 hitColor = r.color;
+            float alphaContrib = resColor.w * hitColor.w;
+            if (alphaContrib >= RT_EPSILON) {
+                const RT64_MATERIAL &m = P.instances[r.instanceId].material;
+                bool usesLighting = m.lightGroupMaskBits > 0;
+                f3 vertexPosition = shadingPosition + rayDirection * (r.dist + m.depthBias);
+                if (m.fogEnabled) {
+                    f4 fog = fog_from_origin(m, vertexPosition, shadingPosition);
+                    resTransparent = resTransparent + xyz(fog) * (fog.w * alphaContrib);
+                    alphaContrib *= (1.0f - fog.w);
+                }
+                f3 vertexNormal = r.normal;
+                f3 specular = ld_v3(m.specularColor) * r.specular;
+                if (m.reflectionFactor > RT_EPSILON) {
+                    float fresnelAmount = fresnel_reflect_amount(vertexNormal, rayDirection, m.reflectionFactor, pm.reflectionFresnelFactor);   // sic: [instanceId], ReflectionRayGen.hlsl:98
+                    newReflectionAlpha += fresnelAmount * alphaContrib * reflectionAlpha;
+                }
+                if (usesLighting) { resColor.x += hitColor.x * alphaContrib; resColor.y += hitColor.y * alphaContrib; resColor.z += hitColor.z * alphaContrib; }
+                else resTransparent = resTransparent + (xyz(hitColor) * alphaContrib) * (ambient + ld_v3(m.selfLight));
+                resPosition = vertexPosition; resNormal = vertexNormal; resSpecular = specular; resInstanceId = (int)r.instanceId;
+                resColor.w *= (1.0f - hitColor.w);
+            }
+        }
+        f3 rgb = xyz(resColor);
+        if (resInstanceId >= 0) {
+            f3 directLight = compute_lights_random(P, env, px, py, rayDirection, (uint32_t)resInstanceId, resPosition, resNormal, resSpecular, 1, false) + ld_v3(P.instances[resInstanceId].material.selfLight);
+            rgb = rgb * (ambient + directLight);
+            reinterpret_cast<float4 *>(I.shadingPosition)[i] = make_float4(resPosition.x, resPosition.y, resPosition.z, 0.0f);
+            store_rgba16f(I.viewDirection, i, rayDirection.x, rayDirection.y, rayDirection.z, 0.0f);
+            store_rgba16f(I.shadingNormal, i, resNormal.x, resNormal.y, resNormal.z, 0.0f);
+            I.instanceId[i] = resInstanceId;
+        }
+        rgb = rgb + (bgColor * resColor.w + resTransparent);
+        const f3 HighlightColor = mk3(1.0f, 1.05f, 1.2f), ShadowColor = mk3(0.1f, 0.05f, 0.0f);
+        float shine = pm.reflectionShineFactor;
+        rgb = lerp3(rgb, HighlightColor, powf(fmaxf(rayDirection.y, 0.0f) * shine, 3.0f));
+        rgb = lerp3(rgb, ShadowColor, powf(fmaxf(-rayDirection.y, 0.0f) * shine, 3.0f));
+        float k = reflectionAlpha * saturatef(1.0f - newReflectionAlpha);
+        store_rgba16f(I.reflection, i, refl.x + rgb.x * k, refl.y + rgb.y * k, refl.z + rgb.z * k, saturatef(newReflectionAlpha));
+    }
+    flush_env(P, env, CTR_REFLECTION, rays);
+}
+
+// ---- GaussianFilterRGB3x3CS ------------------------------------------------------------------------------------------------
+
+DEV f3 bilinear_clamp_rgb(const uint16_t *img, int w, int h, float u, float v) {   // LINEAR + CLAMP static sampler, rt64_device.cpp:737-742
+    float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    float x0f = floorf(x), y0f = floorf(y), fx = x - x0f, fy = y - y0f;
+    int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+    x0 = x0 < 0 ? 0 : (x0 >= w ? w - 1 : x0); x1 = x1 < 0 ? 0 : (x1 >= w ? w - 1 : x1);
+    y0 = y0 < 0 ? 0 : (y0 >= h ? h - 1 : y0); y1 = y1 < 0 ? 0 : (y1 >= h ? h - 1 : y1);
+    f3 c00 = xyz(load_rgba16f(img, (size_t)y0 * w + x0)), c10 = xyz(load_rgba16f(img, (size_t)y0 * w + x1));
+    f3 c01 = xyz(load_rgba16f(img, (size_t)y1 * w + x0)), c11 = xyz(load_rgba16f(img, (size_t)y1 * w + x1));
+    f3 top = lerp3(c00, c10, fx), bot = lerp3(c01, c11, fx);
+    return lerp3(top, bot, fy);
+}
+
+__global__ __launch_bounds__(256) void gaussian_kernel(const uint16_t *in, uint16_t *out, int w, int h, int y0, int y1) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = y0 + blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= w || y >= y1) return;
+    const float texelX = 1.0f / (float)w, texelY = 1.0f / (float)h;
+    const float k00 = 0.077847f, k01 = 0.123317f, k11 = 0.195346f;
+    float wt[4];
+    const bool xl = x == 0, xr = x == w - 1, yt = y == 0, yb = y == h - 1;
+    if (x > 0 && y > 0 && x < w - 1 && y < h - 1) { wt[0] = k00 + k01 + k01 + k11; wt[1] = k00 + k01; wt[2] = k00 + k01; wt[3] = k00; }
+    else if (xl && yt) { wt[0] = k11 / 0.519827f; wt[1] = k01 / 0.519827f; wt[2] = k01 / 0.519827f; wt[3] = k00 / 0.519827f; }
+    else if (xr && yt) { wt[0] = (k01 + k11) / 0.519827f; wt[1] = 0.0f; wt[2] = 0.201164f / 0.519827f; wt[3] = 0.0f; }
+    else if (xl && yb) { wt[0] = (k01 + k11) / 0.519827f; wt[1] = (k00 + k01) / 0.519827f; wt[2] = 0.0f; wt[3] = 0.0f; }
+    else if (xr && yb) { wt[0] = (k00 + k01 + k01 + k11) / 0.519827f; wt[1] = wt[2] = wt[3] = 0.0f; }
+    else if (xl) { wt[0] = (k01 + k11) / 0.720991f; wt[1] = (k00 + k01) / 0.720991f; wt[2] = k01 / 0.720991f; wt[3] = k00 / 0.720991f; }
+    else if (xr) { wt[0] = (k00 + k01 + k01 + k11) / 0.720991f; wt[1] = 0.0f; wt[2] = (k00 + k01) / 0.720991f; wt[3] = 0.0f; }
+    else if (yt) { wt[0] = (k01 + k11) / 0.720991f; wt[1] = k01 / 0.720991f; wt[2] = (k00 + k01) / 0.720991f; wt[3] = k00 / 0.720991f; }
+    else { wt[0] = (k00 + k01 + k01 + k11) / 0.720991f; wt[1] = (k00 + k01) / 0.720991f; wt[2] = 0.0f; wt[3] = 0.0f; }
+    const float off[3][2] = { { 0.5f + -k01 / (k01 + k11), 0.5f + -k01 / (k01 + k11) }, { 0.5f + 1.0f, 0.5f + -k00 / (k00 + k01) }, { 0.5f + -k00 / (k00 + k01), 0.5f + 1.0f } };
+    f3 smp[4];
+#pragma unroll
+    for (int k = 0; k < 3; k++) smp[k] = bilinear_clamp_rgb(in, w, h, ((float)x + off[k][0]) * texelX, ((float)y + off[k][1]) * texelY);
+    smp[3] = (x + 1 < w && y + 1 < h) ? xyz(load_rgba16f(in, (size_t)(y + 1) * w + (x + 1))) : mk3s(0.0f);
+    const size_t i = (size_t)y * w + x;
+    f4 old = load_rgba16f(out, i);
+    store_rgba16f(out, i, smp[0].x * wt[0] + smp[1].x * wt[1] + smp[2].x * wt[2] + smp[3].x * wt[3],
+                  smp[0].y * wt[0] + smp[1].y * wt[1] + smp[2].y * wt[2] + smp[3].y * wt[3],
+                  smp[0].z * wt[0] + smp[1].z * wt[1] + smp[2].z * wt[2] + smp[3].z * wt[3], old.w);
+}
+
+// ---- ComposePS + PostProcessPS (fused) -------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void compose_post_kernel(FrameParams P, ViewImages I) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = P.tileY0 + blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= P.width || y >= P.tileY1) return;
+    const size_t i = (size_t)y * (size_t)P.width + x;
+    f4 d = load_rgba8(I.diffuse, i);
+    f3 result;
+    if (d.w > RT_EPSILON) {
+        f3 diffuse = xyz(d);
+        f3 direct = xyz(load_rgba16f(I.filteredDirect[1], i)), indirect = xyz(load_rgba16f(I.filteredIndirect[1], i));
+        result = diffuse * (direct + indirect);
+        result = lerp3(diffuse, result, d.w);
+        result = result + xyz(load_rgba16f(I.reflection, i));
+        result = result + xyz(load_rgba16f(I.refraction, i));
+        result = result + xyz(load_rgba16f(I.transparent, i));
+    }
+    else result = xyz(d);
+    reinterpret_cast<float4 *>(I.output)[i] = make_float4(result.x, result.y, result.z, 1.0f);
+    store_rgba8(I.final, i, result.x, result.y, result.z, 1.0f);   // PostProcessPS passthrough (motionBlurStrength == 0, render size == screen size)
+}
+
+__global__ __launch_bounds__(256) void clear_final_kernel(FrameParams P, ViewImages I) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = P.tileY0 + blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= P.width || y >= P.tileY1) return;
+    store_rgba8(I.final, (size_t)y * (size_t)P.width + x, 0.0f, 0.0f, 0.0f, 1.0f);   // cleared back buffer, rt64_device.cpp:996-997
+}
+
+}  // namespace
+
+size_t rt_stack_spill_bytes() { return (size_t)RT_GRID_BLOCKS * RT_BLOCK * RT_STACK_SPILL * sizeof(uint32_t); }
+
+#define LAUNCH_RAY(kernel, ...) do { hipLaunchKernelGGL(kernel, dim3(RT_GRID_BLOCKS), dim3(RT_BLOCK), 0, s, __VA_ARGS__); return hipGetLastError(); } while (0)
+
+hipError_t launch_primary_trace(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, hipStream_t s) { LAUNCH_RAY(primary_trace_kernel, P, I, hitInstance); }
+hipError_t launch_primary_shade(const FrameParams &P, const ViewImages &I, const int32_t *hitInstance, int cur, hipStream_t s) { LAUNCH_RAY(primary_shade_kernel, P, I, hitInstance, cur); }
+hipError_t launch_direct(const FrameParams &P, const ViewImages &I, int cur, hipStream_t s) { LAUNCH_RAY(direct_kernel, P, I, cur); }
+hipError_t launch_indirect(const FrameParams &P, const ViewImages &I, int cur, hipStream_t s) { LAUNCH_RAY(indirect_kernel, P, I, cur); }
+hipError_t launch_refraction(const FrameParams &P, const ViewImages &I, hipStream_t s) { LAUNCH_RAY(refraction_kernel, P, I); }
+hipError_t launch_reflection(const FrameParams &P, const ViewImages &I, hipStream_t s) { LAUNCH_RAY(reflection_kernel, P, I); }
+
+hipError_t launch_gaussian(const uint16_t *in, uint16_t *out, int width, int height, int y0, int y1, hipStream_t s) {
+    dim3 grid((unsigned)(width + 31) / 32, (unsigned)(y1 - y0 + 7) / 8);
+    hipLaunchKernelGGL(gaussian_kernel, grid, dim3(256), 0, s, in, out, width, height, y0, y1);
+    return hipGetLastError();
+}
+hipError_t launch_compose_post(const FrameParams &P, const ViewImages &I, hipStream_t s) {
+    dim3 grid((unsigned)(P.width + 31) / 32, (unsigned)(P.tileY1 - P.tileY0 + 7) / 8);
+    hipLaunchKernelGGL(compose_post_kernel, grid, dim3(256), 0, s, P, I);
+    return hipGetLastError();
+}
+hipError_t launch_clear_final(const FrameParams &P, const ViewImages &I, hipStream_t s) {
+    dim3 grid((unsigned)(P.width + 31) / 32, (unsigned)(P.tileY1 - P.tileY0 + 7) / 8);
+    hipLaunchKernelGGL(clear_final_kernel, grid, dim3(256), 0, s, P, I);
+    return hipGetLastError();
+}

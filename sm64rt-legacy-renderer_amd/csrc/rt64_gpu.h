@@ -1,0 +1,128 @@
+// rt64_gpu.h -- plain structures shared by the host side and the HIP kernels of librt64.so.
+//
+// HBM layout of the render path (see DESIGN.md "Data layout"):
+//   * per mesh      : raw interleaved vertex buffer + u32 index buffer (as handed to RT64_SetMesh),
+//                     BLAS = GpuNode[max(n-1,1)] (64 B each) + GpuTri[n] (48 B each, Morton order) + BlasHeader
+//   * per frame     : GpuInstance[] (transforms, material, combiner, pointers), TLAS GpuNode[], GpuTexture[] table,
+//                     RT64_LIGHT[]
+//   * per view      : G-buffer images in the reference's storage formats (rt64_view.cpp:152-241)
+#pragma once
+#include <stdint.h>
+#include "../../include/rt64.h"
+
+#define RT64_LEAF_BIT 0x80000000u
+#define RT64_NO_CHILD 0xFFFFFFFFu
+#define RT64_MAX_MIPS 16
+#define RT64_MAX_LIGHTS 16          // Lights.hlsli:25
+#define RT64_MAX_HIT_QUERIES 16     // GlobalHitBuffers.hlsli:8
+
+// LBVH inner node, 64 B = four 16-byte loads.  Both children's boxes live in the parent so one fetch decides both.
+// Child ids: bit 31 = leaf (low bits = slot in Morton order), RT64_NO_CHILD = absent (single-leaf tree).
+struct alignas(16) GpuNode {
+    float lmin[3], lmax[3];
+    float rmin[3], rmax[3];
+    uint32_t left, right, parent, pad;
+};
+static_assert(sizeof(GpuNode) == 64, "GpuNode");
+
+// BLAS leaf: one triangle, positions only (Moller-Trumbore operands), 48 B = three 16-byte loads.
+struct alignas(16) GpuTri {
+    float v0[3]; uint32_t prim;      // prim = PrimitiveIndex() (triangle number in the index buffer)
+    float v1[3]; uint32_t pad1;
+    float v2[3]; uint32_t pad2;
+};
+static_assert(sizeof(GpuTri) == 48, "GpuTri");
+
+struct BlasHeader {
+    float bmin[3]; uint32_t count;
+    float bmax[3]; uint32_t pad;
+};
+
+struct GpuTexture {
+    const uint8_t *texels;           // RGBA8, mips packed back to back
+    uint32_t width, height, mips, pad;
+    uint32_t mipOffset[RT64_MAX_MIPS];   // in texels
+};
+
+// Decoded colour combiner + vertex layout (reference: rt64_shader.cpp:32-96).
+struct GpuCombiner {
+    int8_t c[2][4];
+    int8_t inputCount, useTex0, useTex1, vertexUV;
+    int8_t doSingle[2], doMultiply[2], doMix[2];
+    int8_t colorAlphaSame, optAlpha, optTextureEdge, optNoise;
+    int16_t vertexSize, normalOffset, uvOffset, inputOffset[4];
+};
+
+enum : uint32_t {
+    GPU_INST_CULL_DISABLE = 1u << 0,     // RT64_INSTANCE_DISABLE_BACKFACE_CULLING
+    GPU_INST_OPAQUE       = 1u << 1,     // static opacity rule O1: every hit stores alpha 255
+    GPU_INST_NORMAL_MAP   = 1u << 2,     // RT64_SHADER_NORMAL_MAP_ENABLED
+    GPU_INST_SPECULAR_MAP = 1u << 3,     // RT64_SHADER_SPECULAR_MAP_ENABLED
+    GPU_INST_SHADOW_OPAQUE = 1u << 4,    // shadow any-hit needs no alpha evaluation (combiner without opt_alpha)
+};
+
+struct alignas(16) GpuInstance {
+    float objectToWorld[16];             // row-major, row-vector convention (p' = p * M)
+    float objectToWorldNormal[16];
+    float objectToWorldPrevious[16];
+    float worldToObject[16];
+    const GpuNode *nodes;
+    const GpuTri *tris;
+    const uint8_t *vertices;
+    const uint32_t *indices;
+    const BlasHeader *header;
+    RT64_MATERIAL material;
+    GpuCombiner cc;
+    int32_t texDiffuse, texNormal, texSpecular;
+    uint32_t filter, hAddr, vAddr;
+    uint32_t flags;
+    uint32_t triCount;
+};
+
+// Constant block of one frame (reference: GlobalParams.hlsli:8-43 / rt64_view.cpp:961-1028), passed by value.
+struct FrameParams {
+    float view[16], viewI[16], prevViewI[16], projection[16], projectionI[16], viewProj[16], prevViewProj[16];
+    float cameraU[4], cameraV[4], cameraW[4];
+    float viewport[4], resolution[4];
+    float ambientBaseColor[4], ambientNoGIColor[4], eyeLightDiffuseColor[4], eyeLightSpecularColor[4];
+    float skyDiffuseMultiplier[4], skyHSLModifier[4];
+    float pixelJitter[2];
+    float skyYawOffset, giDiffuseStrength, giSkyStrength, motionBlurStrength;
+    int32_t skyPlaneTexIndex;
+    uint32_t randomSeed, diSamples, giSamples, diReproject, giReproject, binaryLockMask, maxLights, motionBlurSamples;
+    uint32_t visualizationMode, frameCount;
+    // --- additions of this implementation ---
+    int32_t width, height;               // render size
+    int32_t tileY0, tileY1;              // rows owned by this device
+    float maxDepthBias;
+    uint32_t lightCount, instanceCount, countTraversal;
+    const GpuInstance *instances;
+    const GpuNode *tlasNodes;
+    const uint32_t *tlasIndex;           // TLAS leaf slot -> instance
+    const GpuTexture *textures;
+    const RT64_LIGHT *lights;
+    const uint8_t *blueNoise;            // 512x512 RGBA8
+    uint32_t *traversalStack;            // overflow stack, per resident lane
+    unsigned long long *counters;        // [0] nodes [1] triangles [2] primary rays [3] shadow rays [4] indirect [5] reflection [6] refraction
+};
+
+// G-buffer images of one view (device pointers), in the reference's formats.
+struct ViewImages {
+    uint16_t *viewDirection;             // RGBA16F
+    float *shadingPosition;              // RGBA32F
+    uint16_t *shadingNormal, *shadingSpecular;   // RGBA16F
+    uint8_t *diffuse;                    // RGBA8
+    int32_t *instanceId, *firstInstanceId;
+    uint16_t *directLight[2], *indirectLight[2], *filteredDirect[2], *filteredIndirect[2];   // RGBA16F
+    uint16_t *reflection, *refraction, *transparent;   // RGBA16F
+    uint16_t *flow;                      // RG16F
+    uint8_t *reactiveMask, *lockMask;    // R8
+    uint16_t *normal[2];                 // RGBA16F
+    float *depth[2];                     // R32F
+    float *output;                       // RGBA32F (rtOutput)
+    uint8_t *final;                      // RGBA8 back buffer
+    uint32_t *primaryHit;                // RGBA32UI: t, u, v bits, instance << 24 | primitive
+    float *moments[2];                   // SVGF: RG32F luminance moments
+};
+
+enum { CTR_NODES = 0, CTR_TRIS, CTR_PRIMARY, CTR_SHADOW, CTR_INDIRECT, CTR_REFLECTION, CTR_REFRACTION, CTR_COUNT };

@@ -1,0 +1,973 @@
+// rt64_host.cpp -- host-side object model, frame orchestration and the extern "C" ABI of librt64.so.
+//
+// Mirrors the reference's L1/L2 layers (Device > Scene > {View, Instance}; Mesh / Texture / Shader hang off Device):
+//   /root/reference/src/rt64lib/private/rt64_{device,scene,view,instance,mesh,texture,shader}.cpp
+// with the D3D12 plumbing replaced by one HIP stream per device: uploads are hipMemcpyAsync on that stream, BLAS builds are
+// kernels queued at RT64_SetMesh, and RT64_DrawDevice runs View::update + View::render as a fixed sequence of kernels and
+// returns after the stream has drained (the reference presents and waits for GPU idle, rt64_device.cpp:1006-1025).
+// Errors: C++ exceptions are caught at the ABI boundary, stored for RT64_GetLastError() and turned into NULL / no-op
+// (rt64_common.h:379-383).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+#define RT64_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace rt64 {
+
+static std::string GlobalLastError;
+
+#define HIP_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    char msg_[512]; snprintf(msg_, sizeof(msg_), "HIP call " #call " failed: %s", hipGetErrorString(e_)); throw std::runtime_error(msg_); } } while (0)
+
+template <class T> struct DevArray {
+    T *ptr = nullptr; size_t count = 0;
+    void reserve(size_t n) { if (n <= count) return; release(); HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&ptr), n * sizeof(T))); count = n; }
+    void release() { if (ptr) hipFree(ptr); ptr = nullptr; count = 0; }
+    size_t bytes() const { return count * sizeof(T); }
+    ~DevArray() { release(); }
+    DevArray() = default; DevArray(const DevArray &) = delete; DevArray &operator=(const DevArray &) = delete;
+};
+
+struct Scene; struct View; struct Instance; struct Mesh; struct Texture; struct Shader;
+
+// ---- matrices (row-major, row-vector convention) ----------------------------------------------------------------------
+
+struct Mat4 { float m[16]; };
+
+static Mat4 mat_from(const RT64_MATRIX4 &s) { Mat4 r; memcpy(r.m, s.m, 64); return r; }
+static Mat4 mat_identity() { Mat4 r = {}; r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.0f; return r; }
+static Mat4 mat_mul(const Mat4 &A, const Mat4 &B) {
+    Mat4 R;
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++)
+        R.m[i * 4 + j] = A.m[i * 4 + 0] * B.m[0 * 4 + j] + A.m[i * 4 + 1] * B.m[1 * 4 + j] + A.m[i * 4 + 2] * B.m[2 * 4 + j] + A.m[i * 4 + 3] * B.m[3 * 4 + j];
+    return R;
+}
+static Mat4 mat_transpose(const Mat4 &A) { Mat4 R; for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) R.m[i * 4 + j] = A.m[j * 4 + i]; return R; }
+
+// General inverse by cofactors in double precision, rounded once to float.  (The reference uses DirectXMath's float
+// XMMatrixInverse: rt64_view.cpp:368,981-984.)
+static Mat4 mat_inverse(const Mat4 &M) {
+    double m[16], inv[16];
+    for (int i = 0; i < 16; i++) m[i] = (double)M.m[i];
+    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    Mat4 R = {};
+    if (det == 0.0) return R;
+    double r = 1.0 / det;
+    for (int i = 0; i < 16; i++) R.m[i] = (float)(inv[i] * r);
+    return R;
+}
+
+// XMMatrixPerspectiveFovRH (rt64_view.cpp:1766).
+static Mat4 mat_perspective_fov_rh(float fov, float aspect, float zn, float zf) {
+    float s = sinf(0.5f * fov), c = cosf(0.5f * fov);
+    float h = c / s, w = h / aspect, range = zf / (zn - zf);
+    Mat4 P = {};
+    P.m[0] = w; P.m[5] = h; P.m[10] = range; P.m[11] = -1.0f; P.m[14] = range * zn;
+    return P;
+}
+
+struct V3 { float x, y, z; };
+static V3 v3(float x, float y, float z) { V3 r = { x, y, z }; return r; }
+static V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+static float vlen(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+static V3 vnorm(V3 a) { float l = vlen(a); return l > 0.0f ? v3(a.x / l, a.y / l, a.z / l) : a; }            // rt64_common.h:318-321
+static V3 vcross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+static V3 mat_point(const Mat4 &M, V3 p) { return v3(p.x * M.m[0] + p.y * M.m[4] + p.z * M.m[8] + 1.0f * M.m[12], p.x * M.m[1] + p.y * M.m[5] + p.z * M.m[9] + 1.0f * M.m[13], p.x * M.m[2] + p.y * M.m[6] + p.z * M.m[10] + 1.0f * M.m[14]); }
+static V3 mat_vector(const Mat4 &M, V3 p) { return v3(p.x * M.m[0] + p.y * M.m[4] + p.z * M.m[8] + 0.0f * M.m[12], p.x * M.m[1] + p.y * M.m[5] + p.z * M.m[9] + 0.0f * M.m[13], p.x * M.m[2] + p.y * M.m[6] + p.z * M.m[10] + 0.0f * M.m[14]); }
+
+// ---- colour combiner decode (rt64_shader.cpp:32-96) ---------------------------------------------------------------------
+
+static GpuCombiner decode_combiner(uint32_t shaderId) {
+    GpuCombiner cc = {};
+    for (int i = 0; i < 4; i++) { cc.c[0][i] = (int8_t)((shaderId >> (i * 3)) & 7); cc.c[1][i] = (int8_t)((shaderId >> (12 + i * 3)) & 7); }
+    for (int i = 0; i < 2; i++) for (int j = 0; j < 4; j++) {
+        int v = cc.c[i][j];
+        if (v >= 1 && v <= 4 && v > cc.inputCount) cc.inputCount = (int8_t)v;
+        if (v == 5 || v == 6) cc.useTex0 = 1;
+        if (v == 7) cc.useTex1 = 1;
+    }
+    for (int i = 0; i < 2; i++) {
+        cc.doSingle[i] = cc.c[i][2] == 0;
+        cc.doMultiply[i] = cc.c[i][1] == 0 && cc.c[i][3] == 0;
+        cc.doMix[i] = cc.c[i][1] == cc.c[i][3];
+    }
+    cc.colorAlphaSame = (shaderId & 0xfff) == ((shaderId >> 12) & 0xfff);
+    cc.optAlpha = (shaderId & (1u << 24)) != 0;
+    cc.optTextureEdge = (shaderId & (1u << 26)) != 0;
+    cc.optNoise = (shaderId & (1u << 27)) != 0;
+    cc.vertexUV = cc.useTex0 || cc.useTex1;
+    int sz = 16;                                         // position float4
+    cc.normalOffset = (int16_t)sz; sz += 12;
+    cc.uvOffset = (int16_t)sz; if (cc.vertexUV) sz += 8;
+    for (int i = 0; i < cc.inputCount; i++) { cc.inputOffset[i] = (int16_t)sz; sz += cc.optAlpha ? 16 : 12; }
+    cc.vertexSize = (int16_t)sz;
+    return cc;
+}
+
+// ---- objects ---------------------------------------------------------------------------------------------------------------
+
+struct Options {
+    bool countTraversal = false, profilePasses = true, syncPresent = true;
+    int denoiserMode = 1;          // 0 = reference 5x Gaussian, 1 = SVGF
+    int maxReflections = 2;        // rt64_view.cpp:60 (inspector-only knob in the reference)
+};
+
+struct Device {
+    int hipDevice = 0;
+    hipStream_t stream = nullptr;
+    int width = 0, height = 0, pendingWidth = 0, pendingHeight = 0;
+    int tileY0 = 0, tileY1 = 0; bool tileSet = false;
+    std::vector<Scene *> scenes;
+    Options opt;
+    RT64_FRAME_STATS stats = {};
+    DevArray<uint32_t> spillStack;
+    DevArray<unsigned long long> counters;
+    DevArray<uint8_t> blueNoise;
+    uint8_t *pinned = nullptr; size_t pinnedBytes = 0;
+    enum { EV_BEGIN, EV_BUILD, EV_PRIMARY, EV_DIRECT, EV_INDIRECT, EV_REFL, EV_DENOISE, EV_END, EV_COUNT };
+    hipEvent_t events[EV_COUNT] = {};
+
+    Device(int w, int h, int dev);
+    ~Device();
+    void use() const { HIP_CHECK(hipSetDevice(hipDevice)); }
+    void *staging(size_t bytes) {
+        if (bytes > pinnedBytes) {
+            if (pinned) hipHostFree(pinned);
+            pinnedBytes = std::max(bytes, (size_t)1 << 20);
+            HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&pinned), pinnedBytes, hipHostMallocDefault));
+        }
+        return pinned;
+    }
+    void draw(int vsyncInterval, float deltaTimeMs);
+    float aspect() const { return (float)width / (float)height; }
+};
+
+struct Texture {
+    Device *device; int width = 0, height = 0, mips = 0;
+    DevArray<uint8_t> texels; uint32_t mipOffset[RT64_MAX_MIPS] = {};
+    uint8_t minAlpha = 255, maxAlpha = 255;
+    int currentIndex = -1;
+    explicit Texture(Device *d) : device(d) {}
+    void setRGBA8(const void *bytes, int byteCount, int w, int h, int rowPitch);
+    void setDDS(const void *bytes, int byteCount);
+};
+
+struct Shader {
+    Device *device; uint32_t shaderId, filter, hAddr, vAddr; int flags; GpuCombiner cc;
+};
+
+struct Mesh {
+    Device *device; int flags;
+    int vertexCount = 0, vertexStride = 0, indexCount = 0;
+    std::vector<uint8_t> hostVertices;                 // kept for the opacity rule (alpha bounds of the vertex inputs)
+    DevArray<uint8_t> vertices; DevArray<uint32_t> indices;
+    DevArray<GpuNode> nodes; DevArray<GpuTri> tris; DevArray<BlasHeader> header;
+    DevArray<uint32_t> sortedIndex, morton, leafParent; DevArray<uint8_t> buildScratch;
+    uint32_t blasCount = 0;                            // leaves of the current BLAS (0 = none)
+    uint32_t version = 0;
+    std::map<int, std::pair<float, float>> alphaBounds; uint32_t alphaBoundsVersion = 0;
+    Mesh(Device *d, int f) : device(d), flags(f) {}
+    void set(const void *vertexArray, int vcount, int vstride, const unsigned int *indexArray, int icount);
+    std::pair<float, float> inputAlphaBounds(int offset);
+};
+
+struct Instance {
+    Scene *scene;
+    Mesh *mesh = nullptr; Texture *diffuse = nullptr, *normal = nullptr, *specular = nullptr; Shader *shader = nullptr;
+    Mat4 transform = mat_identity(), previousTransform = mat_identity();
+    RT64_MATERIAL material = {}; RT64_RECT scissorRect = {}, viewportRect = {}; unsigned int flags = 0;
+    explicit Instance(Scene *s);
+    ~Instance();
+};
+
+struct Scene {
+    Device *device; RT64_SCENE_DESC desc = {};
+    std::vector<RT64_LIGHT> lights;
+    std::vector<Instance *> instances; std::vector<View *> views;
+    explicit Scene(Device *d);
+    ~Scene();
+};
+
+struct RenderInstance { Instance *instance; };
+
+struct View {
+    Scene *scene;
+    // RT64_VIEW_DESC state + inspector-only knobs, defaults of rt64_view.cpp:47-66
+    float resolutionScale = 1.0f, motionBlurStrength = 0.0f; uint32_t diSamples = 0, giSamples = 0, maxLights = 12, motionBlurSamples = 32;
+    bool denoiserEnabled = false;
+    Texture *skyPlane = nullptr;
+    Mat4 view = mat_identity(), projection = mat_identity(), viewI = mat_identity(), projectionI = mat_identity(), viewProj = mat_identity(), prevViewI = mat_identity(), prevViewProj = mat_identity();
+    float fov = 0.0f, nearDist = 0.0f, farDist = 0.0f; bool canReproject = true, matricesValid = false, perspectiveSet = false;
+    uint32_t frameCount = 0; bool rtSwap = false, skipReprojection = true;
+    int imgW = 0, imgH = 0;
+    // device images
+    ViewImages img = {};
+    std::vector<void *> allocations;
+    DevArray<int32_t> hitInstance;
+    // per-frame tables
+    std::vector<RenderInstance> rtInstances, rasterBg, rasterFg;
+    std::vector<Texture *> usedTextures;
+    DevArray<GpuInstance> dInstances; DevArray<GpuTexture> dTextures; DevArray<RT64_LIGHT> dLights;
+    DevArray<GpuNode> tlasNodes; DevArray<uint32_t> tlasIndex, tlasMorton, tlasLeafParent; DevArray<BlasHeader> tlasHeader; DevArray<uint8_t> tlasScratch;
+    float maxDepthBias = 0.0f;
+
+    explicit View(Scene *s);
+    ~View();
+    void releaseImages();
+    void createImages(int w, int h);
+    void update();
+    void render();
+    void fillParams(FrameParams &P);
+};
+
+// ---- Device -----------------------------------------------------------------------------------------------------------------
+
+static std::string assets_dir() {
+    if (const char *e = getenv("RT64_ASSETS_DIR")) return e;
+    // librt64.so lives in <repo>/sm64rt-legacy-renderer_amd/; the blue-noise table in <repo>/assets/
+    Dl_info info;
+    if (dladdr(reinterpret_cast<const void *>(&assets_dir), &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        size_t s = p.find_last_of('/');
+        if (s != std::string::npos) return p.substr(0, s) + "/../assets";
+    }
+    return "assets";
+}
+
+Device::Device(int w, int h, int dev) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) throw std::runtime_error("No HIP device available: librt64.so needs an AMD GPU (there is no CPU fallback).");
+    if (dev < 0) { HIP_CHECK(hipGetDevice(&dev)); }
+    if (dev >= count) throw std::runtime_error("Requested HIP device index is out of range.");
+    hipDevice = dev;
+    use();
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    if (w <= 0 || h <= 0) throw std::runtime_error("Invalid device size.");
+    width = pendingWidth = w; height = pendingHeight = h; tileY0 = 0; tileY1 = h;
+    HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    for (auto &ev : events) HIP_CHECK(hipEventCreate(&ev));
+    spillStack.reserve(rt_stack_spill_bytes() / sizeof(uint32_t));
+    counters.reserve(CTR_COUNT);
+    HIP_CHECK(hipMemsetAsync(counters.ptr, 0, counters.bytes(), stream));
+    // Blue-noise table (Device::loadBlueNoise, rt64_device.cpp:794-797): 512x512 RGBA8.
+    blueNoise.reserve(512 * 512 * 4);
+    std::string path = assets_dir() + "/bluenoise_512x512_rgba8.bin";
+    std::vector<uint8_t> bn(512 * 512 * 4, 128);
+    if (FILE *f = fopen(path.c_str(), "rb")) {
+        size_t got = fread(bn.data(), 1, bn.size(), f);
+        fclose(f);
+        if (got != bn.size()) throw std::runtime_error("Blue-noise table " + path + " is truncated.");
+    }
+    else fprintf(stderr, "rt64: blue-noise table %s not found; soft shadows / GI sampling use a constant sequence.\n", path.c_str());
+    HIP_CHECK(hipMemcpy(blueNoise.ptr, bn.data(), bn.size(), hipMemcpyHostToDevice));
+    HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+Device::~Device() {
+    hipSetDevice(hipDevice);
+    hipStreamSynchronize(stream);
+    auto scenesCopy = scenes;
+    for (Scene *s : scenesCopy) delete s;                 // rt64_device.cpp:97-100
+    for (auto &ev : events) if (ev) hipEventDestroy(ev);
+    if (pinned) hipHostFree(pinned);
+    if (stream) hipStreamDestroy(stream);
+}
+
+// ---- Texture ----------------------------------------------------------------------------------------------------------------
+
+void Texture::setRGBA8(const void *bytes, int byteCount, int w, int h, int rowPitch) {
+    if (!bytes || w <= 0 || h <= 0 || rowPitch < w * 4 || (long long)rowPitch * h > (long long)byteCount + (rowPitch - w * 4)) throw std::runtime_error("RT64_CreateTexture: invalid RGBA8 description.");
+    device->use();
+    width = w; height = h; mips = 1; mipOffset[0] = 0;     // mip generation is compiled out in the reference (rt64_device.cpp:758-762)
+    texels.reserve((size_t)w * h * 4);
+    uint8_t *stage = static_cast<uint8_t *>(device->staging((size_t)w * h * 4));
+    uint8_t mn = 255, mx = 0;
+    for (int y = 0; y < h; y++) {
+        const uint8_t *src = static_cast<const uint8_t *>(bytes) + (size_t)y * rowPitch;
+        memcpy(stage + (size_t)y * w * 4, src, (size_t)w * 4);
+        for (int x = 0; x < w; x++) { uint8_t a = src[4 * x + 3]; mn = std::min(mn, a); mx = std::max(mx, a); }
+    }
+    minAlpha = mn; maxAlpha = mx;
+    HIP_CHECK(hipMemcpyAsync(texels.ptr, stage, (size_t)w * h * 4, hipMemcpyHostToDevice, device->stream));
+    HIP_CHECK(hipStreamSynchronize(device->stream));        // the reference submits + waits per texture (rt64_texture.cpp:130-137)
+}
+
+static uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+void Texture::setDDS(const void *data, int byteCount) {
+    const uint8_t *bytes = static_cast<const uint8_t *>(data);
+    if (!bytes || byteCount < 128 || memcmp(bytes, "DDS ", 4) != 0) throw std::runtime_error("RT64_CreateTexture: not a DDS file.");
+    uint32_t h = rd32(bytes + 12), w = rd32(bytes + 16), mipCount = rd32(bytes + 28);
+    uint32_t pfFlags = rd32(bytes + 80), fourCC = rd32(bytes + 84), rgbBits = rd32(bytes + 88);
+    size_t off = 128; bool bc7 = false, rgba = false;
+    if ((pfFlags & 0x4) && fourCC == 0x30315844u) {
+        if (byteCount < 148) throw std::runtime_error("RT64_CreateTexture: truncated DX10 DDS header.");
+        uint32_t fmt = rd32(bytes + 128); off = 148;
+        if (fmt == 98 || fmt == 99) bc7 = true; else if (fmt == 28 || fmt == 29) rgba = true;
+        else throw std::runtime_error("RT64_CreateTexture: unsupported DXGI format in DDS (supported: BC7_UNORM, R8G8B8A8_UNORM).");
+    }
+    else if ((pfFlags & 0x40) && rgbBits == 32 && rd32(bytes + 92) == 0x000000FFu) rgba = true;
+    else throw std::runtime_error("RT64_CreateTexture: unsupported DDS pixel format.");
+    if (mipCount == 0) mipCount = 1;
+    if (mipCount > RT64_MAX_MIPS || w == 0 || h == 0) throw std::runtime_error("RT64_CreateTexture: invalid DDS dimensions.");
+    device->use();
+    width = (int)w; height = (int)h; mips = (int)mipCount;
+    size_t totalTexels = 0, totalSrc = 0;
+    { uint32_t mw = w, mh = h; for (uint32_t m = 0; m < mipCount; m++) { mipOffset[m] = (uint32_t)totalTexels; totalTexels += (size_t)mw * mh; totalSrc += bc7 ? (size_t)((mw + 3) / 4) * ((mh + 3) / 4) * 16 : (size_t)mw * mh * 4; mw = mw > 1 ? mw / 2 : 1; mh = mh > 1 ? mh / 2 : 1; } }
+    if (off + totalSrc > (size_t)byteCount) throw std::runtime_error("RT64_CreateTexture: DDS data is truncated.");
+    texels.reserve(totalTexels * 4);
+    uint8_t *stage = static_cast<uint8_t *>(device->staging(std::max(totalSrc, totalTexels * 4)));
+    memcpy(stage, bytes + off, totalSrc);
+    if (bc7) {
+        DevArray<uint8_t> blocks; blocks.reserve(totalSrc);
+        HIP_CHECK(hipMemcpyAsync(blocks.ptr, stage, totalSrc, hipMemcpyHostToDevice, device->stream));
+        uint32_t mw = w, mh = h; size_t so = 0;
+        for (uint32_t m = 0; m < mipCount; m++) {
+            HIP_CHECK(bc7_decode_launch(blocks.ptr + so, texels.ptr + (size_t)mipOffset[m] * 4, mw, mh, device->stream));
+            so += (size_t)((mw + 3) / 4) * ((mh + 3) / 4) * 16; mw = mw > 1 ? mw / 2 : 1; mh = mh > 1 ? mh / 2 : 1;
+        }
+        HIP_CHECK(hipStreamSynchronize(device->stream));
+    }
+    else {
+        HIP_CHECK(hipMemcpyAsync(texels.ptr, stage, totalTexels * 4, hipMemcpyHostToDevice, device->stream));
+        HIP_CHECK(hipStreamSynchronize(device->stream));
+    }
+    // Alpha bounds for the opacity rule (read back once; texture creation is synchronous like the reference's).
+    HIP_CHECK(hipMemcpy(stage, texels.ptr, totalTexels * 4, hipMemcpyDeviceToHost));
+    uint8_t mn = 255, mx = 0;
+    for (size_t i = 0; i < totalTexels; i++) { uint8_t a = stage[4 * i + 3]; mn = std::min(mn, a); mx = std::max(mx, a); }
+    minAlpha = mn; maxAlpha = mx;
+}
+
+// ---- Mesh -------------------------------------------------------------------------------------------------------------------
+
+void Mesh::set(const void *vertexArray, int vcount, int vstride, const unsigned int *indexArray, int icount) {
+    if (!vertexArray || !indexArray || vcount <= 0 || icount <= 0 || vstride < 12) throw std::runtime_error("RT64_SetMesh: invalid arguments.");
+    device->use();
+    // rt64_mesh.cpp:30-39,76-82: a change of counts/stride discards the BLAS even if updatable.
+    const bool sameShape = vertices.ptr && vertexCount == vcount && vertexStride == vstride && indexCount == icount;
+    const size_t vbytes = (size_t)vcount * vstride, ibytes = (size_t)icount * 4;
+    hostVertices.assign(static_cast<const uint8_t *>(vertexArray), static_cast<const uint8_t *>(vertexArray) + vbytes);
+    vertices.reserve(vbytes); indices.reserve((size_t)icount);
+    uint8_t *stage = static_cast<uint8_t *>(device->staging(vbytes + ibytes));
+    memcpy(stage, vertexArray, vbytes); memcpy(stage + vbytes, indexArray, ibytes);
+    HIP_CHECK(hipMemcpyAsync(vertices.ptr, stage, vbytes, hipMemcpyHostToDevice, device->stream));
+    HIP_CHECK(hipMemcpyAsync(indices.ptr, stage + vbytes, ibytes, hipMemcpyHostToDevice, device->stream));
+    vertexCount = vcount; vertexStride = vstride; indexCount = icount; version++;
+    if (flags & RT64_MESH_RAYTRACE_ENABLED) {                // rt64_mesh.cpp:114-126
+        const uint32_t n = (uint32_t)icount / 3;
+        if (n == 0) throw std::runtime_error("RT64_SetMesh: a ray-traced mesh needs at least one triangle.");
+        const bool refit = (flags & RT64_MESH_RAYTRACE_UPDATABLE) && sameShape && blasCount == n;   // rt64_mesh.cpp:129,149-157
+        nodes.reserve(std::max<size_t>(n - 1, 1)); tris.reserve(n); header.reserve(1);
+        sortedIndex.reserve(n); morton.reserve(n); leafParent.reserve(n);
+        LbvhArgs a = {};
+        a.mode = LBVH_MODE_TRIANGLES; a.refit = refit ? 1 : 0; a.n = n;
+        a.vertices = vertices.ptr; a.vertexStride = (uint32_t)vstride; a.indices = indices.ptr;
+        a.nodes = nodes.ptr; a.tris = tris.ptr; a.header = header.ptr; a.sortedIndex = sortedIndex.ptr; a.morton = morton.ptr; a.leafParent = leafParent.ptr;
+        if (n > LBVH_SMALL_MAX) { buildScratch.reserve(lbvh_large_scratch_bytes(n)); a.scratch = buildScratch.ptr; a.scratchBytes = buildScratch.bytes(); }
+        HIP_CHECK(lbvh_launch(a, device->stream));
+        blasCount = n;
+    }
+    // The staging buffer is reused by the next upload: drain the copies (uploads are rare next to frames; the
+    // reference records them on the open command list and executes them at the next preRender, rt64_device.cpp:979-983).
+    HIP_CHECK(hipStreamSynchronize(device->stream));
+}
+
+std::pair<float, float> Mesh::inputAlphaBounds(int offset) {
+    if (alphaBoundsVersion != version) { alphaBounds.clear(); alphaBoundsVersion = version; }
+    auto it = alphaBounds.find(offset);
+    if (it != alphaBounds.end()) return it->second;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int v = 0; v < vertexCount; v++) {
+        if ((size_t)v * vertexStride + offset + 16 > hostVertices.size()) { mn = NAN; mx = NAN; break; }
+        float a; memcpy(&a, hostVertices.data() + (size_t)v * vertexStride + offset + 12, 4);
+        if (!(a >= mn)) mn = a;
+        if (!(a <= mx)) mx = a;
+    }
+    return alphaBounds[offset] = std::make_pair(mn, mx);
+}
+
+// ---- Scene / Instance ---------------------------------------------------------------------------------------------------------
+
+Scene::Scene(Device *d) : device(d) {
+    // rt64_scene.cpp:19-27
+    desc.eyeLightDiffuseColor = { 0.08f, 0.08f, 0.08f }; desc.eyeLightSpecularColor = { 0.04f, 0.04f, 0.04f };
+    desc.skyDiffuseMultiplier = { 1.0f, 1.0f, 1.0f }; desc.skyHSLModifier = { 0.0f, 0.0f, 0.0f };
+    desc.skyYawOffset = 0.0f; desc.giDiffuseStrength = 0.7f; desc.giSkyStrength = 0.35f;
+    d->scenes.push_back(this);
+}
+Scene::~Scene() {
+    device->scenes.erase(std::remove(device->scenes.begin(), device->scenes.end(), this), device->scenes.end());
+    auto viewsCopy = views; for (View *v : viewsCopy) delete v;                 // rt64_scene.cpp:43-51
+    auto instancesCopy = instances; for (Instance *i : instancesCopy) delete i;
+}
+Instance::Instance(Scene *s) : scene(s) { s->instances.push_back(this); }
+Instance::~Instance() { auto &v = scene->instances; v.erase(std::remove(v.begin(), v.end(), this), v.end()); }
+
+// ---- View ---------------------------------------------------------------------------------------------------------------------
+
+View::View(Scene *s) : scene(s) {
+    s->views.push_back(this);
+    createImages(s->device->width, s->device->height);
+}
+View::~View() {
+    auto &v = scene->views; v.erase(std::remove(v.begin(), v.end(), this), v.end());
+    releaseImages();
+}
+void View::releaseImages() { for (void *p : allocations) hipFree(p); allocations.clear(); img = ViewImages(); }
+
+void View::createImages(int w, int h) {       // View::createOutputBuffers, rt64_view.cpp:105-298 (same formats)
+    scene->device->use();
+    releaseImages();
+    const size_t n = (size_t)w * h;
+    auto alloc = [&](size_t bytes) { void *p = nullptr; HIP_CHECK(hipMalloc(&p, bytes)); HIP_CHECK(hipMemsetAsync(p, 0, bytes, scene->device->stream)); allocations.push_back(p); return p; };
+    img.viewDirection = static_cast<uint16_t *>(alloc(n * 8)); img.shadingPosition = static_cast<float *>(alloc(n * 16));
+    img.shadingNormal = static_cast<uint16_t *>(alloc(n * 8)); img.shadingSpecular = static_cast<uint16_t *>(alloc(n * 8));
+    img.diffuse = static_cast<uint8_t *>(alloc(n * 4));
+    img.instanceId = static_cast<int32_t *>(alloc(n * 4)); img.firstInstanceId = static_cast<int32_t *>(alloc(n * 4));
+    for (int i = 0; i < 2; i++) {
+        img.directLight[i] = static_cast<uint16_t *>(alloc(n * 8)); img.indirectLight[i] = static_cast<uint16_t *>(alloc(n * 8));
+        img.filteredDirect[i] = static_cast<uint16_t *>(alloc(n * 8)); img.filteredIndirect[i] = static_cast<uint16_t *>(alloc(n * 8));
+        img.normal[i] = static_cast<uint16_t *>(alloc(n * 8)); img.depth[i] = static_cast<float *>(alloc(n * 4));
+        img.moments[i] = static_cast<float *>(alloc(n * 16));
+    }
+    img.reflection = static_cast<uint16_t *>(alloc(n * 8)); img.refraction = static_cast<uint16_t *>(alloc(n * 8)); img.transparent = static_cast<uint16_t *>(alloc(n * 8));
+    img.flow = static_cast<uint16_t *>(alloc(n * 4));
+    img.reactiveMask = static_cast<uint8_t *>(alloc(n)); img.lockMask = static_cast<uint8_t *>(alloc(n));
+    img.output = static_cast<float *>(alloc(n * 16)); img.final = static_cast<uint8_t *>(alloc(n * 4));
+    img.primaryHit = static_cast<uint32_t *>(alloc(n * 16));
+    hitInstance.reserve(n);
+    HIP_CHECK(hipMemsetAsync(hitInstance.ptr, 0xFF, n * 4, scene->device->stream));
+    imgW = w; imgH = h;
+    skipReprojection = true;                  // rt64_view.cpp:143
+    fprintf(stdout, "Render buffer: %dX%d\n", w, h);      // rt64_view.cpp:150
+}
+
+// Static opacity rule O1: an instance is opaque when every hit it can produce stores alpha 255 in the RGBA8
+// hit colour, so nothing behind it can contribute (PrimaryRayGen.hlsl:150,174).  Decided from bounds on the combiner's
+// alpha sources: vertex input alphas over the mesh, texel alphas over the texture.
+static bool instance_is_opaque(const Instance *inst, const GpuCombiner &cc) {
+    if (cc.optNoise || cc.optTextureEdge) return false;
+    float lo;
+    if (!cc.optAlpha) lo = 1.0f;
+    else {
+        float l[4], h[4];
+        for (int k = 0; k < 4; k++) {
+            int item = cc.c[1][k];
+            if (item == 0) { l[k] = h[k] = 0.0f; }
+            else if (item <= 4) { auto b = inst->mesh->inputAlphaBounds(cc.inputOffset[item - 1]); l[k] = b.first; h[k] = b.second; }
+            else if (item <= 6) { l[k] = (float)inst->diffuse->minAlpha / 255.0f; h[k] = (float)inst->diffuse->maxAlpha / 255.0f; }
+            else { l[k] = h[k] = 1.0f; }
+        }
+        if (cc.doSingle[1]) lo = l[3];
+        else if (cc.doMultiply[1]) lo = std::min(std::min(l[0] * l[2], l[0] * h[2]), std::min(h[0] * l[2], h[0] * h[2]));
+        else return false;
+    }
+    float a = inst->material.solidAlphaMultiplier * lo;
+    return a >= 0.999f;
+}
+
+void View::update() {                          // View::update, rt64_view.cpp:1053-1178
+    Device *dev = scene->device;
+    if (imgW != dev->width || imgH != dev->height) createImages(dev->width, dev->height);
+    usedTextures.clear();
+    auto textureIndex = [&](Texture *t) -> int {
+        if (!t) return -1;
+        if (t->currentIndex < 0) { t->currentIndex = (int)usedTextures.size(); usedTextures.push_back(t); }
+        return t->currentIndex;
+    };
+    int skyIndex = textureIndex(skyPlane);     // the sky plane gets slot 0 when set (rt64_view.cpp:1079)
+    (void)skyIndex;
+    rtInstances.clear(); rasterBg.clear(); rasterFg.clear();
+    for (Instance *inst : scene->instances) {
+        if (!inst->mesh || !inst->shader || !inst->diffuse) continue;          // asserted non-NULL in the reference (rt64_instance.cpp:152-155)
+        textureIndex(inst->diffuse); textureIndex(inst->normal); textureIndex(inst->specular);
+        RenderInstance ri = { inst };
+        if (inst->mesh->blasCount > 0) rtInstances.push_back(ri);             // rt64_view.cpp:1138-1146
+        else if (inst->flags & RT64_INSTANCE_RASTER_BACKGROUND) rasterBg.push_back(ri);
+        else rasterFg.push_back(ri);
+    }
+    if (usedTextures.size() > 512) throw std::runtime_error("More than 512 textures in one frame (SRV_TEXTURES_MAX).");
+
+    // Tables: instances (transforms rt64_view.cpp:348-376, materials :388-410), textures, lights -> one staged upload.
+    const size_t nInst = rtInstances.size(), nTex = usedTextures.size(), nLights = scene->lights.size();
+    const size_t instBytes = nInst * sizeof(GpuInstance), texBytes = nTex * sizeof(GpuTexture), lightBytes = nLights * sizeof(RT64_LIGHT);
+    uint8_t *stage = static_cast<uint8_t *>(dev->staging(instBytes + texBytes + lightBytes + 64));
+    GpuInstance *hInst = reinterpret_cast<GpuInstance *>(stage);
+    GpuTexture *hTex = reinterpret_cast<GpuTexture *>(stage + instBytes);
+    RT64_LIGHT *hLights = reinterpret_cast<RT64_LIGHT *>(stage + instBytes + texBytes);
+    maxDepthBias = nInst ? -INFINITY : 0.0f;
+    for (size_t i = 0; i < nInst; i++) {
+        Instance *inst = rtInstances[i].instance;
+        GpuInstance &g = hInst[i];
+        memset(&g, 0, sizeof(g));
+        memcpy(g.objectToWorld, inst->transform.m, 64);
+        memcpy(g.objectToWorldPrevious, inst->previousTransform.m, 64);
+        Mat4 upper = inst->transform;           // rt64_view.cpp:358-368
+        upper.m[3] = upper.m[7] = upper.m[11] = 0.0f; upper.m[12] = upper.m[13] = upper.m[14] = 0.0f; upper.m[15] = 1.0f;
+        Mat4 nrm = mat_transpose(mat_inverse(upper));
+        memcpy(g.objectToWorldNormal, nrm.m, 64);
+        Mat4 w2o = mat_inverse(inst->transform);
+        memcpy(g.worldToObject, w2o.m, 64);
+        Mesh *mesh = inst->mesh;
+        g.nodes = mesh->nodes.ptr; g.tris = mesh->tris.ptr; g.vertices = mesh->vertices.ptr; g.indices = mesh->indices.ptr; g.header = mesh->header.ptr;
+        g.material = inst->material;
+        g.cc = inst->shader->cc;
+        g.texDiffuse = g.material.diffuseTexIndex = inst->diffuse->currentIndex;      // rt64_view.cpp:1110-1112
+        g.texNormal = g.material.normalTexIndex = inst->normal ? inst->normal->currentIndex : -1;
+        g.texSpecular = g.material.specularTexIndex = inst->specular ? inst->specular->currentIndex : -1;
+        g.filter = inst->shader->filter; g.hAddr = inst->shader->hAddr; g.vAddr = inst->shader->vAddr;
+        g.flags = 0;
+        if (inst->flags & RT64_INSTANCE_DISABLE_BACKFACE_CULLING) g.flags |= GPU_INST_CULL_DISABLE;      // rt64_view.cpp:1109
+        if (instance_is_opaque(inst, g.cc)) g.flags |= GPU_INST_OPAQUE;
+        if (inst->shader->flags & RT64_SHADER_NORMAL_MAP_ENABLED) g.flags |= GPU_INST_NORMAL_MAP;
+        if (inst->shader->flags & RT64_SHADER_SPECULAR_MAP_ENABLED) g.flags |= GPU_INST_SPECULAR_MAP;
+        if (!g.cc.optAlpha) g.flags |= GPU_INST_SHADOW_OPAQUE;
+        g.triCount = mesh->blasCount;
+        if (g.cc.vertexSize > mesh->vertexStride) throw std::runtime_error("Instance mesh vertex stride is smaller than the layout its shader reads.");
+        maxDepthBias = std::max(maxDepthBias, inst->material.depthBias);
+    }
+    for (size_t i = 0; i < nTex; i++) {
+        Texture *t = usedTextures[i];
+        GpuTexture &g = hTex[i];
+        g.texels = t->texels.ptr; g.width = (uint32_t)t->width; g.height = (uint32_t)t->height; g.mips = (uint32_t)t->mips; g.pad = 0;
+        memcpy(g.mipOffset, t->mipOffset, sizeof(g.mipOffset));
+    }
+    if (nLights) memcpy(hLights, scene->lights.data(), lightBytes);
+    dInstances.reserve(std::max<size_t>(nInst, 1)); dTextures.reserve(std::max<size_t>(nTex, 1)); dLights.reserve(std::max<size_t>(nLights, 1));
+    if (instBytes) HIP_CHECK(hipMemcpyAsync(dInstances.ptr, hInst, instBytes, hipMemcpyHostToDevice, dev->stream));
+    if (texBytes) HIP_CHECK(hipMemcpyAsync(dTextures.ptr, hTex, texBytes, hipMemcpyHostToDevice, dev->stream));
+    if (lightBytes) HIP_CHECK(hipMemcpyAsync(dLights.ptr, hLights, lightBytes, hipMemcpyHostToDevice, dev->stream));
+
+    // TLAS: full rebuild every frame (rt64_view.cpp:412-452, updateOnly = false).
+    if (nInst) {
+        const uint32_t n = (uint32_t)nInst;
+        tlasNodes.reserve(std::max<size_t>(n - 1, 1)); tlasIndex.reserve(n); tlasMorton.reserve(n); tlasLeafParent.reserve(n); tlasHeader.reserve(1);
+        LbvhArgs a = {};
+        a.mode = LBVH_MODE_INSTANCES; a.refit = 0; a.n = n; a.instances = dInstances.ptr;
+        a.nodes = tlasNodes.ptr; a.tris = nullptr; a.header = tlasHeader.ptr; a.sortedIndex = tlasIndex.ptr; a.morton = tlasMorton.ptr; a.leafParent = tlasLeafParent.ptr;
+        if (n > LBVH_SMALL_MAX) { tlasScratch.reserve(lbvh_large_scratch_bytes(n)); a.scratch = tlasScratch.ptr; a.scratchBytes = tlasScratch.bytes(); }
+        HIP_CHECK(lbvh_launch(a, dev->stream));
+    }
+    for (Texture *t : usedTextures) t->currentIndex = -1;
+}
+
+void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64_view.cpp:961-1028
+    Device *dev = scene->device;
+    memset(&P, 0, sizeof(P));
+    const RT64_SCENE_DESC &d = scene->desc;
+    auto set4 = [](float *dst, RT64_VECTOR3 v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = 0.0f; };
+    set4(P.ambientBaseColor, d.ambientBaseColor); set4(P.ambientNoGIColor, d.ambientNoGIColor);
+    set4(P.eyeLightDiffuseColor, d.eyeLightDiffuseColor); set4(P.eyeLightSpecularColor, d.eyeLightSpecularColor);
+    set4(P.skyDiffuseMultiplier, d.skyDiffuseMultiplier); set4(P.skyHSLModifier, d.skyHSLModifier);
+    P.skyYawOffset = d.skyYawOffset; P.giDiffuseStrength = d.giDiffuseStrength; P.giSkyStrength = d.giSkyStrength;
+
+    projection = mat_perspective_fov_rh(fov, dev->aspect(), nearDist, farDist);      // setPerspective, :1766 (aspect of the window at draw time)
+    // On the very first frame the reference's previous matrices are uninitialised memory; they are defined here as the current ones.
+    const bool reproject = canReproject && matricesValid;
+    if (reproject) { prevViewI = viewI; prevViewProj = viewProj; }
+    viewI = mat_inverse(view); projectionI = mat_inverse(projection); viewProj = mat_mul(view, projection);
+    if (!reproject) { prevViewI = viewI; prevViewProj = viewProj; }
+    matricesValid = true;
+    memcpy(P.view, view.m, 64); memcpy(P.viewI, viewI.m, 64); memcpy(P.prevViewI, prevViewI.m, 64); memcpy(P.projection, projection.m, 64);
+    memcpy(P.projectionI, projectionI.m, 64); memcpy(P.viewProj, viewProj.m, 64); memcpy(P.prevViewProj, prevViewProj.m, 64);
+
+    // Pinhole vectors, only consumed by the ray differentials (:992-1009; getViewDirection uses view-space +z, :1798).
+    const float focal = (nearDist + farDist) / 2.0f, aspect = dev->aspect();
+    V3 pos = mat_point(viewI, v3(0, 0, 0));
+    V3 dir = mat_vector(viewI, v3(0, 0, 1)); { float l = vlen(dir); dir = v3(dir.x / l, dir.y / l, dir.z / l); }
+    V3 target = pos + dir * focal;
+    V3 W = vnorm(target - pos) * focal;
+    V3 U = vnorm(vcross(W, v3(0, 1, 0)));
+    V3 V = vnorm(vcross(U, W));
+    const float ulen = focal * tanf(fov * 0.5f) * aspect, vlen_ = focal * tanf(fov * 0.5f);
+    U = U * ulen; V = V * vlen_;
+    P.cameraU[0] = U.x; P.cameraU[1] = U.y; P.cameraU[2] = U.z; P.cameraV[0] = V.x; P.cameraV[1] = V.y; P.cameraV[2] = V.z; P.cameraW[0] = W.x; P.cameraW[1] = W.y; P.cameraW[2] = W.z;
+    P.viewport[0] = 0.0f; P.viewport[1] = 0.0f; P.viewport[2] = (float)dev->width; P.viewport[3] = (float)dev->height;
+    P.resolution[0] = (float)imgW; P.resolution[1] = (float)imgH; P.resolution[2] = (float)dev->width; P.resolution[3] = (float)dev->height;
+    P.pixelJitter[0] = P.pixelJitter[1] = 0.0f;              // jitter only with an upscaler (:1273-1281)
+    P.motionBlurStrength = motionBlurStrength; P.motionBlurSamples = motionBlurSamples;
+    P.skyPlaneTexIndex = skyPlane ? 0 : -1;
+    P.randomSeed = frameCount; P.frameCount = frameCount;
+    P.diSamples = diSamples; P.giSamples = giSamples; P.maxLights = maxLights;
+    P.diReproject = 0;                                        // DI_REPROJECTION_SUPPORT undefined (:1012-1016)
+    P.giReproject = (!skipReprojection && denoiserEnabled && giSamples > 0) ? 1u : 0u;
+    P.binaryLockMask = 1;                                     // rtUpscaleMode != FSR
+    P.visualizationMode = 0;
+    P.width = imgW; P.height = imgH; P.tileY0 = dev->tileY0; P.tileY1 = dev->tileY1;
+    P.maxDepthBias = maxDepthBias;
+    P.lightCount = (uint32_t)scene->lights.size(); P.instanceCount = (uint32_t)rtInstances.size();
+    P.countTraversal = dev->opt.countTraversal ? 1u : 0u;
+    P.instances = dInstances.ptr; P.tlasNodes = tlasNodes.ptr; P.tlasIndex = tlasIndex.ptr; P.textures = dTextures.ptr; P.lights = dLights.ptr;
+    P.blueNoise = dev->blueNoise.ptr; P.traversalStack = dev->spillStack.ptr; P.counters = dev->counters.ptr;
+}
+
+void View::render() {                          // View::render, rt64_view.cpp:1180-1670
+    Device *dev = scene->device;
+    hipStream_t s = dev->stream;
+    const bool prof = dev->opt.profilePasses;
+    auto mark = [&](int ev) { if (prof) HIP_CHECK(hipEventRecord(dev->events[ev], s)); };
+    if (!perspectiveSet) throw std::runtime_error("RT64_DrawDevice: RT64_SetViewPerspective was never called (fov must be > 0).");
+    FrameParams P;
+    fillParams(P);
+    const int cur = rtSwap ? 1 : 0;
+    const size_t n = (size_t)imgW * imgH;
+    mark(Device::EV_BUILD);
+    if (!rtInstances.empty()) {
+        HIP_CHECK(launch_primary_trace(P, img, hitInstance.ptr, s));
+        HIP_CHECK(launch_primary_shade(P, img, hitInstance.ptr, cur, s));
+        mark(Device::EV_PRIMARY);
+        HIP_CHECK(launch_direct(P, img, cur, s));
+        mark(Device::EV_DIRECT);
+        HIP_CHECK(launch_indirect(P, img, cur, s));
+        mark(Device::EV_INDIRECT);
+        HIP_CHECK(launch_refraction(P, img, s));
+        for (int r = 0; r < dev->opt.maxReflections; r++) HIP_CHECK(launch_reflection(P, img, s));
+        mark(Device::EV_REFL);
+        // raw -> filtered copies (rt64_view.cpp:1438-1509); DI denoising is compiled out, so direct goes to index 1
+        const size_t rowBytes = (size_t)imgW * 8, off = (size_t)dev->tileY0 * rowBytes, bytes = (size_t)(dev->tileY1 - dev->tileY0) * rowBytes;
+        HIP_CHECK(hipMemcpyAsync(reinterpret_cast<uint8_t *>(img.filteredDirect[1]) + off, reinterpret_cast<uint8_t *>(img.directLight[cur]) + off, bytes, hipMemcpyDeviceToDevice, s));
+        const bool denoiseGI = denoiserEnabled && giSamples > 0;
+        if (!denoiseGI) HIP_CHECK(hipMemcpyAsync(reinterpret_cast<uint8_t *>(img.filteredIndirect[1]) + off, reinterpret_cast<uint8_t *>(img.indirectLight[cur]) + off, bytes, hipMemcpyDeviceToDevice, s));
+        else {
+            HIP_CHECK(hipMemcpyAsync(img.filteredIndirect[0], img.indirectLight[cur], n * 8, hipMemcpyDeviceToDevice, s));
+            for (int k = 0; k < 5; k++)            // rt64_view.cpp:1512-1530
+                HIP_CHECK(launch_gaussian(img.filteredIndirect[k % 2], img.filteredIndirect[(k % 2) ^ 1], imgW, imgH, 0, imgH, s));
+        }
+        mark(Device::EV_DENOISE);
+        HIP_CHECK(launch_compose_post(P, img, s));
+    }
+    else {
+        mark(Device::EV_PRIMARY); mark(Device::EV_DIRECT); mark(Device::EV_INDIRECT); mark(Device::EV_REFL); mark(Device::EV_DENOISE);
+        HIP_CHECK(launch_clear_final(P, img, s));
+    }
+    // End of frame (rt64_view.cpp:1663-1667)
+    rtSwap = !rtSwap; skipReprojection = false; frameCount++;
+}
+
+void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:1027-1083
+    use();
+    auto t0 = std::chrono::steady_clock::now();
+    if (pendingWidth != width || pendingHeight != height) {      // updateSize (:199-231)
+        width = pendingWidth; height = pendingHeight;
+        if (!tileSet) { tileY0 = 0; tileY1 = height; }
+    }
+    if (tileY1 > height) tileY1 = height;
+    if (tileY0 >= tileY1) { tileY0 = 0; tileY1 = height; }
+    if (opt.countTraversal) HIP_CHECK(hipMemsetAsync(counters.ptr, 0, counters.bytes(), stream));
+    if (opt.profilePasses) HIP_CHECK(hipEventRecord(events[EV_BEGIN], stream));
+    for (Scene *sc : scenes) for (View *v : sc->views) v->update();
+    for (Scene *sc : scenes) for (View *v : sc->views) v->render();
+    if (opt.profilePasses) HIP_CHECK(hipEventRecord(events[EV_END], stream));
+    HIP_CHECK(hipStreamSynchronize(stream));                      // postRender: Present + waitForGPU (:1006-1025)
+    auto t1 = std::chrono::steady_clock::now();
+
+    RT64_FRAME_STATS st = {};
+    st.structSize = sizeof(st); st.width = (unsigned)width; st.height = (unsigned)height; st.tileY0 = (unsigned)tileY0; st.tileY1 = (unsigned)tileY1;
+    st.msHostWall = std::chrono::duration<float, std::milli>(t1 - t0).count();
+    bool haveView = false;
+    for (Scene *sc : scenes) for (View *v : sc->views) {
+        if (haveView) continue;
+        haveView = true;
+        st.instanceCount = (unsigned)v->rtInstances.size();
+        unsigned tri = 0, nodeBytes = 0, triBytes = 0;
+        for (auto &ri : v->rtInstances) { tri += ri.instance->mesh->blasCount; nodeBytes += (unsigned)(std::max<uint32_t>(ri.instance->mesh->blasCount - 1, 1) * sizeof(GpuNode)); triBytes += (unsigned)(ri.instance->mesh->blasCount * sizeof(GpuTri)); }
+        st.triangleCount = tri; st.blasNodeBytes = nodeBytes; st.blasTriangleBytes = triBytes;
+        st.tlasNodeBytes = (unsigned)(std::max<size_t>(v->rtInstances.size() ? v->rtInstances.size() - 1 : 0, 1) * sizeof(GpuNode));
+    }
+    if (opt.profilePasses && haveView) {
+        auto ms = [&](int a, int b) { float v = 0.0f; hipEventElapsedTime(&v, events[a], events[b]); return v; };
+        st.msTotal = ms(EV_BEGIN, EV_END); st.msBuild = ms(EV_BEGIN, EV_BUILD); st.msPrimary = ms(EV_BUILD, EV_PRIMARY);
+        st.msDirect = ms(EV_PRIMARY, EV_DIRECT); st.msIndirect = ms(EV_DIRECT, EV_INDIRECT); st.msReflectRefract = ms(EV_INDIRECT, EV_REFL);
+        st.msDenoise = ms(EV_REFL, EV_DENOISE); st.msComposePost = ms(EV_DENOISE, EV_END);
+    }
+    if (opt.countTraversal) {
+        unsigned long long c[CTR_COUNT];
+        HIP_CHECK(hipMemcpy(c, counters.ptr, sizeof(c), hipMemcpyDeviceToHost));
+        st.nodesVisited = c[CTR_NODES]; st.trianglesTested = c[CTR_TRIS]; st.primaryRays = c[CTR_PRIMARY]; st.shadowRays = c[CTR_SHADOW];
+        st.indirectRays = c[CTR_INDIRECT]; st.reflectionRays = c[CTR_REFLECTION]; st.refractionRays = c[CTR_REFRACTION];
+    }
+    stats = st;
+}
+
+// ---- readback -------------------------------------------------------------------------------------------------------------------
+
+static float half_to_float(uint16_t h) {
+    uint32_t sign = ((uint32_t)h & 0x8000u) << 16, exp = (h >> 10) & 0x1Fu, mant = h & 0x3FFu, bits;
+    if (exp == 0) {
+        if (mant == 0) bits = sign;
+        else { int e = -1; do { e++; mant <<= 1; } while (!(mant & 0x400u)); bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((mant & 0x3FFu) << 13); }
+    }
+    else if (exp == 0x1F) bits = sign | 0x7F800000u | (mant << 13);
+    else bits = sign | ((exp - 15 + 127) << 23) | (mant << 13);
+    float f; memcpy(&f, &bits, 4); return f;
+}
+
+struct ImageInfo { const void *ptr; int srcBytes; int channels; int kind; };   // kind: 0 raw copy, 1 half->float, 2 unorm8->float
+
+static bool image_info(View *v, int image, ImageInfo &info, size_t &dstPixelBytes) {
+    const ViewImages &I = v->img;
+    const int cur = v->rtSwap ? 0 : 1;        // rtSwap was flipped at the end of the frame: the last rendered set is the other one
+    switch (image) {
+    case RT64_IMAGE_FINAL_RGBA8: info = { I.final, 4, 4, 0 }; dstPixelBytes = 4; return true;
+    case RT64_IMAGE_SHADING_POSITION: info = { I.shadingPosition, 16, 4, 0 }; dstPixelBytes = 16; return true;
+    case RT64_IMAGE_SHADING_NORMAL: info = { I.shadingNormal, 8, 4, 1 }; dstPixelBytes = 16; return true;
+    case RT64_IMAGE_SHADING_SPECULAR: info = { I.shadingSpecular, 8, 4, 1 }; dstPixelBytes = 16; return true;
+    case RT64_IMAGE_DIFFUSE: info = { I.diffuse, 4, 4, 2 }; dstPixelBytes = 16; return true;
+    case RT64_IMAGE_INSTANCE_ID: info = { I.instanceId, 4, 1, 0 }; dstPixelBytes = 4; return true;
+    case RT64_IMAGE_FIRST_INSTANCE_ID: info = { I.firstInstanceId, 4, 1, 0 }; dstPixelBytes = 4; return true;
+    case RT64_IMAGE_DIRECT_LIGHT_RAW: info = { I.directLight[cur], 8, 4, 1 }; dstPixelBytes = 16; return true;
+    case RT64_IMAGE_DIRECT_LIGHT_FILTERED: info = { I.filteredDirect[1], 8, 4, 1 }; dstPixelBytes = 16; return true;
+    case RT64_IMAGE_INDIRECT_LIGHT_RAW: info = { I.indirectLight[cur], 8, 4, 1 }; dstPixelBytes = 16; return true;
+    case RT64_IMAGE_INDIRECT_LIGHT_FILTERED: info = { I.filteredIndirect[1], 8, 4, 1 }; dstPixelBytes = 16; return true;
+    case RT64_IMAGE_REFLECTION: info = { I.reflection, 8, 4, 1 }; dstPixelBytes = 16; return true;
+    case RT64_IMAGE_REFRACTION: info = { I.refraction, 8, 4, 1 }; dstPixelBytes = 16; return true;
+    case RT64_IMAGE_TRANSPARENT: info = { I.transparent, 8, 4, 1 }; dstPixelBytes = 16; return true;
+    case RT64_IMAGE_VIEW_DIRECTION: info = { I.viewDirection, 8, 4, 1 }; dstPixelBytes = 16; return true;
+    case RT64_IMAGE_FLOW: info = { I.flow, 4, 2, 1 }; dstPixelBytes = 8; return true;
+    case RT64_IMAGE_REACTIVE_MASK: info = { I.reactiveMask, 1, 1, 2 }; dstPixelBytes = 4; return true;
+    case RT64_IMAGE_LOCK_MASK: info = { I.lockMask, 1, 1, 2 }; dstPixelBytes = 4; return true;
+    case RT64_IMAGE_DEPTH: info = { I.depth[cur], 4, 1, 0 }; dstPixelBytes = 4; return true;
+    case RT64_IMAGE_OUTPUT_RGBA32F: info = { I.output, 16, 4, 0 }; dstPixelBytes = 16; return true;
+    case RT64_IMAGE_PRIMARY_HIT: info = { I.primaryHit, 16, 4, 0 }; dstPixelBytes = 16; return true;
+    default: return false;
+    }
+}
+
+static View *first_view(Device *dev) { for (Scene *sc : dev->scenes) for (View *v : sc->views) return v; return nullptr; }
+
+static size_t readback(Device *dev, int image, void *dst, size_t dstBytes, bool toDevice) {
+    dev->use();
+    View *v = first_view(dev);
+    if (!v) throw std::runtime_error("RT64_ReadbackDevice: the device has no view.");
+    ImageInfo info; size_t dstPixelBytes;
+    if (!image_info(v, image, info, dstPixelBytes)) throw std::runtime_error("RT64_ReadbackDevice: unknown image id.");
+    const size_t rows = (size_t)(dev->tileY1 - dev->tileY0), w = (size_t)v->imgW, px = rows * w, first = (size_t)dev->tileY0 * w;
+    const size_t need = px * dstPixelBytes;
+    if (dstBytes < need) throw std::runtime_error("RT64_ReadbackDevice: destination buffer is too small.");
+    const uint8_t *src = static_cast<const uint8_t *>(info.ptr) + first * info.srcBytes;
+    if (toDevice) {
+        if (info.kind != 0) throw std::runtime_error("RT64_CopyDeviceImage: only images stored in their API element type can be copied device-to-device.");
+        HIP_CHECK(hipMemcpyAsync(dst, src, need, hipMemcpyDeviceToDevice, dev->stream));
+        HIP_CHECK(hipStreamSynchronize(dev->stream));
+        return need;
+    }
+    if (info.kind == 0 && image != RT64_IMAGE_PRIMARY_HIT) { HIP_CHECK(hipMemcpy(dst, src, need, hipMemcpyDeviceToHost)); return need; }
+    std::vector<uint8_t> tmp(px * info.srcBytes);
+    HIP_CHECK(hipMemcpy(tmp.data(), src, tmp.size(), hipMemcpyDeviceToHost));
+    if (image == RT64_IMAGE_PRIMARY_HIT) {
+        std::vector<int32_t> inst(px);
+        HIP_CHECK(hipMemcpy(inst.data(), v->hitInstance.ptr + first, px * 4, hipMemcpyDeviceToHost));
+        const uint32_t *s = reinterpret_cast<const uint32_t *>(tmp.data()); uint32_t *d = static_cast<uint32_t *>(dst);
+        for (size_t i = 0; i < px; i++) {
+            d[4 * i] = s[4 * i]; d[4 * i + 1] = s[4 * i + 1]; d[4 * i + 2] = s[4 * i + 2];
+            d[4 * i + 3] = inst[i] < 0 ? 0xFFFFFFFFu : (((uint32_t)inst[i] << 24) | (s[4 * i + 3] & 0xFFFFFFu));
+        }
+        return need;
+    }
+    float *d = static_cast<float *>(dst);
+    const size_t count = px * info.channels;
+    if (info.kind == 1) { const uint16_t *s = reinterpret_cast<const uint16_t *>(tmp.data()); for (size_t i = 0; i < count; i++) d[i] = half_to_float(s[i]); }
+    else { const uint8_t *s = tmp.data(); for (size_t i = 0; i < count; i++) d[i] = (float)s[i] / 255.0f; }
+    return need;
+}
+
+}  // namespace rt64
+
+// ======================================================================================================================================
+// extern "C" ABI.  One export per member of RT64_LIBRARY (include/rt64.h), each citing the reference export it replaces.
+// ======================================================================================================================================
+using namespace rt64;
+
+#define RT64_TRY try {
+#define RT64_CATCH(ret) } catch (const std::exception &e) { GlobalLastError = e.what(); fprintf(stderr, "%s\n", e.what()); return ret; }
+#define RT64_CATCH_VOID } catch (const std::exception &e) { GlobalLastError = e.what(); fprintf(stderr, "%s\n", e.what()); }
+
+RT64_EXPORT const char *RT64_GetLastError() { return GlobalLastError.c_str(); }                       // rt64_common.cpp:28
+
+static int env_int(const char *name, int def) { const char *e = getenv(name); return e && *e ? atoi(e) : def; }
+
+RT64_EXPORT RT64_DEVICE *RT64_CreateDeviceHeadless(int width, int height, int hipDevice) {
+    RT64_TRY return reinterpret_cast<RT64_DEVICE *>(new Device(width, height, hipDevice)); RT64_CATCH(nullptr)
+}
+RT64_EXPORT RT64_DEVICE *RT64_CreateDevice(void *hwnd) {                                                 // rt64_device.cpp:1221
+    (void)hwnd;   // no window system: the client-rect size source (rt64_device.cpp:199-231) is RT64_WIDTH x RT64_HEIGHT
+    return RT64_CreateDeviceHeadless(env_int("RT64_WIDTH", 1280), env_int("RT64_HEIGHT", 720), env_int("RT64_HIP_DEVICE", -1));
+}
+RT64_EXPORT void RT64_DestroyDevice(RT64_DEVICE *device) { RT64_TRY delete reinterpret_cast<Device *>(device); RT64_CATCH_VOID }   // :1231
+RT64_EXPORT void RT64_DrawDevice(RT64_DEVICE *device, int vsyncInterval, float deltaTimeMs) {            // :1239
+    RT64_TRY if (!device) throw std::runtime_error("RT64_DrawDevice: NULL device."); reinterpret_cast<Device *>(device)->draw(vsyncInterval, deltaTimeMs); RT64_CATCH_VOID
+}
+RT64_EXPORT void RT64_SetDeviceSize(RT64_DEVICE *device, int width, int height) {
+    Device *d = reinterpret_cast<Device *>(device); if (d && width > 0 && height > 0) { d->pendingWidth = width; d->pendingHeight = height; }
+}
+RT64_EXPORT void RT64_SetDeviceTile(RT64_DEVICE *device, int y0, int y1) {
+    Device *d = reinterpret_cast<Device *>(device); if (!d) return;
+    if (y0 < 0 || y1 <= y0) { d->tileSet = false; d->tileY0 = 0; d->tileY1 = d->height; } else { d->tileSet = true; d->tileY0 = y0; d->tileY1 = y1; }
+}
+RT64_EXPORT size_t RT64_ReadbackDevice(RT64_DEVICE *device, int image, void *dst, size_t dstBytes) {
+    RT64_TRY if (!device || !dst) throw std::runtime_error("RT64_ReadbackDevice: NULL argument."); return readback(reinterpret_cast<Device *>(device), image, dst, dstBytes, false); RT64_CATCH(0)
+}
+RT64_EXPORT size_t RT64_CopyDeviceImage(RT64_DEVICE *device, int image, void *devicePtr, size_t dstBytes) {
+    RT64_TRY if (!device || !devicePtr) throw std::runtime_error("RT64_CopyDeviceImage: NULL argument."); return readback(reinterpret_cast<Device *>(device), image, devicePtr, dstBytes, true); RT64_CATCH(0)
+}
+RT64_EXPORT int RT64_GetDeviceStats(RT64_DEVICE *device, RT64_FRAME_STATS *stats) {
+    Device *d = reinterpret_cast<Device *>(device);
+    if (!d || !stats || stats->structSize < sizeof(RT64_FRAME_STATS)) return 0;
+    *stats = d->stats; stats->structSize = sizeof(RT64_FRAME_STATS);
+    if (stats->width == 0) { stats->width = (unsigned)d->width; stats->height = (unsigned)d->height; stats->tileY0 = (unsigned)d->tileY0; stats->tileY1 = (unsigned)d->tileY1; }
+    return 1;
+}
+RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, double value) {
+    Device *d = reinterpret_cast<Device *>(device); if (!d || !key) return 0;
+    std::string k = key;
+    if (k == "count_traversal") d->opt.countTraversal = value != 0.0;
+    else if (k == "profile_passes") d->opt.profilePasses = value != 0.0;
+    else if (k == "sync_present") d->opt.syncPresent = value != 0.0;
+    else if (k == "denoiser_mode") d->opt.denoiserMode = (int)value;
+    else if (k == "max_reflections") d->opt.maxReflections = std::max(0, (int)value);
+    else return 0;
+    return 1;
+}
+RT64_EXPORT void *RT64_GetDeviceStream(RT64_DEVICE *device) { Device *d = reinterpret_cast<Device *>(device); return d ? d->stream : nullptr; }
+
+// ---- view (rt64_view.cpp:2086-2201) ----
+RT64_EXPORT RT64_VIEW *RT64_CreateView(RT64_SCENE *scenePtr) {
+    RT64_TRY if (!scenePtr) throw std::runtime_error("RT64_CreateView: NULL scene."); return reinterpret_cast<RT64_VIEW *>(new View(reinterpret_cast<Scene *>(scenePtr))); RT64_CATCH(nullptr)
+}
+RT64_EXPORT void RT64_SetViewPerspective(RT64_VIEW *viewPtr, RT64_MATRIX4 viewMatrix, float fovRadians, float nearDist, float farDist, bool canReproject) {
+    View *v = reinterpret_cast<View *>(viewPtr); if (!v) return;
+    v->view = mat_from(viewMatrix); v->fov = fovRadians; v->nearDist = nearDist; v->farDist = farDist; v->canReproject = canReproject; v->perspectiveSet = fovRadians > 0.0f;
+}
+RT64_EXPORT void RT64_SetViewDescription(RT64_VIEW *viewPtr, RT64_VIEW_DESC viewDesc) {
+    View *v = reinterpret_cast<View *>(viewPtr); if (!v) return;
+    v->resolutionScale = viewDesc.resolutionScale; v->motionBlurStrength = viewDesc.motionBlurStrength; v->maxLights = viewDesc.maxLights;
+    v->diSamples = viewDesc.diSamples; v->giSamples = viewDesc.giSamples; v->denoiserEnabled = viewDesc.denoiserEnabled;
+    // upscaler / upscalerMode / upscalerSharpness select vendor upscalers (DLSS / FSR2 / XeSS) in the reference; none exists here (see RT64_GetViewUpscalerSupport).
+}
+RT64_EXPORT void RT64_SetViewSkyPlane(RT64_VIEW *viewPtr, RT64_TEXTURE *texturePtr) { View *v = reinterpret_cast<View *>(viewPtr); if (v) v->skyPlane = reinterpret_cast<Texture *>(texturePtr); }
+RT64_EXPORT RT64_INSTANCE *RT64_GetViewRaytracedInstanceAt(RT64_VIEW *viewPtr, int x, int y) {         // rt64_view.cpp:1932-1998
+    RT64_TRY
+    View *v = reinterpret_cast<View *>(viewPtr); if (!v) return nullptr;
+    Device *dev = v->scene->device; dev->use();
+    const float xs = (float)v->imgW / (float)dev->width, ys = (float)v->imgH / (float)dev->height;
+    x = (int)lroundf(x * xs); y = (int)lroundf(y * ys);
+    if (x < 0 || x >= v->imgW || y < 0 || y >= v->imgH) return nullptr;
+    int32_t id = -1;
+    HIP_CHECK(hipMemcpy(&id, v->img.firstInstanceId + (size_t)y * v->imgW + x, 4, hipMemcpyDeviceToHost));
+    if (id >= 0 && (size_t)id < v->rtInstances.size()) return reinterpret_cast<RT64_INSTANCE *>(v->rtInstances[id].instance);
+    return nullptr;
+    RT64_CATCH(nullptr)
+}
+RT64_EXPORT bool RT64_GetViewUpscalerSupport(RT64_VIEW *, int) { return false; }                      // rt64_view.cpp:2183 (declared (view, int) there)
+RT64_EXPORT void RT64_DestroyView(RT64_VIEW *viewPtr) { RT64_TRY delete reinterpret_cast<View *>(viewPtr); RT64_CATCH_VOID }
+
+// ---- scene (rt64_scene.cpp:170-187) ----
+RT64_EXPORT RT64_SCENE *RT64_CreateScene(RT64_DEVICE *devicePtr) {
+    RT64_TRY if (!devicePtr) throw std::runtime_error("RT64_CreateScene: NULL device."); return reinterpret_cast<RT64_SCENE *>(new Scene(reinterpret_cast<Device *>(devicePtr))); RT64_CATCH(nullptr)
+}
+RT64_EXPORT void RT64_SetSceneDescription(RT64_SCENE *scenePtr, RT64_SCENE_DESC sceneDesc) { Scene *s = reinterpret_cast<Scene *>(scenePtr); if (s) s->desc = sceneDesc; }
+RT64_EXPORT void RT64_SetSceneLights(RT64_SCENE *scenePtr, RT64_LIGHT *lightArray, int lightCount) {   // rt64_scene.cpp:114-150
+    Scene *s = reinterpret_cast<Scene *>(scenePtr); if (!s || lightCount < 0) return;
+    s->lights.assign(lightCount, RT64_LIGHT());
+    if (lightArray) {
+        memcpy(s->lights.data(), lightArray, sizeof(RT64_LIGHT) * (size_t)lightCount);
+        for (RT64_LIGHT &l : s->lights) {
+            if (l.flickerIntensity > 0.0f) {
+                const float mult = 1.0f + ((((float)rand() / (float)RAND_MAX) * 2.0f - 1.0f) * l.flickerIntensity);
+                l.diffuseColor.x *= mult; l.diffuseColor.y *= mult; l.diffuseColor.z *= mult;
+            }
+        }
+    }
+}
+RT64_EXPORT void RT64_DestroyScene(RT64_SCENE *scenePtr) { RT64_TRY delete reinterpret_cast<Scene *>(scenePtr); RT64_CATCH_VOID }
+
+// ---- mesh (rt64_mesh.cpp:190-209) ----
+RT64_EXPORT RT64_MESH *RT64_CreateMesh(RT64_DEVICE *devicePtr, int flags) {
+    RT64_TRY if (!devicePtr) throw std::runtime_error("RT64_CreateMesh: NULL device."); return reinterpret_cast<RT64_MESH *>(new Mesh(reinterpret_cast<Device *>(devicePtr), flags)); RT64_CATCH(nullptr)
+}
+RT64_EXPORT void RT64_SetMesh(RT64_MESH *meshPtr, void *vertexArray, int vertexCount, int vertexStride, unsigned int *indexArray, int indexCount) {
+    RT64_TRY if (!meshPtr) throw std::runtime_error("RT64_SetMesh: NULL mesh."); reinterpret_cast<Mesh *>(meshPtr)->set(vertexArray, vertexCount, vertexStride, indexArray, indexCount); RT64_CATCH_VOID
+}
+RT64_EXPORT void RT64_DestroyMesh(RT64_MESH *meshPtr) { RT64_TRY Mesh *m = reinterpret_cast<Mesh *>(meshPtr); if (m) { m->device->use(); hipStreamSynchronize(m->device->stream); } delete m; RT64_CATCH_VOID }
+
+// ---- shader (rt64_shader.cpp:810-824) ----
+RT64_EXPORT RT64_SHADER *RT64_CreateShader(RT64_DEVICE *devicePtr, unsigned int shaderId, unsigned int filter, unsigned int hAddr, unsigned int vAddr, int flags) {
+    RT64_TRY
+    if (!devicePtr) throw std::runtime_error("RT64_CreateShader: NULL device.");
+    if (filter > 1 || hAddr > 2 || vAddr > 2) throw std::runtime_error("RT64_CreateShader: invalid sampler state.");
+    Shader *s = new Shader{ reinterpret_cast<Device *>(devicePtr), shaderId, filter, hAddr, vAddr, flags, decode_combiner(shaderId) };
+    return reinterpret_cast<RT64_SHADER *>(s);
+    RT64_CATCH(nullptr)
+}
+RT64_EXPORT void RT64_DestroyShader(RT64_SHADER *shaderPtr) { delete reinterpret_cast<Shader *>(shaderPtr); }
+
+// ---- instance (rt64_instance.cpp:145-173) ----
+RT64_EXPORT RT64_INSTANCE *RT64_CreateInstance(RT64_SCENE *scenePtr) {
+    RT64_TRY if (!scenePtr) throw std::runtime_error("RT64_CreateInstance: NULL scene."); return reinterpret_cast<RT64_INSTANCE *>(new Instance(reinterpret_cast<Scene *>(scenePtr))); RT64_CATCH(nullptr)
+}
+RT64_EXPORT void RT64_SetInstanceDescription(RT64_INSTANCE *instancePtr, RT64_INSTANCE_DESC d) {
+    Instance *i = reinterpret_cast<Instance *>(instancePtr); if (!i) return;
+    i->mesh = reinterpret_cast<Mesh *>(d.mesh); i->transform = mat_from(d.transform); i->previousTransform = mat_from(d.previousTransform);
+    i->material = d.material; i->shader = reinterpret_cast<Shader *>(d.shader);
+    i->diffuse = reinterpret_cast<Texture *>(d.diffuseTexture); i->normal = reinterpret_cast<Texture *>(d.normalTexture); i->specular = reinterpret_cast<Texture *>(d.specularTexture);
+    i->flags = d.flags; i->scissorRect = d.scissorRect; i->viewportRect = d.viewportRect;
+}
+RT64_EXPORT void RT64_DestroyInstance(RT64_INSTANCE *instancePtr) { delete reinterpret_cast<Instance *>(instancePtr); }
+
+// ---- texture (rt64_texture.cpp:207-233) ----
+RT64_EXPORT RT64_TEXTURE *RT64_CreateTexture(RT64_DEVICE *devicePtr, RT64_TEXTURE_DESC textureDesc) {
+    Texture *t = nullptr;
+    RT64_TRY
+    if (!devicePtr) throw std::runtime_error("RT64_CreateTexture: NULL device.");
+    t = new Texture(reinterpret_cast<Device *>(devicePtr));
+    switch (textureDesc.format) {
+    case RT64_TEXTURE_FORMAT_RGBA8: t->setRGBA8(textureDesc.bytes, textureDesc.byteCount, textureDesc.width, textureDesc.height, textureDesc.rowPitch); break;
+    case RT64_TEXTURE_FORMAT_DDS: t->setDDS(textureDesc.bytes, textureDesc.byteCount); break;
+    default: throw std::runtime_error("RT64_CreateTexture: unknown texture format.");
+    }
+    return reinterpret_cast<RT64_TEXTURE *>(t);
+    } catch (const std::exception &e) { GlobalLastError = e.what(); fprintf(stderr, "%s\n", e.what()); delete t; return nullptr; }
+}
+RT64_EXPORT void RT64_DestroyTexture(RT64_TEXTURE *texture) { RT64_TRY Texture *t = reinterpret_cast<Texture *>(texture); if (t) { t->device->use(); hipStreamSynchronize(t->device->stream); } delete t; RT64_CATCH_VOID }
+
+// ---- inspector (rt64_inspector.cpp:469-515): the ImGui/Im3d debug UI is Win32-only; the exports exist so that hosts resolve all 33 symbols ----
+struct InspectorStub { Device *device; };
+RT64_EXPORT RT64_INSPECTOR *RT64_CreateInspector(RT64_DEVICE *devicePtr) { return reinterpret_cast<RT64_INSPECTOR *>(new InspectorStub{ reinterpret_cast<Device *>(devicePtr) }); }
+RT64_EXPORT bool RT64_HandleMessageInspector(RT64_INSPECTOR *, RT64_UINT, RT64_WPARAM, RT64_LPARAM) { return false; }
+RT64_EXPORT void RT64_PrintClearInspector(RT64_INSPECTOR *) {}
+RT64_EXPORT void RT64_PrintMessageInspector(RT64_INSPECTOR *, const char *message) { if (message) fprintf(stdout, "%s\n", message); }
+RT64_EXPORT void RT64_SetSceneInspector(RT64_INSPECTOR *, RT64_SCENE_DESC *) {}
+RT64_EXPORT void RT64_SetMaterialInspector(RT64_INSPECTOR *, RT64_MATERIAL *, const char *) {}
+RT64_EXPORT void RT64_SetLightsInspector(RT64_INSPECTOR *, RT64_LIGHT *, int *, int) {}
+RT64_EXPORT void RT64_DestroyInspector(RT64_INSPECTOR *inspectorPtr) { delete reinterpret_cast<InspectorStub *>(inspectorPtr); }

@@ -1,0 +1,139 @@
+"""GPU parity tests: HIP render path (through the C ABI) vs the CPU oracle on the reference's sample scene.
+
+Bars: geometry (hit records: t, u, v, instance, primitive; BVH nodes; Morton order) is BIT-EXACT;
+shading is compared within tolerances written next to each assert (libm vs device transcendental functions).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scene_256(rt64_lib, sample_data):
+    from sm64rt_legacy_renderer_amd import sample_scene
+    s = sample_scene.Rt64Scene(rt64_lib, sample_data, 256, 256, hip_device=0)
+    s.option("count_traversal", 1)
+    s.draw()
+    yield s
+    s.close()
+
+
+@pytest.fixture(scope="module")
+def oracle_256(sample_data, oracle_lib):
+    from oracle import oracle_py
+    o = oracle_py.OracleScene(sample_data)
+    r = o.render(256, 256)
+    yield o, r
+    o.close()
+
+
+def test_c1_primary_visibility_bit_exact(scene_256, oracle_256):
+    """BASELINE config C1: 256x256 primary visibility.  t/u/v bits, instance and primitive ids must be identical."""
+    from sm64rt_legacy_renderer_amd import rt64
+    _, ref = oracle_256
+    hit = scene_256.readback(rt64.IMAGE_PRIMARY_HIT)
+    assert hit.shape == ref["primaryHit"].shape
+    mism = np.any(hit != ref["primaryHit"], axis=-1)
+    assert mism.sum() == 0, f"{mism.sum()} pixels differ, first at {np.argwhere(mism)[:5]}"
+    ids = scene_256.readback(rt64.IMAGE_INSTANCE_ID)
+    assert np.array_equal(ids, ref["instanceId"])
+    # coverage probed by brute force in SURVEY 8 (43.7 % at 16:9); at 1:1 just require both instances visible
+    assert (ids == 0).any() and (ids == 1).any() and (ids == -1).any()
+
+
+def test_traversal_counters_match_oracle(scene_256, oracle_256):
+    """Same BVH + same traversal order => identical node / triangle visit counts (they define the algorithmic bytes)."""
+    _, ref = oracle_256
+    st = scene_256.stats()
+    c = ref["counters"]
+    assert st.primaryRays == c["primaryRays"] == 256 * 256
+    assert st.shadowRays == c["shadowRays"]
+    assert st.nodesVisited == c["nodesVisited"]
+    assert st.trianglesTested == c["trianglesTested"]
+
+
+def test_gbuffer_parity(scene_256, oracle_256):
+    from sm64rt_legacy_renderer_amd import rt64
+    _, ref = oracle_256
+    pos = scene_256.readback(rt64.IMAGE_SHADING_POSITION)
+    # shading position = origin + dir * t with identical t: exact
+    assert np.array_equal(pos, ref["shadingPosition"])
+    depth = scene_256.readback(rt64.IMAGE_DEPTH)
+    assert np.allclose(depth, ref["depth"], rtol=0, atol=1e-6)
+    # normals / specular are RGBA16F, diffuse RGBA8: allow one quantisation step on a tiny fraction of pixels
+    # (device log2f/sqrt chains vs libm flip a rounding here and there)
+    for image, key, step in ((rt64.IMAGE_SHADING_NORMAL, "shadingNormal", 2e-3), (rt64.IMAGE_SHADING_SPECULAR, "shadingSpecular", 2e-3),
+                             (rt64.IMAGE_DIFFUSE, "diffuse", 1.0 / 255.0 + 1e-6)):
+        a = scene_256.readback(image)
+        d = np.abs(a - ref[key])
+        assert d.max() <= step, (key, float(d.max()))
+        assert (d > 0).mean() < 0.01, (key, float((d > 0).mean()))
+    vd = scene_256.readback(rt64.IMAGE_VIEW_DIRECTION)
+    assert np.array_equal(vd, ref["viewDirection"])
+    flow = scene_256.readback(rt64.IMAGE_FLOW)
+    assert np.allclose(flow, ref["flow"], atol=1e-3)
+
+
+def test_c2_full_frame_rmse(rt64_lib, sample_data, oracle_lib):
+    """BASELINE config C2 at reduced size (480x270, 16:9): primary + shadow rays, direct light, compose, post.
+    Gate from BASELINE.json: per-pixel fp32 RMSE <= 1e-3 on the composed RGBA32F output."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    from oracle import oracle_py
+    W, H = 480, 270
+    s = sample_scene.Rt64Scene(rt64_lib, sample_data, W, H, hip_device=0)
+    try:
+        s.draw()
+        out = s.readback(rt64.IMAGE_OUTPUT_RGBA32F)
+        final = s.readback(rt64.IMAGE_FINAL_RGBA8)
+        direct = s.readback(rt64.IMAGE_DIRECT_LIGHT_RAW)
+        indirect = s.readback(rt64.IMAGE_INDIRECT_LIGHT_RAW)
+    finally:
+        s.close()
+    o = oracle_py.OracleScene(sample_data)
+    try:
+        ref = o.render(W, H)
+    finally:
+        o.close()
+    rmse = float(np.sqrt(np.mean((out[..., :3].astype(np.float64) - ref["output"][..., :3]) ** 2)))
+    assert rmse <= 1e-3, rmse
+    rmse8 = float(np.sqrt(np.mean(((final[..., :3].astype(np.float64) - ref["final"][..., :3]) / 255.0) ** 2)))
+    assert rmse8 <= 1e-3, rmse8
+    assert np.abs(final.astype(np.int32) - ref["final"].astype(np.int32)).max() <= 1
+    assert np.abs(direct - ref["directLight"]).max() <= 4e-3          # RGBA16F steps near 1.0 are 9.8e-4
+    assert np.array_equal(indirect, ref["indirectLight"])              # constant ambient (giSamples = 0)
+    # the frame is not trivially black / constant
+    assert final[..., :3].std() > 20
+
+
+def test_blas_tlas_bit_exact(rt64_lib, sample_data, oracle_lib):
+    """LBVH built on the GPU (LDS radix sort + Karras + fit) == CPU oracle LBVH: same Morton order, same nodes."""
+    pytest.skip("covered through hit-record and counter equality; raw node readback export lands with the debug API")
+
+
+def test_picking_returns_instance_pointer(scene_256):
+    lib = scene_256.lib
+    centre = lib.GetViewRaytracedInstanceAt(scene_256.view, 128, 150)
+    assert centre == scene_256.instances[1]          # the sphere instance handle (scene order: hudB, sphere, hudA, floor)
+    floor = lib.GetViewRaytracedInstanceAt(scene_256.view, 20, 250)
+    assert floor == scene_256.instances[3]
+    sky = lib.GetViewRaytracedInstanceAt(scene_256.view, 10, 10)
+    assert not sky
+    assert not lib.GetViewRaytracedInstanceAt(scene_256.view, -5, 1000)
+
+
+def test_error_convention(rt64_lib):
+    """NULL + RT64_GetLastError() instead of exceptions across the C boundary (rt64_common.h:379-383)."""
+    from sm64rt_legacy_renderer_amd import rt64
+    dev = rt64_lib.CreateDeviceHeadless(64, 64, 0)
+    assert dev
+    d = rt64.TEXTURE_DESC()
+    junk = (C.c_uint8 * 64)()
+    d.bytes = C.addressof(junk); d.byteCount = 64; d.format = rt64.TEXTURE_FORMAT_DDS; d.width = d.height = d.rowPitch = -1
+    assert not rt64_lib.CreateTexture(dev, d)
+    assert "DDS" in rt64_lib.last_error()
+    assert not rt64_lib.CreateDeviceHeadless(64, 64, 4096)
+    assert "out of range" in rt64_lib.last_error()
+    rt64_lib.DestroyDevice(dev)
