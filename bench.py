@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the RT64 render path on MI355X.
+
+Metric (BASELINE.json): Mrays/s + ms/frame on the reference's sample scene, 1920x1080, 1 spp.
+A "step" is one RT64_DrawDevice of configuration C2 (TLAS build, primary rays, any-hit shading, direct light with
+shadow rays, constant ambient, compose, post -> RGBA8 back buffer) through the C ABI of librt64.so, with every input
+already resident in HBM.  value = (primary + shadow rays of the frame, counted on the device) / frame time.
+
+N GPUs: one process per GPU (torch.distributed, backend nccl == RCCL).  The SAME 1080p frame is image-tile partitioned:
+rank r renders the 16-row strips r, r+N, ... and every step ends with one gather of the packed RGBA8 strips to rank 0
+over xGMI (strong scaling: total work fixed).
+
+Extra objects in the JSON line:
+  roofline      dominant kernel of the step: algorithmic bytes per launch / its mean launch duration (HIP events recorded
+                on the library's stream inside the timed region) against the 8 TB/s HBM peak
+  cpu_baseline  the scalar C oracle (same BVH, same shading math, OpenMP over rows) on the box's host cores, rank 0, N=1
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+# Algorithmic bytes (DESIGN.md "Kernels and rooflines"): a BVH node record is 64 B, a triangle record 48 B.
+NODE_B, TRI_B = 64, 48
+PRIMARY_TRACE_PIXEL_B = 16 + 4                 # hit record (t,u,v,prim) + instance id written per primary ray
+PRIMARY_SHADE_PIXEL_B = 20 + 90                # hit record read + 14 G-buffer images written (90 B/px)
+PRIMARY_SHADE_HIT_B = 3 * 52 + 4 * 16 * 4      # 3 vertices of the sample layout + 4 bilinear fetches x 4 texels x 4 B
+PRIMARY_SHADE_MISS_B = 16                      # one bilinear sky fetch
+DIRECT_PIXEL_B = 4 + 8                         # instance id read + RGBA16F light written
+DIRECT_HIT_B = 16 + 8 + 8                      # position + normal + specular read for lit pixels
+COMPOSE_PIXEL_B = 44 + 16 + 4                  # compose reads 44 B, writes 16 B; post writes 4 B (fused: output not re-read)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--gi-samples", type=int, default=0, help="C3: 1 (with --denoiser)")
+    ap.add_argument("--denoiser", action="store_true")
+    ap.add_argument("--subdiv", type=int, default=0, help="stress variant: sphere subdivision levels")
+    ap.add_argument("--floor-grid", type=int, default=1, help="stress variant: floor tessellation")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-height", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = all)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import __graft_entry__ as graft
+    graft.load_package()
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene, tiles
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    N = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback.")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if N > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    W, H = args.width, args.height
+    lib = rt64.Library()
+    data = sample_scene.make_sample_scene(subdiv=args.subdiv, floor_grid=args.floor_grid)
+    scene = sample_scene.Rt64Scene(lib, data, W, H, hip_device=local_rank)
+    scene.set_interleave(rank, N)
+    if args.gi_samples or args.denoiser:
+        scene.set_view_description(gi_samples=args.gi_samples, denoiser=args.denoiser)
+
+    max_rows = tiles.max_owned_rows(H, N)
+    local = torch.zeros(max_rows * W * 4, dtype=torch.uint8, device="cuda")
+    my_bytes = tiles.owned_rows(H, rank, N) * W * 4
+
+    def step():
+        scene.draw()
+        n = lib.CopyDeviceImage(scene.device, rt64.IMAGE_FINAL_RGBA8, local.data_ptr(), local.numel())
+        if n != my_bytes:
+            raise RuntimeError("RT64_CopyDeviceImage returned %d, expected %d: %s" % (n, my_bytes, lib.last_error()))
+        return tiles.gather_frame(local, H, W, rank, N)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if N > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # --- instrumented frame (untimed): ray / node / triangle counts of this rank's strips ---
+    scene.option("count_traversal", 1)
+    step()
+    st = scene.stats()
+    counts = dict(primary=st.primaryRays, shadow=st.shadowRays, indirect=st.indirectRays, nodesPrimary=st.nodesPrimary,
+                  trisPrimary=st.trianglesPrimary, nodesDirect=st.nodesDirect, trisDirect=st.trianglesDirect,
+                  nodesIndirect=st.nodesIndirect, trisIndirect=st.trianglesIndirect)
+    hit_pixels = int((scene.readback(rt64.IMAGE_FIRST_INSTANCE_ID) >= 0).sum())
+    scene.option("count_traversal", 0)
+    rays_local = counts["primary"] + counts["shadow"] + counts["indirect"]
+    rays_total = rays_local
+    if N > 1:
+        t = torch.tensor([rays_local], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t)
+        rays_total = int(t.item())
+
+    for _ in range(args.warmup):
+        step()
+    acc = dict(trace=0.0, shade=0.0, direct=0.0, indirect=0.0, compose=0.0, build=0.0, total=0.0, denoise=0.0)
+    barrier()
+    t0 = time.perf_counter()
+    frame = None
+    for _ in range(args.steps):
+        frame = step()
+        s = scene.stats()
+        acc["trace"] += s.msPrimaryTrace; acc["shade"] += s.msPrimaryShade; acc["direct"] += s.msDirect
+        acc["indirect"] += s.msIndirect; acc["compose"] += s.msComposePost; acc["build"] += s.msBuild; acc["total"] += s.msTotal
+        acc["denoise"] += s.msDenoise
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if N > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = rays_total / (elapsed / args.steps) / 1e6
+
+    if rank == 0:
+        K = float(args.steps)
+        kms = {k: v / K for k, v in acc.items()}
+        my_pixels = tiles.owned_rows(H, 0, N) * W
+        kernels = {
+            "primary_trace": (kms["trace"], my_pixels * PRIMARY_TRACE_PIXEL_B + NODE_B * counts["nodesPrimary"] + TRI_B * counts["trisPrimary"]),
+            "primary_shade": (kms["shade"], my_pixels * PRIMARY_SHADE_PIXEL_B + hit_pixels * PRIMARY_SHADE_HIT_B + (my_pixels - hit_pixels) * PRIMARY_SHADE_MISS_B),
+            "direct": (kms["direct"], my_pixels * DIRECT_PIXEL_B + hit_pixels * DIRECT_HIT_B + NODE_B * counts["nodesDirect"] + TRI_B * counts["trisDirect"] + 4 * counts["shadow"]),
+            "compose_post": (kms["compose"], my_pixels * COMPOSE_PIXEL_B),
+        }
+        if args.gi_samples:
+            kernels["indirect"] = (kms["indirect"], my_pixels * 12 + hit_pixels * 24 + NODE_B * counts["nodesIndirect"] + TRI_B * counts["trisIndirect"])
+        dominant = max(kernels, key=lambda k: kernels[k][0])
+        d_ms, d_bytes = kernels[dominant]
+        achieved = d_bytes / (d_ms * 1e-3) / 1e9 if d_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dominant)
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": int(d_bytes), "ms_per_launch": round(d_ms, 5),
+                    "kernels": {k: {"ms": round(v[0], 5), "alg_bytes": int(v[1]), "GBps": round(v[1] / (v[0] * 1e-3) / 1e9, 2) if v[0] > 0 else 0.0} for k, v in kernels.items()},
+                    "frame_gpu_ms": round(kms["total"], 5), "build_ms": round(kms["build"], 5),
+                    "nodes_per_primary_ray": round(counts["nodesPrimary"] / max(counts["primary"], 1), 3),
+                    "tris_per_primary_ray": round(counts["trisPrimary"] / max(counts["primary"], 1), 3),
+                    "nodes_per_shadow_ray": round(counts["nodesDirect"] / max(counts["shadow"], 1), 3),
+                    "tris_per_shadow_ray": round(counts["trisDirect"] / max(counts["shadow"], 1), 3)}
+        result = {
+            "metric": "Mrays/s (primary+shadow), sample scene 1080p 1spp", "value": round(value, 2), "unit": "Mrays/s",
+            "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2: src/sample scene, primary+shadow rays + shading + compose, %dx%d 1spp%s" % (
+                W, H, "" if not (args.gi_samples or args.subdiv or args.floor_grid > 1) else " [gi=%d denoiser=%d subdiv=%d floor_grid=%d]" % (
+                    args.gi_samples, int(args.denoiser), args.subdiv, args.floor_grid)),
+                "rays_per_frame": int(rays_total), "width": W, "height": H,
+                "partition": "interleaved 16-row strips x%d + RCCL gather of RGBA8" % N if N > 1 else "single GPU"},
+            "roofline": roofline,
+        }
+        if N == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(data, W, H, args.cpu_baseline_height)
+        if frame is not None:
+            result["frame_checksum"] = int(frame.to(torch.int64).sum().item())
+        print(json.dumps(result), flush=True)
+
+    scene.close()
+    if N > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(data, W, H, rows):
+    """The scalar C oracle (kind "port": same LBVH, same traversal, same shading math) on the host cores."""
+    from oracle import oracle_py
+    threads = min(os.cpu_count() or 1, 16)
+    ora = oracle_py.OracleScene(data)
+    try:
+        tile = (0, rows) if rows and rows < H else None
+        t0 = time.perf_counter()
+        r = ora.render(W, H, threads=threads, tile=tile)
+        dt = time.perf_counter() - t0
+        c = r["counters"]
+        rays = c["primaryRays"] + c["shadowRays"] + c["indirectRays"]
+        return {"value": round(rays / c["secondsRender"] / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                "sample": "1 frame of the same C2 workload at %dx%d (%d rows), %d rays, %.2f s render + %.3f s BVH build" % (
+                    W, H, (tile[1] if tile else H), rays, c["secondsRender"], c["secondsBuild"]),
+                "ms_per_frame": round(dt * 1e3, 1)}
+    finally:
+        ora.close()
+
+
+if __name__ == "__main__":
+    main()

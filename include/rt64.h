@@ -342,6 +342,12 @@ typedef struct {
     float msPrimary, msDirect, msIndirect, msReflectRefract, msDenoise, msComposePost;
     float msHostWall;                  /* host wall clock of RT64_DrawDevice */
     unsigned int blasNodeBytes, blasTriangleBytes, tlasNodeBytes, instanceCount, triangleCount;
+    float msPrimaryTrace, msPrimaryShade;   /* split of msPrimary: pure traversal kernel / shading kernel */
+    unsigned int stripRank, stripCount;     /* interleaved 16-row strips (RT64_SetDeviceInterleave), count 1 = off */
+    unsigned int rowsRendered;              /* rows of the frame this device rendered */
+    unsigned int reserved0;
+    /* per-pass split of nodesVisited / trianglesTested (count_traversal = 1) */
+    unsigned long long nodesPrimary, trianglesPrimary, nodesDirect, trianglesDirect, nodesIndirect, trianglesIndirect;
 } RT64_FRAME_STATS;
 
 #define RT64_EXT_API_LIST(X) \
@@ -352,8 +358,11 @@ typedef struct {
     X(SetDeviceSize, RT64_SetDeviceSize, void, (RT64_DEVICE *device, int width, int height)) \
     /* Image-tile partition: this device renders rows [y0, y1) of the frame (default: all). */ \
     X(SetDeviceTile, RT64_SetDeviceTile, void, (RT64_DEVICE *device, int y0, int y1)) \
+    /* Interleaved partition for load balance: the frame is cut into 16-row strips and this device renders strips \
+       rank, rank+count, rank+2*count, ... (count <= 1 turns it off).  Combines with the row range of SetDeviceTile. */ \
+    X(SetDeviceInterleave, RT64_SetDeviceInterleave, void, (RT64_DEVICE *device, int rank, int count)) \
     /* Copy image `image` (RT64_IMAGE_*) of the first view to host memory. Returns bytes written, 0 on error. \
-       Rows [tileY0, tileY1) only; layout is tightly packed row-major starting at row tileY0. */ \
+       Only the rows this device rendered are returned, tightly packed in ascending row order. */ \
     X(ReadbackDevice, RT64_ReadbackDevice, size_t, (RT64_DEVICE *device, int image, void *dst, size_t dstBytes)) \
     /* Same, device-to-device into a caller-owned device pointer (e.g. a torch tensor feeding an RCCL gather), \
        ordered on the device's stream; the call returns after the copy has completed. */ \

@@ -22,12 +22,15 @@ namespace {
 
 struct Pixel { uint32_t x, y; bool valid; };
 
-DEV uint32_t tile_count(const FrameParams &P) {
-    return (uint32_t)((P.width + 15) / 16) * (uint32_t)((P.tileY1 - P.tileY0 + 15) / 16);
+// Tile rows owned by this device: strips stripRank, stripRank + stripCount, ... of the 16-row strips in [tileY0, tileY1).
+DEV uint32_t tile_rows(const FrameParams &P) {
+    const uint32_t all = (uint32_t)(P.tileY1 - P.tileY0 + 15) / 16;
+    return all > (uint32_t)P.stripRank ? (all - (uint32_t)P.stripRank + (uint32_t)P.stripCount - 1) / (uint32_t)P.stripCount : 0u;
 }
+DEV uint32_t tile_count(const FrameParams &P) { return (uint32_t)((P.width + 15) / 16) * tile_rows(P); }
 DEV Pixel tile_pixel(const FrameParams &P, uint32_t tile) {
     const uint32_t tilesX = (uint32_t)(P.width + 15) / 16;
-    const uint32_t tx = tile % tilesX, ty = tile / tilesX;
+    const uint32_t tx = tile % tilesX, ty = (tile / tilesX) * (uint32_t)P.stripCount + (uint32_t)P.stripRank;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     Pixel p;
     p.x = tx * 16 + (wave & 1) * 8 + (lane & 7);
@@ -36,6 +39,8 @@ DEV Pixel tile_pixel(const FrameParams &P, uint32_t tile) {
     return p;
 }
 
+DEV bool row_owned(const FrameParams &P, int y) { return (((y - P.tileY0) / 16) % P.stripCount) == P.stripRank; }
+
 DEV TraceStack make_stack(const FrameParams &P, uint32_t *ldsStack) {
     TraceStack s;
     s.lds = ldsStack + threadIdx.x;
@@ -43,8 +48,8 @@ DEV TraceStack make_stack(const FrameParams &P, uint32_t *ldsStack) {
     return s;
 }
 
-DEV void flush_env(const FrameParams &P, const ShadeEnv &env, int rayCounter, uint32_t rays) {
-    flush_counts(P, env.cnt);
+DEV void flush_env(const FrameParams &P, const ShadeEnv &env, int pass, int rayCounter, uint32_t rays) {
+    flush_counts(P, env.cnt, pass);
     if (!P.countTraversal) return;
     unsigned long long a = rays, b = env.shadowRays;
 #pragma unroll
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(RT_BLOCK) void primary_trace_kernel(FrameParams P, 
         else { rec.x = rec.y = rec.z = rec.w = 0xFFFFFFFFu; hitInstance[i] = -1; }
         reinterpret_cast<uint4 *>(I.primaryHit)[i] = rec;
     }
-    flush_env(P, env, CTR_PRIMARY, rays);
+    flush_env(P, env, PASS_PRIMARY_TRACE, CTR_PRIMARY, rays);
 }
 
 // ---- PrimaryRayGen resolve + G-buffer -------------------------------------------------------------------------------------
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(RT_BLOCK) void primary_shade_kernel(FrameParams P, 
         store_rgba16f(I.normal[cur], i, resNormal.x, resNormal.y, resNormal.z, 0.0f);
         I.depth[cur][i] = resDepth;
     }
-    flush_env(P, env, CTR_PRIMARY, 0);
+    flush_env(P, env, PASS_PRIMARY_SHADE, CTR_PRIMARY, 0);
 }
 
 // ---- DirectRayGen ----------------------------------------------------------------------------------------------------------
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(RT_BLOCK) void direct_kernel(FrameParams P, ViewIma
         newDirect = lerp3(newDirect, resDirect, 1.0f / historyLength);
         store_rgba16f(I.directLight[cur], i, newDirect.x, newDirect.y, newDirect.z, historyLength);
     }
-    flush_env(P, env, CTR_PRIMARY, 0);
+    flush_env(P, env, PASS_DIRECT, CTR_PRIMARY, 0);
 }
 
 // ---- bounce-ray resolve shared by Indirect / Refraction / Reflection ------------------------------------------------------
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(RT_BLOCK) void indirect_kernel(FrameParams P, ViewI
         }
         store_rgba16f(I.indirectLight[cur], i, newIndirect.x, newIndirect.y, newIndirect.z, historyLength);
     }
-    flush_env(P, env, CTR_INDIRECT, rays);
+    flush_env(P, env, PASS_INDIRECT, CTR_INDIRECT, rays);
 }
 
 DEV f3 hlsl_refract(f3 i, f3 n, float eta) {
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(RT_BLOCK) void refraction_kernel(FrameParams P, Vie
         rgb = rgb + (bgColor * resColor.w + resTransparent);
         store_rgba16f(I.refraction, i, refr.x + rgb.x * refractionAlpha, refr.y + rgb.y * refractionAlpha, refr.z + rgb.z * refractionAlpha, refr.w);
     }
-    flush_env(P, env, CTR_REFRACTION, rays);
+    flush_env(P, env, PASS_REFRACTION, CTR_REFRACTION, rays);
 }
 
 __global__ __launch_bounds__(RT_BLOCK) void reflection_kernel(FrameParams P, ViewImages I) {
@@ -468,7 +473,7 @@ __global__ __launch_bounds__(RT_BLOCK) void reflection_kernel(FrameParams P, Vie
         float k = reflectionAlpha * saturatef(1.0f - newReflectionAlpha);
         store_rgba16f(I.reflection, i, refl.x + rgb.x * k, refl.y + rgb.y * k, refl.z + rgb.z * k, saturatef(newReflectionAlpha));
     }
-    flush_env(P, env, CTR_REFLECTION, rays);
+    flush_env(P, env, PASS_REFLECTION, CTR_REFLECTION, rays);
 }
 
 // ---- GaussianFilterRGB3x3CS ------------------------------------------------------------------------------------------------
@@ -517,7 +522,7 @@ __global__ __launch_bounds__(256) void gaussian_kernel(const uint16_t *in, uint1
 
 __global__ __launch_bounds__(256) void compose_post_kernel(FrameParams P, ViewImages I) {
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = P.tileY0 + blockIdx.y * 8 + (threadIdx.x >> 5);
-    if (x >= P.width || y >= P.tileY1) return;
+    if (x >= P.width || y >= P.tileY1 || !row_owned(P, y)) return;
     const size_t i = (size_t)y * (size_t)P.width + x;
     f4 d = load_rgba8(I.diffuse, i);
     f3 result;
@@ -537,7 +542,7 @@ __global__ __launch_bounds__(256) void compose_post_kernel(FrameParams P, ViewIm
 
 __global__ __launch_bounds__(256) void clear_final_kernel(FrameParams P, ViewImages I) {
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = P.tileY0 + blockIdx.y * 8 + (threadIdx.x >> 5);
-    if (x >= P.width || y >= P.tileY1) return;
+    if (x >= P.width || y >= P.tileY1 || !row_owned(P, y)) return;
     store_rgba8(I.final, (size_t)y * (size_t)P.width + x, 0.0f, 0.0f, 0.0f, 1.0f);   // cleared back buffer, rt64_device.cpp:996-997
 }
 

@@ -93,7 +93,8 @@ struct FrameParams {
     uint32_t visualizationMode, frameCount;
     // --- additions of this implementation ---
     int32_t width, height;               // render size
-    int32_t tileY0, tileY1;              // rows owned by this device
+    int32_t tileY0, tileY1;              // row range owned by this device
+    int32_t stripRank, stripCount;       // interleaved 16-row strips inside the range (count 1 = all)
     float maxDepthBias;
     uint32_t lightCount, instanceCount, countTraversal;
     const GpuInstance *instances;
@@ -125,4 +126,7 @@ struct ViewImages {
     float *moments[2];                   // SVGF: RG32F luminance moments
 };
 
-enum { CTR_NODES = 0, CTR_TRIS, CTR_PRIMARY, CTR_SHADOW, CTR_INDIRECT, CTR_REFLECTION, CTR_REFRACTION, CTR_COUNT };
+enum { CTR_NODES = 0, CTR_TRIS, CTR_PRIMARY, CTR_SHADOW, CTR_INDIRECT, CTR_REFLECTION, CTR_REFRACTION,
+       CTR_PASS_BASE,                    // then {nodes, triangles} per pass:
+       CTR_COUNT = CTR_PASS_BASE + 2 * 6 };
+enum { PASS_PRIMARY_TRACE = 0, PASS_PRIMARY_SHADE, PASS_DIRECT, PASS_INDIRECT, PASS_REFRACTION, PASS_REFLECTION };

@@ -145,6 +145,7 @@ struct Device {
     hipStream_t stream = nullptr;
     int width = 0, height = 0, pendingWidth = 0, pendingHeight = 0;
     int tileY0 = 0, tileY1 = 0; bool tileSet = false;
+    int stripRank = 0, stripCount = 1;
     std::vector<Scene *> scenes;
     Options opt;
     RT64_FRAME_STATS stats = {};
@@ -152,7 +153,7 @@ struct Device {
     DevArray<unsigned long long> counters;
     DevArray<uint8_t> blueNoise;
     uint8_t *pinned = nullptr; size_t pinnedBytes = 0;
-    enum { EV_BEGIN, EV_BUILD, EV_PRIMARY, EV_DIRECT, EV_INDIRECT, EV_REFL, EV_DENOISE, EV_END, EV_COUNT };
+    enum { EV_BEGIN, EV_BUILD, EV_PRIMARY_TRACE, EV_PRIMARY, EV_DIRECT, EV_INDIRECT, EV_REFL, EV_DENOISE, EV_END, EV_COUNT };
     hipEvent_t events[EV_COUNT] = {};
 
     Device(int w, int h, int dev);
@@ -168,6 +169,11 @@ struct Device {
     }
     void draw(int vsyncInterval, float deltaTimeMs);
     float aspect() const { return (float)width / (float)height; }
+    // Rows of [tileY0, tileY1) in strips stripRank, stripRank + stripCount, ... (16 rows each).
+    template <class F> void forEachOwnedStrip(F &&f) const {
+        for (int y = tileY0 + stripRank * 16; y < tileY1; y += stripCount * 16) f(y, std::min(y + 16, tileY1));
+    }
+    int ownedRows() const { int r = 0; forEachOwnedStrip([&](int a, int b) { r += b - a; }); return r; }
 };
 
 struct Texture {
@@ -624,7 +630,7 @@ void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64
     P.giReproject = (!skipReprojection && denoiserEnabled && giSamples > 0) ? 1u : 0u;
     P.binaryLockMask = 1;                                     // rtUpscaleMode != FSR
     P.visualizationMode = 0;
-    P.width = imgW; P.height = imgH; P.tileY0 = dev->tileY0; P.tileY1 = dev->tileY1;
+    P.width = imgW; P.height = imgH; P.tileY0 = dev->tileY0; P.tileY1 = dev->tileY1; P.stripRank = dev->stripRank; P.stripCount = dev->stripCount;
     P.maxDepthBias = maxDepthBias;
     P.lightCount = (uint32_t)scene->lights.size(); P.instanceCount = (uint32_t)rtInstances.size();
     P.countTraversal = dev->opt.countTraversal ? 1u : 0u;
@@ -645,6 +651,7 @@ void View::render() {                          // View::render, rt64_view.cpp:11
     mark(Device::EV_BUILD);
     if (!rtInstances.empty()) {
         HIP_CHECK(launch_primary_trace(P, img, hitInstance.ptr, s));
+        mark(Device::EV_PRIMARY_TRACE);
         HIP_CHECK(launch_primary_shade(P, img, hitInstance.ptr, cur, s));
         mark(Device::EV_PRIMARY);
         HIP_CHECK(launch_direct(P, img, cur, s));
@@ -668,7 +675,7 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         HIP_CHECK(launch_compose_post(P, img, s));
     }
     else {
-        mark(Device::EV_PRIMARY); mark(Device::EV_DIRECT); mark(Device::EV_INDIRECT); mark(Device::EV_REFL); mark(Device::EV_DENOISE);
+        mark(Device::EV_PRIMARY_TRACE); mark(Device::EV_PRIMARY); mark(Device::EV_DIRECT); mark(Device::EV_INDIRECT); mark(Device::EV_REFL); mark(Device::EV_DENOISE);
         HIP_CHECK(launch_clear_final(P, img, s));
     }
     // End of frame (rt64_view.cpp:1663-1667)
@@ -695,6 +702,7 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
     RT64_FRAME_STATS st = {};
     st.structSize = sizeof(st); st.width = (unsigned)width; st.height = (unsigned)height; st.tileY0 = (unsigned)tileY0; st.tileY1 = (unsigned)tileY1;
     st.msHostWall = std::chrono::duration<float, std::milli>(t1 - t0).count();
+    st.stripRank = (unsigned)stripRank; st.stripCount = (unsigned)stripCount; st.rowsRendered = (unsigned)ownedRows();
     bool haveView = false;
     for (Scene *sc : scenes) for (View *v : sc->views) {
         if (haveView) continue;
@@ -708,6 +716,7 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
     if (opt.profilePasses && haveView) {
         auto ms = [&](int a, int b) { float v = 0.0f; hipEventElapsedTime(&v, events[a], events[b]); return v; };
         st.msTotal = ms(EV_BEGIN, EV_END); st.msBuild = ms(EV_BEGIN, EV_BUILD); st.msPrimary = ms(EV_BUILD, EV_PRIMARY);
+        st.msPrimaryTrace = ms(EV_BUILD, EV_PRIMARY_TRACE); st.msPrimaryShade = ms(EV_PRIMARY_TRACE, EV_PRIMARY);
         st.msDirect = ms(EV_PRIMARY, EV_DIRECT); st.msIndirect = ms(EV_DIRECT, EV_INDIRECT); st.msReflectRefract = ms(EV_INDIRECT, EV_REFL);
         st.msDenoise = ms(EV_REFL, EV_DENOISE); st.msComposePost = ms(EV_DENOISE, EV_END);
     }
@@ -716,6 +725,9 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
         HIP_CHECK(hipMemcpy(c, counters.ptr, sizeof(c), hipMemcpyDeviceToHost));
         st.nodesVisited = c[CTR_NODES]; st.trianglesTested = c[CTR_TRIS]; st.primaryRays = c[CTR_PRIMARY]; st.shadowRays = c[CTR_SHADOW];
         st.indirectRays = c[CTR_INDIRECT]; st.reflectionRays = c[CTR_REFLECTION]; st.refractionRays = c[CTR_REFRACTION];
+        st.nodesPrimary = c[CTR_PASS_BASE + 2 * PASS_PRIMARY_TRACE]; st.trianglesPrimary = c[CTR_PASS_BASE + 2 * PASS_PRIMARY_TRACE + 1];
+        st.nodesDirect = c[CTR_PASS_BASE + 2 * PASS_DIRECT]; st.trianglesDirect = c[CTR_PASS_BASE + 2 * PASS_DIRECT + 1];
+        st.nodesIndirect = c[CTR_PASS_BASE + 2 * PASS_INDIRECT]; st.trianglesIndirect = c[CTR_PASS_BASE + 2 * PASS_INDIRECT + 1];
     }
     stats = st;
 }
@@ -772,22 +784,45 @@ static size_t readback(Device *dev, int image, void *dst, size_t dstBytes, bool 
     if (!v) throw std::runtime_error("RT64_ReadbackDevice: the device has no view.");
     ImageInfo info; size_t dstPixelBytes;
     if (!image_info(v, image, info, dstPixelBytes)) throw std::runtime_error("RT64_ReadbackDevice: unknown image id.");
-    const size_t rows = (size_t)(dev->tileY1 - dev->tileY0), w = (size_t)v->imgW, px = rows * w, first = (size_t)dev->tileY0 * w;
+    const size_t rows = (size_t)dev->ownedRows(), w = (size_t)v->imgW, px = rows * w;
     const size_t need = px * dstPixelBytes;
     if (dstBytes < need) throw std::runtime_error("RT64_ReadbackDevice: destination buffer is too small.");
-    const uint8_t *src = static_cast<const uint8_t *>(info.ptr) + first * info.srcBytes;
+    const uint8_t *base = static_cast<const uint8_t *>(info.ptr);
+    // Gather the owned strips (ascending rows) into one packed block of `srcBytes` per pixel.
+    auto gather = [&](void *out, hipMemcpyKind kind, const void *srcBase, size_t srcPixelBytes) {
+        size_t o = 0;
+        if (dev->stripCount <= 1) {
+            const size_t first = (size_t)dev->tileY0 * w;
+            HIP_CHECK(hipMemcpyAsync(out, static_cast<const uint8_t *>(srcBase) + first * srcPixelBytes, px * srcPixelBytes, kind, dev->stream));
+            return;
+        }
+        // strips are equally spaced: one 2-D copy for the full strips, one more for a ragged last strip
+        const size_t stripBytes = 16 * w * srcPixelBytes, pitch = (size_t)dev->stripCount * stripBytes;
+        const int firstRow = dev->tileY0 + dev->stripRank * 16;
+        if (firstRow >= dev->tileY1) return;
+        const size_t fullStrips = (size_t)((dev->tileY1 - firstRow) / (dev->stripCount * 16)) + (((dev->tileY1 - firstRow) % (dev->stripCount * 16)) >= 16 ? 1 : 0);
+        const uint8_t *src = static_cast<const uint8_t *>(srcBase) + (size_t)firstRow * w * srcPixelBytes;
+        if (fullStrips) { HIP_CHECK(hipMemcpy2DAsync(out, stripBytes, src, pitch, stripBytes, fullStrips, kind, dev->stream)); o = fullStrips * stripBytes; }
+        const int lastRow = firstRow + (int)fullStrips * dev->stripCount * 16;
+        if (lastRow < dev->tileY1) {
+            const size_t rem = (size_t)(dev->tileY1 - lastRow) * w * srcPixelBytes;
+            HIP_CHECK(hipMemcpyAsync(static_cast<uint8_t *>(out) + o, src + fullStrips * pitch, rem, kind, dev->stream));
+        }
+    };
     if (toDevice) {
-        if (info.kind != 0) throw std::runtime_error("RT64_CopyDeviceImage: only images stored in their API element type can be copied device-to-device.");
-        HIP_CHECK(hipMemcpyAsync(dst, src, need, hipMemcpyDeviceToDevice, dev->stream));
+        if (info.kind != 0 || image == RT64_IMAGE_PRIMARY_HIT) throw std::runtime_error("RT64_CopyDeviceImage: only images stored in their API element type can be copied device-to-device.");
+        gather(dst, hipMemcpyDeviceToDevice, base, (size_t)info.srcBytes);
         HIP_CHECK(hipStreamSynchronize(dev->stream));
         return need;
     }
-    if (info.kind == 0 && image != RT64_IMAGE_PRIMARY_HIT) { HIP_CHECK(hipMemcpy(dst, src, need, hipMemcpyDeviceToHost)); return need; }
+    if (info.kind == 0 && image != RT64_IMAGE_PRIMARY_HIT) { gather(dst, hipMemcpyDeviceToHost, base, (size_t)info.srcBytes); HIP_CHECK(hipStreamSynchronize(dev->stream)); return need; }
     std::vector<uint8_t> tmp(px * info.srcBytes);
-    HIP_CHECK(hipMemcpy(tmp.data(), src, tmp.size(), hipMemcpyDeviceToHost));
+    gather(tmp.data(), hipMemcpyDeviceToHost, base, (size_t)info.srcBytes);
+    HIP_CHECK(hipStreamSynchronize(dev->stream));
     if (image == RT64_IMAGE_PRIMARY_HIT) {
         std::vector<int32_t> inst(px);
-        HIP_CHECK(hipMemcpy(inst.data(), v->hitInstance.ptr + first, px * 4, hipMemcpyDeviceToHost));
+        gather(inst.data(), hipMemcpyDeviceToHost, v->hitInstance.ptr, 4);
+        HIP_CHECK(hipStreamSynchronize(dev->stream));
         const uint32_t *s = reinterpret_cast<const uint32_t *>(tmp.data()); uint32_t *d = static_cast<uint32_t *>(dst);
         for (size_t i = 0; i < px; i++) {
             d[4 * i] = s[4 * i]; d[4 * i + 1] = s[4 * i + 1]; d[4 * i + 2] = s[4 * i + 2];
@@ -834,6 +869,10 @@ RT64_EXPORT void RT64_SetDeviceSize(RT64_DEVICE *device, int width, int height) 
 RT64_EXPORT void RT64_SetDeviceTile(RT64_DEVICE *device, int y0, int y1) {
     Device *d = reinterpret_cast<Device *>(device); if (!d) return;
     if (y0 < 0 || y1 <= y0) { d->tileSet = false; d->tileY0 = 0; d->tileY1 = d->height; } else { d->tileSet = true; d->tileY0 = y0; d->tileY1 = y1; }
+}
+RT64_EXPORT void RT64_SetDeviceInterleave(RT64_DEVICE *device, int rank, int count) {
+    Device *d = reinterpret_cast<Device *>(device); if (!d) return;
+    if (count <= 1 || rank < 0 || rank >= count) { d->stripRank = 0; d->stripCount = 1; } else { d->stripRank = rank; d->stripCount = count; }
 }
 RT64_EXPORT size_t RT64_ReadbackDevice(RT64_DEVICE *device, int image, void *dst, size_t dstBytes) {
     RT64_TRY if (!device || !dst) throw std::runtime_error("RT64_ReadbackDevice: NULL argument."); return readback(reinterpret_cast<Device *>(device), image, dst, dstBytes, false); RT64_CATCH(0)

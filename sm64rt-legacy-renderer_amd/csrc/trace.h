@@ -147,10 +147,13 @@ DEV void trace_ray(const FrameParams &P, const float o[3], const float d[3], flo
 }
 
 // Wave-level add of the per-lane traversal counters into the frame counters (only when instrumentation is on).
-DEV void flush_counts(const FrameParams &P, const TraceCounts &c) {
+DEV void flush_counts(const FrameParams &P, const TraceCounts &c, int pass) {
     if (!P.countTraversal) return;
     unsigned long long n = c.nodes, t = c.tris;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { n += __shfl_down(n, d, 64); t += __shfl_down(t, d, 64); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&P.counters[CTR_NODES], n); atomicAdd(&P.counters[CTR_TRIS], t); }
+    if ((threadIdx.x & 63) == 0 && (n | t)) {
+        atomicAdd(&P.counters[CTR_NODES], n); atomicAdd(&P.counters[CTR_TRIS], t);
+        atomicAdd(&P.counters[CTR_PASS_BASE + 2 * pass], n); atomicAdd(&P.counters[CTR_PASS_BASE + 2 * pass + 1], t);
+    }
 }

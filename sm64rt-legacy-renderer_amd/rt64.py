@@ -125,7 +125,11 @@ class FRAME_STATS(C.Structure):
                 ("msIndirect", C.c_float), ("msReflectRefract", C.c_float), ("msDenoise", C.c_float), ("msComposePost", C.c_float),
                 ("msHostWall", C.c_float),
                 ("blasNodeBytes", C.c_uint), ("blasTriangleBytes", C.c_uint), ("tlasNodeBytes", C.c_uint),
-                ("instanceCount", C.c_uint), ("triangleCount", C.c_uint)]
+                ("instanceCount", C.c_uint), ("triangleCount", C.c_uint),
+                ("msPrimaryTrace", C.c_float), ("msPrimaryShade", C.c_float),
+                ("stripRank", C.c_uint), ("stripCount", C.c_uint), ("rowsRendered", C.c_uint), ("reserved0", C.c_uint),
+                ("nodesPrimary", C.c_ulonglong), ("trianglesPrimary", C.c_ulonglong), ("nodesDirect", C.c_ulonglong),
+                ("trianglesDirect", C.c_ulonglong), ("nodesIndirect", C.c_ulonglong), ("trianglesIndirect", C.c_ulonglong)]
 
 
 assert C.sizeof(MATERIAL) == 132 and C.sizeof(LIGHT) == 60 and C.sizeof(SCENE_DESC) == 84
@@ -173,6 +177,7 @@ EXT_API = [
     ("CreateDeviceHeadless", "RT64_CreateDeviceHeadless", _P, [C.c_int, C.c_int, C.c_int]),
     ("SetDeviceSize", "RT64_SetDeviceSize", None, [_P, C.c_int, C.c_int]),
     ("SetDeviceTile", "RT64_SetDeviceTile", None, [_P, C.c_int, C.c_int]),
+    ("SetDeviceInterleave", "RT64_SetDeviceInterleave", None, [_P, C.c_int, C.c_int]),
     ("ReadbackDevice", "RT64_ReadbackDevice", C.c_size_t, [_P, C.c_int, _P, C.c_size_t]),
     ("CopyDeviceImage", "RT64_CopyDeviceImage", C.c_size_t, [_P, C.c_int, _P, C.c_size_t]),
     ("GetDeviceStats", "RT64_GetDeviceStats", C.c_int, [_P, C.POINTER(FRAME_STATS)]),

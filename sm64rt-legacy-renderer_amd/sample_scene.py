@@ -333,7 +333,7 @@ class Rt64Scene:
         dt, ch = rt64.IMAGE_FORMATS[image]
         st = rt64.FRAME_STATS(); st.structSize = C.sizeof(rt64.FRAME_STATS)
         self.lib.GetDeviceStats(self.device, C.byref(st))
-        rows = st.tileY1 - st.tileY0
+        rows = st.rowsRendered if st.rowsRendered else st.tileY1 - st.tileY0
         out = np.empty((rows, st.width, ch), dtype=dt)
         n = self.lib.ReadbackDevice(self.device, image, out.ctypes.data, out.nbytes)
         if n != out.nbytes:
@@ -344,6 +344,9 @@ class Rt64Scene:
         st = rt64.FRAME_STATS(); st.structSize = C.sizeof(rt64.FRAME_STATS)
         self.lib.GetDeviceStats(self.device, C.byref(st))
         return st
+
+    def set_interleave(self, rank, count):
+        self.lib.SetDeviceInterleave(self.device, rank, count)
 
     def option(self, key, value):
         return self.lib.SetDeviceOption(self.device, key.encode(), float(value))
