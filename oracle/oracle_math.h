@@ -36,7 +36,7 @@ static inline of3 v3cross(of3 a, of3 b) {
     return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 static inline float v3len(of3 a) { return sqrtf(v3dot(a, a)); }
-static inline of3 v3normalize(of3 a) { float l = v3len(a); return v3(a.x / l, a.y / l, a.z / l); }
+static inline of3 v3normalize(of3 a) { float inv = 1.0f / v3len(a); return v3(a.x * inv, a.y * inv, a.z * inv); }   /* HLSL normalize = v * rsqrt(dot); one IEEE divide */
 static inline of3 v3lerp(of3 a, of3 b, float t) { return v3add(a, v3scale(v3sub(b, a), t)); }   /* HLSL lerp: a + t*(b-a) */
 static inline float flerp(float a, float b, float t) { return a + t * (b - a); }
 static inline float fclampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }

@@ -145,7 +145,7 @@ static of2 sky_plane_uv(of2 uv, const om4 *viewI, of2 viewportSz, float yawOffse
     base.x /= SKYBOX_WIDTH;
     base.y = (SKYBOX_HEIGHT - base.y) / SKYBOX_HEIGHT;
     float ratioDivision = aspectRatio / (4.0f / 3.0f);
-    base.x += uv.x * 0.25f * ratioDivision;
+    base.x += uv.x * (0.25f * ratioDivision);     /* HLSL: uv.x * 0.25f * ratioDivision; the view-only factor is folded once per frame */
     base.y += uv.y * 0.25f;
     return base;
 }
@@ -222,7 +222,7 @@ of3 oshade_blue_noise(const OShadeCtx *c, uint32_t px, uint32_t py, uint32_t fra
     uint32_t f = frame % 64u;
     uint32_t bx = (f % 8u) * 64u + px % 64u, by = (f / 8u) * 64u + py % 64u;
     const uint8_t *p = c->blueNoise + ((size_t)by * 512u + bx) * 4u;
-    return v3((float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f);
+    return v3((float)p[0] * (1.0f / 255.0f), (float)p[1] * (1.0f / 255.0f), (float)p[2] * (1.0f / 255.0f));
 }
 
 /* ---- ray differentials, ref:shaders/Ray.hlsli:37-94 ---------------------------------------------------------- */

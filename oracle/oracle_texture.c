@@ -7,7 +7,7 @@
  * LOD bias 0 (ref:private/rt64_view.cpp:699-722); ray-gen static sampler LINEAR/WRAP (ref:rt64_device.cpp:958-973).
  *
  * Texture spec (shared contract with the HIP sampler; everything except log2f is bit-reproducible):
- *   T1 texel value = byte / 255.0f.
+ *   T1 texel value = byte * (1.0f / 255.0f)   (one multiply; 255 maps to exactly 1.0f).
  *   T2 LINEAR: x = u*w - 0.5f, x0 = floorf(x), fx = x - x0 (same for y); the four texels (x0|x0+1, y0|y0+1) addressed
  *      per axis by WRAP i mod w / MIRROR reflect with period 2w / CLAMP to [0, w-1];
  *      c = (c00 + fx*(c10 - c00)) + fy*((c01 + fx*(c11 - c01)) - (c00 + fx*(c10 - c00))).
@@ -199,7 +199,7 @@ static int address(int i, int n, int mode) {
 
 static void texel(const OTexture *t, int level, int x, int y, float out[4]) {
     const uint8_t *p = t->rgba[level] + ((size_t)y * t->w[level] + x) * 4;
-    for (int c = 0; c < 4; c++) out[c] = (float)p[c] / 255.0f;
+    for (int c = 0; c < 4; c++) out[c] = (float)p[c] * (1.0f / 255.0f);
 }
 
 void otex_sample_level(const OTexture *t, float u, float v, int level, int filter, int hAddr, int vAddr, float out[4]) {

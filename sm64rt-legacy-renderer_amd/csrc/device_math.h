@@ -35,7 +35,7 @@ HD f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 HD float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 HD f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 HD float len3(f3 a) { return sqrtf(dot3(a, a)); }
-HD f3 normalize3(f3 a) { float l = len3(a); return mk3(a.x / l, a.y / l, a.z / l); }
+HD f3 normalize3(f3 a) { float inv = 1.0f / len3(a); return mk3(a.x * inv, a.y * inv, a.z * inv); }   // HLSL normalize = v * rsqrt(dot); one IEEE divide
 HD float lerpf(float a, float b, float t) { return a + t * (b - a); }        // HLSL lerp
 HD f3 lerp3(f3 a, f3 b, float t) { return a + (b - a) * t; }
 HD float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }

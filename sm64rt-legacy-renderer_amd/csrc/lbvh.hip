@@ -14,6 +14,7 @@
 #include "device_math.h"
 
 #define LBVH_THREADS 1024
+#define LBVH_COUNTING_MAX 1024u
 
 namespace {
 
@@ -84,7 +85,7 @@ DEV int delta64(const uint32_t *key, const uint32_t *val, int n, int i, int j) {
 // LDS carve (uint32 words): keyA[n] valA[n] keyB[n] valB[n] parentLeaf[n] parentNode[n] counters[n] scratch[64]
 __global__ __launch_bounds__(LBVH_THREADS) void lbvh_small_kernel(LbvhArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const uint32_t n = a.n, tid = threadIdx.x;
+    const uint32_t n = a.n, tid = threadIdx.x, T = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6;
     uint32_t *keyA = lds, *valA = lds + n, *keyB = lds + 2 * n, *valB = lds + 3 * n;
     uint32_t *parentLeaf = lds + 4 * n, *parentNode = lds + 5 * n, *counters = lds + 6 * n, *scratch = lds + 7 * n;
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(LBVH_THREADS) void lbvh_small_kernel(LbvhArgs a) {
         __syncthreads();
         {
             uint32_t mn[3] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu }, mx[3] = { 0, 0, 0 };
-            for (uint32_t i = tid; i < n; i += LBVH_THREADS) {
+            for (uint32_t i = tid; i < n; i += T) {
                 Box b = leaf_box(a, i);
 #pragma unroll
                 for (int k = 0; k < 3; k++) { mn[k] = min(mn[k], float_to_ordered(b.mn[k])); mx[k] = max(mx[k], float_to_ordered(b.mx[k])); }
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(LBVH_THREADS) void lbvh_small_kernel(LbvhArgs a) {
             scale[k] = ext > 0.0f ? 1024.0f / ext : 0.0f;
         }
         // ---- Morton keys ---------------------------------------------------------------------------------------
-        for (uint32_t i = tid; i < n; i += LBVH_THREADS) {
+        for (uint32_t i = tid; i < n; i += T) {
             Box b = leaf_box(a, i);
             uint32_t q[3];
 #pragma unroll
@@ -127,9 +128,24 @@ __global__ __launch_bounds__(LBVH_THREADS) void lbvh_small_kernel(LbvhArgs a) {
             valA[i] = i;
         }
         __syncthreads();
-        // ---- G3: stable LSD radix sort on the 30 code bits, one bit per pass, staged in LDS ---------------------
+        // ---- G3: sort by (code, leaf) ----------------------------------------------------------------------------
+        // Small inputs: rank by counting.  Every lane reads the same keyA[j] (LDS broadcast), n*n/T compares per thread,
+        // no barriers inside -- 1-2 us for the few hundred leaves of a game mesh or the instances of a frame.
+        if (n <= LBVH_COUNTING_MAX) {
+            for (uint32_t i = tid; i < n; i += T) {
+                const uint32_t k = keyA[i];
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < n; j++) { const uint32_t kj = keyA[j]; rank += (kj < k || (kj == k && j < i)) ? 1u : 0u; }
+                keyB[rank] = k; valB[rank] = i;
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += T) { keyA[i] = keyB[i]; valA[i] = valB[i]; }
+            __syncthreads();
+        }
+        else {
+        // Larger inputs: stable LSD radix sort on the 30 code bits, one bit per pass, staged in LDS.
         // Blocked arrangement: thread t owns items [t*ipt, (t+1)*ipt), so rank order == index order (stable).
-        const uint32_t ipt = (n + LBVH_THREADS - 1) / LBVH_THREADS;
+        const uint32_t ipt = (n + T - 1) / T;
         const uint32_t first = min(tid * ipt, n), last = min(first + ipt, n);
         uint32_t *ksrc = keyA, *vsrc = valA, *kdst = keyB, *vdst = valB;
         for (int bit = 0; bit < 30; bit++) {
@@ -139,9 +155,9 @@ __global__ __launch_bounds__(LBVH_THREADS) void lbvh_small_kernel(LbvhArgs a) {
             if (lane == 63) scratch[8 + wave] = incl;
             __syncthreads();
             if (wave == 0) {
-                uint32_t v = lane < (LBVH_THREADS / 64) ? scratch[8 + lane] : 0u;
+                uint32_t v = lane < (T / 64) ? scratch[8 + lane] : 0u;
                 uint32_t s = wave_inclusive_scan(v, lane);
-                if (lane < (LBVH_THREADS / 64)) scratch[8 + lane] = s - v;
+                if (lane < (T / 64)) scratch[8 + lane] = s - v;
                 if (lane == 63) scratch[24] = s;
             }
             __syncthreads();
@@ -159,10 +175,11 @@ __global__ __launch_bounds__(LBVH_THREADS) void lbvh_small_kernel(LbvhArgs a) {
             __syncthreads();
         }
         if (ksrc != keyA) {   // uniform: every thread took the same branches
-            for (uint32_t i = tid; i < n; i += LBVH_THREADS) { keyA[i] = keyB[i]; valA[i] = valB[i]; }
+            for (uint32_t i = tid; i < n; i += T) { keyA[i] = keyB[i]; valA[i] = valB[i]; }
             __syncthreads();
         }
-        for (uint32_t s = tid; s < n; s += LBVH_THREADS) { a.sortedIndex[s] = valA[s]; a.morton[s] = keyA[s]; }
+        }
+        for (uint32_t s = tid; s < n; s += T) { a.sortedIndex[s] = valA[s]; a.morton[s] = keyA[s]; }
         // ---- G4: Karras radix tree -------------------------------------------------------------------------------
         if (n == 1) {
             if (tid == 0) { a.nodes[0].left = RT64_LEAF_BIT; a.nodes[0].right = RT64_NO_CHILD; a.nodes[0].parent = RT64_NO_CHILD; a.nodes[0].pad = 0; parentLeaf[0] = 0; a.leafParent[0] = 0; }
@@ -170,7 +187,7 @@ __global__ __launch_bounds__(LBVH_THREADS) void lbvh_small_kernel(LbvhArgs a) {
         else {
             if (tid == 0) { parentNode[0] = RT64_NO_CHILD; a.nodes[0].parent = RT64_NO_CHILD; }
             const int N = (int)n;
-            for (int i = (int)tid; i < N - 1; i += LBVH_THREADS) {
+            for (int i = (int)tid; i < N - 1; i += T) {
                 int d = (delta64(keyA, valA, N, i, i + 1) - delta64(keyA, valA, N, i, i - 1)) >= 0 ? 1 : -1;
                 int dmin = delta64(keyA, valA, N, i, i - d);
                 int lmax = 2;
@@ -199,14 +216,14 @@ __global__ __launch_bounds__(LBVH_THREADS) void lbvh_small_kernel(LbvhArgs a) {
     }
     else {
         // G6 refit: topology from the previous build (written by an earlier launch).
-        for (uint32_t s = tid; s < n; s += LBVH_THREADS) parentLeaf[s] = a.leafParent[s];
-        for (uint32_t i = tid; i + 1 < n; i += LBVH_THREADS) parentNode[i] = a.nodes[i].parent;
+        for (uint32_t s = tid; s < n; s += T) parentLeaf[s] = a.leafParent[s];
+        for (uint32_t i = tid; i + 1 < n; i += T) parentNode[i] = a.nodes[i].parent;
     }
-    for (uint32_t i = tid; i < n; i += LBVH_THREADS) counters[i] = 0;
+    for (uint32_t i = tid; i < n; i += T) counters[i] = 0;
     __syncthreads();   // also orders this workgroup's global child-link stores before the loads below (one CU, shared L1)
 
     // ---- G5: leaves in Morton order + bottom-up box fit ------------------------------------------------------------
-    for (uint32_t s = tid; s < n; s += LBVH_THREADS) {
+    for (uint32_t s = tid; s < n; s += T) {
         const uint32_t leaf = a.sortedIndex[s];
         Box b;
         if (a.mode == LBVH_MODE_TRIANGLES) {
@@ -268,7 +285,8 @@ hipError_t lbvh_launch(const LbvhArgs &args, hipStream_t stream) {
             if (e != hipSuccess) return e;
             attrSet = true;
         }
-        hipLaunchKernelGGL(lbvh_small_kernel, dim3(1), dim3(LBVH_THREADS), lds, stream, args);
+        const uint32_t threads = args.n >= LBVH_THREADS ? LBVH_THREADS : ((args.n + 63u) / 64u) * 64u;
+        hipLaunchKernelGGL(lbvh_small_kernel, dim3(1), dim3(threads), lds, stream, args);
         return hipGetLastError();
     }
     return lbvh_launch_large(args, stream);

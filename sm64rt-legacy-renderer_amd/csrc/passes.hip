@@ -79,7 +79,11 @@ DEV void trace_surface(const FrameParams &P, ShadeEnv &env, f3 o, f3 d, SurfaceH
 
 __global__ __launch_bounds__(RT_BLOCK) void primary_trace_kernel(FrameParams P, ViewImages I, int32_t *hitInstance) {
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
+    __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
+    __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
+    env.lightIntensity = ldsLightIntensity + threadIdx.x; env.lightIndex = ldsLightIndex + threadIdx.x;
+    env.lightIntensity = nullptr; env.lightIndex = nullptr;
     uint32_t rays = 0;
     const uint32_t tiles = tile_count(P);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
@@ -101,9 +105,15 @@ __global__ __launch_bounds__(RT_BLOCK) void primary_trace_kernel(FrameParams P, 
 
 // ---- PrimaryRayGen resolve + G-buffer -------------------------------------------------------------------------------------
 
+// TRANSPARENT_LIGHT: some instance is not provably opaque, so the 'transparent geometry that needs lighting' path of
+// PrimaryRayGen.hlsl:136-148 (one random light + shadow ray from inside the resolve loop) can be reached.
+template <bool TRANSPARENT_LIGHT>
 __global__ __launch_bounds__(RT_BLOCK) void primary_shade_kernel(FrameParams P, ViewImages I, const int32_t *hitInstance, int cur) {
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
+    __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
+    __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
+    env.lightIntensity = ldsLightIntensity + threadIdx.x; env.lightIndex = ldsLightIndex + threadIdx.x;
     const uint32_t tiles = tile_count(P);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         Pixel p = tile_pixel(P, tile);
@@ -172,7 +182,7 @@ __global__ __launch_bounds__(RT_BLOCK) void primary_shade_kernel(FrameParams P, 
                     storeHit = true;
                     resColor.x += resColorAdd.x; resColor.y += resColorAdd.y; resColor.z += resColorAdd.z;
                 }
-                else if (usesLighting) {
+                else if (TRANSPARENT_LIGHT && usesLighting) {
                     if (!resTransparentLightComputed) {
                         resTransparentLight = compute_lights_random(P, env, px, py, rayDirection, instanceId, vertexPosition, vertexNormal, specular, 1, true);
                         resTransparentLightComputed = true;
@@ -237,7 +247,10 @@ DEV float history_weight(const FrameParams &P, const ViewImages &I, size_t i, ui
 
 __global__ __launch_bounds__(RT_BLOCK) void direct_kernel(FrameParams P, ViewImages I, int cur) {
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
+    __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
+    __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
+    env.lightIntensity = ldsLightIntensity + threadIdx.x; env.lightIndex = ldsLightIndex + threadIdx.x;
     const uint32_t tiles = tile_count(P);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         Pixel p = tile_pixel(P, tile);
@@ -245,7 +258,7 @@ __global__ __launch_bounds__(RT_BLOCK) void direct_kernel(FrameParams P, ViewIma
         const uint32_t px = p.x, py = p.y;
         const size_t i = (size_t)py * (size_t)P.width + px;
         const int instanceId = I.instanceId[i];
-        if (instanceId < 0) { store_rgba16f(I.directLight[cur], i, 1.0f, 1.0f, 1.0f, 0.0f); continue; }
+        if (instanceId < 0) { store_rgba16f(I.directLight[cur], i, 1.0f, 1.0f, 1.0f, 0.0f); store_rgba16f(I.filteredDirect[1], i, 1.0f, 1.0f, 1.0f, 0.0f); continue; }
         f3 o, rayDirection; f2 ndc;
         primary_ray(P, px, py, o, rayDirection, ndc);
         const float4 pos4 = reinterpret_cast<const float4 *>(I.shadingPosition)[i];
@@ -267,6 +280,7 @@ __global__ __launch_bounds__(RT_BLOCK) void direct_kernel(FrameParams P, ViewIma
         historyLength = fminf(historyLength + 1.0f, 64.0f);
         newDirect = lerp3(newDirect, resDirect, 1.0f / historyLength);
         store_rgba16f(I.directLight[cur], i, newDirect.x, newDirect.y, newDirect.z, historyLength);
+        store_rgba16f(I.filteredDirect[1], i, newDirect.x, newDirect.y, newDirect.z, historyLength);
     }
     flush_env(P, env, PASS_DIRECT, CTR_PRIMARY, 0);
 }
@@ -281,9 +295,12 @@ DEV bool bounce_record(const FrameParams &P, ShadeEnv &env, f3 origin, f3 dir, u
     return surface_anyhit(P, h.instance, h.prim, h.t, h.u, h.v, dir, rd, px, py, r);
 }
 
-__global__ __launch_bounds__(RT_BLOCK) void indirect_kernel(FrameParams P, ViewImages I, int cur) {
+__global__ __launch_bounds__(RT_BLOCK) void indirect_kernel(FrameParams P, ViewImages I, int cur, int writeFiltered) {
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
+    __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
+    __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
+    env.lightIntensity = ldsLightIntensity + threadIdx.x; env.lightIndex = ldsLightIndex + threadIdx.x;
     uint32_t rays = 0;
     const f3 ambientBase = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]);
     const f3 ambient = ambientBase + mk3(P.ambientNoGIColor[0], P.ambientNoGIColor[1], P.ambientNoGIColor[2]);
@@ -294,7 +311,11 @@ __global__ __launch_bounds__(RT_BLOCK) void indirect_kernel(FrameParams P, ViewI
         const uint32_t px = p.x, py = p.y;
         const size_t i = (size_t)py * (size_t)P.width + px;
         const int instanceId = I.instanceId[i];
-        if (!(instanceId >= 0 && P.giSamples > 0)) { store_rgba16f(I.indirectLight[cur], i, ambient.x, ambient.y, ambient.z, 0.0f); continue; }
+        if (!(instanceId >= 0 && P.giSamples > 0)) {
+            store_rgba16f(I.indirectLight[cur], i, ambient.x, ambient.y, ambient.z, 0.0f);
+            if (writeFiltered) store_rgba16f(I.filteredIndirect[1], i, ambient.x, ambient.y, ambient.z, 0.0f);
+            continue;
+        }
         const float4 pos4 = reinterpret_cast<const float4 *>(I.shadingPosition)[i];
         f3 rayOrigin = mk3(pos4.x, pos4.y, pos4.z), shadingNormal = xyz(load_rgba16f(I.shadingNormal, i));
         f3 newIndirect = mk3s(0.0f); float historyLength = 0.0f;
@@ -337,6 +358,7 @@ __global__ __launch_bounds__(RT_BLOCK) void indirect_kernel(FrameParams P, ViewI
             maxSamples--;
         }
         store_rgba16f(I.indirectLight[cur], i, newIndirect.x, newIndirect.y, newIndirect.z, historyLength);
+        if (writeFiltered) store_rgba16f(I.filteredIndirect[1], i, newIndirect.x, newIndirect.y, newIndirect.z, historyLength);
     }
     flush_env(P, env, PASS_INDIRECT, CTR_INDIRECT, rays);
 }
@@ -350,7 +372,10 @@ DEV f3 hlsl_refract(f3 i, f3 n, float eta) {
 
 __global__ __launch_bounds__(RT_BLOCK) void refraction_kernel(FrameParams P, ViewImages I) {
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
+    __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
+    __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
+    env.lightIntensity = ldsLightIntensity + threadIdx.x; env.lightIndex = ldsLightIndex + threadIdx.x;
     uint32_t rays = 0;
     const f3 ambient = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]) + mk3(P.ambientNoGIColor[0], P.ambientNoGIColor[1], P.ambientNoGIColor[2]);
     const uint32_t tiles = tile_count(P);
@@ -407,7 +432,10 @@ __global__ __launch_bounds__(RT_BLOCK) void refraction_kernel(FrameParams P, Vie
 
 __global__ __launch_bounds__(RT_BLOCK) void reflection_kernel(FrameParams P, ViewImages I) {
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
+    __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
+    __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
+    env.lightIntensity = ldsLightIntensity + threadIdx.x; env.lightIndex = ldsLightIndex + threadIdx.x;
     uint32_t rays = 0;
     const f3 ambient = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]) + mk3(P.ambientNoGIColor[0], P.ambientNoGIColor[1], P.ambientNoGIColor[2]);
     const uint32_t tiles = tile_count(P);
@@ -540,6 +568,16 @@ __global__ __launch_bounds__(256) void compose_post_kernel(FrameParams P, ViewIm
     store_rgba8(I.final, i, result.x, result.y, result.z, 1.0f);   // PostProcessPS passthrough (motionBlurStrength == 0, render size == screen size)
 }
 
+// IndirectRayGen with giSamples == 0 (IndirectRayGen.hlsl:135): every pixel gets ambientBase + ambientNoGI, history 0.
+__global__ __launch_bounds__(256) void indirect_constant_kernel(FrameParams P, ViewImages I, int cur) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = P.tileY0 + blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= P.width || y >= P.tileY1 || !row_owned(P, y)) return;
+    const size_t i = (size_t)y * (size_t)P.width + x;
+    const float r = P.ambientBaseColor[0] + P.ambientNoGIColor[0], g = P.ambientBaseColor[1] + P.ambientNoGIColor[1], b = P.ambientBaseColor[2] + P.ambientNoGIColor[2];
+    store_rgba16f(I.indirectLight[cur], i, r, g, b, 0.0f);
+    store_rgba16f(I.filteredIndirect[1], i, r, g, b, 0.0f);
+}
+
 __global__ __launch_bounds__(256) void clear_final_kernel(FrameParams P, ViewImages I) {
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = P.tileY0 + blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= P.width || y >= P.tileY1 || !row_owned(P, y)) return;
@@ -553,9 +591,17 @@ size_t rt_stack_spill_bytes() { return (size_t)RT_GRID_BLOCKS * RT_BLOCK * RT_ST
 #define LAUNCH_RAY(kernel, ...) do { hipLaunchKernelGGL(kernel, dim3(RT_GRID_BLOCKS), dim3(RT_BLOCK), 0, s, __VA_ARGS__); return hipGetLastError(); } while (0)
 
 hipError_t launch_primary_trace(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, hipStream_t s) { LAUNCH_RAY(primary_trace_kernel, P, I, hitInstance); }
-hipError_t launch_primary_shade(const FrameParams &P, const ViewImages &I, const int32_t *hitInstance, int cur, hipStream_t s) { LAUNCH_RAY(primary_shade_kernel, P, I, hitInstance, cur); }
+hipError_t launch_primary_shade(const FrameParams &P, const ViewImages &I, const int32_t *hitInstance, int cur, bool transparentLighting, hipStream_t s) {
+    if (transparentLighting) LAUNCH_RAY(primary_shade_kernel<true>, P, I, hitInstance, cur);
+    LAUNCH_RAY(primary_shade_kernel<false>, P, I, hitInstance, cur);
+}
 hipError_t launch_direct(const FrameParams &P, const ViewImages &I, int cur, hipStream_t s) { LAUNCH_RAY(direct_kernel, P, I, cur); }
-hipError_t launch_indirect(const FrameParams &P, const ViewImages &I, int cur, hipStream_t s) { LAUNCH_RAY(indirect_kernel, P, I, cur); }
+hipError_t launch_indirect(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, hipStream_t s) { LAUNCH_RAY(indirect_kernel, P, I, cur, writeFiltered ? 1 : 0); }
+hipError_t launch_indirect_constant(const FrameParams &P, const ViewImages &I, int cur, hipStream_t s) {
+    dim3 grid((unsigned)(P.width + 31) / 32, (unsigned)(P.tileY1 - P.tileY0 + 7) / 8);
+    hipLaunchKernelGGL(indirect_constant_kernel, grid, dim3(256), 0, s, P, I, cur);
+    return hipGetLastError();
+}
 hipError_t launch_refraction(const FrameParams &P, const ViewImages &I, hipStream_t s) { LAUNCH_RAY(refraction_kernel, P, I); }
 hipError_t launch_reflection(const FrameParams &P, const ViewImages &I, hipStream_t s) { LAUNCH_RAY(reflection_kernel, P, I); }
 

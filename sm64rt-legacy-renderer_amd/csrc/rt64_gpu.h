@@ -96,6 +96,7 @@ struct FrameParams {
     int32_t tileY0, tileY1;              // row range owned by this device
     int32_t stripRank, stripCount;       // interleaved 16-row strips inside the range (count 1 = all)
     float maxDepthBias;
+    float skyBase[4];                    // ComputeSkyPlaneUV: base u, base v, 0.25 * ratioDivision, 0.25
     uint32_t lightCount, instanceCount, countTraversal;
     const GpuInstance *instances;
     const GpuNode *tlasNodes;

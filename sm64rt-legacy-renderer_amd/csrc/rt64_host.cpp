@@ -244,6 +244,7 @@ struct View {
     DevArray<GpuInstance> dInstances; DevArray<GpuTexture> dTextures; DevArray<RT64_LIGHT> dLights;
     DevArray<GpuNode> tlasNodes; DevArray<uint32_t> tlasIndex, tlasMorton, tlasLeafParent; DevArray<BlasHeader> tlasHeader; DevArray<uint8_t> tlasScratch;
     float maxDepthBias = 0.0f;
+    bool anyNonOpaque = false, anyReflection = false, anyRefraction = false;
 
     explicit View(Scene *s);
     ~View();
@@ -533,6 +534,7 @@ void View::update() {                          // View::update, rt64_view.cpp:10
     GpuTexture *hTex = reinterpret_cast<GpuTexture *>(stage + instBytes);
     RT64_LIGHT *hLights = reinterpret_cast<RT64_LIGHT *>(stage + instBytes + texBytes);
     maxDepthBias = nInst ? -INFINITY : 0.0f;
+    anyNonOpaque = anyReflection = anyRefraction = false;
     for (size_t i = 0; i < nInst; i++) {
         Instance *inst = rtInstances[i].instance;
         GpuInstance &g = hInst[i];
@@ -562,6 +564,9 @@ void View::update() {                          // View::update, rt64_view.cpp:10
         g.triCount = mesh->blasCount;
         if (g.cc.vertexSize > mesh->vertexStride) throw std::runtime_error("Instance mesh vertex stride is smaller than the layout its shader reads.");
         maxDepthBias = std::max(maxDepthBias, inst->material.depthBias);
+        if (!(g.flags & GPU_INST_OPAQUE)) anyNonOpaque = true;
+        if (inst->material.reflectionFactor > 1e-6f) anyReflection = true;       // the passes below are no-ops otherwise
+        if (inst->material.refractionFactor > 1e-6f) anyRefraction = true;
     }
     for (size_t i = 0; i < nTex; i++) {
         Texture *t = usedTextures[i];
@@ -632,6 +637,25 @@ void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64
     P.visualizationMode = 0;
     P.width = imgW; P.height = imgH; P.tileY0 = dev->tileY0; P.tileY1 = dev->tileY1; P.stripRank = dev->stripRank; P.stripCount = dev->stripCount;
     P.maxDepthBias = maxDepthBias;
+    {   // ComputeSkyPlaneUV (BgSky.hlsli:20-52): the view-only part, once per frame
+        const float SCREEN_WIDTH = 320.0f, SCREEN_HEIGHT = 240.0f, SKYBOX_WIDTH = 4.0f * SCREEN_WIDTH, SKYBOX_HEIGHT = 4.0f * SCREEN_HEIGHT, PI = 3.14159265f, TWO_PI = PI * 2.0f;
+        V3 vd = mat_vector(viewI, v3(0, 0, 1)); { float inv = 1.0f / vlen(vd); vd = v3(vd.x * inv, vd.y * inv, vd.z * inv); }
+        auto hfmod = [](float x, float y) { return x - y * truncf(x / y); };
+        float skyYawRadians = hfmod(d.skyYawOffset + atan2f(vd.x, -vd.z) + PI, TWO_PI);
+        float baseX = SCREEN_WIDTH * 360.0f * (skyYawRadians - PI) / (90.0f * PI * 2.0f);
+        float skyPitchRadians = atan2f(-vd.y, sqrtf(vd.x * vd.x + vd.z * vd.z));
+        float pitchInDegrees = skyPitchRadians * 360.0f / (PI * 2.0f);
+        float degreesToScale = 360.0f * pitchInDegrees / 90.0f;
+        float baseY = degreesToScale + 5.0f * (SCREEN_HEIGHT / 2.0f);
+        baseY = std::min(std::max(baseY, SCREEN_HEIGHT), SKYBOX_HEIGHT);
+        float aspectRatio = P.viewport[2] / P.viewport[3];
+        baseX += SCREEN_WIDTH / 2.0f;
+        baseX -= (SCREEN_HEIGHT * aspectRatio) / 2.0f;
+        baseX /= SKYBOX_WIDTH;
+        baseY = (SKYBOX_HEIGHT - baseY) / SKYBOX_HEIGHT;
+        float ratioDivision = aspectRatio / (4.0f / 3.0f);
+        P.skyBase[0] = baseX; P.skyBase[1] = baseY; P.skyBase[2] = 0.25f * ratioDivision; P.skyBase[3] = 0.25f;
+    }
     P.lightCount = (uint32_t)scene->lights.size(); P.instanceCount = (uint32_t)rtInstances.size();
     P.countTraversal = dev->opt.countTraversal ? 1u : 0u;
     P.instances = dInstances.ptr; P.tlasNodes = tlasNodes.ptr; P.tlasIndex = tlasIndex.ptr; P.textures = dTextures.ptr; P.lights = dLights.ptr;
@@ -652,21 +676,21 @@ void View::render() {                          // View::render, rt64_view.cpp:11
     if (!rtInstances.empty()) {
         HIP_CHECK(launch_primary_trace(P, img, hitInstance.ptr, s));
         mark(Device::EV_PRIMARY_TRACE);
-        HIP_CHECK(launch_primary_shade(P, img, hitInstance.ptr, cur, s));
+        HIP_CHECK(launch_primary_shade(P, img, hitInstance.ptr, cur, anyNonOpaque, s));
         mark(Device::EV_PRIMARY);
+        // DirectRayGen also writes the "filtered" copy: DI denoising is compiled out in the reference (rt64_view.cpp:1438-1463),
+        // so rtFilteredDirectLight[1] is always a plain copy of the raw accumulation.
         HIP_CHECK(launch_direct(P, img, cur, s));
         mark(Device::EV_DIRECT);
-        HIP_CHECK(launch_indirect(P, img, cur, s));
-        mark(Device::EV_INDIRECT);
-        HIP_CHECK(launch_refraction(P, img, s));
-        for (int r = 0; r < dev->opt.maxReflections; r++) HIP_CHECK(launch_reflection(P, img, s));
-        mark(Device::EV_REFL);
-        // raw -> filtered copies (rt64_view.cpp:1438-1509); DI denoising is compiled out, so direct goes to index 1
-        const size_t rowBytes = (size_t)imgW * 8, off = (size_t)dev->tileY0 * rowBytes, bytes = (size_t)(dev->tileY1 - dev->tileY0) * rowBytes;
-        HIP_CHECK(hipMemcpyAsync(reinterpret_cast<uint8_t *>(img.filteredDirect[1]) + off, reinterpret_cast<uint8_t *>(img.directLight[cur]) + off, bytes, hipMemcpyDeviceToDevice, s));
         const bool denoiseGI = denoiserEnabled && giSamples > 0;
-        if (!denoiseGI) HIP_CHECK(hipMemcpyAsync(reinterpret_cast<uint8_t *>(img.filteredIndirect[1]) + off, reinterpret_cast<uint8_t *>(img.indirectLight[cur]) + off, bytes, hipMemcpyDeviceToDevice, s));
-        else {
+        if (giSamples == 0) HIP_CHECK(launch_indirect_constant(P, img, cur, s));      // IndirectRayGen.hlsl:135: constant ambient
+        else HIP_CHECK(launch_indirect(P, img, cur, !denoiseGI, s));
+        mark(Device::EV_INDIRECT);
+        // Refraction / reflection touch only pixels whose primary hit has a refraction / reflection factor (alpha > EPSILON).
+        if (anyRefraction) HIP_CHECK(launch_refraction(P, img, s));
+        if (anyReflection) for (int r = 0; r < dev->opt.maxReflections; r++) HIP_CHECK(launch_reflection(P, img, s));
+        mark(Device::EV_REFL);
+        if (denoiseGI) {
             HIP_CHECK(hipMemcpyAsync(img.filteredIndirect[0], img.indirectLight[cur], n * 8, hipMemcpyDeviceToDevice, s));
             for (int k = 0; k < 5; k++)            // rt64_view.cpp:1512-1530
                 HIP_CHECK(launch_gaussian(img.filteredIndirect[k % 2], img.filteredIndirect[(k % 2) ^ 1], imgW, imgH, 0, imgH, s));

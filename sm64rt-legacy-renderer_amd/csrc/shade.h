@@ -23,7 +23,8 @@ DEV int tex_address(int i, int n, uint32_t mode) {
 DEV f4 tex_texel(const GpuTexture &t, uint32_t level, int x, int y, int w) {
     const uint32_t *base = reinterpret_cast<const uint32_t *>(t.texels) + t.mipOffset[level];
     uint32_t v = base[(size_t)y * (size_t)w + (size_t)x];
-    return mk4((float)(v & 0xFF) / 255.0f, (float)((v >> 8) & 0xFF) / 255.0f, (float)((v >> 16) & 0xFF) / 255.0f, (float)(v >> 24) / 255.0f);
+    const float k = 1.0f / 255.0f;
+    return mk4((float)(v & 0xFF) * k, (float)((v >> 8) & 0xFF) * k, (float)((v >> 16) & 0xFF) * k, (float)(v >> 24) * k);
 }
 
 DEV f4 tex_sample_level(const GpuTexture &t, float u, float v, uint32_t level, uint32_t filter, uint32_t hAddr, uint32_t vAddr) {
@@ -100,27 +101,13 @@ DEV f2 fake_envmap_uv(f3 d, float yawOffset) {                                  
     f2 r; r.x = yaw / RT_TWO_PI; r.y = pitch / RT_TWO_PI; return r;
 }
 
-DEV f2 sky_plane_uv(const FrameParams &P, f2 uv) {                              // BgSky.hlsli:20-52
-    const float SCREEN_WIDTH = 320.0f, SCREEN_HEIGHT = 240.0f;
-    const float SKYBOX_WIDTH = 4.0f * SCREEN_WIDTH, SKYBOX_HEIGHT = 4.0f * SCREEN_HEIGHT;
-    f2 base; base.x = 0.0f; base.y = 0.0f;
-    f3 vd = normalize3(mul_vector(P.viewI, mk3(0.0f, 0.0f, 1.0f)));
-    float skyYawRadians = hlsl_fmod(P.skyYawOffset + atan2f(vd.x, -vd.z) + RT_PI, RT_TWO_PI);
-    base.x = SCREEN_WIDTH * 360.0f * (skyYawRadians - RT_PI) / (90.0f * RT_PI * 2.0f);
-    float skyPitchRadians = atan2f(-vd.y, sqrtf(vd.x * vd.x + vd.z * vd.z));
-    float pitchInDegrees = skyPitchRadians * 360.0f / (RT_PI * 2.0f);
-    float degreesToScale = 360.0f * pitchInDegrees / 90.0f;
-    base.y = degreesToScale + 5.0f * (SCREEN_HEIGHT / 2.0f);
-    base.y = clampf(base.y, SCREEN_HEIGHT, SKYBOX_HEIGHT);
-    float aspectRatio = P.viewport[2] / P.viewport[3];
-    base.x += SCREEN_WIDTH / 2.0f;
-    base.x -= (SCREEN_HEIGHT * aspectRatio) / 2.0f;
-    base.x /= SKYBOX_WIDTH;
-    base.y = (SKYBOX_HEIGHT - base.y) / SKYBOX_HEIGHT;
-    float ratioDivision = aspectRatio / (4.0f / 3.0f);
-    base.x += uv.x * 0.25f * ratioDivision;
-    base.y += uv.y * 0.25f;
-    return base;
+// ComputeSkyPlaneUV, BgSky.hlsli:20-52.  Everything that depends only on the view (yaw, pitch, aspect) is evaluated once
+// per frame on the host (sky_plane_base in rt64_host.cpp: P.skyBase = {baseU, baseV, 0.25 * ratioDivision, 0.25}).
+DEV f2 sky_plane_uv(const FrameParams &P, f2 uv) {
+    f2 r;
+    r.x = P.skyBase[0] + uv.x * P.skyBase[2];
+    r.y = P.skyBase[1] + uv.y * P.skyBase[3];
+    return r;
 }
 
 DEV f4 sky_finish(const FrameParams &P, f4 tex) {
@@ -160,7 +147,8 @@ DEV f3 blue_noise(const FrameParams &P, uint32_t px, uint32_t py, uint32_t frame
     uint32_t f = frame % 64u;
     uint32_t bx = (f % 8u) * 64u + px % 64u, by = (f / 8u) * 64u + py % 64u;
     uint32_t v = reinterpret_cast<const uint32_t *>(P.blueNoise)[(size_t)by * 512u + bx];
-    return mk3((float)(v & 0xFF) / 255.0f, (float)((v >> 8) & 0xFF) / 255.0f, (float)((v >> 16) & 0xFF) / 255.0f);
+    const float k = 1.0f / 255.0f;
+    return mk3((float)(v & 0xFF) * k, (float)((v >> 8) & 0xFF) * k, (float)((v >> 16) & 0xFF) * k);
 }
 
 // ---- ray differentials, Ray.hlsli:37-94 ----------------------------------------------------------------------------
@@ -209,15 +197,19 @@ DEV void get_vertex_data(const GpuInstance &in, uint32_t prim, const float b[3],
         vd.vertexUV.x = vd.uv[0].x * b[0] + vd.uv[1].x * b[1] + vd.uv[2].x * b[2];
         vd.vertexUV.y = vd.uv[0].y * b[0] + vd.uv[1].y * b[1] + vd.uv[2].y * b[2];
     }
-    for (int i = 0; i < cc.inputCount; i++) {
-        float r[4];
-        const float *f0 = reinterpret_cast<const float *>(vp[0] + cc.inputOffset[i]);
-        const float *f1 = reinterpret_cast<const float *>(vp[1] + cc.inputOffset[i]);
-        const float *f2p = reinterpret_cast<const float *>(vp[2] + cc.inputOffset[i]);
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++) r[ch] = f0[ch] * b[0] + f1[ch] * b[1] + f2p[ch] * b[2];
-        r[3] = cc.optAlpha ? (f0[3] * b[0] + f1[3] * b[1] + f2p[3] * b[2]) : 1.0f;
-        vd.input[i] = mk4(r[0], r[1], r[2], r[3]);
+    for (int i = 0; i < 4; i++) {          // fully unrolled + predicated: keeps VertexData in registers (no dynamic indexing)
+        if (i < cc.inputCount) {
+            float r[4];
+            const float *f0 = reinterpret_cast<const float *>(vp[0] + cc.inputOffset[i]);
+            const float *f1 = reinterpret_cast<const float *>(vp[1] + cc.inputOffset[i]);
+            const float *f2p = reinterpret_cast<const float *>(vp[2] + cc.inputOffset[i]);
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) r[ch] = f0[ch] * b[0] + f1[ch] * b[1] + f2p[ch] * b[2];
+            r[3] = cc.optAlpha ? (f0[3] * b[0] + f1[3] * b[1] + f2p[3] * b[2]) : 1.0f;
+            vd.input[i] = mk4(r[0], r[1], r[2], r[3]);
+        }
+        else vd.input[i] = mk4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     if (wantTangent) {                                                          // :201-225
         float uva = vd.uv[1].x - vd.uv[0].x, uvb = vd.uv[2].x - vd.uv[0].x;
@@ -238,12 +230,23 @@ DEV void get_vertex_data(const GpuInstance &in, uint32_t prim, const float b[3],
     }
 }
 
+DEV f4 pick_input(const VertexData &vd, int item) {      // vd.input[item - 1] without a dynamically indexed array
+    // component-wise value selects (a ?: over the struct lvalues would become a pointer select and pin VertexData in scratch)
+    const f4 a = vd.input[0], b = vd.input[1], c = vd.input[2], d = vd.input[3];
+    f4 r;
+    r.x = item == 1 ? a.x : (item == 2 ? b.x : (item == 3 ? c.x : d.x));
+    r.y = item == 1 ? a.y : (item == 2 ? b.y : (item == 3 ? c.y : d.y));
+    r.z = item == 1 ? a.z : (item == 2 ? b.z : (item == 3 ? c.z : d.z));
+    r.w = item == 1 ? a.w : (item == 2 ? b.w : (item == 3 ? c.w : d.w));
+    return r;
+}
+
 DEV f4 color_input(int item, bool with_alpha, bool inputs_have_alpha, bool hint_single, const VertexData &vd, f4 t0, f4 t1) {   // :228-258
     f4 r;
     switch (item) {
     default: case 0: return mk4(0.0f, 0.0f, 0.0f, with_alpha ? 0.0f : 1.0f);
     case 1: case 2: case 3: case 4:
-        r = vd.input[item - 1];
+        r = pick_input(vd, item);
         if (!(with_alpha || !inputs_have_alpha)) r.w = 1.0f;
         return r;
     case 5: r = t0; if (!with_alpha) r.w = 1.0f; return r;
@@ -272,7 +275,7 @@ DEV f4 color_formula(const GpuCombiner &cc, bool with_alpha, bool opt_alpha, con
 DEV float alpha_input(int item, const VertexData &vd, f4 t0, f4 t1) {            // :275-295
     switch (item) {
     default: case 0: return 0.0f;
-    case 1: case 2: case 3: case 4: return vd.input[item - 1].w;
+    case 1: case 2: case 3: case 4: return pick_input(vd, item).w;
     case 5: case 6: return t0.w;
     case 7: return t1.w;
     }
@@ -402,6 +405,8 @@ struct ShadeEnv {                // per-lane traversal resources handed down to 
     TraceStack stk;
     TraceCounts cnt;
     uint32_t shadowRays;
+    float *lightIntensity;       // LDS, [RT64_MAX_LIGHTS + 1][RT_BLOCK] (&array[threadIdx.x]): candidate intensities of ComputeLightsRandom
+    uint8_t *lightIndex;         // LDS, [RT64_MAX_LIGHTS + 1][RT_BLOCK]
 };
 
 DEV float trace_shadow(const FrameParams &P, ShadeEnv &env, f3 origin, f3 dir, float tmin, float tmax, uint32_t px, uint32_t py) {   // :27-52
@@ -472,11 +477,14 @@ DEV f3 compute_lights_random(const FrameParams &P, ShadeEnv &env, uint32_t px, u
     f3 result = mk3s(0.0f);
     const RT64_MATERIAL &m = P.instances[instanceId].material;
     if (m.lightGroupMaskBits == 0) return result;
-    uint32_t sCount = 0, sIdx[RT64_MAX_LIGHTS + 1]; float sInt[RT64_MAX_LIGHTS + 1], total = 0.0f;
+    // sLightIntensities / sLightIndices (Lights.hlsli:121-122) live in LDS, one column per lane: dynamically indexed
+    // per-lane arrays would otherwise go to scratch memory.
+    float *sInt = env.lightIntensity; uint8_t *sIdx = env.lightIndex;
+    uint32_t sCount = 0; float total = 0.0f;
     for (uint32_t l = 0; l < P.lightCount && sCount < RT64_MAX_LIGHTS; l++) {
         if (m.lightGroupMaskBits & P.lights[l].groupBits) {
             float li = light_intensity_simple(P.lights[l], position, normal, m.ignoreNormalFactor);
-            if (li > RT_EPSILON) { sInt[sCount] = li; sIdx[sCount] = l; total += li; sCount++; }
+            if (li > RT_EPSILON) { sInt[sCount * RT_BLOCK] = li; sIdx[sCount * RT_BLOCK] = (uint8_t)l; total += li; sCount++; }
         }
     }
     float randomRange = total;
@@ -484,11 +492,11 @@ DEV f3 compute_lights_random(const FrameParams &P, ShadeEnv &env, uint32_t px, u
     bool useProbability = lCount == 1;
     for (uint32_t s = 0; s < lCount; s++) {
         float r = blue_noise(P, px, py, P.frameCount + s).x * randomRange;
-        uint32_t chosen = 0; float rInt = sInt[chosen];
-        while (chosen < sCount - 1 && r >= rInt) { chosen++; rInt += sInt[chosen]; }
-        float cInt = sInt[chosen]; uint32_t cIdx = sIdx[chosen];
+        uint32_t chosen = 0; float rInt = sInt[0];
+        while (chosen < sCount - 1 && r >= rInt) { chosen++; rInt += sInt[chosen * RT_BLOCK]; }
+        float cInt = sInt[chosen * RT_BLOCK]; uint32_t cIdx = sIdx[chosen * RT_BLOCK];
         float invProbability = useProbability ? (randomRange / cInt) : 1.0f;
-        sInt[chosen] = 0.0f; randomRange -= cInt;
+        sInt[chosen * RT_BLOCK] = 0.0f; randomRange -= cInt;
         result = result + compute_light(P, env, px, py, cIdx, rayDirection, m, position, normal, specular, checkShadows) * invProbability;
     }
     return result;
