@@ -32,10 +32,31 @@ HD f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
 HD f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
 HD f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 HD f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+// Shading-side fast math (device only): v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 / v_exp_f32 / v_log_f32 are 1-ulp hardware ops.
+// The HLSL this path replaces compiles to the same class of approximate GPU instructions (pow = exp2(y * log2(x)),
+// normalize = v * rsqrt(dot)), so IEEE-exact libm results are not the specification here; the tests compare shading
+// with a tolerance.  Geometry code (trace.h, lbvh.hip) never uses these.
+#if defined(__HIP_DEVICE_COMPILE__)
+DEV float s_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+DEV float s_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+DEV float s_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+DEV float s_pow(float x, float y) { return y == 0.0f ? 1.0f : __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+#else
+HD float s_rcp(float x) { return 1.0f / x; }
+HD float s_rsqrt(float x) { return 1.0f / sqrtf(x); }
+HD float s_sqrt(float x) { return sqrtf(x); }
+HD float s_pow(float x, float y) { return powf(x, y); }
+#endif
+HD float s_div(float a, float b) { return a * s_rcp(b); }
+
 HD float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 HD f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-HD float len3(f3 a) { return sqrtf(dot3(a, a)); }
-HD f3 normalize3(f3 a) { float inv = 1.0f / len3(a); return mk3(a.x * inv, a.y * inv, a.z * inv); }   // HLSL normalize = v * rsqrt(dot); one IEEE divide
+HD float len3(f3 a) { return s_sqrt(dot3(a, a)); }
+HD f3 normalize3(f3 a) { float inv = s_rsqrt(dot3(a, a)); return mk3(a.x * inv, a.y * inv, a.z * inv); }   // HLSL normalize = v * rsqrt(dot)
+// IEEE-exact variants for values that define RAYS (shadow-ray direction / length): traversal decisions stay bit-identical
+// to the scalar reference tracer.
+HD float len3_exact(f3 a) { return sqrtf(dot3(a, a)); }
+HD f3 normalize3_exact(f3 a) { float inv = 1.0f / len3_exact(a); return mk3(a.x * inv, a.y * inv, a.z * inv); }
 HD float lerpf(float a, float b, float t) { return a + t * (b - a); }        // HLSL lerp
 HD f3 lerp3(f3 a, f3 b, float t) { return a + (b - a) * t; }
 HD float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(RT_BLOCK) void primary_shade_kernel(FrameParams P, 
                     f4 projPos = mul4(P.viewProj, mk4(vertexPosition.x, vertexPosition.y, vertexPosition.z, 1.0f));
                     resPosition = vertexPosition; resNormal = vertexNormal; resSpecular = specular; resInstanceId = (int)instanceId;
                     resFlowX = (curPos.x - prevPos.x) * (float)P.width; resFlowY = (curPos.y - prevPos.y) * (float)P.height;
-                    resDepth = projPos.z / projPos.w;
+                    resDepth = s_div(projPos.z, projPos.w);
                 }
             }
             if (resColor.w <= RT_EPSILON) break;
@@ -241,7 +241,7 @@ DEV float history_weight(const FrameParams &P, const ViewImages &I, size_t i, ui
         prevIndex = (long)j;
     }
     float weightDepth = fabsf(I.depth[cur][i] - prevDepth) / 0.01f;
-    float weightNormal = powf(fmaxf(0.0f, dot3(prevNormal, normal)), 128.0f);
+    float weightNormal = s_pow(fmaxf(0.0f, dot3(prevNormal, normal)), 128.0f);
     return expf(-weightDepth) * weightNormal;
 }
 
@@ -274,11 +274,11 @@ __global__ __launch_bounds__(RT_BLOCK) void direct_kernel(FrameParams P, ViewIma
         resDirect = resDirect + ld_v3(m.selfLight);
         float eyeLambert = fmaxf(dot3(normal, -rayDirection), 0.0f);
         f3 eyeReflected = reflect3(rayDirection, normal);
-        float eyeSpec = powf(fmaxf(saturatef(dot3(eyeReflected, -rayDirection)), 0.0f), m.specularExponent);
+        float eyeSpec = s_pow(fmaxf(saturatef(dot3(eyeReflected, -rayDirection)), 0.0f), m.specularExponent);
         f3 eyeD = mk3(P.eyeLightDiffuseColor[0], P.eyeLightDiffuseColor[1], P.eyeLightDiffuseColor[2]), eyeS = mk3(P.eyeLightSpecularColor[0], P.eyeLightSpecularColor[1], P.eyeLightSpecularColor[2]);
         resDirect = resDirect + (eyeD * eyeLambert + eyeS * (specular * eyeSpec));
         historyLength = fminf(historyLength + 1.0f, 64.0f);
-        newDirect = lerp3(newDirect, resDirect, 1.0f / historyLength);
+        newDirect = lerp3(newDirect, resDirect, s_rcp(historyLength));
         store_rgba16f(I.directLight[cur], i, newDirect.x, newDirect.y, newDirect.z, historyLength);
         store_rgba16f(I.filteredDirect[1], i, newDirect.x, newDirect.y, newDirect.z, historyLength);
     }
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(RT_BLOCK) void indirect_kernel(FrameParams P, ViewI
             }
             resIndirect = resIndirect + bgColor * (P.giSkyStrength * resColor.w);
             historyLength = fminf(historyLength + 1.0f, 64.0f);
-            newIndirect = lerp3(newIndirect, resIndirect, 1.0f / historyLength);
+            newIndirect = lerp3(newIndirect, resIndirect, s_rcp(historyLength));
             maxSamples--;
         }
         store_rgba16f(I.indirectLight[cur], i, newIndirect.x, newIndirect.y, newIndirect.z, historyLength);
@@ -496,8 +496,8 @@ __global__ __launch_bounds__(RT_BLOCK) void reflection_kernel(FrameParams P, Vie
         rgb = rgb + (bgColor * resColor.w + resTransparent);
         const f3 HighlightColor = mk3(1.0f, 1.05f, 1.2f), ShadowColor = mk3(0.1f, 0.05f, 0.0f);
         float shine = pm.reflectionShineFactor;
-        rgb = lerp3(rgb, HighlightColor, powf(fmaxf(rayDirection.y, 0.0f) * shine, 3.0f));
-        rgb = lerp3(rgb, ShadowColor, powf(fmaxf(-rayDirection.y, 0.0f) * shine, 3.0f));
+        rgb = lerp3(rgb, HighlightColor, s_pow(fmaxf(rayDirection.y, 0.0f) * shine, 3.0f));
+        rgb = lerp3(rgb, ShadowColor, s_pow(fmaxf(-rayDirection.y, 0.0f) * shine, 3.0f));
         float k = reflectionAlpha * saturatef(1.0f - newReflectionAlpha);
         store_rgba16f(I.reflection, i, refl.x + rgb.x * k, refl.y + rgb.y * k, refl.z + rgb.z * k, saturatef(newReflectionAlpha));
     }

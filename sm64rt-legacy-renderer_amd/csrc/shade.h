@@ -51,7 +51,7 @@ DEV f4 tex_sample_grad(const GpuTexture &t, float u, float v, f2 ddx, f2 ddy, ui
     if (t.mips == 1) return tex_sample_level(t, u, v, 0, filter, hAddr, vAddr);
     float w0 = (float)t.width, h0 = (float)t.height;
     float ax = ddx.x * w0, ay = ddx.y * h0, bx = ddy.x * w0, by = ddy.y * h0;
-    float rho = fmaxf(sqrtf(ax * ax + ay * ay), sqrtf(bx * bx + by * by));
+    float rho = fmaxf(s_sqrt(ax * ax + ay * ay), s_sqrt(bx * bx + by * by));
     float lod = rho > 0.0f ? log2f(rho) : 0.0f;
     float maxLod = (float)(t.mips - 1);
     if (!(lod > 0.0f)) lod = 0.0f;
@@ -157,10 +157,10 @@ struct RayDiff { f3 dOdx, dOdy, dDdx, dDdy; };
 
 DEV void compute_ray_diffs(f3 nonNormDir, f3 right, f3 up, float vw, float vh, f3 &dDdx, f3 &dDdy) {
     float dd = dot3(nonNormDir, nonNormDir);
-    float divd = 2.0f / (dd * sqrtf(dd));
+    float divd = s_div(2.0f, dd * s_sqrt(dd));
     float dr = dot3(nonNormDir, right), du = dot3(nonNormDir, up);
-    dDdx = ((right * dd - nonNormDir * dr) * divd) * (1.0f / vw);
-    dDdy = -(((up * dd - nonNormDir * du) * divd) * (1.0f / vh));
+    dDdx = ((right * dd - nonNormDir * dr) * divd) * s_rcp(vw);
+    dDdy = -(((up * dd - nonNormDir * du) * divd) * s_rcp(vh));
 }
 
 // ---- vertex fetch + combiner ----------------------------------------------------------------------------------------
@@ -217,9 +217,9 @@ DEV void get_vertex_data(const GpuInstance &in, uint32_t prim, const float b[3],
         float uvk = uvb * uvc - uva * uvd;
         f3 dpos1 = vd.pos[1] - vd.pos[0], dpos2 = vd.pos[2] - vd.pos[0];
         f3 tangent;
-        if (uvk != 0.0f) { f3 n = dpos2 * uvc - dpos1 * uvd; tangent = normalize3(mk3(n.x / uvk, n.y / uvk, n.z / uvk)); }
-        else if (uva != 0.0f) tangent = normalize3(mk3(dpos1.x / uva, dpos1.y / uva, dpos1.z / uva));
-        else if (uvb != 0.0f) tangent = normalize3(mk3(dpos2.x / uvb, dpos2.y / uvb, dpos2.z / uvb));
+        if (uvk != 0.0f) { f3 n = dpos2 * uvc - dpos1 * uvd; tangent = normalize3(n * s_rcp(uvk)); }
+        else if (uva != 0.0f) tangent = normalize3(dpos1 * s_rcp(uva));
+        else if (uvb != 0.0f) tangent = normalize3(dpos2 * s_rcp(uvb));
         else tangent = mk3s(0.0f);
         float d1x = vd.uv[1].x - vd.uv[0].x, d1y = -(vd.uv[1].y - vd.uv[0].y);
         float d2x = vd.uv[2].x - vd.uv[1].x, d2y = -(vd.uv[2].y - vd.uv[1].y);
@@ -315,13 +315,14 @@ DEV bool surface_anyhit(const FrameParams &P, uint32_t instance, uint32_t prim, 
         // propagateRayDiffs + computeBarycentricDifferentials + computeTextureDifferentials, Ray.hlsli:47-94
         f3 N = vd.triangleNormal;
         f3 dodx = payloadDiff.dOdx + payloadDiff.dDdx * t, dody = payloadDiff.dOdy + payloadDiff.dDdy * t;
-        float rcpDN = 1.0f / dot3(rayDirW, N);
+        float rcpDN = s_rcp(dot3(rayDirW, N));
         float dtdx = -dot3(dodx, N) * rcpDN, dtdy = -dot3(dody, N) * rcpDN;
         dodx = dodx + rayDirW * dtdx; dody = dody + rayDirW * dtdy;
         f3 e01 = vd.posW[1] - vd.posW[0], e02 = vd.posW[2] - vd.posW[0];
         f3 Nu = cross3(e02, N), Nv = cross3(e01, N);
         float du = dot3(Nu, e01), dv = dot3(Nv, e02);
-        f3 Lu = mk3(Nu.x / du, Nu.y / du, Nu.z / du), Lv = mk3(Nv.x / dv, Nv.y / dv, Nv.z / dv);
+        const float rdu = s_rcp(du), rdv = s_rcp(dv);
+        f3 Lu = Nu * rdu, Lv = Nv * rdv;
         float dBdx_x = dot3(Lu, dodx), dBdx_y = dot3(Lv, dodx), dBdy_x = dot3(Lu, dody), dBdy_y = dot3(Lv, dody);
         float uv01x = vd.uv[1].x - vd.uv[0].x, uv01y = vd.uv[1].y - vd.uv[0].y, uv02x = vd.uv[2].x - vd.uv[0].x, uv02y = vd.uv[2].y - vd.uv[0].y;
         ddx.x = dBdx_x * uv01x + dBdx_y * uv02x; ddx.y = dBdx_x * uv01y + dBdx_y * uv02y;
@@ -432,7 +433,7 @@ DEV float light_intensity_simple(const RT64_LIGHT &L, f3 position, f3 normal, fl
     f3 lightDirection = normalize3(lp - position);
     float NdotL = dot3(normal, lightDirection);
     float surfaceBias = fmaxf(lerpf(NdotL, 1.0f, ignoreNormalFactor) + 0.707106f, 0.0f);
-    float f = powf(fmaxf(1.0f - (lightDistance / L.attenuationRadius), 0.0f), L.attenuationExponent) * surfaceBias;
+    float f = s_pow(fmaxf(1.0f - s_div(lightDistance, L.attenuationRadius), 0.0f), L.attenuationExponent) * surfaceBias;
     return f * (L.diffuseColor.x + L.diffuseColor.y + L.diffuseColor.z);
 }
 
@@ -450,22 +451,23 @@ DEV f3 compute_light(const FrameParams &P, ShadeEnv &env, uint32_t px, uint32_t 
     while (samples > 0) {
         f3 bn = blue_noise(P, px, py, P.frameCount + samples);
         float scx = bn.x * 2.0f - 1.0f, scy = bn.y * 2.0f - 1.0f;
-        float len = sqrtf(scx * scx + scy * scy), sat = saturatef(len);
-        scx = scx / len * sat; scy = scy / len * sat;
+        float len = s_sqrt(scx * scx + scy * scy), sat = saturatef(len), rlen = s_rcp(len);
+        scx = scx * rlen * sat; scy = scy * rlen * sat;
         f3 samplePosition = (lp + (perpX * scx) * lightPointRadius) + (perpY * scy) * lightPointRadius;
-        float sampleDistance = len3(position - samplePosition);
-        f3 sampleDirection = normalize3(samplePosition - position);
-        float sampleIntensityFactor = powf(fmaxf(1.0f - (sampleDistance / L.attenuationRadius), 0.0f), L.attenuationExponent);
+        float sampleDistance = len3_exact(position - samplePosition);          // ray tmax and ...
+        f3 sampleDirection = normalize3_exact(samplePosition - position);      // ... ray direction: exact
+        float sampleIntensityFactor = s_pow(fmaxf(1.0f - s_div(sampleDistance, L.attenuationRadius), 0.0f), L.attenuationExponent);
         f3 reflectedLight = reflect3(-sampleDirection, normal);
         float NdotL = fmaxf(dot3(normal, sampleDirection), 0.0f);
         float sampleLambert = lerpf(NdotL, 1.0f, m.ignoreNormalFactor) * sampleIntensityFactor;
         float sampleShadow = 1.0f;
         if (checkShadows)
             sampleShadow = trace_shadow(P, env, position, sampleDirection, RT_RAY_MIN_DISTANCE + m.shadowRayBias, sampleDistance - L.shadowOffset, px, py);
-        float sp = powf(fmaxf(saturatef(dot3(reflectedLight, -rayDirection) * sampleIntensityFactor), 0.0f), m.specularExponent);
-        lLambert += sampleLambert / (float)maxSamples;
-        lSpec = lSpec + (specular * sp) * (1.0f / (float)maxSamples);
-        lShadow += sampleShadow / (float)maxSamples;
+        float sp = s_pow(fmaxf(saturatef(dot3(reflectedLight, -rayDirection) * sampleIntensityFactor), 0.0f), m.specularExponent);
+        const float rs = s_rcp((float)maxSamples);
+        lLambert += sampleLambert * rs;
+        lSpec = lSpec + (specular * sp) * rs;
+        lShadow += sampleShadow * rs;
         samples--;
     }
     f3 r = ld_v3(L.diffuseColor) * lLambert + ld_v3(L.specularColor) * lSpec;
@@ -495,7 +497,7 @@ DEV f3 compute_lights_random(const FrameParams &P, ShadeEnv &env, uint32_t px, u
         uint32_t chosen = 0; float rInt = sInt[0];
         while (chosen < sCount - 1 && r >= rInt) { chosen++; rInt += sInt[chosen * RT_BLOCK]; }
         float cInt = sInt[chosen * RT_BLOCK]; uint32_t cIdx = sIdx[chosen * RT_BLOCK];
-        float invProbability = useProbability ? (randomRange / cInt) : 1.0f;
+        float invProbability = useProbability ? s_div(randomRange, cInt) : 1.0f;
         sInt[chosen * RT_BLOCK] = 0.0f; randomRange -= cInt;
         result = result + compute_light(P, env, px, py, cIdx, rayDirection, m, position, normal, specular, checkShadows) * invProbability;
     }
@@ -520,10 +522,11 @@ DEV f3 cos_hemisphere_blue_noise(const FrameParams &P, uint32_t px, uint32_t py,
 
 DEV f2 world_to_screen(const float *viewProj, f3 p) {                            // PrimaryRayGen.hlsl:19-23
     f4 clip = mul4(viewProj, mk4(p.x, p.y, p.z, 1.0f));
-    f2 r; r.x = 0.5f + (clip.x / clip.w) / 2.0f; r.y = 0.5f + (clip.y / clip.w) / 2.0f; return r;
+    const float rw = s_rcp(clip.w);
+    f2 r; r.x = 0.5f + (clip.x * rw) * 0.5f; r.y = 0.5f + (clip.y * rw) * 0.5f; return r;
 }
 DEV float fresnel_reflect_amount(f3 normal, f3 incident, float reflectivity, float fresnelMultiplier) {   // :25-29
-    float ret = powf(clampf(1.0f + dot3(normal, incident), RT_EPSILON, 1.0f), 5.0f);
+    float ret = s_pow(clampf(1.0f + dot3(normal, incident), RT_EPSILON, 1.0f), 5.0f);
     return reflectivity + ((1.0f - reflectivity) * ret * fresnelMultiplier);
 }
 DEV void primary_ray(const FrameParams &P, uint32_t px, uint32_t py, f3 &origin, f3 &dir, f2 &d) {          // :33-39
