@@ -1,0 +1,72 @@
+"""Multi-rank path on CPU: strip partition + gather of the composited framebuffer with torch.distributed (gloo, world_size 2)."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))     # spawned workers import this module without conftest
+import __graft_entry__ as graft  # noqa: E402
+
+graft.load_package()
+from sm64rt_legacy_renderer_amd import tiles  # noqa: E402
+
+
+def test_strip_partition_covers_every_row_once():
+    for h in (1, 15, 16, 17, 270, 1080, 2160):
+        for n in (1, 2, 3, 4, 8):
+            rows = np.zeros(h, dtype=np.int32)
+            for r in range(n):
+                for a, b in tiles.strip_ranges(h, r, n):
+                    assert a % 16 == 0 and b - a <= 16
+                    rows[a:b] += 1
+                assert tiles.owned_rows(h, r, n) == sum(b - a for a, b in tiles.strip_ranges(h, r, n))
+            assert (rows == 1).all()
+            assert tiles.max_owned_rows(h, n) >= -(-h // n) - 16
+
+
+def test_assemble_numpy_roundtrip():
+    rng = np.random.default_rng(5)
+    for h, w, n in ((1080, 64, 8), (270, 48, 3), (33, 16, 2)):
+        frame = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+        mx = tiles.max_owned_rows(h, n) * w * 4
+        packed = np.zeros((n, mx), dtype=np.uint8)
+        for r in range(n):
+            flat = np.concatenate([frame[a:b].reshape(-1) for a, b in tiles.strip_ranges(h, r, n)]) if tiles.strip_ranges(h, r, n) else np.zeros(0, np.uint8)
+            packed[r, :flat.size] = flat
+        assert np.array_equal(tiles.assemble(packed, h, w, n), frame)
+        import torch
+        assert np.array_equal(tiles.assemble_fast(torch.from_numpy(packed), h, w, n).numpy(), frame)
+
+
+def _worker(rank, world, init_file, h, w, out_file):
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
+    rng = np.random.default_rng(11)
+    frame = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)            # every rank knows the expected frame
+    mx = tiles.max_owned_rows(h, world) * w * 4
+    local = torch.zeros(mx, dtype=torch.uint8)
+    mine = np.concatenate([frame[a:b].reshape(-1) for a, b in tiles.strip_ranges(h, rank, world)])
+    local[:mine.size] = torch.from_numpy(mine)
+    for fast in (True, False):
+        full = tiles.gather_frame(local, h, w, rank, world, fast=fast)
+        if rank == 0:
+            assert np.array_equal(full.numpy(), frame)
+        else:
+            assert full is None
+    dist.barrier()
+    if rank == 0:
+        open(out_file, "w").write("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("h,w", [(270, 32), (1080, 8)])
+def test_gather_frame_gloo_world2(h, w):
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as d:
+        init_file = os.path.join(d, "init"); out_file = os.path.join(d, "out")
+        mp.spawn(_worker, args=(2, init_file, h, w, out_file), nprocs=2, join=True)
+        assert open(out_file).read() == "ok"
