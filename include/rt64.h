@@ -330,6 +330,15 @@ enum {
     RT64_IMAGE_COUNT_ = 21
 };
 
+/* Arrays returned by RT64_ReadbackMeshAccel / RT64_ReadbackViewAccel. */
+enum {
+    RT64_ACCEL_NODES = 0,              /* 64-byte LBVH nodes: lmin[3] lmax[3] rmin[3] rmax[3] left right parent pad, max(n-1,1) of them */
+    RT64_ACCEL_TRIANGLES = 1,          /* 48-byte leaves in Morton order: v0[3] prim v1[3] pad v2[3] pad (BLAS only) */
+    RT64_ACCEL_SORTED_INDEX = 2,       /* u32[n]: leaf slot -> primitive (BLAS) / instance (TLAS) */
+    RT64_ACCEL_MORTON = 3,             /* u32[n]: 30-bit Morton code per leaf slot */
+    RT64_ACCEL_HEADER = 4              /* bmin[3] count bmax[3] pad */
+};
+
 /* Per-frame counters and GPU timings of the last RT64_DrawDevice (milliseconds, HIP events on the device stream). */
 typedef struct {
     unsigned int structSize;           /* caller sets to sizeof(RT64_FRAME_STATS) */
@@ -371,7 +380,11 @@ typedef struct {
     /* Named numeric knobs ("count_traversal", "profile_passes", "sync_present", ...). Returns 0 when the key is unknown. */ \
     X(SetDeviceOption, RT64_SetDeviceOption, int, (RT64_DEVICE *device, const char *key, double value)) \
     /* hipStream_t the device submits on, as void*. */ \
-    X(GetDeviceStream, RT64_GetDeviceStream, void *, (RT64_DEVICE *device))
+    X(GetDeviceStream, RT64_GetDeviceStream, void *, (RT64_DEVICE *device)) \
+    /* Debug readback of acceleration structures (RT64_ACCEL_*): the mesh's BLAS / the view's TLAS of the last frame. \
+       Returns bytes written (0 on error); pass dst = NULL to query the size. */ \
+    X(ReadbackMeshAccel, RT64_ReadbackMeshAccel, size_t, (RT64_MESH *mesh, int what, void *dst, size_t dstBytes)) \
+    X(ReadbackViewAccel, RT64_ReadbackViewAccel, size_t, (RT64_VIEW *view, int what, void *dst, size_t dstBytes))
 
 #define RT64_X(member, symbol, ret, args) typedef ret (*member##Ptr) args;
 RT64_EXT_API_LIST(RT64_X)

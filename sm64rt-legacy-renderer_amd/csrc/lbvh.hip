@@ -10,6 +10,7 @@
 // parent links and the fit counters staged in LDS (1-bit split radix passes with wave-ballot-free prefix sums); only
 // the final GpuNode / GpuTri arrays touch HBM.  One launch per RT64_SetMesh and one per frame for the TLAS.
 // Large trees: multi-kernel path (global Morton pass, multi-block LSD radix sort, Karras pass, level-synchronous fit).
+#include <algorithm>
 #include "kernels.h"
 #include "device_math.h"
 
@@ -292,6 +293,261 @@ hipError_t lbvh_launch(const LbvhArgs &args, hipStream_t stream) {
     return lbvh_launch_large(args, stream);
 }
 
-// ---- large trees (n > LBVH_SMALL_MAX) ---------------------------------------------------------------------------------------
-size_t lbvh_large_scratch_bytes(uint32_t n) { return (size_t)n * 64; }
-hipError_t lbvh_launch_large(const LbvhArgs &, hipStream_t) { return hipErrorNotSupported; }
+// ---- large trees (n > LBVH_SMALL_MAX) -----------------------------------------------------------------------------------------
+// Same Geometry spec (G1-G6), spread over the whole chip:
+//   bounds (ordered-uint atomics) -> Morton keys -> 4 x 8-bit stable LSD radix passes {histogram, scan, scatter} -> Karras
+//   nodes -> leaves in Morton order -> level-synchronous box fit (one launch per tree level, <= 30 + log2(n) + 2 launches;
+//   kernel boundaries give the cross-XCD visibility the bottom-up atomic version would need fences for).
+// Scratch (caller-allocated, lbvh_large_scratch_bytes): keys/vals x2, histogram, bounds, leaf boxes, node boxes, done stamps.
+namespace {
+
+#define LG_THREADS 256
+#define LG_TILE 2048            // keys per workgroup in the radix passes
+
+struct LargeScratch {
+    uint32_t *keyA, *valA, *keyB, *valB, *hist, *bounds, *done;
+    float *leafBox, *nodeBox;   // [n][6]
+    uint32_t blocks;
+};
+
+__host__ __device__ inline LargeScratch carve(void *base, uint32_t n) {
+    LargeScratch L;
+    const uint32_t blocks = (n + LG_TILE - 1) / LG_TILE;
+    uint8_t *p = static_cast<uint8_t *>(base);
+    auto take = [&](size_t bytes) { uint8_t *r = p; p += (bytes + 255) & ~(size_t)255; return r; };
+    L.keyA = reinterpret_cast<uint32_t *>(take((size_t)n * 4)); L.valA = reinterpret_cast<uint32_t *>(take((size_t)n * 4));
+    L.keyB = reinterpret_cast<uint32_t *>(take((size_t)n * 4)); L.valB = reinterpret_cast<uint32_t *>(take((size_t)n * 4));
+    L.hist = reinterpret_cast<uint32_t *>(take((size_t)blocks * 256 * 4));
+    L.bounds = reinterpret_cast<uint32_t *>(take(64));
+    L.done = reinterpret_cast<uint32_t *>(take((size_t)n * 4));
+    L.leafBox = reinterpret_cast<float *>(take((size_t)n * 24)); L.nodeBox = reinterpret_cast<float *>(take((size_t)n * 24));
+    L.blocks = blocks;
+    return L;
+}
+
+__global__ void lg_init_bounds(uint32_t *bounds) { if (threadIdx.x < 6) bounds[threadIdx.x] = threadIdx.x < 3 ? 0xFFFFFFFFu : 0u; }
+
+__global__ __launch_bounds__(LG_THREADS) void lg_bounds_kernel(LbvhArgs a, uint32_t *bounds) {
+    __shared__ uint32_t sb[6];
+    if (threadIdx.x < 6) sb[threadIdx.x] = threadIdx.x < 3 ? 0xFFFFFFFFu : 0u;
+    __syncthreads();
+    uint32_t mn[3] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu }, mx[3] = { 0, 0, 0 };
+    for (uint32_t i = blockIdx.x * LG_THREADS + threadIdx.x; i < a.n; i += gridDim.x * LG_THREADS) {
+        Box b = leaf_box(a, i);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { mn[k] = min(mn[k], float_to_ordered(b.mn[k])); mx[k] = max(mx[k], float_to_ordered(b.mx[k])); }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { atomicMin(&sb[k], mn[k]); atomicMax(&sb[3 + k], mx[k]); }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicMin(&bounds[threadIdx.x], sb[threadIdx.x]);
+    else if (threadIdx.x < 6) atomicMax(&bounds[threadIdx.x], sb[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(LG_THREADS) void lg_morton_kernel(LbvhArgs a, const uint32_t *bounds, uint32_t *key, uint32_t *val) {
+    float bmin[3], scale[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        bmin[k] = ordered_to_float(bounds[k]);
+        float ext = ordered_to_float(bounds[3 + k]) - bmin[k];
+        scale[k] = ext > 0.0f ? 1024.0f / ext : 0.0f;
+    }
+    for (uint32_t i = blockIdx.x * LG_THREADS + threadIdx.x; i < a.n; i += gridDim.x * LG_THREADS) {
+        Box b = leaf_box(a, i);
+        uint32_t q[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float c = (b.mn[k] + b.mx[k]) * 0.5f;
+            float f = (c - bmin[k]) * scale[k];
+            int qi = (int)f;
+            q[k] = (uint32_t)(qi < 0 ? 0 : (qi > 1023 ? 1023 : qi));
+        }
+        key[i] = morton30(q[0], q[1], q[2]); val[i] = i;
+    }
+}
+
+// hist[digit * blocks + block] = number of keys of this block's tile with that digit
+__global__ __launch_bounds__(LG_THREADS) void lg_hist_kernel(const uint32_t *key, uint32_t n, int shift, uint32_t *hist, uint32_t blocks) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * LG_TILE;
+    for (uint32_t r = 0; r < LG_TILE / LG_THREADS; r++) {
+        uint32_t i = base + r * LG_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&h[(key[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * blocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// exclusive scan of hist[0 .. 256*blocks) in place (single workgroup of 1024)
+__global__ __launch_bounds__(1024) void lg_scan_kernel(uint32_t *hist, uint32_t total) {
+    __shared__ uint32_t waveTot[16];
+    __shared__ uint32_t carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < total; base += 1024) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = i < total ? hist[i] : 0u;
+        uint32_t incl = wave_inclusive_scan(v, lane);
+        if (lane == 63) waveTot[wave] = incl;
+        __syncthreads();
+        if (wave == 0) {
+            uint32_t w = lane < 16 ? waveTot[lane] : 0u;
+            uint32_t s2 = wave_inclusive_scan(w, lane);
+            if (lane < 16) waveTot[lane] = s2 - w;
+        }
+        __syncthreads();
+        const uint32_t c = carry;
+        if (i < total) hist[i] = c + waveTot[wave] + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + waveTot[15] + incl;
+        __syncthreads();
+    }
+}
+
+// stable scatter of one tile: rounds of 256 keys in index order; rank inside a wave by ballot matching
+__global__ __launch_bounds__(LG_THREADS) void lg_scatter_kernel(const uint32_t *keyIn, const uint32_t *valIn, uint32_t *keyOut, uint32_t *valOut,
+                                                                uint32_t n, int shift, const uint32_t *hist, uint32_t blocks) {
+    __shared__ uint32_t digitOffset[256];
+    __shared__ uint32_t waveCount[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    digitOffset[threadIdx.x] = hist[threadIdx.x * blocks + blockIdx.x];
+    const uint32_t base = blockIdx.x * LG_TILE;
+    for (uint32_t r = 0; r < LG_TILE / LG_THREADS; r++) {
+        for (int w = 0; w < 4; w++) waveCount[w][threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t i = base + r * LG_THREADS + threadIdx.x;
+        const bool valid = i < n;
+        const uint32_t k = valid ? keyIn[i] : 0u, v = valid ? valIn[i] : 0u;
+        const uint32_t d = (k >> shift) & 255u;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; bit++) {
+            unsigned long long b = __ballot((d >> bit) & 1u);
+            peers &= ((d >> bit) & 1u) ? b : ~b;
+        }
+        const unsigned long long lower = peers & ((1ull << lane) - 1ull);
+        const uint32_t rank = (uint32_t)__popcll(lower);
+        if (valid && lower == 0) waveCount[wave][d] = (uint32_t)__popcll(peers);      // one leader per (wave, digit)
+        __syncthreads();
+        if (valid) {
+            uint32_t pos = digitOffset[d] + rank;
+            for (int w = 0; w < wave; w++) pos += waveCount[w][d];
+            keyOut[pos] = k; valOut[pos] = v;
+        }
+        __syncthreads();
+        digitOffset[threadIdx.x] += waveCount[0][threadIdx.x] + waveCount[1][threadIdx.x] + waveCount[2][threadIdx.x] + waveCount[3][threadIdx.x];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(LG_THREADS) void lg_karras_kernel(LbvhArgs a, const uint32_t *key, const uint32_t *val) {
+    const int N = (int)a.n;
+    for (int i = (int)(blockIdx.x * LG_THREADS + threadIdx.x); i < N; i += (int)(gridDim.x * LG_THREADS)) {
+        a.sortedIndex[i] = val[i]; a.morton[i] = key[i];
+        if (i >= N - 1) continue;
+        if (i == 0) a.nodes[0].parent = RT64_NO_CHILD;
+        int d = (delta64(key, val, N, i, i + 1) - delta64(key, val, N, i, i - 1)) >= 0 ? 1 : -1;
+        int dmin = delta64(key, val, N, i, i - d);
+        int lmax = 2;
+        while (delta64(key, val, N, i, i + lmax * d) > dmin) lmax *= 2;
+        int l = 0;
+        for (int t = lmax / 2; t >= 1; t /= 2)
+            if (delta64(key, val, N, i, i + (l + t) * d) > dmin) l += t;
+        int j = i + l * d;
+        int dnode = delta64(key, val, N, i, j);
+        int s = 0;
+        for (int div = 2;; div *= 2) {
+            int t = (l + div - 1) / div;
+            if (delta64(key, val, N, i, i + (s + t) * d) > dnode) s += t;
+            if (t <= 1) break;
+        }
+        int g = i + s * d + (d < 0 ? -1 : 0);
+        int lo = i < j ? i : j, hi = i < j ? j : i;
+        uint32_t left, right;
+        if (lo == g) { left = RT64_LEAF_BIT | (uint32_t)g; a.leafParent[g] = (uint32_t)i; } else { left = (uint32_t)g; a.nodes[g].parent = (uint32_t)i; }
+        if (hi == g + 1) { right = RT64_LEAF_BIT | (uint32_t)(g + 1); a.leafParent[g + 1] = (uint32_t)i; } else { right = (uint32_t)(g + 1); a.nodes[g + 1].parent = (uint32_t)i; }
+        a.nodes[i].left = left; a.nodes[i].right = right; a.nodes[i].pad = 0;
+    }
+}
+
+// leaves in Morton order (+ their boxes) and reset of the fit stamps
+__global__ __launch_bounds__(LG_THREADS) void lg_leaves_kernel(LbvhArgs a, float *leafBox, uint32_t *done) {
+    for (uint32_t s = blockIdx.x * LG_THREADS + threadIdx.x; s < a.n; s += gridDim.x * LG_THREADS) {
+        const uint32_t leaf = a.sortedIndex[s];
+        Box b;
+        if (a.mode == LBVH_MODE_TRIANGLES) {
+            float v[3][3]; load_positions(a, leaf, v);
+            GpuTri t;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { t.v0[k] = v[0][k]; t.v1[k] = v[1][k]; t.v2[k] = v[2][k]; b.mn[k] = fminf(fminf(v[0][k], v[1][k]), v[2][k]); b.mx[k] = fmaxf(fmaxf(v[0][k], v[1][k]), v[2][k]); }
+            t.prim = leaf; t.pad1 = 0; t.pad2 = 0;
+            a.tris[s] = t;
+        }
+        else b = leaf_box(a, leaf);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { leafBox[6 * s + k] = b.mn[k]; leafBox[6 * s + 3 + k] = b.mx[k]; }
+        done[s] = 0;
+    }
+}
+
+// One tree level: an inner node whose children were finished by EARLIER launches (stamp in [1, pass]) takes their boxes.
+__global__ __launch_bounds__(LG_THREADS) void lg_fit_kernel(LbvhArgs a, const float *leafBox, float *nodeBox, uint32_t *done, uint32_t pass) {
+    for (uint32_t i = blockIdx.x * LG_THREADS + threadIdx.x; i + 1 < a.n; i += gridDim.x * LG_THREADS) {
+        if (done[i]) continue;
+        GpuNode &nd = a.nodes[i];
+        const uint32_t l = nd.left, r = nd.right;
+        const bool lLeaf = l & RT64_LEAF_BIT, rLeaf = r & RT64_LEAF_BIT;
+        if (!lLeaf) { uint32_t st = done[l]; if (st == 0 || st > pass) continue; }
+        if (!rLeaf) { uint32_t st = done[r]; if (st == 0 || st > pass) continue; }
+        const float *lb = lLeaf ? leafBox + 6 * (size_t)(l & 0x7FFFFFFFu) : nodeBox + 6 * (size_t)l;
+        const float *rb = rLeaf ? leafBox + 6 * (size_t)(r & 0x7FFFFFFFu) : nodeBox + 6 * (size_t)r;
+        float mn[3], mx[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            nd.lmin[k] = lb[k]; nd.lmax[k] = lb[3 + k]; nd.rmin[k] = rb[k]; nd.rmax[k] = rb[3 + k];
+            mn[k] = fminf(lb[k], rb[k]); mx[k] = fmaxf(lb[3 + k], rb[3 + k]);
+            nodeBox[6 * (size_t)i + k] = mn[k]; nodeBox[6 * (size_t)i + 3 + k] = mx[k];
+        }
+        if (i == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { a.header->bmin[k] = mn[k]; a.header->bmax[k] = mx[k]; }
+            a.header->count = a.n; a.header->pad = 0;
+        }
+        done[i] = pass + 1;
+    }
+}
+
+}  // namespace
+
+size_t lbvh_large_scratch_bytes(uint32_t n) {
+    const size_t blocks = ((size_t)n + LG_TILE - 1) / LG_TILE;
+    return (size_t)n * (4 * 4 + 4 + 24 + 24) + blocks * 256 * 4 + 64 + 16 * 256;
+}
+
+hipError_t lbvh_launch_large(const LbvhArgs &args, hipStream_t stream) {
+    if (!args.scratch || args.scratchBytes < lbvh_large_scratch_bytes(args.n)) return hipErrorInvalidValue;
+    const uint32_t n = args.n;
+    LargeScratch L = carve(args.scratch, n);
+    const uint32_t grid = std::min<uint32_t>((n + LG_THREADS - 1) / LG_THREADS, 2048u);
+    if (!args.refit) {
+        hipLaunchKernelGGL(lg_init_bounds, dim3(1), dim3(64), 0, stream, L.bounds);
+        hipLaunchKernelGGL(lg_bounds_kernel, dim3(grid), dim3(LG_THREADS), 0, stream, args, L.bounds);
+        hipLaunchKernelGGL(lg_morton_kernel, dim3(grid), dim3(LG_THREADS), 0, stream, args, L.bounds, L.keyA, L.valA);
+        uint32_t *kin = L.keyA, *vin = L.valA, *kout = L.keyB, *vout = L.valB;
+        for (int shift = 0; shift < 32; shift += 8) {      // 30 code bits: four 8-bit digits
+            hipLaunchKernelGGL(lg_hist_kernel, dim3(L.blocks), dim3(LG_THREADS), 0, stream, kin, n, shift, L.hist, L.blocks);
+            hipLaunchKernelGGL(lg_scan_kernel, dim3(1), dim3(1024), 0, stream, L.hist, L.blocks * 256u);
+            hipLaunchKernelGGL(lg_scatter_kernel, dim3(L.blocks), dim3(LG_THREADS), 0, stream, kin, vin, kout, vout, n, shift, L.hist, L.blocks);
+            std::swap(kin, kout); std::swap(vin, vout);
+        }
+        hipLaunchKernelGGL(lg_karras_kernel, dim3(grid), dim3(LG_THREADS), 0, stream, args, kin, vin);
+    }
+    hipLaunchKernelGGL(lg_leaves_kernel, dim3(grid), dim3(LG_THREADS), 0, stream, args, L.leafBox, L.done);
+    uint32_t depthBound = 32; { uint32_t m = n; while (m) { depthBound++; m >>= 1; } }      // 30 code bits + log2(n) index bits + slack
+    for (uint32_t pass = 1; pass <= depthBound; pass++)
+        hipLaunchKernelGGL(lg_fit_kernel, dim3(grid), dim3(LG_THREADS), 0, stream, args, L.leafBox, L.nodeBox, L.done, pass);
+    return hipGetLastError();
+}

@@ -1024,6 +1024,40 @@ RT64_EXPORT RT64_TEXTURE *RT64_CreateTexture(RT64_DEVICE *devicePtr, RT64_TEXTUR
 }
 RT64_EXPORT void RT64_DestroyTexture(RT64_TEXTURE *texture) { RT64_TRY Texture *t = reinterpret_cast<Texture *>(texture); if (t) { t->device->use(); hipStreamSynchronize(t->device->stream); } delete t; RT64_CATCH_VOID }
 
+// ---- debug readback of acceleration structures (additive) ----
+static size_t accel_readback(Device *dev, int what, uint32_t n, const GpuNode *nodes, const GpuTri *tris, const uint32_t *sorted, const uint32_t *morton,
+                             const BlasHeader *header, void *dst, size_t dstBytes) {
+    dev->use();
+    const void *src = nullptr; size_t bytes = 0;
+    switch (what) {
+    case RT64_ACCEL_NODES: src = nodes; bytes = (size_t)std::max<uint32_t>(n > 0 ? n - 1 : 0, 1) * sizeof(GpuNode); break;
+    case RT64_ACCEL_TRIANGLES: src = tris; bytes = (size_t)n * sizeof(GpuTri); break;
+    case RT64_ACCEL_SORTED_INDEX: src = sorted; bytes = (size_t)n * 4; break;
+    case RT64_ACCEL_MORTON: src = morton; bytes = (size_t)n * 4; break;
+    case RT64_ACCEL_HEADER: src = header; bytes = sizeof(BlasHeader); break;
+    default: throw std::runtime_error("RT64_Readback*Accel: unknown array id.");
+    }
+    if (!src || n == 0) throw std::runtime_error("RT64_Readback*Accel: no acceleration structure.");
+    if (!dst) return bytes;
+    if (dstBytes < bytes) throw std::runtime_error("RT64_Readback*Accel: destination buffer is too small.");
+    HIP_CHECK(hipStreamSynchronize(dev->stream));
+    HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return bytes;
+}
+RT64_EXPORT size_t RT64_ReadbackMeshAccel(RT64_MESH *meshPtr, int what, void *dst, size_t dstBytes) {
+    RT64_TRY
+    Mesh *m = reinterpret_cast<Mesh *>(meshPtr); if (!m) throw std::runtime_error("RT64_ReadbackMeshAccel: NULL mesh.");
+    return accel_readback(m->device, what, m->blasCount, m->nodes.ptr, m->tris.ptr, m->sortedIndex.ptr, m->morton.ptr, m->header.ptr, dst, dstBytes);
+    RT64_CATCH(0)
+}
+RT64_EXPORT size_t RT64_ReadbackViewAccel(RT64_VIEW *viewPtr, int what, void *dst, size_t dstBytes) {
+    RT64_TRY
+    View *v = reinterpret_cast<View *>(viewPtr); if (!v) throw std::runtime_error("RT64_ReadbackViewAccel: NULL view.");
+    if (what == RT64_ACCEL_TRIANGLES) throw std::runtime_error("RT64_ReadbackViewAccel: a TLAS has no triangle array.");
+    return accel_readback(v->scene->device, what, (uint32_t)v->rtInstances.size(), v->tlasNodes.ptr, nullptr, v->tlasIndex.ptr, v->tlasMorton.ptr, v->tlasHeader.ptr, dst, dstBytes);
+    RT64_CATCH(0)
+}
+
 // ---- inspector (rt64_inspector.cpp:469-515): the ImGui/Im3d debug UI is Win32-only; the exports exist so that hosts resolve all 33 symbols ----
 struct InspectorStub { Device *device; };
 RT64_EXPORT RT64_INSPECTOR *RT64_CreateInspector(RT64_DEVICE *devicePtr) { return reinterpret_cast<RT64_INSPECTOR *>(new InspectorStub{ reinterpret_cast<Device *>(devicePtr) }); }

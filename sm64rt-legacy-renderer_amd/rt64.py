@@ -20,6 +20,7 @@ INSTANCE_RASTER_BACKGROUND, INSTANCE_DISABLE_BACKFACE_CULLING = 0x1, 0x2
 LIGHT_GROUP_MASK_ALL, LIGHT_GROUP_DEFAULT = 0xFFFFFFFF, 0x1
 TEXTURE_FORMAT_RGBA8, TEXTURE_FORMAT_DDS = 0x1, 0x2
 UPSCALER_OFF = 0
+ACCEL_NODES, ACCEL_TRIANGLES, ACCEL_SORTED_INDEX, ACCEL_MORTON, ACCEL_HEADER = range(5)
 
 (IMAGE_FINAL_RGBA8, IMAGE_SHADING_POSITION, IMAGE_SHADING_NORMAL, IMAGE_SHADING_SPECULAR, IMAGE_DIFFUSE,
  IMAGE_INSTANCE_ID, IMAGE_DIRECT_LIGHT_RAW, IMAGE_DIRECT_LIGHT_FILTERED, IMAGE_INDIRECT_LIGHT_RAW,
@@ -183,6 +184,8 @@ EXT_API = [
     ("GetDeviceStats", "RT64_GetDeviceStats", C.c_int, [_P, C.POINTER(FRAME_STATS)]),
     ("SetDeviceOption", "RT64_SetDeviceOption", C.c_int, [_P, C.c_char_p, C.c_double]),
     ("GetDeviceStream", "RT64_GetDeviceStream", _P, [_P]),
+    ("ReadbackMeshAccel", "RT64_ReadbackMeshAccel", C.c_size_t, [_P, C.c_int, _P, C.c_size_t]),
+    ("ReadbackViewAccel", "RT64_ReadbackViewAccel", C.c_size_t, [_P, C.c_int, _P, C.c_size_t]),
 ]
 
 

@@ -108,9 +108,70 @@ def test_c2_full_frame_rmse(rt64_lib, sample_data, oracle_lib):
     assert final[..., :3].std() > 20
 
 
-def test_blas_tlas_bit_exact(rt64_lib, sample_data, oracle_lib):
-    """LBVH built on the GPU (LDS radix sort + Karras + fit) == CPU oracle LBVH: same Morton order, same nodes."""
-    pytest.skip("covered through hit-record and counter equality; raw node readback export lands with the debug API")
+def _accel(lib, fn, handle, what, dtype):
+    n = fn(handle, what, None, 0)
+    assert n > 0, lib.last_error()
+    buf = np.empty(n, dtype=np.uint8)
+    assert fn(handle, what, buf.ctypes.data, n) == n
+    return buf.view(dtype)
+
+
+def test_blas_tlas_bit_exact(scene_256, oracle_256):
+    """LBVH built on the GPU (LDS sort + Karras + fit) == CPU oracle LBVH: same Morton order, same nodes, same leaves."""
+    from sm64rt_legacy_renderer_amd import rt64
+    from oracle import oracle_py
+    o, _ = oracle_256
+    lib = scene_256.lib
+    for mesh_index in (0, 3):                                     # sphere (320 triangles), floor (2)
+        ref = o.mesh_bvh(mesh_index)
+        h = scene_256.meshes[mesh_index]
+        assert np.array_equal(_accel(lib, lib.ReadbackMeshAccel, h, rt64.ACCEL_MORTON, np.uint32), ref["morton"])
+        assert np.array_equal(_accel(lib, lib.ReadbackMeshAccel, h, rt64.ACCEL_SORTED_INDEX, np.uint32), ref["sortedIndex"])
+        nodes = _accel(lib, lib.ReadbackMeshAccel, h, rt64.ACCEL_NODES, oracle_py.NODE_DTYPE)
+        for f in ("lmin", "lmax", "rmin", "rmax", "left", "right"):
+            assert np.array_equal(nodes[f], ref["nodes"][f]), (mesh_index, f)
+        assert np.array_equal(nodes["parent"][1:], ref["nodes"]["parent"][1:])
+        tris = _accel(lib, lib.ReadbackMeshAccel, h, rt64.ACCEL_TRIANGLES, oracle_py.TRI_DTYPE)
+        rt = o.mesh_tris(mesh_index)
+        for f in ("v0", "v1", "v2", "prim"):
+            assert np.array_equal(tris[f], rt[f])
+        hdr = _accel(lib, lib.ReadbackMeshAccel, h, rt64.ACCEL_HEADER, np.float32)
+        assert np.array_equal(hdr[0:3], ref["bmin"]) and np.array_equal(hdr[4:7], ref["bmax"])
+    tl = o.tlas()
+    assert np.array_equal(_accel(lib, lib.ReadbackViewAccel, scene_256.view, rt64.ACCEL_SORTED_INDEX, np.uint32), tl["sortedIndex"])
+    nodes = _accel(lib, lib.ReadbackViewAccel, scene_256.view, rt64.ACCEL_NODES, oracle_py.NODE_DTYPE)
+    for f in ("lmin", "lmax", "rmin", "rmax", "left", "right"):
+        assert np.array_equal(nodes[f], tl["nodes"][f]), f
+
+
+@pytest.mark.parametrize("subdiv,grid", [(2, 1), (3, 64)])
+def test_large_meshes_bit_exact(rt64_lib, oracle_lib, subdiv, grid):
+    """Stress variant of the sample scene: 5 120 / 20 480-triangle spheres (multi-block radix path above 4096
+    leaves), 8 192-triangle floor.  BLAS arrays and the rendered hit records must still equal the oracle's bit for bit."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    from oracle import oracle_py
+    data = sample_scene.make_sample_scene(subdiv=subdiv, floor_grid=grid)
+    s = sample_scene.Rt64Scene(rt64_lib, data, 320, 180, hip_device=0)
+    o = oracle_py.OracleScene(data)
+    try:
+        s.option("count_traversal", 1)
+        s.draw()
+        ref = o.render(320, 180)
+        for mesh_index in (0, 3):
+            rb = o.mesh_bvh(mesh_index)
+            h = s.meshes[mesh_index]
+            assert np.array_equal(_accel(rt64_lib, rt64_lib.ReadbackMeshAccel, h, rt64.ACCEL_MORTON, np.uint32), rb["morton"])
+            assert np.array_equal(_accel(rt64_lib, rt64_lib.ReadbackMeshAccel, h, rt64.ACCEL_SORTED_INDEX, np.uint32), rb["sortedIndex"])
+            nodes = _accel(rt64_lib, rt64_lib.ReadbackMeshAccel, h, rt64.ACCEL_NODES, oracle_py.NODE_DTYPE)
+            for f in ("lmin", "lmax", "rmin", "rmax", "left", "right"):
+                assert np.array_equal(nodes[f], rb["nodes"][f]), (mesh_index, f)
+        assert np.array_equal(s.readback(rt64.IMAGE_PRIMARY_HIT), ref["primaryHit"])
+        st = s.stats()
+        assert st.nodesVisited == ref["counters"]["nodesVisited"] and st.trianglesTested == ref["counters"]["trianglesTested"]
+        out = s.readback(rt64.IMAGE_OUTPUT_RGBA32F)
+        assert float(np.sqrt(np.mean((out[..., :3].astype(np.float64) - ref["output"][..., :3]) ** 2))) <= 1e-3
+    finally:
+        s.close(); o.close()
 
 
 def test_picking_returns_instance_pointer(scene_256):
