@@ -57,26 +57,73 @@ DEV void flush_env(const FrameParams &P, const ShadeEnv &env, int pass, int rayC
     if ((threadIdx.x & 63) == 0) { if (a) atomicAdd(&P.counters[rayCounter], a); if (b) atomicAdd(&P.counters[CTR_SHADOW], b); }
 }
 
-// ---- surface rays: closest hit over opaque instances ------------------------------------------------------------------
-// Hits on instances flagged opaque shorten tmax (R5): lim = (t - depthBias) + maxDepthBias.  Sort key = t - depthBias,
-// ties keep the first-come hit like the reference's strict '<' insertion (rt64_shader.cpp:557).
+// ---- surface rays ---------------------------------------------------------------------------------------------------------
+// Sort key = t - depthBias (WithDistanceBias, Instances.hlsli:17-19); ties keep the first-come hit like the reference's
+// strict '<' insertion (rt64_shader.cpp:557).  Hits on instances flagged opaque (rule O1) shorten tmax (R5):
+// lim = (t - depthBias) + maxDepthBias.
+//   KLIST = false: every instance of the frame is provably opaque -> the list degenerates to the closest hit (registers).
+//   KLIST = true : sorted insertion into the per-pixel list in HBM, 16 entries + 1 scratch slot, exactly the any-hit of
+//                  rt64_shader.cpp:547-581 (a hit that lands in slot 15 commits tmax; nhits keeps counting).
 struct SurfaceHit { float key, t, u, v; uint32_t instance, prim; bool hit; };
 
-DEV void trace_surface(const FrameParams &P, ShadeEnv &env, f3 o, f3 d, SurfaceHit &best) {
+template <bool KLIST>
+DEV uint32_t trace_surface(const FrameParams &P, ShadeEnv &env, const ViewImages &I, size_t pixel, f3 o, f3 d, const RayDiff &rayDiff,
+                           uint32_t px, uint32_t py, SurfaceHit &best) {
     float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
     best.hit = false; best.key = INFINITY;
+    uint32_t nhits = 0;
+    const size_t stride = (size_t)P.width * (size_t)P.height;
     trace_ray(P, oo, dd, RT_RAY_MIN_DISTANCE, RT_RAY_MAX_DISTANCE, true, env.stk,
               [&](float t, float u, float v, uint32_t instance, uint32_t prim, float &tmax) -> bool {
-                  float key = t - P.instances[instance].material.depthBias;
-                  if (key < best.key) { best.key = key; best.t = t; best.u = u; best.v = v; best.instance = instance; best.prim = prim; best.hit = true; }
-                  float lim = key + P.maxDepthBias;
+                  const GpuInstance &in = P.instances[instance];
+                  const float key = t - in.material.depthBias;
+                  if (!KLIST) {
+                      if (key < best.key) { best.key = key; best.t = t; best.u = u; best.v = v; best.instance = instance; best.prim = prim; best.hit = true; }
+                  }
+                  else {
+                      if (in.cc.optTextureEdge) {            // IgnoreHit() before the hit is stored (rt64_shader.cpp:502-511)
+                          HitRecord tmp;
+                          if (!surface_anyhit(P, instance, prim, t, u, v, d, rayDiff, px, py, tmp)) return false;
+                      }
+                      uint32_t hi = nhits < RT64_MAX_HIT_QUERIES ? nhits : RT64_MAX_HIT_QUERIES;
+                      while (hi > 0) {
+                          const uint4 prev = I.klistA[(size_t)(hi - 1) * stride + pixel];
+                          if (!(key < __uint_as_float(prev.x))) break;
+                          I.klistA[(size_t)hi * stride + pixel] = prev;
+                          I.klistB[(size_t)hi * stride + pixel] = I.klistB[(size_t)(hi - 1) * stride + pixel];
+                          hi--;
+                      }
+                      if (hi < RT64_MAX_HIT_QUERIES) {
+                          I.klistA[(size_t)hi * stride + pixel] = make_uint4(__float_as_uint(key), __float_as_uint(u), __float_as_uint(v), prim);
+                          I.klistB[(size_t)hi * stride + pixel] = make_uint2(__float_as_uint(t), instance);
+                          ++nhits;
+                          if (hi == RT64_MAX_HIT_QUERIES - 1 && t < tmax) tmax = t;      // not IgnoreHit(): the hit is committed
+                      }
+                      if (!(in.flags & GPU_INST_OPAQUE)) return false;
+                  }
+                  const float lim = key + P.maxDepthBias;
                   if (lim < tmax) tmax = lim;
                   return false;
               }, env.cnt);
+    return KLIST ? nhits : (best.hit ? 1u : 0u);
+}
+
+// Entry `hit` of the list as a shaded record (the any-hit program runs here, on coherent data, instead of during traversal).
+// Reads beyond the 17 allocated slots return an empty record like an out-of-bounds typed UAV load.
+template <bool KLIST>
+DEV bool surface_record(const FrameParams &P, const ViewImages &I, size_t pixel, uint32_t hit, const SurfaceHit &best, f3 dir,
+                        const RayDiff &rayDiff, uint32_t px, uint32_t py, HitRecord &r) {
+    if (!KLIST) return surface_anyhit(P, best.instance, best.prim, best.t, best.u, best.v, dir, rayDiff, px, py, r);
+    if (hit > RT64_MAX_HIT_QUERIES) return false;
+    const size_t stride = (size_t)P.width * (size_t)P.height;
+    const uint4 a = I.klistA[(size_t)hit * stride + pixel];
+    const uint2 b = I.klistB[(size_t)hit * stride + pixel];
+    return surface_anyhit(P, b.y, a.w, __uint_as_float(b.x), __uint_as_float(a.y), __uint_as_float(a.z), dir, rayDiff, px, py, r);
 }
 
 // ---- primary visibility --------------------------------------------------------------------------------------------------
 
+template <bool KLIST>
 __global__ __launch_bounds__(RT_BLOCK) void primary_trace_kernel(FrameParams P, ViewImages I, int32_t *hitInstance) {
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -91,12 +138,26 @@ __global__ __launch_bounds__(RT_BLOCK) void primary_trace_kernel(FrameParams P, 
         if (!p.valid) continue;
         f3 o, d; f2 ndc;
         primary_ray(P, p.x, p.y, o, d, ndc);
-        SurfaceHit h;
-        trace_surface(P, env, o, d, h);
-        rays++;
         const size_t i = (size_t)p.y * (size_t)P.width + p.x;
+        RayDiff rayDiff;
+        if (KLIST) {    // the texture-edge any-hit samples with the primary ray differentials (PrimaryRayGen.hlsl:55-59)
+            f3 cU = mk3(P.cameraU[0], P.cameraU[1], P.cameraU[2]), cV = mk3(P.cameraV[0], P.cameraV[1], P.cameraV[2]), cW = mk3(P.cameraW[0], P.cameraW[1], P.cameraW[2]);
+            rayDiff.dOdx = mk3s(0.0f); rayDiff.dOdy = mk3s(0.0f);
+            compute_ray_diffs((cU * ndc.x + cV * ndc.y) + cW, cU, cV, P.resolution[2], P.resolution[3], rayDiff.dDdx, rayDiff.dDdy);
+        }
+        SurfaceHit h;
+        const uint32_t nhits = trace_surface<KLIST>(P, env, I, i, o, d, rayDiff, p.x, p.y, h);
+        rays++;
         uint4 rec;
-        if (h.hit) { rec.x = __float_as_uint(h.t); rec.y = __float_as_uint(h.u); rec.z = __float_as_uint(h.v); rec.w = h.prim; hitInstance[i] = (int32_t)h.instance; }
+        if (KLIST) {
+            I.klistCount[i] = nhits;
+            if (nhits) {
+                const uint4 a = I.klistA[i]; const uint2 b = I.klistB[i];
+                rec = make_uint4(b.x, a.y, a.z, a.w); hitInstance[i] = (int32_t)b.y;
+            }
+            else { rec.x = rec.y = rec.z = rec.w = 0xFFFFFFFFu; hitInstance[i] = -1; }
+        }
+        else if (h.hit) { rec.x = __float_as_uint(h.t); rec.y = __float_as_uint(h.u); rec.z = __float_as_uint(h.v); rec.w = h.prim; hitInstance[i] = (int32_t)h.instance; }
         else { rec.x = rec.y = rec.z = rec.w = 0xFFFFFFFFu; hitInstance[i] = -1; }
         reinterpret_cast<uint4 *>(I.primaryHit)[i] = rec;
     }
@@ -107,7 +168,7 @@ __global__ __launch_bounds__(RT_BLOCK) void primary_trace_kernel(FrameParams P, 
 
 // TRANSPARENT_LIGHT: some instance is not provably opaque, so the 'transparent geometry that needs lighting' path of
 // PrimaryRayGen.hlsl:136-148 (one random light + shadow ray from inside the resolve loop) can be reached.
-template <bool TRANSPARENT_LIGHT>
+template <bool TRANSPARENT_LIGHT, bool KLIST>
 __global__ __launch_bounds__(RT_BLOCK) void primary_shade_kernel(FrameParams P, ViewImages I, const int32_t *hitInstance, int cur) {
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -148,10 +209,13 @@ __global__ __launch_bounds__(RT_BLOCK) void primary_shade_kernel(FrameParams P, 
 
         const uint4 hrec = reinterpret_cast<const uint4 *>(I.primaryHit)[i];
         const int hInst = hitInstance[i];
-        const uint32_t nhits = hInst >= 0 ? 1u : 0u;
+        SurfaceHit best;
+        best.hit = hInst >= 0; best.instance = (uint32_t)hInst; best.prim = hrec.w;
+        best.t = __uint_as_float(hrec.x); best.u = __uint_as_float(hrec.y); best.v = __uint_as_float(hrec.z);
+        const uint32_t nhits = KLIST ? I.klistCount[i] : (hInst >= 0 ? 1u : 0u);
         for (uint32_t hit = 0; hit < nhits; hit++) {
             HitRecord r;
-            if (!surface_anyhit(P, (uint32_t)hInst, hrec.w, __uint_as_float(hrec.x), __uint_as_float(hrec.y), __uint_as_float(hrec.z), rayDirection, rayDiff, px, py, r)) continue;
+            if (!surface_record<KLIST>(P, I, i, hit, best, rayDirection, rayDiff, px, py, r)) continue;
             f4 hitColor = r.color;
             float alphaContrib = resColor.w * hitColor.w;
             if (alphaContrib >= RT_EPSILON) {
@@ -287,14 +351,7 @@ __global__ __launch_bounds__(RT_BLOCK) void direct_kernel(FrameParams P, ViewIma
 
 // ---- bounce-ray resolve shared by Indirect / Refraction / Reflection ------------------------------------------------------
 
-DEV bool bounce_record(const FrameParams &P, ShadeEnv &env, f3 origin, f3 dir, uint32_t px, uint32_t py, HitRecord &r) {
-    SurfaceHit h;
-    trace_surface(P, env, origin, dir, h);
-    if (!h.hit) return false;
-    RayDiff rd; rd.dOdx = rd.dOdy = rd.dDdx = rd.dDdy = mk3s(0.0f);
-    return surface_anyhit(P, h.instance, h.prim, h.t, h.u, h.v, dir, rd, px, py, r);
-}
-
+template <bool KLIST>
 __global__ __launch_bounds__(RT_BLOCK) void indirect_kernel(FrameParams P, ViewImages I, int cur, int writeFiltered) {
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -327,14 +384,17 @@ __global__ __launch_bounds__(RT_BLOCK) void indirect_kernel(FrameParams P, ViewI
         uint32_t maxSamples = P.giSamples; const uint32_t blueNoiseMult = 64u / P.giSamples;
         while (maxSamples > 0) {
             f3 rayDirection = cos_hemisphere_blue_noise(P, px, py, P.frameCount + maxSamples * blueNoiseMult, shadingNormal);
-            HitRecord r;
-            bool have = bounce_record(P, env, rayOrigin, rayDirection, px, py, r);
+            RayDiff rd; rd.dOdx = rd.dOdy = rd.dDdx = rd.dDdy = mk3s(0.0f);
+            SurfaceHit best;
+            const uint32_t nhits = trace_surface<KLIST>(P, env, I, i, rayOrigin, rayDirection, rd, px, py, best);
             rays++;
             f3 bgColor = sample_background_envmap(P, rayDirection);
             f4 sky = sample_sky_plane(P, rayDirection);
             bgColor = lerp3(bgColor, xyz(sky), sky.w);
             f3 resPosition = mk3s(0.0f), resNormal = mk3s(0.0f), resSpecular = mk3s(0.0f); f4 resColor = mk4(0, 0, 0, 1); int resInstanceId = -1;
-            if (have) {
+            for (uint32_t hit = 0; hit < nhits; hit++) {
+                HitRecord r;
+                if (!surface_record<KLIST>(P, I, i, hit, best, rayDirection, rd, px, py, r)) continue;
                 f4 hitColor = r.color;
                 float alphaContrib = resColor.w * hitColor.w;
                 if (alphaContrib >= RT_EPSILON) {
@@ -345,6 +405,7 @@ __global__ __launch_bounds__(RT_BLOCK) void indirect_kernel(FrameParams P, ViewI
                     resColor.w *= (1.0f - hitColor.w);
                     resInstanceId = (int)r.instanceId;
                 }
+                if (resColor.w <= RT_EPSILON) break;
             }
             f3 resIndirect = ambientBase;
             if (resInstanceId >= 0) {
@@ -370,6 +431,7 @@ DEV f3 hlsl_refract(f3 i, f3 n, float eta) {
     return i * eta - n * (eta * cosi + sqrtf(k));
 }
 
+template <bool KLIST>
 __global__ __launch_bounds__(RT_BLOCK) void refraction_kernel(FrameParams P, ViewImages I) {
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -395,11 +457,14 @@ __global__ __launch_bounds__(RT_BLOCK) void refraction_kernel(FrameParams P, Vie
         f3 bgColor = sample_background_2d(P, screenUV);
         f4 sky = sample_sky_2d(P, screenUV);
         bgColor = lerp3(bgColor, xyz(sky), sky.w);
-        HitRecord r;
-        bool have = bounce_record(P, env, rayOrigin, rayDirection, px, py, r);
+        RayDiff rd; rd.dOdx = rd.dOdy = rd.dDdx = rd.dDdy = mk3s(0.0f);
+        SurfaceHit best;
+        const uint32_t nhits = trace_surface<KLIST>(P, env, I, i, rayOrigin, rayDirection, rd, px, py, best);
         rays++;
         f3 resPosition = mk3s(0.0f), resNormal = mk3s(0.0f), resSpecular = mk3s(0.0f), resTransparent = mk3s(0.0f); f4 resColor = mk4(0, 0, 0, 1); int resInstanceId = -1;
-        if (have) {
+        for (uint32_t hit = 0; hit < nhits; hit++) {
+            HitRecord r;
+            if (!surface_record<KLIST>(P, I, i, hit, best, rayDirection, rd, px, py, r)) continue;
             f4 hitColor = r.color;
             float alphaContrib = resColor.w * hitColor.w;
             if (alphaContrib >= RT_EPSILON) {
@@ -418,6 +483,7 @@ __global__ __launch_bounds__(RT_BLOCK) void refraction_kernel(FrameParams P, Vie
                 else resTransparent = resTransparent + (xyz(hitColor) * alphaContrib) * (ambient + ld_v3(m.selfLight));
                 resColor.w *= (1.0f - hitColor.w);
             }
+            if (resColor.w <= RT_EPSILON) break;
         }
         f3 rgb = xyz(resColor);
         if (resInstanceId >= 0) {
@@ -430,6 +496,7 @@ __global__ __launch_bounds__(RT_BLOCK) void refraction_kernel(FrameParams P, Vie
     flush_env(P, env, PASS_REFRACTION, CTR_REFRACTION, rays);
 }
 
+template <bool KLIST>
 __global__ __launch_bounds__(RT_BLOCK) void reflection_kernel(FrameParams P, ViewImages I) {
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -455,12 +522,15 @@ __global__ __launch_bounds__(RT_BLOCK) void reflection_kernel(FrameParams P, Vie
         f3 bgColor = sample_background_envmap(P, rayDirection);
         f4 sky = sample_sky_plane(P, rayDirection);
         bgColor = lerp3(bgColor, xyz(sky), sky.w);
-        HitRecord r;
-        bool have = bounce_record(P, env, shadingPosition, rayDirection, px, py, r);
+        RayDiff rd; rd.dOdx = rd.dOdy = rd.dDdx = rd.dDdy = mk3s(0.0f);
+        SurfaceHit best;
+        const uint32_t nhits = trace_surface<KLIST>(P, env, I, i, shadingPosition, rayDirection, rd, px, py, best);
         rays++;
         const RT64_MATERIAL &pm = P.instances[instanceId].material;
         f3 resPosition = mk3s(0.0f), resNormal = mk3s(0.0f), resSpecular = mk3s(0.0f), resTransparent = mk3s(0.0f); f4 resColor = mk4(0, 0, 0, 1); int resInstanceId = -1;
-        if (have) {
+        for (uint32_t hit = 0; hit < nhits; hit++) {
+            HitRecord r;
+            if (!surface_record<KLIST>(P, I, i, hit, best, rayDirection, rd, px, py, r)) continue;
             f4 hitColor = r.color;
             float alphaContrib = resColor.w * hitColor.w;
             if (alphaContrib >= RT_EPSILON) {
@@ -483,6 +553,7 @@ __global__ __launch_bounds__(RT_BLOCK) void reflection_kernel(FrameParams P, Vie
                 resPosition = vertexPosition; resNormal = vertexNormal; resSpecular = specular; resInstanceId = (int)r.instanceId;
                 resColor.w *= (1.0f - hitColor.w);
             }
+            if (resColor.w <= RT_EPSILON) break;
         }
         f3 rgb = xyz(resColor);
         if (resInstanceId >= 0) {
@@ -590,20 +661,32 @@ size_t rt_stack_spill_bytes() { return (size_t)RT_GRID_BLOCKS * RT_BLOCK * RT_ST
 
 #define LAUNCH_RAY(kernel, ...) do { hipLaunchKernelGGL(kernel, dim3(RT_GRID_BLOCKS), dim3(RT_BLOCK), 0, s, __VA_ARGS__); return hipGetLastError(); } while (0)
 
-hipError_t launch_primary_trace(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, hipStream_t s) { LAUNCH_RAY(primary_trace_kernel, P, I, hitInstance); }
+hipError_t launch_primary_trace(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, bool klist, hipStream_t s) {
+    if (klist) LAUNCH_RAY(primary_trace_kernel<true>, P, I, hitInstance);
+    LAUNCH_RAY(primary_trace_kernel<false>, P, I, hitInstance);
+}
 hipError_t launch_primary_shade(const FrameParams &P, const ViewImages &I, const int32_t *hitInstance, int cur, bool transparentLighting, hipStream_t s) {
-    if (transparentLighting) LAUNCH_RAY(primary_shade_kernel<true>, P, I, hitInstance, cur);
-    LAUNCH_RAY(primary_shade_kernel<false>, P, I, hitInstance, cur);
+    if (transparentLighting) LAUNCH_RAY((primary_shade_kernel<true, true>), P, I, hitInstance, cur);
+    LAUNCH_RAY((primary_shade_kernel<false, false>), P, I, hitInstance, cur);
 }
 hipError_t launch_direct(const FrameParams &P, const ViewImages &I, int cur, hipStream_t s) { LAUNCH_RAY(direct_kernel, P, I, cur); }
-hipError_t launch_indirect(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, hipStream_t s) { LAUNCH_RAY(indirect_kernel, P, I, cur, writeFiltered ? 1 : 0); }
+hipError_t launch_indirect(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, hipStream_t s) {
+    if (klist) LAUNCH_RAY(indirect_kernel<true>, P, I, cur, writeFiltered ? 1 : 0);
+    LAUNCH_RAY(indirect_kernel<false>, P, I, cur, writeFiltered ? 1 : 0);
+}
 hipError_t launch_indirect_constant(const FrameParams &P, const ViewImages &I, int cur, hipStream_t s) {
     dim3 grid((unsigned)(P.width + 31) / 32, (unsigned)(P.tileY1 - P.tileY0 + 7) / 8);
     hipLaunchKernelGGL(indirect_constant_kernel, grid, dim3(256), 0, s, P, I, cur);
     return hipGetLastError();
 }
-hipError_t launch_refraction(const FrameParams &P, const ViewImages &I, hipStream_t s) { LAUNCH_RAY(refraction_kernel, P, I); }
-hipError_t launch_reflection(const FrameParams &P, const ViewImages &I, hipStream_t s) { LAUNCH_RAY(reflection_kernel, P, I); }
+hipError_t launch_refraction(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s) {
+    if (klist) LAUNCH_RAY(refraction_kernel<true>, P, I);
+    LAUNCH_RAY(refraction_kernel<false>, P, I);
+}
+hipError_t launch_reflection(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s) {
+    if (klist) LAUNCH_RAY(reflection_kernel<true>, P, I);
+    LAUNCH_RAY(reflection_kernel<false>, P, I);
+}
 
 hipError_t launch_gaussian(const uint16_t *in, uint16_t *out, int width, int height, int y0, int y1, hipStream_t s) {
     dim3 grid((unsigned)(width + 31) / 32, (unsigned)(y1 - y0 + 7) / 8);

@@ -125,6 +125,11 @@ struct ViewImages {
     uint8_t *final;                      // RGBA8 back buffer
     uint32_t *primaryHit;                // RGBA32UI: t, u, v bits, instance << 24 | primitive
     float *moments[2];                   // SVGF: RG32F luminance moments
+    // Per-pixel sorted hit list (k-buffer), [RT64_MAX_HIT_QUERIES + 1][pixels]; allocated only while some instance is not
+    // provably opaque.  The reference keeps 17 x 34 B per pixel for every frame (rt64_view.cpp:237-241).
+    uint4 *klistA;                       // sort key (t - depthBias) bits, u bits, v bits, primitive
+    uint2 *klistB;                       // t bits, instance
+    uint32_t *klistCount;                // payload.nhits of the primary ray (per pixel)
 };
 
 enum { CTR_NODES = 0, CTR_TRIS, CTR_PRIMARY, CTR_SHADOW, CTR_INDIRECT, CTR_REFLECTION, CTR_REFRACTION,

@@ -674,7 +674,16 @@ void View::render() {                          // View::render, rt64_view.cpp:11
     const size_t n = (size_t)imgW * imgH;
     mark(Device::EV_BUILD);
     if (!rtInstances.empty()) {
-        HIP_CHECK(launch_primary_trace(P, img, hitInstance.ptr, s));
+        if (anyNonOpaque && !img.klistA) {          // sorted per-pixel hit lists, only while some instance is not provably opaque
+            const size_t slots = (size_t)(RT64_MAX_HIT_QUERIES + 1) * n;
+            void *a = nullptr, *b = nullptr, *c = nullptr;
+            HIP_CHECK(hipMalloc(&a, slots * sizeof(uint4))); allocations.push_back(a);
+            HIP_CHECK(hipMalloc(&b, slots * sizeof(uint2))); allocations.push_back(b);
+            HIP_CHECK(hipMalloc(&c, n * sizeof(uint32_t))); allocations.push_back(c);
+            img.klistA = static_cast<uint4 *>(a); img.klistB = static_cast<uint2 *>(b); img.klistCount = static_cast<uint32_t *>(c);
+        }
+        const bool klist = anyNonOpaque;
+        HIP_CHECK(launch_primary_trace(P, img, hitInstance.ptr, klist, s));
         mark(Device::EV_PRIMARY_TRACE);
         HIP_CHECK(launch_primary_shade(P, img, hitInstance.ptr, cur, anyNonOpaque, s));
         mark(Device::EV_PRIMARY);
@@ -684,11 +693,11 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         mark(Device::EV_DIRECT);
         const bool denoiseGI = denoiserEnabled && giSamples > 0;
         if (giSamples == 0) HIP_CHECK(launch_indirect_constant(P, img, cur, s));      // IndirectRayGen.hlsl:135: constant ambient
-        else HIP_CHECK(launch_indirect(P, img, cur, !denoiseGI, s));
+        else HIP_CHECK(launch_indirect(P, img, cur, !denoiseGI, klist, s));
         mark(Device::EV_INDIRECT);
         // Refraction / reflection touch only pixels whose primary hit has a refraction / reflection factor (alpha > EPSILON).
-        if (anyRefraction) HIP_CHECK(launch_refraction(P, img, s));
-        if (anyReflection) for (int r = 0; r < dev->opt.maxReflections; r++) HIP_CHECK(launch_reflection(P, img, s));
+        if (anyRefraction) HIP_CHECK(launch_refraction(P, img, klist, s));
+        if (anyReflection) for (int r = 0; r < dev->opt.maxReflections; r++) HIP_CHECK(launch_reflection(P, img, klist, s));
         mark(Device::EV_REFL);
         if (denoiseGI) {
             HIP_CHECK(hipMemcpyAsync(img.filteredIndirect[0], img.indirectLight[cur], n * 8, hipMemcpyDeviceToDevice, s));
