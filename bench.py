@@ -51,6 +51,8 @@ def parse_args():
     ap.add_argument("--subdiv", type=int, default=0, help="stress variant: sphere subdivision levels")
     ap.add_argument("--floor-grid", type=int, default=1, help="stress variant: floor tessellation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU-staged rehearsal of the N>1 path")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal on a 1-GPU box: every rank renders on device 0")
     ap.add_argument("--cpu-baseline-height", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = all)")
     return ap.parse_args()
 
@@ -71,12 +73,18 @@ def main():
     N = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback.")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if N > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
+    comm_device = "cuda" if args.backend == "nccl" else "cpu" 
 
     W, H = args.width, args.height
     lib = rt64.Library()
@@ -95,7 +103,7 @@ def main():
         n = lib.CopyDeviceImage(scene.device, rt64.IMAGE_FINAL_RGBA8, local.data_ptr(), local.numel())
         if n != my_bytes:
             raise RuntimeError("RT64_CopyDeviceImage returned %d, expected %d: %s" % (n, my_bytes, lib.last_error()))
-        return tiles.gather_frame(local, H, W, rank, N)
+        return tiles.gather_frame(local if comm_device == "cuda" else local.cpu(), H, W, rank, N)
 
     def barrier():
         torch.cuda.synchronize()
@@ -115,7 +123,7 @@ def main():
     rays_local = counts["primary"] + counts["shadow"] + counts["indirect"]
     rays_total = rays_local
     if N > 1:
-        t = torch.tensor([rays_local], dtype=torch.float64, device="cuda")
+        t = torch.tensor([rays_local], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t)
         rays_total = int(t.item())
 
@@ -134,7 +142,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if N > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed * 1e3 / args.steps
