@@ -499,13 +499,21 @@ static void pass_indirect(OScene *s, OShadeCtx *c, uint32_t px, uint32_t py, int
     size_t i = (size_t)py * (size_t)c->width + px;
     int instanceId = s->instanceId[i];
     of3 ambient = v3add(c->desc.ambientBaseColor, c->desc.ambientNoGIColor);
-    if (!(instanceId >= 0 && c->giSamples > 0)) { st4(s->indirectLight[cur], i, q_f16(ambient.x), q_f16(ambient.y), q_f16(ambient.z), 0.0f); return; }
+    if (!(instanceId >= 0 && c->giSamples > 0)) {
+        st4(s->indirectLight[cur], i, q_f16(ambient.x), q_f16(ambient.y), q_f16(ambient.z), 0.0f);
+        s->moments[cur][2 * i] = s->moments[cur][2 * i + 1] = 0.0f;
+        return;
+    }
     of3 rayOrigin = ld3i(s->shadingPosition, i), shadingNormal = ld3i(s->shadingNormal, i);
     of3 newIndirect = v3s(0.0f); float historyLength = 0.0f;
+    float prevM1 = 0.0f, prevM2 = 0.0f, sumL = 0.0f, sumL2 = 0.0f;      /* SVGF luminance moments (oracle_svgf.c) */
     if (c->giReproject) {
         int j; float w = history_weight(s, c, i, px, py, shadingNormal, cur, &j);
         of4 prevAccum = { 0, 0, 0, 0 };
-        if (j >= 0) { const float *q = s->indirectLight[cur ^ 1] + 4 * (size_t)j; prevAccum.x = q[0]; prevAccum.y = q[1]; prevAccum.z = q[2]; prevAccum.w = q[3]; }
+        if (j >= 0) {
+            const float *q = s->indirectLight[cur ^ 1] + 4 * (size_t)j; prevAccum.x = q[0]; prevAccum.y = q[1]; prevAccum.z = q[2]; prevAccum.w = q[3];
+            prevM1 = s->moments[cur ^ 1][2 * (size_t)j]; prevM2 = s->moments[cur ^ 1][2 * (size_t)j + 1];
+        }
         newIndirect = v3(prevAccum.x, prevAccum.y, prevAccum.z); historyLength = prevAccum.w * w;
     }
     uint32_t maxSamples = c->giSamples; const uint32_t blueNoiseMult = 64u / c->giSamples;
@@ -543,9 +551,15 @@ static void pass_indirect(OScene *s, OShadeCtx *c, uint32_t px, uint32_t py, int
         resIndirect = v3add(resIndirect, v3scale(bgColor, c->desc.giSkyStrength * resColor.w));
         historyLength = fminf(historyLength + 1.0f, 64.0f);
         newIndirect = v3lerp(newIndirect, resIndirect, 1.0f / historyLength);
+        { float l = 0.2126f * resIndirect.x + 0.7152f * resIndirect.y + 0.0722f * resIndirect.z; sumL += l; sumL2 += l * l; }
         maxSamples--;
     }
     st4(s->indirectLight[cur], i, q_f16(newIndirect.x), q_f16(newIndirect.y), q_f16(newIndirect.z), q_f16(historyLength));
+    {
+        float n = (float)c->giSamples, alphaM = fminf(n / historyLength, 1.0f);
+        s->moments[cur][2 * i] = flerp(prevM1, sumL / n, alphaM);
+        s->moments[cur][2 * i + 1] = flerp(prevM2, sumL2 / n, alphaM);
+    }
 }
 
 /* ---- RefractionRayGen ------------------------------------------------------------------------------------------------ */

@@ -46,3 +46,7 @@ hipError_t launch_reflection(const FrameParams &P, const ViewImages &I, bool kli
 hipError_t launch_gaussian(const uint16_t *in, uint16_t *out, int width, int height, int y0, int y1, hipStream_t s);
 hipError_t launch_compose_post(const FrameParams &P, const ViewImages &I, hipStream_t s);
 hipError_t launch_clear_final(const FrameParams &P, const ViewImages &I, hipStream_t s);
+
+// ---- svgf.hip ------------------------------------------------------------------------------------------------------
+// variance estimate + 5 a-trous iterations over the GI buffer; result in filteredIndirect[1]
+hipError_t launch_svgf(const ViewImages &I, int cur, int width, int height, hipStream_t s);

@@ -370,15 +370,18 @@ __global__ __launch_bounds__(RT_BLOCK) void indirect_kernel(FrameParams P, ViewI
         const int instanceId = I.instanceId[i];
         if (!(instanceId >= 0 && P.giSamples > 0)) {
             store_rgba16f(I.indirectLight[cur], i, ambient.x, ambient.y, ambient.z, 0.0f);
+            reinterpret_cast<float2 *>(I.moments[cur])[i] = make_float2(0.0f, 0.0f);
             if (writeFiltered) store_rgba16f(I.filteredIndirect[1], i, ambient.x, ambient.y, ambient.z, 0.0f);
             continue;
         }
         const float4 pos4 = reinterpret_cast<const float4 *>(I.shadingPosition)[i];
         f3 rayOrigin = mk3(pos4.x, pos4.y, pos4.z), shadingNormal = xyz(load_rgba16f(I.shadingNormal, i));
         f3 newIndirect = mk3s(0.0f); float historyLength = 0.0f;
+        float2 prevM = make_float2(0.0f, 0.0f); float sumL = 0.0f, sumL2 = 0.0f;      // SVGF luminance moments (svgf.hip)
         if (P.giReproject) {
             long j; float w = history_weight(P, I, i, px, py, shadingNormal, cur, j);
             f4 prevAccum = j >= 0 ? load_rgba16f(I.indirectLight[cur ^ 1], (size_t)j) : mk4(0, 0, 0, 0);
+            if (j >= 0) prevM = reinterpret_cast<const float2 *>(I.moments[cur ^ 1])[j];
             newIndirect = xyz(prevAccum); historyLength = prevAccum.w * w;
         }
         uint32_t maxSamples = P.giSamples; const uint32_t blueNoiseMult = 64u / P.giSamples;
@@ -416,9 +419,14 @@ __global__ __launch_bounds__(RT_BLOCK) void indirect_kernel(FrameParams P, ViewI
             resIndirect = resIndirect + bgColor * (P.giSkyStrength * resColor.w);
             historyLength = fminf(historyLength + 1.0f, 64.0f);
             newIndirect = lerp3(newIndirect, resIndirect, s_rcp(historyLength));
+            { const float l = 0.2126f * resIndirect.x + 0.7152f * resIndirect.y + 0.0722f * resIndirect.z; sumL += l; sumL2 += l * l; }
             maxSamples--;
         }
         store_rgba16f(I.indirectLight[cur], i, newIndirect.x, newIndirect.y, newIndirect.z, historyLength);
+        {
+            const float nS = (float)P.giSamples, alphaM = fminf(nS / historyLength, 1.0f);
+            reinterpret_cast<float2 *>(I.moments[cur])[i] = make_float2(lerpf(prevM.x, sumL / nS, alphaM), lerpf(prevM.y, sumL2 / nS, alphaM));
+        }
         if (writeFiltered) store_rgba16f(I.filteredIndirect[1], i, newIndirect.x, newIndirect.y, newIndirect.z, historyLength);
     }
     flush_env(P, env, PASS_INDIRECT, CTR_INDIRECT, rays);

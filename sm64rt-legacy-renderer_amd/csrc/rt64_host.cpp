@@ -699,7 +699,8 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         if (anyRefraction) HIP_CHECK(launch_refraction(P, img, klist, s));
         if (anyReflection) for (int r = 0; r < dev->opt.maxReflections; r++) HIP_CHECK(launch_reflection(P, img, klist, s));
         mark(Device::EV_REFL);
-        if (denoiseGI) {
+        if (denoiseGI && dev->opt.denoiserMode == 1) HIP_CHECK(launch_svgf(img, cur, imgW, imgH, s));
+        else if (denoiseGI) {
             HIP_CHECK(hipMemcpyAsync(img.filteredIndirect[0], img.indirectLight[cur], n * 8, hipMemcpyDeviceToDevice, s));
             for (int k = 0; k < 5; k++)            // rt64_view.cpp:1512-1530
                 HIP_CHECK(launch_gaussian(img.filteredIndirect[k % 2], img.filteredIndirect[(k % 2) ^ 1], imgW, imgH, 0, imgH, s));

@@ -162,6 +162,20 @@ def test_c3_gi_bounce_temporal_and_gaussian_filter(rt64_lib, sample_data):
     assert st.indirectRays == ref["counters"]["indirectRays"] > 0
 
 
+def test_c3_gi_svgf_denoiser(rt64_lib, sample_data):
+    """BASELINE config C3 at reduced size: 1 GI sample + SVGF (temporal moments, variance estimate, 5 a-trous iterations)."""
+    got, ref, st = _render_pair(rt64_lib, sample_data, frames=6, view_desc=dict(gi_samples=1, denoiser=True), options={"denoiser_mode": 1})
+    assert np.array_equal(got["PRIMARY_HIT"], ref["primaryHit"])
+    assert _rmse(got["OUTPUT_RGBA32F"][..., :3], ref["output"][..., :3]) <= 1e-3
+    assert _rmse(got["INDIRECT_LIGHT_FILTERED"][..., :3], ref["filteredIndirect"][..., :3]) <= 2e-3
+    # the filter does something: filtered GI is smoother than the raw accumulation on lit pixels
+    lit = ref["instanceId"] >= 0
+    raw, flt = ref["indirectLight"][..., 1], ref["filteredIndirect"][..., 1]
+    def roughness(a):
+        d = np.abs(np.diff(a, axis=1)); return d[lit[:, 1:] & lit[:, :-1]].mean()
+    assert roughness(flt) < 0.6 * roughness(raw)
+
+
 def test_c4_refit_of_updatable_mesh(rt64_lib, sample_data):
     """Per-frame vertex animation of an UPDATABLE mesh (rt64_mesh.cpp:129,149-157): SetMesh with unchanged counts refits the BLAS;
     hits stay bit-identical to the oracle's refit."""
