@@ -46,6 +46,7 @@ typedef struct {
     om4 worldToObject;
     int cullDisable;
     int opaque;                             /* every hit stores alpha 255 (see oracle_render.c: instance_is_opaque) */
+    int shadowOpaque;                       /* rule O2: every shadow any-hit saturates payload.shadowHit */
 } OInst;
 
 typedef struct {

@@ -159,9 +159,10 @@ static void alpha_source_bounds(const OInst *in, int item, float *lo, float *hi)
     }
 }
 
-static int instance_is_opaque(const OInst *in) {
+/* Lower bound of the combiner's alpha over the whole instance, or a negative value when nothing is proven. */
+static float instance_alpha_lower_bound(const OInst *in) {
     const OCombiner *cc = &in->cc;
-    if (cc->opt_noise || cc->opt_texture_edge) return 0;
+    if (cc->opt_noise || cc->opt_texture_edge) return -1.0f;
     float lo;
     if (!cc->opt_alpha) lo = 1.0f;                                  /* float4(..., 1.0f) everywhere, rt64_shader.cpp:232-256 */
     else {
@@ -169,10 +170,24 @@ static int instance_is_opaque(const OInst *in) {
         for (int k = 0; k < 4; k++) alpha_source_bounds(in, cc->c[1][k], &l[k], &h[k]);
         if (cc->do_single[1]) lo = l[3];
         else if (cc->do_multiply[1]) lo = fminf(fminf(l[0] * l[2], l[0] * h[2]), fminf(h[0] * l[2], h[0] * h[2]));
-        else return 0;                                              /* mix / general formula: not proven, use the k-buffer path */
+        else return -1.0f;                                          /* mix / general formula: not proven, use the k-buffer path */
     }
-    float a = in->desc.material.solidAlphaMultiplier * lo;
-    return a >= 0.999f;                                             /* to_unorm8(0.999) == 255 */
+    return lo;
+}
+
+static int instance_is_opaque(const OInst *in) {
+    float lo = instance_alpha_lower_bound(in);
+    return lo >= 0.0f && in->desc.material.solidAlphaMultiplier * lo >= 0.999f;     /* to_unorm8(0.999) == 255 */
+}
+
+/* Rule O2 (shared with the HIP host side): the shadow any-hit (rt64_shader.cpp:611-659) subtracts
+ * clamp(alpha * shadowAlphaMultiplier) from payload.shadowHit and ends the search at 0.  When that product is provably
+ * >= 0.999 for every hit of the instance, the first hit is treated as saturating (deviation from the reference <= 1e-3 in the
+ * shadow factor, and only for alphas within 1e-3 of 1).  A combiner without opt_alpha always saturates (:661). */
+static int instance_is_shadow_opaque(const OInst *in) {
+    if (!in->cc.opt_alpha) return 1;
+    float lo = instance_alpha_lower_bound(in);
+    return lo >= 0.0f && in->desc.material.shadowAlphaMultiplier * lo >= 0.999f;
 }
 
 static void update_view(OScene *s, const OFrameParams *p) {
@@ -191,6 +206,7 @@ static void update_view(OScene *s, const OFrameParams *p) {
         omatrix_inverse_d(&d->transform, &in->worldToObject);
         in->cullDisable = (d->flags & 0x2) != 0;                    /* RT64_INSTANCE_DISABLE_BACKFACE_CULLING */
         in->opaque = p->cullBehindOpaque ? instance_is_opaque(in) : 0;
+        in->shadowOpaque = p->cullBehindOpaque ? instance_is_shadow_opaque(in) : !in->cc.opt_alpha;
     }
     /* TLAS over world boxes of the instances (G1/G7). */
     obvh_free(&s->tlas);

@@ -452,7 +452,7 @@ float oshade_shadow_anyhit_alpha(const OShadeCtx *c, const OHit *hit, uint32_t p
     const OInst *in = &c->rt[hit->instance];
     const OCombiner *cc = &in->cc;
     const OMaterial *mat = &in->desc.material;
-    if (!cc->opt_alpha) return 2.0f;                                /* payload.shadowHit = 0 (:661): more than enough to saturate */
+    if (in->shadowOpaque) return 2.0f;                              /* payload.shadowHit = 0 (:661) / rule O2: more than enough to saturate */
     float b[3] = { 1.0f - hit->u - hit->v, hit->u, hit->v };
     VertexData vd; memset(&vd, 0, sizeof(vd));
     get_vertex_data(in, hit->prim, b, 0, &vd);

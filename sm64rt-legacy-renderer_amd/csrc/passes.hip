@@ -22,19 +22,30 @@ namespace {
 
 struct Pixel { uint32_t x, y; bool valid; };
 
+// Pixel tiles.  A workgroup (4 waves) owns one tile per loop trip; two shapes:
+//   SQUARE 16x16, wave = 8x8 pixels   : traversal kernels (coherent rays share BVH nodes)
+//   ROWS   32x8,  wave = 32x2 pixels  : shading kernels (a wave's image store covers whole 128/256-byte lines)
 // Tile rows owned by this device: strips stripRank, stripRank + stripCount, ... of the 16-row strips in [tileY0, tileY1).
-DEV uint32_t tile_rows(const FrameParams &P) {
+enum TileShape { TILE_SQUARE = 0, TILE_ROWS = 1 };
+template <int SHAPE> struct TileDim { static constexpr int W = SHAPE == TILE_SQUARE ? 16 : 32, H = SHAPE == TILE_SQUARE ? 16 : 8; };
+
+DEV uint32_t owned_strips(const FrameParams &P) {
     const uint32_t all = (uint32_t)(P.tileY1 - P.tileY0 + 15) / 16;
     return all > (uint32_t)P.stripRank ? (all - (uint32_t)P.stripRank + (uint32_t)P.stripCount - 1) / (uint32_t)P.stripCount : 0u;
 }
-DEV uint32_t tile_count(const FrameParams &P) { return (uint32_t)((P.width + 15) / 16) * tile_rows(P); }
-DEV Pixel tile_pixel(const FrameParams &P, uint32_t tile) {
-    const uint32_t tilesX = (uint32_t)(P.width + 15) / 16;
-    const uint32_t tx = tile % tilesX, ty = (tile / tilesX) * (uint32_t)P.stripCount + (uint32_t)P.stripRank;
+template <int SHAPE = TILE_SQUARE> DEV uint32_t tile_count(const FrameParams &P) {
+    return (uint32_t)((P.width + TileDim<SHAPE>::W - 1) / TileDim<SHAPE>::W) * owned_strips(P) * (16u / TileDim<SHAPE>::H);
+}
+template <int SHAPE = TILE_SQUARE> DEV Pixel tile_pixel(const FrameParams &P, uint32_t tile) {
+    constexpr uint32_t TW = TileDim<SHAPE>::W, TH = TileDim<SHAPE>::H, perStrip = 16u / TH;
+    const uint32_t tilesX = ((uint32_t)P.width + TW - 1) / TW;
+    const uint32_t tx = tile % tilesX, lt = tile / tilesX;
+    const uint32_t strip = (lt / perStrip) * (uint32_t)P.stripCount + (uint32_t)P.stripRank;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     Pixel p;
-    p.x = tx * 16 + (wave & 1) * 8 + (lane & 7);
-    p.y = (uint32_t)P.tileY0 + ty * 16 + (wave >> 1) * 8 + (lane >> 3);
+    if (SHAPE == TILE_SQUARE) { p.x = tx * TW + (wave & 1) * 8 + (lane & 7); p.y = (wave >> 1) * 8 + (lane >> 3); }
+    else { p.x = tx * TW + (lane & 31); p.y = wave * 2 + (lane >> 5); }
+    p.y += (uint32_t)P.tileY0 + strip * 16 + (lt % perStrip) * TH;
     p.valid = p.x < (uint32_t)P.width && p.y < (uint32_t)P.tileY1;
     return p;
 }
@@ -168,16 +179,28 @@ __global__ __launch_bounds__(RT_BLOCK) void primary_trace_kernel(FrameParams P, 
 
 // TRANSPARENT_LIGHT: some instance is not provably opaque, so the 'transparent geometry that needs lighting' path of
 // PrimaryRayGen.hlsl:136-148 (one random light + shadow ray from inside the resolve loop) can be reached.
+#ifndef SHADE_TILE
+#define SHADE_TILE TILE_ROWS
+#endif
+#ifndef DIRECT_TILE
+#define DIRECT_TILE TILE_SQUARE
+#endif
+#ifndef SHADE_WAVES
+#define SHADE_WAVES 3
+#endif
+#ifndef DIRECT_WAVES
+#define DIRECT_WAVES 3
+#endif
 template <bool TRANSPARENT_LIGHT, bool KLIST>
-__global__ __launch_bounds__(RT_BLOCK) void primary_shade_kernel(FrameParams P, ViewImages I, const int32_t *hitInstance, int cur) {
+__global__ __launch_bounds__(RT_BLOCK, SHADE_WAVES) void primary_shade_kernel(FrameParams P, ViewImages I, const int32_t *hitInstance, int cur) {
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
     env.lightIntensity = ldsLightIntensity + threadIdx.x; env.lightIndex = ldsLightIndex + threadIdx.x;
-    const uint32_t tiles = tile_count(P);
+    const uint32_t tiles = tile_count<SHADE_TILE>(P);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        Pixel p = tile_pixel(P, tile);
+        Pixel p = tile_pixel<SHADE_TILE>(P, tile);
         if (!p.valid) continue;
         const uint32_t px = p.x, py = p.y;
         const size_t i = (size_t)py * (size_t)P.width + px;
@@ -309,15 +332,15 @@ DEV float history_weight(const FrameParams &P, const ViewImages &I, size_t i, ui
     return expf(-weightDepth) * weightNormal;
 }
 
-__global__ __launch_bounds__(RT_BLOCK) void direct_kernel(FrameParams P, ViewImages I, int cur) {
+__global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void direct_kernel(FrameParams P, ViewImages I, int cur) {
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
     env.lightIntensity = ldsLightIntensity + threadIdx.x; env.lightIndex = ldsLightIndex + threadIdx.x;
-    const uint32_t tiles = tile_count(P);
+    const uint32_t tiles = tile_count<DIRECT_TILE>(P);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        Pixel p = tile_pixel(P, tile);
+        Pixel p = tile_pixel<DIRECT_TILE>(P, tile);
         if (!p.valid) continue;
         const uint32_t px = p.x, py = p.y;
         const size_t i = (size_t)py * (size_t)P.width + px;

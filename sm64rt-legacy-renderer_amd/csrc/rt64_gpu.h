@@ -58,7 +58,7 @@ enum : uint32_t {
     GPU_INST_OPAQUE       = 1u << 1,     // static opacity rule O1: every hit stores alpha 255
     GPU_INST_NORMAL_MAP   = 1u << 2,     // RT64_SHADER_NORMAL_MAP_ENABLED
     GPU_INST_SPECULAR_MAP = 1u << 3,     // RT64_SHADER_SPECULAR_MAP_ENABLED
-    GPU_INST_SHADOW_OPAQUE = 1u << 4,    // shadow any-hit needs no alpha evaluation (combiner without opt_alpha)
+    GPU_INST_SHADOW_OPAQUE = 1u << 4,    // rule O2: the first shadow-ray hit saturates (no opt_alpha, or alpha * shadowAlphaMultiplier provably >= 0.999)
 };
 
 struct alignas(16) GpuInstance {
@@ -77,6 +77,7 @@ struct alignas(16) GpuInstance {
     uint32_t filter, hAddr, vAddr;
     uint32_t flags;
     uint32_t triCount;
+    uint32_t meshVersion;                // bumps on every RT64_SetMesh: part of the frame-table cache key
 };
 
 // Constant block of one frame (reference: GlobalParams.hlsli:8-43 / rt64_view.cpp:961-1028), passed by value.

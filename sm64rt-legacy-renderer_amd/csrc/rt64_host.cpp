@@ -135,7 +135,7 @@ static GpuCombiner decode_combiner(uint32_t shaderId) {
 // ---- objects ---------------------------------------------------------------------------------------------------------------
 
 struct Options {
-    bool countTraversal = false, profilePasses = true, syncPresent = true;
+    bool countTraversal = false, profilePasses = true, syncPresent = true, alwaysRebuild = false;
     int denoiserMode = 1;          // 0 = reference 5x Gaussian, 1 = SVGF
     int maxReflections = 2;        // rt64_view.cpp:60 (inspector-only knob in the reference)
 };
@@ -243,6 +243,7 @@ struct View {
     std::vector<Texture *> usedTextures;
     DevArray<GpuInstance> dInstances; DevArray<GpuTexture> dTextures; DevArray<RT64_LIGHT> dLights;
     DevArray<GpuNode> tlasNodes; DevArray<uint32_t> tlasIndex, tlasMorton, tlasLeafParent; DevArray<BlasHeader> tlasHeader; DevArray<uint8_t> tlasScratch;
+    std::vector<uint8_t> uploadedTables;      // bytes of the last uploaded instance/texture/light tables (cache key)
     float maxDepthBias = 0.0f;
     bool anyNonOpaque = false, anyReflection = false, anyRefraction = false;
 
@@ -390,7 +391,8 @@ void Mesh::set(const void *vertexArray, int vcount, int vstride, const unsigned 
     memcpy(stage, vertexArray, vbytes); memcpy(stage + vbytes, indexArray, ibytes);
     HIP_CHECK(hipMemcpyAsync(vertices.ptr, stage, vbytes, hipMemcpyHostToDevice, device->stream));
     HIP_CHECK(hipMemcpyAsync(indices.ptr, stage + vbytes, ibytes, hipMemcpyHostToDevice, device->stream));
-    vertexCount = vcount; vertexStride = vstride; indexCount = icount; version++;
+    static uint32_t globalMeshVersion = 0;      // unique across meshes: a recycled allocation never aliases a cached frame table
+    vertexCount = vcount; vertexStride = vstride; indexCount = icount; version = ++globalMeshVersion;
     if (flags & RT64_MESH_RAYTRACE_ENABLED) {                // rt64_mesh.cpp:114-126
         const uint32_t n = (uint32_t)icount / 3;
         if (n == 0) throw std::runtime_error("RT64_SetMesh: a ray-traced mesh needs at least one triangle.");
@@ -483,8 +485,8 @@ void View::createImages(int w, int h) {       // View::createOutputBuffers, rt64
 // Static opacity rule O1: an instance is opaque when every hit it can produce stores alpha 255 in the RGBA8
 // hit colour, so nothing behind it can contribute (PrimaryRayGen.hlsl:150,174).  Decided from bounds on the combiner's
 // alpha sources: vertex input alphas over the mesh, texel alphas over the texture.
-static bool instance_is_opaque(const Instance *inst, const GpuCombiner &cc) {
-    if (cc.optNoise || cc.optTextureEdge) return false;
+static float instance_alpha_lower_bound(const Instance *inst, const GpuCombiner &cc) {
+    if (cc.optNoise || cc.optTextureEdge) return -1.0f;
     float lo;
     if (!cc.optAlpha) lo = 1.0f;
     else {
@@ -498,10 +500,20 @@ static bool instance_is_opaque(const Instance *inst, const GpuCombiner &cc) {
         }
         if (cc.doSingle[1]) lo = l[3];
         else if (cc.doMultiply[1]) lo = std::min(std::min(l[0] * l[2], l[0] * h[2]), std::min(h[0] * l[2], h[0] * h[2]));
-        else return false;
+        else return -1.0f;
     }
-    float a = inst->material.solidAlphaMultiplier * lo;
-    return a >= 0.999f;
+    return lo;
+}
+static bool instance_is_opaque(const Instance *inst, const GpuCombiner &cc) {
+    const float lo = instance_alpha_lower_bound(inst, cc);
+    return lo >= 0.0f && inst->material.solidAlphaMultiplier * lo >= 0.999f;
+}
+// Rule O2: the shadow any-hit (rt64_shader.cpp:611-659) saturates payload.shadowHit on the first hit when
+// alpha * shadowAlphaMultiplier is provably >= 0.999 for the whole instance; a combiner without opt_alpha always does (:661).
+static bool instance_is_shadow_opaque(const Instance *inst, const GpuCombiner &cc) {
+    if (!cc.optAlpha) return true;
+    const float lo = instance_alpha_lower_bound(inst, cc);
+    return lo >= 0.0f && inst->material.shadowAlphaMultiplier * lo >= 0.999f;
 }
 
 void View::update() {                          // View::update, rt64_view.cpp:1053-1178
@@ -560,8 +572,9 @@ void View::update() {                          // View::update, rt64_view.cpp:10
         if (instance_is_opaque(inst, g.cc)) g.flags |= GPU_INST_OPAQUE;
         if (inst->shader->flags & RT64_SHADER_NORMAL_MAP_ENABLED) g.flags |= GPU_INST_NORMAL_MAP;
         if (inst->shader->flags & RT64_SHADER_SPECULAR_MAP_ENABLED) g.flags |= GPU_INST_SPECULAR_MAP;
-        if (!g.cc.optAlpha) g.flags |= GPU_INST_SHADOW_OPAQUE;
+        if (instance_is_shadow_opaque(inst, g.cc)) g.flags |= GPU_INST_SHADOW_OPAQUE;
         g.triCount = mesh->blasCount;
+        g.meshVersion = mesh->version;
         if (g.cc.vertexSize > mesh->vertexStride) throw std::runtime_error("Instance mesh vertex stride is smaller than the layout its shader reads.");
         maxDepthBias = std::max(maxDepthBias, inst->material.depthBias);
         if (!(g.flags & GPU_INST_OPAQUE)) anyNonOpaque = true;
@@ -575,20 +588,26 @@ void View::update() {                          // View::update, rt64_view.cpp:10
         memcpy(g.mipOffset, t->mipOffset, sizeof(g.mipOffset));
     }
     if (nLights) memcpy(hLights, scene->lights.data(), lightBytes);
-    dInstances.reserve(std::max<size_t>(nInst, 1)); dTextures.reserve(std::max<size_t>(nTex, 1)); dLights.reserve(std::max<size_t>(nLights, 1));
-    if (instBytes) HIP_CHECK(hipMemcpyAsync(dInstances.ptr, hInst, instBytes, hipMemcpyHostToDevice, dev->stream));
-    if (texBytes) HIP_CHECK(hipMemcpyAsync(dTextures.ptr, hTex, texBytes, hipMemcpyHostToDevice, dev->stream));
-    if (lightBytes) HIP_CHECK(hipMemcpyAsync(dLights.ptr, hLights, lightBytes, hipMemcpyHostToDevice, dev->stream));
-
-    // TLAS: full rebuild every frame (rt64_view.cpp:412-452, updateOnly = false).
-    if (nInst) {
-        const uint32_t n = (uint32_t)nInst;
-        tlasNodes.reserve(std::max<size_t>(n - 1, 1)); tlasIndex.reserve(n); tlasMorton.reserve(n); tlasLeafParent.reserve(n); tlasHeader.reserve(1);
-        LbvhArgs a = {};
-        a.mode = LBVH_MODE_INSTANCES; a.refit = 0; a.n = n; a.instances = dInstances.ptr;
-        a.nodes = tlasNodes.ptr; a.tris = nullptr; a.header = tlasHeader.ptr; a.sortedIndex = tlasIndex.ptr; a.morton = tlasMorton.ptr; a.leafParent = tlasLeafParent.ptr;
-        if (n > LBVH_SMALL_MAX) { tlasScratch.reserve(lbvh_large_scratch_bytes(n)); a.scratch = tlasScratch.ptr; a.scratchBytes = tlasScratch.bytes(); }
-        HIP_CHECK(lbvh_launch(a, dev->stream));
+    // The tables (and with them the TLAS) only change when the host changed an instance, a mesh, a texture binding or a light.
+    // Identical bytes => the device copies and the TLAS of the previous frame are still exact: skip upload and rebuild.
+    const size_t tableBytes = instBytes + texBytes + lightBytes;
+    const bool unchanged = uploadedTables.size() == tableBytes && tableBytes && memcmp(uploadedTables.data(), stage, tableBytes) == 0 && !dev->opt.alwaysRebuild;
+    if (!unchanged) {
+        dInstances.reserve(std::max<size_t>(nInst, 1)); dTextures.reserve(std::max<size_t>(nTex, 1)); dLights.reserve(std::max<size_t>(nLights, 1));
+        if (instBytes) HIP_CHECK(hipMemcpyAsync(dInstances.ptr, hInst, instBytes, hipMemcpyHostToDevice, dev->stream));
+        if (texBytes) HIP_CHECK(hipMemcpyAsync(dTextures.ptr, hTex, texBytes, hipMemcpyHostToDevice, dev->stream));
+        if (lightBytes) HIP_CHECK(hipMemcpyAsync(dLights.ptr, hLights, lightBytes, hipMemcpyHostToDevice, dev->stream));
+        // TLAS: full rebuild (rt64_view.cpp:412-452 rebuilds every frame, updateOnly = false).
+        if (nInst) {
+            const uint32_t n = (uint32_t)nInst;
+            tlasNodes.reserve(std::max<size_t>(n - 1, 1)); tlasIndex.reserve(n); tlasMorton.reserve(n); tlasLeafParent.reserve(n); tlasHeader.reserve(1);
+            LbvhArgs a = {};
+            a.mode = LBVH_MODE_INSTANCES; a.refit = 0; a.n = n; a.instances = dInstances.ptr;
+            a.nodes = tlasNodes.ptr; a.tris = nullptr; a.header = tlasHeader.ptr; a.sortedIndex = tlasIndex.ptr; a.morton = tlasMorton.ptr; a.leafParent = tlasLeafParent.ptr;
+            if (n > LBVH_SMALL_MAX) { tlasScratch.reserve(lbvh_large_scratch_bytes(n)); a.scratch = tlasScratch.ptr; a.scratchBytes = tlasScratch.bytes(); }
+            HIP_CHECK(lbvh_launch(a, dev->stream));
+        }
+        uploadedTables.assign(stage, stage + tableBytes);
     }
     for (Texture *t : usedTextures) t->currentIndex = -1;
 }
@@ -928,6 +947,7 @@ RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, doubl
     else if (k == "profile_passes") d->opt.profilePasses = value != 0.0;
     else if (k == "sync_present") d->opt.syncPresent = value != 0.0;
     else if (k == "denoiser_mode") d->opt.denoiserMode = (int)value;
+    else if (k == "always_rebuild") d->opt.alwaysRebuild = value != 0.0;          // upload tables + rebuild the TLAS every frame like the reference
     else if (k == "max_reflections") d->opt.maxReflections = std::max(0, (int)value);
     else return 0;
     return 1;
