@@ -82,7 +82,33 @@ struct TraceStack {
 
 struct TraceCounts { uint32_t nodes, tris; };
 
+// Pointers that were loaded from memory are "generic" to the compiler (flat_load + both wait counters).  Every BVH array
+// lives in HBM, so fetch through address space 1: global_load_dwordx4, vmcnt only.
+template <class T> DEV T load_global(const T *p) {              // scalars / pointers
+    typedef const T __attribute__((address_space(1))) *GP;
+    return *reinterpret_cast<GP>(reinterpret_cast<uintptr_t>(p));
+}
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));      // builtin vector: loads through address space 1 directly
+typedef const u32x4 __attribute__((address_space(1))) *GlobalU4;
+DEV GpuNode load_node(const GpuNode *p) {                         // 4 x global_load_dwordx4
+    GlobalU4 q = reinterpret_cast<GlobalU4>(reinterpret_cast<uintptr_t>(p));
+    union { u32x4 w[4]; GpuNode n; } u;
+    u.w[0] = q[0]; u.w[1] = q[1]; u.w[2] = q[2]; u.w[3] = q[3];
+    return u.n;
+}
+DEV GpuTri load_tri(const GpuTri *p) {                            // 3 x global_load_dwordx4
+    GlobalU4 q = reinterpret_cast<GlobalU4>(reinterpret_cast<uintptr_t>(p));
+    union { u32x4 w[3]; GpuTri t; } u;
+    u.w[0] = q[0]; u.w[1] = q[1]; u.w[2] = q[2];
+    return u.t;
+}
+
 // OnHit: bool operator()(float t, float u, float v, uint32_t instance, uint32_t prim, float &tmax) -> true = end search.
+//
+// Loop shape ("while-while"): the wave first walks inner nodes until every live lane holds a leaf (or has finished), then all
+// lanes process their leaf together (ray/triangle test, or the object-space switch at a TLAS leaf).  Lanes never execute the
+// node path and the leaf path in the same trip, which is what a one-ray-per-lane walk loses most to on wave64.  The order of
+// operations of each individual ray is unchanged (R3), so hits and visit counts stay bit-identical to the scalar tracer.
 template <class OnHit>
 DEV void trace_ray(const FrameParams &P, const float o[3], const float d[3], float tmin, float tmax, bool cullBackFaces,
                    const TraceStack &stk, OnHit &&onHit, TraceCounts &cnt) {
@@ -96,53 +122,61 @@ DEV void trace_ray(const FrameParams &P, const float o[3], const float d[3], flo
     uint32_t inst = 0;
     bool cull = false;
     uint32_t cur = 0;
-    for (;;) {
-        bool doPop = false;
-        if (cur & RT64_LEAF_BIT) {
-            if (cur != RT64_NO_CHILD) {
-                if (blasBase < 0) {
-                    // TLAS leaf: enter the instance (G8)
-                    inst = P.tlasIndex[cur & 0x7FFFFFFFu];
-                    const GpuInstance &in = P.instances[inst];
-                    float oo[3], dd[3];
-                    g_xform_point(in.worldToObject, W.o, oo);
-                    g_xform_vector(in.worldToObject, W.d, dd);
-                    make_ray_space(oo, dd, R);
-                    nodes = in.nodes; tris = in.tris;
-                    cull = cullBackFaces && !(in.flags & GPU_INST_CULL_DISABLE);
-                    blasBase = sp;
-                    cur = 0;
-                    continue;
-                }
-                const GpuTri tri = tris[cur & 0x7FFFFFFFu];
-                cnt.tris++;
-                float t, u, v;
-                if (tri_hit(R, tri, cull, tmin, tmax, t, u, v))
-                    if (onHit(t, u, v, inst, tri.prim, tmax)) return;
-            }
-            doPop = true;
+    bool alive = true;
+    auto popNext = [&]() -> bool {
+        if (blasBase >= 0 && sp == blasBase) {          // BLAS exhausted: resume the TLAS walk in world space
+            blasBase = -1; R = W; nodes = P.tlasNodes;
         }
-        else {
-            const GpuNode nd = nodes[cur];
+        if (sp == 0) return false;
+        cur = stk.pop(sp);
+        return true;
+    };
+    while (alive) {
+        // ---- inner nodes ----
+        while (alive && !(cur & RT64_LEAF_BIT)) {
+            const GpuNode nd = load_node(nodes + cur);
             cnt.nodes++;
             float tl, tr;
-            bool hl = box_hit(R, nd.lmin, nd.lmax, tmin, tmax, tl);
-            bool hr = box_hit(R, nd.rmin, nd.rmax, tmin, tmax, tr);
+            const bool hl = box_hit(R, nd.lmin, nd.lmax, tmin, tmax, tl);
+            const bool hr = box_hit(R, nd.rmin, nd.rmax, tmin, tmax, tr);
             if (hl && hr) {
                 if (tr < tl) { stk.push(sp, nd.left); cur = nd.right; }
                 else { stk.push(sp, nd.right); cur = nd.left; }
             }
             else if (hl) cur = nd.left;
             else if (hr) cur = nd.right;
-            else doPop = true;
+            else alive = popNext();
         }
-        if (doPop) {
-            if (blasBase >= 0 && sp == blasBase) {      // BLAS exhausted: resume the TLAS walk in world space
-                blasBase = -1; R = W; nodes = P.tlasNodes;
+        if (!alive) break;
+        // ---- leaf ----
+        if (cur != RT64_NO_CHILD) {
+            if (blasBase < 0) {
+                // TLAS leaf: enter the instance (G8)
+                inst = load_global(P.tlasIndex + (cur & 0x7FFFFFFFu));
+                const GpuInstance *in = P.instances + inst;
+                float oo[3], dd[3];
+                // p * M with M row-major 4x4: column c of rows 0..3 = M[c], M[4+c], M[8+c], M[12+c]
+                const float *M = in->worldToObject;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float m0 = load_global(M + c), m1 = load_global(M + 4 + c), m2 = load_global(M + 8 + c), m3 = load_global(M + 12 + c);
+                    oo[c] = fmaf(W.o[2], m2, fmaf(W.o[1], m1, fmaf(W.o[0], m0, m3)));
+                    dd[c] = fmaf(W.d[2], m2, fmaf(W.d[1], m1, W.d[0] * m0));
+                }
+                make_ray_space(oo, dd, R);
+                nodes = load_global(&in->nodes); tris = load_global(&in->tris);
+                cull = cullBackFaces && !(load_global(&in->flags) & GPU_INST_CULL_DISABLE);
+                blasBase = sp;
+                cur = 0;
+                continue;
             }
-            if (sp == 0) return;
-            cur = stk.pop(sp);
+            const GpuTri tri = load_tri(tris + (cur & 0x7FFFFFFFu));
+            cnt.tris++;
+            float t, u, v;
+            if (tri_hit(R, tri, cull, tmin, tmax, t, u, v))
+                if (onHit(t, u, v, inst, tri.prim, tmax)) return;
         }
+        alive = popNext();
     }
 }
 
