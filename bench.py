@@ -31,12 +31,14 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 # Algorithmic bytes (DESIGN.md "Kernels and rooflines"): a BVH node record is 64 B, a triangle record 48 B.
 NODE_B, TRI_B = 64, 48
 PRIMARY_TRACE_PIXEL_B = 16 + 4                 # hit record (t,u,v,prim) + instance id written per primary ray
-PRIMARY_SHADE_PIXEL_B = 20 + 90                # hit record read + 14 G-buffer images written (90 B/px)
+PRIMARY_SHADE_PIXEL_B = 20 + 94                # hit record read + 15 G-buffer images written (90 B/px + first-instance copy)
+PRIMARY_SHADE_PIXEL_LEAN_B = 20 + 52           # lean frame: position, normals x2, specular, diffuse, instance id, depth only
 PRIMARY_SHADE_HIT_B = 3 * 52 + 4 * 16 * 4      # 3 vertices of the sample layout + 4 bilinear fetches x 4 texels x 4 B
 PRIMARY_SHADE_MISS_B = 16                      # one bilinear sky fetch
 DIRECT_PIXEL_B = 4 + 8                         # instance id read + RGBA16F light written
 DIRECT_HIT_B = 16 + 8 + 8                      # position + normal + specular read for lit pixels
 COMPOSE_PIXEL_B = 44 + 16 + 4                  # compose reads 44 B, writes 16 B; post writes 4 B (fused: output not re-read)
+COMPOSE_PIXEL_LEAN_B = 12 + 16 + 4             # lean frame: diffuse + direct light read
 
 
 def parse_args():
@@ -98,11 +100,16 @@ def main():
     local = torch.zeros(max_rows * W * 4, dtype=torch.uint8, device="cuda")
     my_bytes = tiles.owned_rows(H, rank, N) * W * 4
 
-    def step():
-        scene.draw()
+    def fetch():
         n = lib.CopyDeviceImage(scene.device, rt64.IMAGE_FINAL_RGBA8, local.data_ptr(), local.numel())
         if n != my_bytes:
             raise RuntimeError("RT64_CopyDeviceImage returned %d, expected %d: %s" % (n, my_bytes, lib.last_error()))
+
+    def step():
+        scene.draw()                 # returns after the frame is complete in the device's back buffer (HBM)
+        if N == 1:
+            return None              # single GPU: the back buffer IS the composited frame, nothing to gather
+        fetch()
         return tiles.gather_frame(local if comm_device == "cuda" else local.cpu(), H, W, rank, N)
 
     def barrier():
@@ -118,6 +125,7 @@ def main():
     counts = dict(primary=st.primaryRays, shadow=st.shadowRays, indirect=st.indirectRays, nodesPrimary=st.nodesPrimary,
                   trisPrimary=st.trianglesPrimary, nodesDirect=st.nodesDirect, trisDirect=st.trianglesDirect,
                   nodesIndirect=st.nodesIndirect, trisIndirect=st.trianglesIndirect)
+    lean = bool(st.leanFrame)
     hit_pixels = int((scene.readback(rt64.IMAGE_FIRST_INSTANCE_ID) >= 0).sum())
     scene.option("count_traversal", 0)
     rays_local = counts["primary"] + counts["shadow"] + counts["indirect"]
@@ -154,9 +162,9 @@ def main():
         my_pixels = tiles.owned_rows(H, 0, N) * W
         kernels = {
             "primary_trace": (kms["trace"], my_pixels * PRIMARY_TRACE_PIXEL_B + NODE_B * counts["nodesPrimary"] + TRI_B * counts["trisPrimary"]),
-            "primary_shade": (kms["shade"], my_pixels * PRIMARY_SHADE_PIXEL_B + hit_pixels * PRIMARY_SHADE_HIT_B + (my_pixels - hit_pixels) * PRIMARY_SHADE_MISS_B),
-            "direct": (kms["direct"], my_pixels * DIRECT_PIXEL_B + hit_pixels * DIRECT_HIT_B + NODE_B * counts["nodesDirect"] + TRI_B * counts["trisDirect"] + 4 * counts["shadow"]),
-            "compose_post": (kms["compose"], my_pixels * COMPOSE_PIXEL_B),
+            "primary_shade": (kms["shade"], my_pixels * (PRIMARY_SHADE_PIXEL_LEAN_B if lean else PRIMARY_SHADE_PIXEL_B) + hit_pixels * PRIMARY_SHADE_HIT_B + (my_pixels - hit_pixels) * PRIMARY_SHADE_MISS_B),
+            "direct": (kms["direct"], my_pixels * (DIRECT_PIXEL_B + (0 if lean else 8)) + hit_pixels * DIRECT_HIT_B + NODE_B * counts["nodesDirect"] + TRI_B * counts["trisDirect"] + 4 * counts["shadow"]),
+            "compose_post": (kms["compose"], my_pixels * (COMPOSE_PIXEL_LEAN_B if lean else COMPOSE_PIXEL_B)),
         }
         if args.gi_samples:
             kernels["indirect"] = (kms["indirect"], my_pixels * 12 + hit_pixels * 24 + NODE_B * counts["nodesIndirect"] + TRI_B * counts["trisIndirect"])
@@ -174,7 +182,7 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(d_bytes), "ms_per_launch": round(d_ms, 5),
                     "kernels": {k: {"ms": round(v[0], 5), "alg_bytes": int(v[1]), "GBps": round(v[1] / (v[0] * 1e-3) / 1e9, 2) if v[0] > 0 else 0.0} for k, v in kernels.items()},
-                    "frame_gpu_ms": round(kms["total"], 5), "build_ms": round(kms["build"], 5),
+                    "lean_frame": lean, "frame_gpu_ms": round(kms["total"], 5), "build_ms": round(kms["build"], 5),
                     "nodes_per_primary_ray": round(counts["nodesPrimary"] / max(counts["primary"], 1), 3),
                     "tris_per_primary_ray": round(counts["trisPrimary"] / max(counts["primary"], 1), 3),
                     "nodes_per_shadow_ray": round(counts["nodesDirect"] / max(counts["shadow"], 1), 3),
@@ -192,6 +200,9 @@ def main():
         }
         if N == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(data, W, H, args.cpu_baseline_height)
+        if N == 1:
+            fetch()
+            frame = local[:H * W * 4]
         if frame is not None:
             result["frame_checksum"] = int(frame.to(torch.int64).sum().item())
         print(json.dumps(result), flush=True)

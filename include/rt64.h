@@ -354,7 +354,7 @@ typedef struct {
     float msPrimaryTrace, msPrimaryShade;   /* split of msPrimary: pure traversal kernel / shading kernel */
     unsigned int stripRank, stripCount;     /* interleaved 16-row strips (RT64_SetDeviceInterleave), count 1 = off */
     unsigned int rowsRendered;              /* rows of the frame this device rendered */
-    unsigned int reserved0;
+    unsigned int leanFrame;                 /* 1: images no pass consumed were skipped this frame (produced on readback) */
     /* per-pass split of nodesVisited / trianglesTested (count_traversal = 1) */
     unsigned long long nodesPrimary, trianglesPrimary, nodesDirect, trianglesDirect, nodesIndirect, trianglesIndirect;
 } RT64_FRAME_STATS;

@@ -191,7 +191,10 @@ __global__ __launch_bounds__(RT_BLOCK) void primary_trace_kernel(FrameParams P, 
 #ifndef DIRECT_WAVES
 #define DIRECT_WAVES 3
 #endif
-template <bool TRANSPARENT_LIGHT, bool KLIST>
+// FULL = false ("lean" frame): no pass of this frame consumes the view direction, reflection / refraction / transparent
+// accumulators, motion vectors or upscaler masks, so they are not written (42 of 94 bytes per pixel); RT64_ReadbackDevice
+// re-runs the FULL variant on demand (View::materialise in rt64_host.cpp).
+template <bool TRANSPARENT_LIGHT, bool KLIST, bool FULL>
 __global__ __launch_bounds__(RT_BLOCK, SHADE_WAVES) void primary_shade_kernel(FrameParams P, ViewImages I, const int32_t *hitInstance, int cur) {
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -208,19 +211,21 @@ __global__ __launch_bounds__(RT_BLOCK, SHADE_WAVES) void primary_shade_kernel(Fr
         primary_ray(P, px, py, rayOrigin, rayDirection, d);
         f3 cU = mk3(P.cameraU[0], P.cameraU[1], P.cameraU[2]), cV = mk3(P.cameraV[0], P.cameraV[1], P.cameraV[2]), cW = mk3(P.cameraW[0], P.cameraW[1], P.cameraW[2]);
         f3 nonNormRayDir = (cU * d.x + cV * d.y) + cW;
-        store_rgba16f(I.viewDirection, i, rayDirection.x, rayDirection.y, rayDirection.z, 0.0f);
+        if (FULL) store_rgba16f(I.viewDirection, i, rayDirection.x, rayDirection.y, rayDirection.z, 0.0f);
         float reflA = 0.0f, refrA = 0.0f;
 
         f2 screenUV; screenUV.x = ((float)px + P.pixelJitter[0]) / (float)P.width; screenUV.y = ((float)py + P.pixelJitter[1]) / (float)P.height;
         f3 bgColor = sample_background_2d(P, screenUV);
         f4 skyColor = sample_sky_2d(P, screenUV);
-        f3 bgPosition = rayOrigin + rayDirection * RT_RAY_MAX_DISTANCE;
-        f2 prevBgPos = world_to_screen(P.prevViewProj, bgPosition), curBgPos = world_to_screen(P.viewProj, bgPosition);
+        f2 prevBgPos, curBgPos; prevBgPos.x = prevBgPos.y = curBgPos.x = curBgPos.y = 0.0f;
+        if (FULL) {
+            f3 bgPosition = rayOrigin + rayDirection * RT_RAY_MAX_DISTANCE;
+            prevBgPos = world_to_screen(P.prevViewProj, bgPosition); curBgPos = world_to_screen(P.viewProj, bgPosition);
+        }
         bgColor = lerp3(bgColor, xyz(skyColor), skyColor.w);
 
         RayDiff rayDiff;
-        rayDiff.dOdx = mk3s(0.0f); rayDiff.dOdy = mk3s(0.0f);
-        compute_ray_diffs(nonNormRayDir, cU, cV, P.resolution[2], P.resolution[3], rayDiff.dDdx, rayDiff.dDdy);
+        rayDiff.dOdx = mk3s(0.0f); rayDiff.dOdy = mk3s(0.0f); rayDiff.dDdx = mk3s(0.0f); rayDiff.dDdy = mk3s(0.0f);
 
         f3 resPosition = mk3s(0.0f), resNormal = -rayDirection, resSpecular = mk3s(0.0f), resTransparent = mk3s(0.0f), resTransparentLight = mk3s(0.0f);
         bool resTransparentLightComputed = false;
@@ -236,6 +241,7 @@ __global__ __launch_bounds__(RT_BLOCK, SHADE_WAVES) void primary_shade_kernel(Fr
         best.hit = hInst >= 0; best.instance = (uint32_t)hInst; best.prim = hrec.w;
         best.t = __uint_as_float(hrec.x); best.u = __uint_as_float(hrec.y); best.v = __uint_as_float(hrec.z);
         const uint32_t nhits = KLIST ? I.klistCount[i] : (hInst >= 0 ? 1u : 0u);
+        if (nhits) compute_ray_diffs(nonNormRayDir, cU, cV, P.resolution[2], P.resolution[3], rayDiff.dDdx, rayDiff.dDdy);
         for (uint32_t hit = 0; hit < nhits; hit++) {
             HitRecord r;
             if (!surface_record<KLIST>(P, I, i, hit, best, rayDirection, rayDiff, px, py, r)) continue;
@@ -280,8 +286,8 @@ __global__ __launch_bounds__(RT_BLOCK, SHADE_WAVES) void primary_shade_kernel(Fr
                 resColor.w *= (1.0f - hitColor.w);
                 if (m.refractionFactor > RT_EPSILON) { storeHit = true; refrA = resColor.w; resColor.w = 0.0f; }
                 if (storeHit && resInstanceId < 0) {
-                    f2 prevPos = world_to_screen(P.prevViewProj, vertexPosition - r.flow);
-                    f2 curPos = world_to_screen(P.viewProj, vertexPosition);
+                    f2 prevPos, curPos; prevPos.x = prevPos.y = curPos.x = curPos.y = 0.0f;
+                    if (FULL) { prevPos = world_to_screen(P.prevViewProj, vertexPosition - r.flow); curPos = world_to_screen(P.viewProj, vertexPosition); }
                     f4 projPos = mul4(P.viewProj, mk4(vertexPosition.x, vertexPosition.y, vertexPosition.z, 1.0f));
                     resPosition = vertexPosition; resNormal = vertexNormal; resSpecular = specular; resInstanceId = (int)instanceId;
                     resFlowX = (curPos.x - prevPos.x) * (float)P.width; resFlowY = (curPos.y - prevPos.y) * (float)P.height;
@@ -294,18 +300,22 @@ __global__ __launch_bounds__(RT_BLOCK, SHADE_WAVES) void primary_shade_kernel(Fr
         resColor.x += bgColor.x * resColor.w; resColor.y += bgColor.y * resColor.w; resColor.z += bgColor.z * resColor.w;
         resColor.w = 1.0f - resColor.w;
 
-        store_rgba16f(I.reflection, i, 0.0f, 0.0f, 0.0f, reflA);
-        store_rgba16f(I.refraction, i, 0.0f, 0.0f, 0.0f, refrA);
+        if (FULL) {
+            store_rgba16f(I.reflection, i, 0.0f, 0.0f, 0.0f, reflA);
+            store_rgba16f(I.refraction, i, 0.0f, 0.0f, 0.0f, refrA);
+        }
         reinterpret_cast<float4 *>(I.shadingPosition)[i] = make_float4(resPosition.x, resPosition.y, resPosition.z, 0.0f);
         store_rgba16f(I.shadingNormal, i, resNormal.x, resNormal.y, resNormal.z, 0.0f);
         store_rgba16f(I.shadingSpecular, i, resSpecular.x, resSpecular.y, resSpecular.z, 0.0f);
         store_rgba8(I.diffuse, i, resColor.x, resColor.y, resColor.z, resColor.w);
         I.instanceId[i] = resInstanceId;
-        I.firstInstanceId[i] = resInstanceId;                       // CopyResource(rtFirstInstanceId, rtInstanceId), rt64_view.cpp:1383
-        store_rgba16f(I.transparent, i, resTransparent.x, resTransparent.y, resTransparent.z, 1.0f);
-        reinterpret_cast<uint32_t *>(I.flow)[i] = (uint32_t)f32_to_f16_bits(-resFlowX) | ((uint32_t)f32_to_f16_bits(resFlowY) << 16);
-        I.reactiveMask[i] = to_unorm8(fminf(resReactiveMask, 0.9f));
-        I.lockMask[i] = to_unorm8(P.binaryLockMask ? (resLockMask >= 0.5f ? 1.0f : 0.0f) : fminf(resLockMask, 1.0f));
+        if (FULL) {
+            I.firstInstanceId[i] = resInstanceId;                   // CopyResource(rtFirstInstanceId, rtInstanceId), rt64_view.cpp:1383
+            store_rgba16f(I.transparent, i, resTransparent.x, resTransparent.y, resTransparent.z, 1.0f);
+            reinterpret_cast<uint32_t *>(I.flow)[i] = (uint32_t)f32_to_f16_bits(-resFlowX) | ((uint32_t)f32_to_f16_bits(resFlowY) << 16);
+            I.reactiveMask[i] = to_unorm8(fminf(resReactiveMask, 0.9f));
+            I.lockMask[i] = to_unorm8(P.binaryLockMask ? (resLockMask >= 0.5f ? 1.0f : 0.0f) : fminf(resLockMask, 1.0f));
+        }
         store_rgba16f(I.normal[cur], i, resNormal.x, resNormal.y, resNormal.z, 0.0f);
         I.depth[cur][i] = resDepth;
     }
@@ -332,6 +342,7 @@ DEV float history_weight(const FrameParams &P, const ViewImages &I, size_t i, ui
     return expf(-weightDepth) * weightNormal;
 }
 
+template <bool FULL>
 __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void direct_kernel(FrameParams P, ViewImages I, int cur) {
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -345,7 +356,7 @@ __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void direct_kernel(FramePar
         const uint32_t px = p.x, py = p.y;
         const size_t i = (size_t)py * (size_t)P.width + px;
         const int instanceId = I.instanceId[i];
-        if (instanceId < 0) { store_rgba16f(I.directLight[cur], i, 1.0f, 1.0f, 1.0f, 0.0f); store_rgba16f(I.filteredDirect[1], i, 1.0f, 1.0f, 1.0f, 0.0f); continue; }
+        if (instanceId < 0) { store_rgba16f(I.directLight[cur], i, 1.0f, 1.0f, 1.0f, 0.0f); if (FULL) store_rgba16f(I.filteredDirect[1], i, 1.0f, 1.0f, 1.0f, 0.0f); continue; }
         f3 o, rayDirection; f2 ndc;
         primary_ray(P, px, py, o, rayDirection, ndc);
         const float4 pos4 = reinterpret_cast<const float4 *>(I.shadingPosition)[i];
@@ -367,7 +378,7 @@ __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void direct_kernel(FramePar
         historyLength = fminf(historyLength + 1.0f, 64.0f);
         newDirect = lerp3(newDirect, resDirect, s_rcp(historyLength));
         store_rgba16f(I.directLight[cur], i, newDirect.x, newDirect.y, newDirect.z, historyLength);
-        store_rgba16f(I.filteredDirect[1], i, newDirect.x, newDirect.y, newDirect.z, historyLength);
+        if (FULL) store_rgba16f(I.filteredDirect[1], i, newDirect.x, newDirect.y, newDirect.z, historyLength);
     }
     flush_env(P, env, PASS_DIRECT, CTR_PRIMARY, 0);
 }
@@ -650,7 +661,10 @@ __global__ __launch_bounds__(256) void gaussian_kernel(const uint16_t *in, uint1
 
 // ---- ComposePS + PostProcessPS (fused) -------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void compose_post_kernel(FrameParams P, ViewImages I) {
+// LEAN: direct light straight from the raw accumulation, constant ambient for the indirect term (giSamples == 0), and no
+// reflection / refraction / transparent reads -- all of them are exact zeros on a lean frame.
+template <bool LEAN>
+__global__ __launch_bounds__(256) void compose_post_kernel(FrameParams P, ViewImages I, int cur) {
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = P.tileY0 + blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= P.width || y >= P.tileY1 || !row_owned(P, y)) return;
     const size_t i = (size_t)y * (size_t)P.width + x;
@@ -658,12 +672,19 @@ __global__ __launch_bounds__(256) void compose_post_kernel(FrameParams P, ViewIm
     f3 result;
     if (d.w > RT_EPSILON) {
         f3 diffuse = xyz(d);
-        f3 direct = xyz(load_rgba16f(I.filteredDirect[1], i)), indirect = xyz(load_rgba16f(I.filteredIndirect[1], i));
+        f3 direct, indirect;
+        if (LEAN) {
+            direct = xyz(load_rgba16f(I.directLight[cur], i));
+            indirect = mk3(q_f16(P.ambientBaseColor[0] + P.ambientNoGIColor[0]), q_f16(P.ambientBaseColor[1] + P.ambientNoGIColor[1]), q_f16(P.ambientBaseColor[2] + P.ambientNoGIColor[2]));
+        }
+        else { direct = xyz(load_rgba16f(I.filteredDirect[1], i)); indirect = xyz(load_rgba16f(I.filteredIndirect[1], i)); }
         result = diffuse * (direct + indirect);
         result = lerp3(diffuse, result, d.w);
-        result = result + xyz(load_rgba16f(I.reflection, i));
-        result = result + xyz(load_rgba16f(I.refraction, i));
-        result = result + xyz(load_rgba16f(I.transparent, i));
+        if (!LEAN) {
+            result = result + xyz(load_rgba16f(I.reflection, i));
+            result = result + xyz(load_rgba16f(I.refraction, i));
+            result = result + xyz(load_rgba16f(I.transparent, i));
+        }
     }
     else result = xyz(d);
     reinterpret_cast<float4 *>(I.output)[i] = make_float4(result.x, result.y, result.z, 1.0f);
@@ -696,11 +717,15 @@ hipError_t launch_primary_trace(const FrameParams &P, const ViewImages &I, int32
     if (klist) LAUNCH_RAY(primary_trace_kernel<true>, P, I, hitInstance);
     LAUNCH_RAY(primary_trace_kernel<false>, P, I, hitInstance);
 }
-hipError_t launch_primary_shade(const FrameParams &P, const ViewImages &I, const int32_t *hitInstance, int cur, bool transparentLighting, hipStream_t s) {
-    if (transparentLighting) LAUNCH_RAY((primary_shade_kernel<true, true>), P, I, hitInstance, cur);
-    LAUNCH_RAY((primary_shade_kernel<false, false>), P, I, hitInstance, cur);
+hipError_t launch_primary_shade(const FrameParams &P, const ViewImages &I, const int32_t *hitInstance, int cur, bool transparentLighting, bool lean, hipStream_t s) {
+    if (transparentLighting) LAUNCH_RAY((primary_shade_kernel<true, true, true>), P, I, hitInstance, cur);
+    if (lean) LAUNCH_RAY((primary_shade_kernel<false, false, false>), P, I, hitInstance, cur);
+    LAUNCH_RAY((primary_shade_kernel<false, false, true>), P, I, hitInstance, cur);
 }
-hipError_t launch_direct(const FrameParams &P, const ViewImages &I, int cur, hipStream_t s) { LAUNCH_RAY(direct_kernel, P, I, cur); }
+hipError_t launch_direct(const FrameParams &P, const ViewImages &I, int cur, bool lean, hipStream_t s) {
+    if (lean) LAUNCH_RAY(direct_kernel<false>, P, I, cur);
+    LAUNCH_RAY(direct_kernel<true>, P, I, cur);
+}
 hipError_t launch_indirect(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, hipStream_t s) {
     if (klist) LAUNCH_RAY(indirect_kernel<true>, P, I, cur, writeFiltered ? 1 : 0);
     LAUNCH_RAY(indirect_kernel<false>, P, I, cur, writeFiltered ? 1 : 0);
@@ -724,9 +749,10 @@ hipError_t launch_gaussian(const uint16_t *in, uint16_t *out, int width, int hei
     hipLaunchKernelGGL(gaussian_kernel, grid, dim3(256), 0, s, in, out, width, height, y0, y1);
     return hipGetLastError();
 }
-hipError_t launch_compose_post(const FrameParams &P, const ViewImages &I, hipStream_t s) {
+hipError_t launch_compose_post(const FrameParams &P, const ViewImages &I, int cur, bool lean, hipStream_t s) {
     dim3 grid((unsigned)(P.width + 31) / 32, (unsigned)(P.tileY1 - P.tileY0 + 7) / 8);
-    hipLaunchKernelGGL(compose_post_kernel, grid, dim3(256), 0, s, P, I);
+    if (lean) hipLaunchKernelGGL(compose_post_kernel<true>, grid, dim3(256), 0, s, P, I, cur);
+    else hipLaunchKernelGGL(compose_post_kernel<false>, grid, dim3(256), 0, s, P, I, cur);
     return hipGetLastError();
 }
 hipError_t launch_clear_final(const FrameParams &P, const ViewImages &I, hipStream_t s) {

@@ -135,7 +135,7 @@ static GpuCombiner decode_combiner(uint32_t shaderId) {
 // ---- objects ---------------------------------------------------------------------------------------------------------------
 
 struct Options {
-    bool countTraversal = false, profilePasses = true, syncPresent = true, alwaysRebuild = false;
+    bool countTraversal = false, profilePasses = true, syncPresent = true, alwaysRebuild = false, leanFrames = true;
     int denoiserMode = 1;          // 0 = reference 5x Gaussian, 1 = SVGF
     int maxReflections = 2;        // rt64_view.cpp:60 (inspector-only knob in the reference)
 };
@@ -245,7 +245,9 @@ struct View {
     DevArray<GpuNode> tlasNodes; DevArray<uint32_t> tlasIndex, tlasMorton, tlasLeafParent; DevArray<BlasHeader> tlasHeader; DevArray<uint8_t> tlasScratch;
     std::vector<uint8_t> uploadedTables;      // bytes of the last uploaded instance/texture/light tables (cache key)
     float maxDepthBias = 0.0f;
-    bool anyNonOpaque = false, anyReflection = false, anyRefraction = false;
+    bool anyNonOpaque = false, anyReflection = false, anyRefraction = false, anyFog = false;
+    bool leanFrame = false;                   // last frame skipped the images no pass consumed (see materialise)
+    FrameParams lastParams; int lastCur = 0;
 
     explicit View(Scene *s);
     ~View();
@@ -254,6 +256,7 @@ struct View {
     void update();
     void render();
     void fillParams(FrameParams &P);
+    void materialise();
 };
 
 // ---- Device -----------------------------------------------------------------------------------------------------------------
@@ -546,7 +549,7 @@ void View::update() {                          // View::update, rt64_view.cpp:10
     GpuTexture *hTex = reinterpret_cast<GpuTexture *>(stage + instBytes);
     RT64_LIGHT *hLights = reinterpret_cast<RT64_LIGHT *>(stage + instBytes + texBytes);
     maxDepthBias = nInst ? -INFINITY : 0.0f;
-    anyNonOpaque = anyReflection = anyRefraction = false;
+    anyNonOpaque = anyReflection = anyRefraction = anyFog = false;
     for (size_t i = 0; i < nInst; i++) {
         Instance *inst = rtInstances[i].instance;
         GpuInstance &g = hInst[i];
@@ -580,6 +583,7 @@ void View::update() {                          // View::update, rt64_view.cpp:10
         if (!(g.flags & GPU_INST_OPAQUE)) anyNonOpaque = true;
         if (inst->material.reflectionFactor > 1e-6f) anyReflection = true;       // the passes below are no-ops otherwise
         if (inst->material.refractionFactor > 1e-6f) anyRefraction = true;
+        if (inst->material.fogEnabled) anyFog = true;
     }
     for (size_t i = 0; i < nTex; i++) {
         Texture *t = usedTextures[i];
@@ -704,14 +708,19 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         const bool klist = anyNonOpaque;
         HIP_CHECK(launch_primary_trace(P, img, hitInstance.ptr, klist, s));
         mark(Device::EV_PRIMARY_TRACE);
-        HIP_CHECK(launch_primary_shade(P, img, hitInstance.ptr, cur, anyNonOpaque, s));
+        // Lean frame: nothing downstream reads the view direction, the reflection / refraction / transparent accumulators,
+        // motion vectors, upscaler masks or a GI buffer -> skip those stores (and the matching loads in Compose).
+        const bool lean = dev->opt.leanFrames && !anyNonOpaque && !anyReflection && !anyRefraction && !anyFog && giSamples == 0 && motionBlurStrength <= 0.0f;
+        leanFrame = lean; lastParams = P; lastCur = cur;
+        HIP_CHECK(launch_primary_shade(P, img, hitInstance.ptr, cur, anyNonOpaque, lean, s));
         mark(Device::EV_PRIMARY);
         // DirectRayGen also writes the "filtered" copy: DI denoising is compiled out in the reference (rt64_view.cpp:1438-1463),
         // so rtFilteredDirectLight[1] is always a plain copy of the raw accumulation.
-        HIP_CHECK(launch_direct(P, img, cur, s));
+        HIP_CHECK(launch_direct(P, img, cur, lean, s));
         mark(Device::EV_DIRECT);
         const bool denoiseGI = denoiserEnabled && giSamples > 0;
-        if (giSamples == 0) HIP_CHECK(launch_indirect_constant(P, img, cur, s));      // IndirectRayGen.hlsl:135: constant ambient
+        if (lean) {}                                                                  // constant ambient folded into Compose
+        else if (giSamples == 0) HIP_CHECK(launch_indirect_constant(P, img, cur, s));  // IndirectRayGen.hlsl:135: constant ambient
         else HIP_CHECK(launch_indirect(P, img, cur, !denoiseGI, klist, s));
         mark(Device::EV_INDIRECT);
         // Refraction / reflection touch only pixels whose primary hit has a refraction / reflection factor (alpha > EPSILON).
@@ -725,14 +734,28 @@ void View::render() {                          // View::render, rt64_view.cpp:11
                 HIP_CHECK(launch_gaussian(img.filteredIndirect[k % 2], img.filteredIndirect[(k % 2) ^ 1], imgW, imgH, 0, imgH, s));
         }
         mark(Device::EV_DENOISE);
-        HIP_CHECK(launch_compose_post(P, img, s));
+        HIP_CHECK(launch_compose_post(P, img, cur, lean, s));
     }
     else {
+        leanFrame = false;
         mark(Device::EV_PRIMARY_TRACE); mark(Device::EV_PRIMARY); mark(Device::EV_DIRECT); mark(Device::EV_INDIRECT); mark(Device::EV_REFL); mark(Device::EV_DENOISE);
         HIP_CHECK(launch_clear_final(P, img, s));
     }
     // End of frame (rt64_view.cpp:1663-1667)
     rtSwap = !rtSwap; skipReprojection = false; frameCount++;
+}
+
+// A lean frame left some images untouched; produce them now from the frame's retained inputs (hit records, parameters).
+void View::materialise() {
+    if (!leanFrame) return;
+    Device *dev = scene->device;
+    dev->use();
+    HIP_CHECK(launch_primary_shade(lastParams, img, hitInstance.ptr, lastCur, false, false, dev->stream));
+    HIP_CHECK(launch_indirect_constant(lastParams, img, lastCur, dev->stream));
+    const size_t rowBytes = (size_t)imgW * 8, off = (size_t)dev->tileY0 * rowBytes, bytes = (size_t)(dev->tileY1 - dev->tileY0) * rowBytes;
+    HIP_CHECK(hipMemcpyAsync(reinterpret_cast<uint8_t *>(img.filteredDirect[1]) + off, reinterpret_cast<uint8_t *>(img.directLight[lastCur]) + off, bytes, hipMemcpyDeviceToDevice, dev->stream));
+    HIP_CHECK(hipStreamSynchronize(dev->stream));
+    leanFrame = false;
 }
 
 void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:1027-1083
@@ -761,6 +784,7 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
         if (haveView) continue;
         haveView = true;
         st.instanceCount = (unsigned)v->rtInstances.size();
+        st.leanFrame = v->leanFrame ? 1u : 0u;
         unsigned tri = 0, nodeBytes = 0, triBytes = 0;
         for (auto &ri : v->rtInstances) { tri += ri.instance->mesh->blasCount; nodeBytes += (unsigned)(std::max<uint32_t>(ri.instance->mesh->blasCount - 1, 1) * sizeof(GpuNode)); triBytes += (unsigned)(ri.instance->mesh->blasCount * sizeof(GpuTri)); }
         st.triangleCount = tri; st.blasNodeBytes = nodeBytes; st.blasTriangleBytes = triBytes;
@@ -835,6 +859,7 @@ static size_t readback(Device *dev, int image, void *dst, size_t dstBytes, bool 
     dev->use();
     View *v = first_view(dev);
     if (!v) throw std::runtime_error("RT64_ReadbackDevice: the device has no view.");
+    if (image != RT64_IMAGE_FINAL_RGBA8 && image != RT64_IMAGE_OUTPUT_RGBA32F) v->materialise();
     ImageInfo info; size_t dstPixelBytes;
     if (!image_info(v, image, info, dstPixelBytes)) throw std::runtime_error("RT64_ReadbackDevice: unknown image id.");
     const size_t rows = (size_t)dev->ownedRows(), w = (size_t)v->imgW, px = rows * w;
@@ -947,6 +972,7 @@ RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, doubl
     else if (k == "profile_passes") d->opt.profilePasses = value != 0.0;
     else if (k == "sync_present") d->opt.syncPresent = value != 0.0;
     else if (k == "denoiser_mode") d->opt.denoiserMode = (int)value;
+    else if (k == "lean_frames") d->opt.leanFrames = value != 0.0;                // 0: always write every image of the reference's G-buffer
     else if (k == "always_rebuild") d->opt.alwaysRebuild = value != 0.0;          // upload tables + rebuild the TLAS every frame like the reference
     else if (k == "max_reflections") d->opt.maxReflections = std::max(0, (int)value);
     else return 0;
@@ -977,6 +1003,7 @@ RT64_EXPORT RT64_INSTANCE *RT64_GetViewRaytracedInstanceAt(RT64_VIEW *viewPtr, i
     x = (int)lroundf(x * xs); y = (int)lroundf(y * ys);
     if (x < 0 || x >= v->imgW || y < 0 || y >= v->imgH) return nullptr;
     int32_t id = -1;
+    v->materialise();
     HIP_CHECK(hipMemcpy(&id, v->img.firstInstanceId + (size_t)y * v->imgW + x, 4, hipMemcpyDeviceToHost));
     if (id >= 0 && (size_t)id < v->rtInstances.size()) return reinterpret_cast<RT64_INSTANCE *>(v->rtInstances[id].instance);
     return nullptr;

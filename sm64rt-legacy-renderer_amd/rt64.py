@@ -128,7 +128,7 @@ class FRAME_STATS(C.Structure):
                 ("blasNodeBytes", C.c_uint), ("blasTriangleBytes", C.c_uint), ("tlasNodeBytes", C.c_uint),
                 ("instanceCount", C.c_uint), ("triangleCount", C.c_uint),
                 ("msPrimaryTrace", C.c_float), ("msPrimaryShade", C.c_float),
-                ("stripRank", C.c_uint), ("stripCount", C.c_uint), ("rowsRendered", C.c_uint), ("reserved0", C.c_uint),
+                ("stripRank", C.c_uint), ("stripCount", C.c_uint), ("rowsRendered", C.c_uint), ("leanFrame", C.c_uint),
                 ("nodesPrimary", C.c_ulonglong), ("trianglesPrimary", C.c_ulonglong), ("nodesDirect", C.c_ulonglong),
                 ("trianglesDirect", C.c_ulonglong), ("nodesIndirect", C.c_ulonglong), ("trianglesIndirect", C.c_ulonglong)]
 
