@@ -326,6 +326,9 @@ class Rt64Scene:
         """One WM_PAINT of main.cpp:97-134."""
         d = self.data
         self.lib.SetViewPerspective(self.view, rt64.MATRIX4.from_rows(d.view), d.fov, d.near, d.far, can_reproject)
+        k = next((i for i, inst in enumerate(d.instances) if inst.name == "sphere"), None)
+        if k is not None:
+            self.set_instance(k, d.instances[k])                                                       # main.cpp:129
         self.lib.SetSceneLights(self.scene, self._lights, len(d.lights))
         self.lib.DrawDevice(self.device, 1, 1000.0 / 60.0)
 
