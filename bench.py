@@ -48,6 +48,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5"],
+                    help="BASELINE.json configs: C2 primary+shadow 1080p (the metric's config, default) | C3 +1 GI sample +SVGF 1080p | "
+                         "C4 1440p, 2 GI samples, SVGF, per-frame SetMesh refit of the UPDATABLE sphere | C5 4K, 4 GI samples, SVGF, reflective floor")
     ap.add_argument("--gi-samples", type=int, default=0, help="C3: 1 (with --denoiser)")
     ap.add_argument("--denoiser", action="store_true")
     ap.add_argument("--subdiv", type=int, default=0, help="stress variant: sphere subdivision levels")
@@ -89,9 +92,36 @@ def main():
             dist.init_process_group(backend="gloo")
     comm_device = "cuda" if args.backend == "nccl" else "cpu" 
 
+    if args.config == "C3":
+        args.gi_samples, args.denoiser = 1, True
+    elif args.config == "C4":
+        args.width, args.height, args.gi_samples, args.denoiser = 2560, 1440, 2, True
+    elif args.config == "C5":
+        args.width, args.height, args.gi_samples, args.denoiser = 3840, 2160, 4, True
     W, H = args.width, args.height
     lib = rt64.Library()
     data = sample_scene.make_sample_scene(subdiv=args.subdiv, floor_grid=args.floor_grid)
+    dbg = os.environ.get("RT64_BENCH_DEBUG", "")          # diagnosis only (never set by the driver): "nosky", "tinytex"
+    if "nosky" in dbg:
+        data.sky = None
+    if "tinytex" in dbg:
+        for t in data.textures:
+            if t.format == rt64.TEXTURE_FORMAT_RGBA8:
+                t.data = np.ascontiguousarray(t.data[:4, :4]); t.width = t.height = 4
+    anim = None
+    if args.config == "C4":         # sphere UPDATABLE, p += 0.1 n sin(frame 0.1 + p.y); 16 precomputed frames, SetMesh (host copy + refit) per step
+        m = data.meshes[0]
+        m.flags |= rt64.MESH_RAYTRACE_UPDATABLE
+        base = m.vertices.copy()
+        anim = []
+        for f in range(16):
+            v = base.copy()
+            v["position"][:, :3] += (0.1 * np.sin(f * 0.1 + base["position"][:, 1]))[:, None].astype(np.float32) * base["normal"]
+            anim.append(v)
+    elif args.config == "C5":       # reflective floor
+        for inst in data.instances:
+            if inst.name == "floor":
+                inst.material.reflectionFactor = 0.3
     scene = sample_scene.Rt64Scene(lib, data, W, H, hip_device=local_rank)
     scene.set_interleave(rank, N)
     if args.gi_samples or args.denoiser:
@@ -106,7 +136,12 @@ def main():
         if n != my_bytes:
             raise RuntimeError("RT64_CopyDeviceImage returned %d, expected %d: %s" % (n, my_bytes, lib.last_error()))
 
+    frame_no = [0]
+
     def step():
+        if anim is not None:
+            frame_no[0] += 1
+            scene.set_mesh(scene.meshes[0], anim[frame_no[0] % len(anim)], data.meshes[0].indices)
         scene.draw()                 # returns after the frame is complete in the device's back buffer (HBM)
         if N == 1:
             return None              # single GPU: the back buffer IS the composited frame, nothing to gather
@@ -125,13 +160,13 @@ def main():
     scene.option("count_traversal", 1)
     step()
     st = scene.stats()
-    counts = dict(primary=st.primaryRays, shadow=st.shadowRays, indirect=st.indirectRays, nodesPrimary=st.nodesPrimary,
+    counts = dict(primary=st.primaryRays, shadow=st.shadowRays, indirect=st.indirectRays, reflection=st.reflectionRays + st.refractionRays, nodesPrimary=st.nodesPrimary,
                   trisPrimary=st.trianglesPrimary, nodesDirect=st.nodesDirect, trisDirect=st.trianglesDirect,
                   nodesIndirect=st.nodesIndirect, trisIndirect=st.trianglesIndirect)
     lean = bool(st.leanFrame)
     hit_pixels = int((scene.readback(rt64.IMAGE_FIRST_INSTANCE_ID) >= 0).sum())
     scene.option("count_traversal", 0)
-    rays_local = counts["primary"] + counts["shadow"] + counts["indirect"]
+    rays_local = counts["primary"] + counts["shadow"] + counts["indirect"] + counts["reflection"]
     rays_total = rays_local
     if N > 1:
         t = torch.tensor([rays_local], dtype=torch.float64, device=comm_device)
@@ -140,7 +175,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    acc = dict(trace=0.0, shade=0.0, direct=0.0, indirect=0.0, compose=0.0, build=0.0, total=0.0, denoise=0.0)
+    acc = dict(trace=0.0, shade=0.0, direct=0.0, indirect=0.0, compose=0.0, build=0.0, total=0.0, denoise=0.0, reflect=0.0)
     barrier()
     t0 = time.perf_counter()
     frame = None
@@ -149,7 +184,7 @@ def main():
         s = scene.stats()
         acc["trace"] += s.msPrimaryTrace; acc["shade"] += s.msPrimaryShade; acc["direct"] += s.msDirect
         acc["indirect"] += s.msIndirect; acc["compose"] += s.msComposePost; acc["build"] += s.msBuild; acc["total"] += s.msTotal
-        acc["denoise"] += s.msDenoise
+        acc["denoise"] += s.msDenoise; acc["reflect"] += s.msReflectRefract
     barrier()
     elapsed = time.perf_counter() - t0
     if N > 1:
@@ -171,7 +206,12 @@ def main():
         }
         if args.gi_samples:
             kernels["indirect"] = (kms["indirect"], my_pixels * 12 + hit_pixels * 24 + NODE_B * counts["nodesIndirect"] + TRI_B * counts["trisIndirect"])
-        dominant = max(kernels, key=lambda k: kernels[k][0])
+        if args.denoiser:
+            # SVGF: variance pass (moments 8 + GI 8 + normal 8 + depth 4 read, 8 written) + 5 a-trous iterations (GI 8 + normal 8 + depth 4 read, 8 written)
+            kernels["svgf_denoise(6 launches)"] = (kms["denoise"], my_pixels * (36 + 5 * 28))
+        if counts["reflection"]:
+            kernels["reflection_refraction"] = (kms["reflect"], 0)
+        dominant = max((k for k in kernels if kernels[k][1] > 0), key=lambda k: kernels[k][0])
         d_ms, d_bytes = kernels[dominant]
         achieved = d_bytes / (d_ms * 1e-3) / 1e9 if d_ms > 0 else 0.0
         traffic = None
@@ -194,8 +234,8 @@ def main():
             "metric": "Mrays/s (primary+shadow), sample scene 1080p 1spp", "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2: src/sample scene, primary+shadow rays + shading + compose, %dx%d 1spp%s" % (
-                W, H, "" if not (args.gi_samples or args.subdiv or args.floor_grid > 1) else " [gi=%d denoiser=%d subdiv=%d floor_grid=%d]" % (
+            "config": {"workload": "%s: src/sample scene, primary+shadow rays + shading + compose, %dx%d 1spp%s" % (
+                args.config, W, H, "" if not (args.gi_samples or args.subdiv or args.floor_grid > 1) else " [gi=%d denoiser=%d subdiv=%d floor_grid=%d]" % (
                     args.gi_samples, int(args.denoiser), args.subdiv, args.floor_grid)),
                 "rays_per_frame": int(rays_total), "width": W, "height": H,
                 "partition": "interleaved 16-row strips x%d + RCCL gather of RGBA8" % N if N > 1 else "single GPU"},

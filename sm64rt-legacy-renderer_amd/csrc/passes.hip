@@ -132,10 +132,13 @@ DEV bool surface_record(const FrameParams &P, const ViewImages &I, size_t pixel,
     return surface_anyhit(P, b.y, a.w, __uint_as_float(b.x), __uint_as_float(a.y), __uint_as_float(a.z), dir, rayDiff, px, py, r);
 }
 
+#ifndef TRACE_WAVES
+#define TRACE_WAVES 4          // waves/SIMD the register allocator must fit for pure-traversal kernels (5 spills, measured no faster)
+#endif
 // ---- primary visibility --------------------------------------------------------------------------------------------------
 
 template <bool KLIST>
-__global__ __launch_bounds__(RT_BLOCK) void primary_trace_kernel(FrameParams P, ViewImages I, int32_t *hitInstance) {
+__global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void primary_trace_kernel(FrameParams P, ViewImages I, int32_t *hitInstance) {
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void direct_kernel(FramePar
 // ---- bounce-ray resolve shared by Indirect / Refraction / Reflection ------------------------------------------------------
 
 template <bool KLIST>
-__global__ __launch_bounds__(RT_BLOCK) void indirect_kernel(FrameParams P, ViewImages I, int cur, int writeFiltered) {
+__global__ __launch_bounds__(RT_BLOCK, 3) void indirect_kernel(FrameParams P, ViewImages I, int cur, int writeFiltered) {
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -464,6 +467,121 @@ __global__ __launch_bounds__(RT_BLOCK) void indirect_kernel(FrameParams P, ViewI
         if (writeFiltered) store_rgba16f(I.filteredIndirect[1], i, newIndirect.x, newIndirect.y, newIndirect.z, historyLength);
     }
     flush_env(P, env, PASS_INDIRECT, CTR_INDIRECT, rays);
+}
+
+// ---- IndirectRayGen as a wavefront pair (opaque frames) --------------------------------------------------------------------
+// The one-kernel form above (bounce traversal + any-hit + texturing + light pick + shadow traversal) is 71 KB of code at 237
+// VGPRs: it overflows the 64 KB instruction cache two CUs share and runs at 2 waves/SIMD.  When every instance is provably opaque
+// (rule O1: the hit list degenerates to the closest hit) the pass splits like the primary pass does:
+//   bounce_trace_kernel  : bounce direction + closest-hit traversal only -> 32-byte record per (sample, pixel)
+//                          { t, u, v, primitive | dir.xyz, instance }
+//   bounce_shade_kernel  : surface any-hit on the recorded hit, sky, light pick + shadow ray, temporal accumulation, moments.
+// Same arithmetic in the same order as indirect_kernel<false>; the records only carry values across the launch boundary.
+__global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_kernel(FrameParams P, ViewImages I) {
+    __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
+    ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
+    env.lightIntensity = nullptr; env.lightIndex = nullptr;
+    uint32_t rays = 0;
+    const size_t stride = (size_t)P.width * (size_t)P.height;
+    const uint32_t tiles = tile_count(P);
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        Pixel p = tile_pixel(P, tile);
+        if (!p.valid) continue;
+        const uint32_t px = p.x, py = p.y;
+        const size_t i = (size_t)py * (size_t)P.width + px;
+        if (I.instanceId[i] < 0) continue;
+        const float4 pos4 = reinterpret_cast<const float4 *>(I.shadingPosition)[i];
+        const f3 rayOrigin = mk3(pos4.x, pos4.y, pos4.z), shadingNormal = xyz(load_rgba16f(I.shadingNormal, i));
+        const uint32_t blueNoiseMult = 64u / P.giSamples;
+        for (uint32_t smp = P.giSamples; smp > 0; smp--) {
+            const f3 rayDirection = cos_hemisphere_blue_noise(P, px, py, P.frameCount + smp * blueNoiseMult, shadingNormal);
+            RayDiff rd; rd.dOdx = rd.dOdy = rd.dDdx = rd.dDdy = mk3s(0.0f);
+            SurfaceHit best;
+            trace_surface<false>(P, env, I, i, rayOrigin, rayDirection, rd, px, py, best);
+            rays++;
+            uint4 a, b;
+            a.x = __float_as_uint(best.t); a.y = __float_as_uint(best.u); a.z = __float_as_uint(best.v); a.w = best.prim;
+            b.x = __float_as_uint(rayDirection.x); b.y = __float_as_uint(rayDirection.y); b.z = __float_as_uint(rayDirection.z);
+            b.w = best.hit ? best.instance : 0xFFFFFFFFu;
+            uint4 *rec = I.bounceRecords + ((size_t)(smp - 1) * stride + i) * 2;
+            rec[0] = a; rec[1] = b;
+        }
+    }
+    flush_env(P, env, PASS_INDIRECT, CTR_INDIRECT, rays);
+}
+
+__global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void bounce_shade_kernel(FrameParams P, ViewImages I, int cur, int writeFiltered) {
+    __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
+    __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
+    __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
+    ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
+    env.lightIntensity = ldsLightIntensity + threadIdx.x; env.lightIndex = ldsLightIndex + threadIdx.x;
+    const f3 ambientBase = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]);
+    const f3 ambient = ambientBase + mk3(P.ambientNoGIColor[0], P.ambientNoGIColor[1], P.ambientNoGIColor[2]);
+    const size_t stride = (size_t)P.width * (size_t)P.height;
+    const uint32_t tiles = tile_count(P);
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        Pixel p = tile_pixel(P, tile);
+        if (!p.valid) continue;
+        const uint32_t px = p.x, py = p.y;
+        const size_t i = (size_t)py * (size_t)P.width + px;
+        if (I.instanceId[i] < 0) {
+            store_rgba16f(I.indirectLight[cur], i, ambient.x, ambient.y, ambient.z, 0.0f);
+            reinterpret_cast<float2 *>(I.moments[cur])[i] = make_float2(0.0f, 0.0f);
+            if (writeFiltered) store_rgba16f(I.filteredIndirect[1], i, ambient.x, ambient.y, ambient.z, 0.0f);
+            continue;
+        }
+        const float4 pos4 = reinterpret_cast<const float4 *>(I.shadingPosition)[i];
+        const f3 rayOrigin = mk3(pos4.x, pos4.y, pos4.z), shadingNormal = xyz(load_rgba16f(I.shadingNormal, i));
+        f3 newIndirect = mk3s(0.0f); float historyLength = 0.0f;
+        float2 prevM = make_float2(0.0f, 0.0f); float sumL = 0.0f, sumL2 = 0.0f;
+        if (P.giReproject) {
+            long j; float w = history_weight(P, I, i, px, py, shadingNormal, cur, j);
+            f4 prevAccum = j >= 0 ? load_rgba16f(I.indirectLight[cur ^ 1], (size_t)j) : mk4(0, 0, 0, 0);
+            if (j >= 0) prevM = reinterpret_cast<const float2 *>(I.moments[cur ^ 1])[j];
+            newIndirect = xyz(prevAccum); historyLength = prevAccum.w * w;
+        }
+        for (uint32_t smp = P.giSamples; smp > 0; smp--) {
+            const uint4 *rec = I.bounceRecords + ((size_t)(smp - 1) * stride + i) * 2;
+            const uint4 a = rec[0], b = rec[1];
+            const f3 rayDirection = mk3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
+            RayDiff rd; rd.dOdx = rd.dOdy = rd.dDdx = rd.dDdy = mk3s(0.0f);
+            f3 bgColor = sample_background_envmap(P, rayDirection);
+            f4 sky = sample_sky_plane(P, rayDirection);
+            bgColor = lerp3(bgColor, xyz(sky), sky.w);
+            f3 resPosition = mk3s(0.0f), resNormal = mk3s(0.0f), resSpecular = mk3s(0.0f); f4 resColor = mk4(0, 0, 0, 1); int resInstanceId = -1;
+            HitRecord r;
+            if (b.w != 0xFFFFFFFFu && surface_anyhit(P, b.w, a.w, __uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), rayDirection, rd, px, py, r)) {
+                f4 hitColor = r.color;
+                float alphaContrib = resColor.w * hitColor.w;
+                if (alphaContrib >= RT_EPSILON) {
+                    const RT64_MATERIAL &m = P.instances[r.instanceId].material;
+                    resPosition = rayOrigin + rayDirection * (r.dist + m.depthBias);
+                    resNormal = r.normal; resSpecular = ld_v3(m.specularColor) * r.specular;
+                    resColor.x += hitColor.x * alphaContrib; resColor.y += hitColor.y * alphaContrib; resColor.z += hitColor.z * alphaContrib;
+                    resColor.w *= (1.0f - hitColor.w);
+                    resInstanceId = (int)r.instanceId;
+                }
+            }
+            f3 resIndirect = ambientBase;
+            if (resInstanceId >= 0) {
+                f3 directLight = compute_lights_random(P, env, px, py, rayDirection, (uint32_t)resInstanceId, resPosition, resNormal, resSpecular, 1, true) + ld_v3(P.instances[resInstanceId].material.selfLight);
+                f3 indirectLight = ((xyz(resColor) * (1.0f - resColor.w)) * (ambient + directLight)) * P.giDiffuseStrength;
+                resIndirect = resIndirect + indirectLight;
+            }
+            resIndirect = resIndirect + bgColor * (P.giSkyStrength * resColor.w);
+            historyLength = fminf(historyLength + 1.0f, 64.0f);
+            newIndirect = lerp3(newIndirect, resIndirect, s_rcp(historyLength));
+            { const float l = 0.2126f * resIndirect.x + 0.7152f * resIndirect.y + 0.0722f * resIndirect.z; sumL += l; sumL2 += l * l; }
+        }
+        store_rgba16f(I.indirectLight[cur], i, newIndirect.x, newIndirect.y, newIndirect.z, historyLength);
+        {
+            const float nS = (float)P.giSamples, alphaM = fminf(nS / historyLength, 1.0f);
+            reinterpret_cast<float2 *>(I.moments[cur])[i] = make_float2(lerpf(prevM.x, sumL / nS, alphaM), lerpf(prevM.y, sumL2 / nS, alphaM));
+        }
+        if (writeFiltered) store_rgba16f(I.filteredIndirect[1], i, newIndirect.x, newIndirect.y, newIndirect.z, historyLength);
+    }
+    flush_env(P, env, PASS_INDIRECT, CTR_INDIRECT, 0);
 }
 
 DEV f3 hlsl_refract(f3 i, f3 n, float eta) {
@@ -728,7 +846,9 @@ hipError_t launch_direct(const FrameParams &P, const ViewImages &I, int cur, boo
 }
 hipError_t launch_indirect(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, hipStream_t s) {
     if (klist) LAUNCH_RAY(indirect_kernel<true>, P, I, cur, writeFiltered ? 1 : 0);
-    LAUNCH_RAY(indirect_kernel<false>, P, I, cur, writeFiltered ? 1 : 0);
+    if (P.giSamples == 0 || !I.bounceRecords) LAUNCH_RAY(indirect_kernel<false>, P, I, cur, writeFiltered ? 1 : 0);
+    hipLaunchKernelGGL(bounce_trace_kernel, dim3(RT_GRID_BLOCKS), dim3(RT_BLOCK), 0, s, P, I);
+    LAUNCH_RAY(bounce_shade_kernel, P, I, cur, writeFiltered ? 1 : 0);
 }
 hipError_t launch_indirect_constant(const FrameParams &P, const ViewImages &I, int cur, hipStream_t s) {
     dim3 grid((unsigned)(P.width + 31) / 32, (unsigned)(P.tileY1 - P.tileY0 + 7) / 8);

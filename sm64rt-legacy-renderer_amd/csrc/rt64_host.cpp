@@ -236,7 +236,7 @@ struct View {
     int imgW = 0, imgH = 0;
     // device images
     ViewImages img = {};
-    std::vector<void *> allocations;
+    std::vector<void *> allocations; uint32_t bounceSamples = 0;
     DevArray<int32_t> hitInstance;
     // per-frame tables
     std::vector<RenderInstance> rtInstances, rasterBg, rasterFg;
@@ -456,7 +456,7 @@ View::~View() {
     auto &v = scene->views; v.erase(std::remove(v.begin(), v.end(), this), v.end());
     releaseImages();
 }
-void View::releaseImages() { for (void *p : allocations) hipFree(p); allocations.clear(); img = ViewImages(); }
+void View::releaseImages() { for (void *p : allocations) hipFree(p); allocations.clear(); img = ViewImages(); bounceSamples = 0; }
 
 void View::createImages(int w, int h) {       // View::createOutputBuffers, rt64_view.cpp:105-298 (same formats)
     scene->device->use();
@@ -472,6 +472,7 @@ void View::createImages(int w, int h) {       // View::createOutputBuffers, rt64
         img.filteredDirect[i] = static_cast<uint16_t *>(alloc(n * 8)); img.filteredIndirect[i] = static_cast<uint16_t *>(alloc(n * 8));
         img.normal[i] = static_cast<uint16_t *>(alloc(n * 8)); img.depth[i] = static_cast<float *>(alloc(n * 4));
         img.moments[i] = static_cast<float *>(alloc(n * 16));
+        if (i == 0) img.svgfGuide = static_cast<uint4 *>(alloc(n * 16));
     }
     img.reflection = static_cast<uint16_t *>(alloc(n * 8)); img.refraction = static_cast<uint16_t *>(alloc(n * 8)); img.transparent = static_cast<uint16_t *>(alloc(n * 8));
     img.flow = static_cast<uint16_t *>(alloc(n * 4));
@@ -704,6 +705,11 @@ void View::render() {                          // View::render, rt64_view.cpp:11
             HIP_CHECK(hipMalloc(&b, slots * sizeof(uint2))); allocations.push_back(b);
             HIP_CHECK(hipMalloc(&c, n * sizeof(uint32_t))); allocations.push_back(c);
             img.klistA = static_cast<uint4 *>(a); img.klistB = static_cast<uint2 *>(b); img.klistCount = static_cast<uint32_t *>(c);
+        }
+        if (!anyNonOpaque && giSamples > 0 && (!img.bounceRecords || bounceSamples < giSamples)) {     // records of the bounce_trace / bounce_shade pair
+            void *a = nullptr;
+            HIP_CHECK(hipMalloc(&a, (size_t)giSamples * n * 2 * sizeof(uint4))); allocations.push_back(a);
+            img.bounceRecords = static_cast<uint4 *>(a); bounceSamples = giSamples;
         }
         const bool klist = anyNonOpaque;
         HIP_CHECK(launch_primary_trace(P, img, hitInstance.ptr, klist, s));

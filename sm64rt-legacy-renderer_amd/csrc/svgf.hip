@@ -9,10 +9,18 @@
 //   a-trous  : 5 iterations (steps 1,2,4,8,16), 5x5 B3-spline, edge stops on depth gradient, normal (^128) and luminance
 //              (sigma_l = 4 x sqrt of the 3x3-Gaussian-filtered variance); variance filtered with squared weights.
 // Images between iterations are RGBA16F (rgb = colour, a = variance) in the reference's filter ping-pong buffers.
-// Both kernels are plain HBM-bound image passes: 25 (49) taps x 8 B + guide reads per pixel, one thread per pixel, 32x8 tiles.
+//
+// MI355X shape.  The variance kernel also packs what the edge stops need into one 16-byte guide record per pixel (normal 3 x f16,
+// valid flag, depth f32, depth gradient f32) so a tap costs two loads (8 B colour + 16 B guide) instead of four.  The a-trous
+// kernel is register-blocked: a lane filters FOUR rows spaced by the step (y, y+s, y+2s, y+3s), so the 8 x 5 taps it fetches
+// serve 4 outputs -- 10 fetched taps per pixel instead of 25, which moves the kernel from the L1 return path (64 B/clk/CU) to
+// the VALU.  Per (tap, pixel) pair the three edge stops collapse into ONE v_exp_f32:
+//     w = h * exp2(128 log2(max(0, n.n')) - log2e (|dz| / (gz dist + 1e-8) + |dl| / phi_l)).
+// Sky pixels (56 % of the sample frame) copy through.
 #include "kernels.h"
 #include "device_math.h"
 
+#pragma clang fp contract(fast)      // image filter, tolerance-tested: let mul+add fuse (the geometry files keep -ffp-contract=off)
 namespace {
 
 DEV float lum3(float r, float g, float b) { return 0.2126f * r + 0.7152f * g + 0.0722f * b; }
@@ -57,59 +65,152 @@ __global__ __launch_bounds__(256) void svgf_variance_kernel(const uint16_t *colo
     store_rgba16f(out, i, c.x, c.y, c.z, var);
 }
 
-__global__ __launch_bounds__(256) void svgf_atrous_kernel(const uint16_t *in, uint16_t *out, const int32_t *instanceId, const uint16_t *normal, const float *depth,
-                                                          int w, int h, int step) {
+struct GuideRec { f3 n; float z, gz; bool valid; };
+DEV GuideRec unpack_guide(uint4 g) {
+    GuideRec r;
+    r.n = mk3(f16_bits_to_f32((uint16_t)(g.x & 0xFFFFu)), f16_bits_to_f32((uint16_t)(g.x >> 16)), f16_bits_to_f32((uint16_t)(g.y & 0xFFFFu)));
+    r.valid = (g.y >> 16) != 0u; r.z = __uint_as_float(g.z); r.gz = __uint_as_float(g.w);
+    return r;
+}
+DEV f4 unpack_rgba16f(uint2 v) {
+    return mk4(f16_bits_to_f32((uint16_t)(v.x & 0xFFFFu)), f16_bits_to_f32((uint16_t)(v.x >> 16)),
+               f16_bits_to_f32((uint16_t)(v.y & 0xFFFFu)), f16_bits_to_f32((uint16_t)(v.y >> 16)));
+}
+DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+DEV float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+#define LOG2E 1.44269504088896f
+
+// guide record of every pixel (svgf_variance_kernel fills it for the frame)
+__global__ __launch_bounds__(256) void svgf_guide_kernel(const int32_t *instanceId, const uint16_t *normal, const float *depth, uint4 *guide, int w, int h) {
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= w || y >= h) return;
     const size_t i = (size_t)y * w + x;
-    const f4 c = load_rgba16f(in, i);
-    if (instanceId[i] < 0) { store_rgba16f(out, i, c.x, c.y, c.z, c.w); return; }
-    const float K[5] = { 1.0f / 16.0f, 1.0f / 4.0f, 3.0f / 8.0f, 1.0f / 4.0f, 1.0f / 16.0f };
-    const float G[3] = { 0.25f, 0.5f, 0.25f };
-    float gv = 0.0f;
+    const uint2 n = reinterpret_cast<const uint2 *>(normal)[i];
+    uint4 g;
+    g.x = n.x; g.y = (n.y & 0xFFFFu) | (instanceId[i] >= 0 ? 0x10000u : 0u);
+    g.z = __float_as_uint(depth[i]); g.w = __float_as_uint(grad_z(depth, x, y, w, h));
+    guide[i] = g;
+}
+
+#define ATROUS_ROWS 4
+__global__ __launch_bounds__(256, 3) void svgf_atrous_kernel(const uint2 *__restrict__ in, uint2 *__restrict__ out, const uint4 *__restrict__ guide, int w, int h, int step) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int t = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int yb = (t / step) * (ATROUS_ROWS * step) + (t % step);          // this lane filters rows yb + j*step, j = 0..3
+    if (x >= w || yb >= h) return;
+
+    f4 c[ATROUS_ROWS]; f3 np[ATROUS_ROWS]; float zp[ATROUS_ROWS], lp[ATROUS_ROWS], kl[ATROUS_ROWS], gzc[ATROUS_ROWS];
+    bool live[ATROUS_ROWS];
+    float sw[ATROUS_ROWS], sr[ATROUS_ROWS], sg[ATROUS_ROWS], sb[ATROUS_ROWS], sv[ATROUS_ROWS];
+    bool any = false;
 #pragma unroll
-    for (int dy = -1; dy <= 1; dy++)
+    for (int j = 0; j < ATROUS_ROWS; j++) {
+        const int y = yb + j * step;
+        live[j] = false; sw[j] = sr[j] = sg[j] = sb[j] = sv[j] = 0.0f;
+        c[j] = mk4(0.0f, 0.0f, 0.0f, 0.0f); np[j] = mk3s(0.0f); zp[j] = lp[j] = kl[j] = gzc[j] = 0.0f;
+        if (y >= h) continue;
+        const size_t i = (size_t)y * w + x;
+        c[j] = unpack_rgba16f(in[i]);
+        const GuideRec g = unpack_guide(guide[i]);
+        if (!g.valid) { out[i] = in[i]; continue; }
+        live[j] = true; any = true;
+        // 3x3 Gaussian of the variance drives the luminance edge stop
+        const float G[3] = { 0.25f, 0.5f, 0.25f };
+        float gv = 0.0f;
 #pragma unroll
-        for (int dx = -1; dx <= 1; dx++) {
-            int qx = x + dx, qy = y + dy;
-            qx = qx < 0 ? 0 : (qx >= w ? w - 1 : qx); qy = qy < 0 ? 0 : (qy >= h ? h - 1 : qy);
-            gv += G[dx + 1] * G[dy + 1] * load_rgba16f(in, (size_t)qy * w + qx).w;
-        }
-    const float phiL = 4.0f * sqrtf(fmaxf(0.0f, gv)) + 1e-6f;
-    const f3 np = xyz(load_rgba16f(normal, i));
-    const float zp = depth[i], gz = grad_z(depth, x, y, w, h), lp = lum3(c.x, c.y, c.z);
-    float sw = 0.0f, sr = 0.0f, sg = 0.0f, sb = 0.0f, sv = 0.0f;
+        for (int dy = -1; dy <= 1; dy++)
 #pragma unroll
-    for (int ky = -2; ky <= 2; ky++)
+            for (int dx = -1; dx <= 1; dx++) {
+                int qx = x + dx, qy = y + dy;
+                qx = qx < 0 ? 0 : (qx >= w ? w - 1 : qx); qy = qy < 0 ? 0 : (qy >= h ? h - 1 : qy);
+                const uint16_t vbits = reinterpret_cast<const uint16_t *>(in)[((size_t)qy * w + qx) * 4 + 3];
+                gv += G[dx + 1] * G[dy + 1] * f16_bits_to_f32(vbits);
+            }
+        const float phiL = 4.0f * s_sqrt(fmaxf(0.0f, gv)) + 1e-6f;
+        kl[j] = LOG2E * s_rcp(phiL);
+        np[j] = g.n; zp[j] = g.z; lp[j] = lum3(c[j].x, c[j].y, c[j].z);
+        gzc[j] = g.gz;
+    }
+    if (!any) return;
+
+    // Tap rows are a rolled loop (8 rows, 5 taps = 10 loads each).  Which of the lane's 4 pixels a row serves (|ky| <= 2) is wave-uniform, so that test is a scalar
+    // branch.  Out-of-frame / sky taps are fetched from a clamped address and get weight 0.
+    const float fstep = (float)step;
+    struct RowTaps { uint4 g[5]; uint2 c[5]; bool rowIn; };
+    auto load_row = [&](RowTaps &r, int ry) {
+        const int qy = yb + (ry - 2) * step;
+        r.rowIn = qy >= 0 && qy < h;
+        const size_t rowBase = (size_t)(qy < 0 ? 0 : (qy >= h ? h - 1 : qy)) * w;
 #pragma unroll
         for (int kx = -2; kx <= 2; kx++) {
-            const int qx = x + kx * step, qy = y + ky * step;
-            if (qx < 0 || qy < 0 || qx >= w || qy >= h) continue;
-            const size_t j = (size_t)qy * w + qx;
-            if (instanceId[j] < 0) continue;
-            const f4 cq = load_rgba16f(in, j);
-            const float hk = K[kx + 2] * K[ky + 2];
-            float wt = hk;
-            if (kx != 0 || ky != 0) {
-                const f3 nq = xyz(load_rgba16f(normal, j));
-                const float dist = sqrtf((float)(kx * kx + ky * ky)) * (float)step;
-                const float wz = expf(-fabsf(zp - depth[j]) / (1.0f * gz * dist + 1e-8f));
-                const float wn = powf(fmaxf(0.0f, dot3(np, nq)), 128.0f);
-                const float wl = expf(-fabsf(lp - lum3(cq.x, cq.y, cq.z)) / phiL);
-                wt = hk * wz * wn * wl;
-            }
-            sw += wt; sr += wt * cq.x; sg += wt * cq.y; sb += wt * cq.z; sv += wt * wt * cq.w;
+            const int qx = x + kx * step;
+            const size_t q = rowBase + (qx < 0 ? 0 : (qx >= w ? w - 1 : qx));
+            r.g[kx + 2] = guide[q]; r.c[kx + 2] = in[q];
         }
-    const float inv = 1.0f / sw;
-    store_rgba16f(out, i, sr * inv, sg * inv, sb * inv, sv * inv * inv);
+    };
+    auto filter_row = [&](const RowTaps &r, int ry) {
+        if (!r.rowIn) return;
+        GuideRec gq[5]; f4 cq[5]; float lq[5], hx[5];
+#pragma unroll
+        for (int kx = -2; kx <= 2; kx++) {
+            const int qx = x + kx * step;
+            gq[kx + 2] = unpack_guide(r.g[kx + 2]);
+            cq[kx + 2] = unpack_rgba16f(r.c[kx + 2]);
+            const bool tapOk = qx >= 0 && qx < w && gq[kx + 2].valid;
+            const float K[5] = { 1.0f / 16.0f, 1.0f / 4.0f, 3.0f / 8.0f, 1.0f / 4.0f, 1.0f / 16.0f };
+            hx[kx + 2] = tapOk ? K[kx + 2] : 0.0f;
+            lq[kx + 2] = lum3(cq[kx + 2].x, cq[kx + 2].y, cq[kx + 2].z);
+        }
+#pragma unroll
+        for (int j = 0; j < ATROUS_ROWS; j++) {
+            const int ky = ry - 2 - j;                               // wave-uniform
+            if (ky < -2 || ky > 2) continue;
+            const int ay = ky < 0 ? -ky : ky;
+            const float hy = ay == 0 ? 3.0f / 8.0f : (ay == 1 ? 1.0f / 4.0f : 1.0f / 16.0f);
+            float kzd[3];                                            // log2e / (gz |(ax, ay)| step + 1e-8) for ax = 0, 1, 2
+#pragma unroll
+            for (int ax = 0; ax <= 2; ax++) kzd[ax] = LOG2E * s_rcp(1.0f * gzc[j] * (s_sqrt((float)(ax * ax + ay * ay)) * fstep) + 1e-8f);
+#pragma unroll
+            for (int kx = -2; kx <= 2; kx++) {
+                const int ax = kx < 0 ? -kx : kx;
+                float e = 128.0f * fast_log2(fmaxf(0.0f, dot3(np[j], gq[kx + 2].n))) - (fabsf(zp[j] - gq[kx + 2].z) * kzd[ax] + fabsf(lp[j] - lq[kx + 2]) * kl[j]);
+                if (kx == 0) e = ky == 0 ? 0.0f : e;                                     // the centre tap carries the plain kernel weight
+                const float wt = (hx[kx + 2] * hy) * fast_exp2(fminf(e, 0.0f));
+                const f4 t = cq[kx + 2];
+                sw[j] += wt; sr[j] += wt * t.x; sg[j] += wt * t.y; sb[j] += wt * t.z; sv[j] += wt * wt * t.w;
+            }
+        }
+    };
+    // (double-buffering the rows costs 50 VGPRs and spills at 3 waves/SIMD: measured slower, so rows are fetched one at a time)
+#pragma unroll 1
+    for (int ry = 0; ry < ATROUS_ROWS + 4; ry++) {
+        RowTaps A;
+        load_row(A, ry);
+        filter_row(A, ry);
+    }
+#pragma unroll
+    for (int j = 0; j < ATROUS_ROWS; j++) {
+        if (!live[j]) continue;
+        const float inv = s_rcp(sw[j]);
+        uint2 v;
+        v.x = (uint32_t)f32_to_f16_bits(sr[j] * inv) | ((uint32_t)f32_to_f16_bits(sg[j] * inv) << 16);
+        v.y = (uint32_t)f32_to_f16_bits(sb[j] * inv) | ((uint32_t)f32_to_f16_bits(sv[j] * inv * inv) << 16);
+        out[(size_t)(yb + j * step) * w + x] = v;
+    }
 }
 
 }  // namespace
 
 hipError_t launch_svgf(const ViewImages &I, int cur, int width, int height, hipStream_t s) {
     dim3 grid((unsigned)(width + 31) / 32, (unsigned)(height + 7) / 8);
+    hipLaunchKernelGGL(svgf_guide_kernel, grid, dim3(256), 0, s, I.instanceId, I.normal[cur], I.depth[cur], I.svgfGuide, width, height);
     hipLaunchKernelGGL(svgf_variance_kernel, grid, dim3(256), 0, s, I.indirectLight[cur], I.moments[cur], I.instanceId, I.normal[cur], I.depth[cur], I.filteredIndirect[0], width, height);
-    for (int k = 0; k < 5; k++)
-        hipLaunchKernelGGL(svgf_atrous_kernel, grid, dim3(256), 0, s, I.filteredIndirect[k % 2], I.filteredIndirect[(k % 2) ^ 1], I.instanceId, I.normal[cur], I.depth[cur], width, height, 1 << k);
+    for (int k = 0; k < 5; k++) {
+        const int step = 1 << k;
+        const unsigned laneRows = (unsigned)((height + ATROUS_ROWS * step - 1) / (ATROUS_ROWS * step)) * (unsigned)step;     // lanes per column
+        dim3 agrid((unsigned)(width + 63) / 64, (laneRows + 3) / 4);
+        hipLaunchKernelGGL(svgf_atrous_kernel, agrid, dim3(256), 0, s, reinterpret_cast<const uint2 *>(I.filteredIndirect[k % 2]),
+                           reinterpret_cast<uint2 *>(I.filteredIndirect[(k % 2) ^ 1]), I.svgfGuide, width, height, step);
+    }
     return hipGetLastError();
 }
