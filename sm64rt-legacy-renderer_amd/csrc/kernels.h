@@ -39,7 +39,7 @@ size_t rt_stack_spill_bytes();        // bytes of FrameParams::traversalStack
 hipError_t launch_primary_trace(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, bool klist, hipStream_t s);
 hipError_t launch_primary_shade(const FrameParams &P, const ViewImages &I, const int32_t *hitInstance, int cur, bool transparentLighting, bool lean, hipStream_t s);
 hipError_t launch_direct(const FrameParams &P, const ViewImages &I, int cur, bool lean, hipStream_t s);
-hipError_t launch_indirect(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, hipStream_t s);
+hipError_t launch_indirect(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, bool refill, hipStream_t s);
 hipError_t launch_indirect_constant(const FrameParams &P, const ViewImages &I, int cur, hipStream_t s);
 hipError_t launch_refraction(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s);
 hipError_t launch_reflection(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s);

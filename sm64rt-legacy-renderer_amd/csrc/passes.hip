@@ -36,18 +36,20 @@ DEV uint32_t owned_strips(const FrameParams &P) {
 template <int SHAPE = TILE_SQUARE> DEV uint32_t tile_count(const FrameParams &P) {
     return (uint32_t)((P.width + TileDim<SHAPE>::W - 1) / TileDim<SHAPE>::W) * owned_strips(P) * (16u / TileDim<SHAPE>::H);
 }
-template <int SHAPE = TILE_SQUARE> DEV Pixel tile_pixel(const FrameParams &P, uint32_t tile) {
+template <int SHAPE = TILE_SQUARE> DEV Pixel tile_pixel_at(const FrameParams &P, uint32_t tile, uint32_t wave, uint32_t lane) {
     constexpr uint32_t TW = TileDim<SHAPE>::W, TH = TileDim<SHAPE>::H, perStrip = 16u / TH;
     const uint32_t tilesX = ((uint32_t)P.width + TW - 1) / TW;
     const uint32_t tx = tile % tilesX, lt = tile / tilesX;
     const uint32_t strip = (lt / perStrip) * (uint32_t)P.stripCount + (uint32_t)P.stripRank;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     Pixel p;
     if (SHAPE == TILE_SQUARE) { p.x = tx * TW + (wave & 1) * 8 + (lane & 7); p.y = (wave >> 1) * 8 + (lane >> 3); }
     else { p.x = tx * TW + (lane & 31); p.y = wave * 2 + (lane >> 5); }
     p.y += (uint32_t)P.tileY0 + strip * 16 + (lt % perStrip) * TH;
     p.valid = p.x < (uint32_t)P.width && p.y < (uint32_t)P.tileY1;
     return p;
+}
+template <int SHAPE = TILE_SQUARE> DEV Pixel tile_pixel(const FrameParams &P, uint32_t tile) {
+    return tile_pixel_at<SHAPE>(P, tile, threadIdx.x >> 6, threadIdx.x & 63);
 }
 
 DEV bool row_owned(const FrameParams &P, int y) { return (((y - P.tileY0) / 16) % P.stripCount) == P.stripRank; }
@@ -138,7 +140,7 @@ DEV bool surface_record(const FrameParams &P, const ViewImages &I, size_t pixel,
 // ---- primary visibility --------------------------------------------------------------------------------------------------
 
 template <bool KLIST>
-__global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void primary_trace_kernel(FrameParams P, ViewImages I, int32_t *hitInstance) {
+__global__ __launch_bounds__(RT_BLOCK, KLIST ? 2 : TRACE_WAVES) void primary_trace_kernel(FrameParams P, ViewImages I, int32_t *hitInstance) {
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(RT_BLOCK, 3) void indirect_kernel(FrameParams P, Vi
 //                          { t, u, v, primitive | dir.xyz, instance }
 //   bounce_shade_kernel  : surface any-hit on the recorded hit, sky, light pick + shadow ray, temporal accumulation, moments.
 // Same arithmetic in the same order as indirect_kernel<false>; the records only carry values across the launch boundary.
-__global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_kernel(FrameParams P, ViewImages I) {
+__global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kernel(FrameParams P, ViewImages I) {
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
     env.lightIntensity = nullptr; env.lightIndex = nullptr;
@@ -506,6 +508,73 @@ __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_kernel(Fra
             uint4 *rec = I.bounceRecords + ((size_t)(smp - 1) * stride + i) * 2;
             rec[0] = a; rec[1] = b;
         }
+    }
+    flush_env(P, env, PASS_INDIRECT, CTR_INDIRECT, rays);
+}
+
+// Bounce rays are incoherent: in a plain one-ray-per-lane walk the wave waits for its longest ray (measured 27 % VALU lane
+// utilisation).  Each wave therefore streams through its work list -- (tile, pixel slot, sample) in tile order -- and lanes whose
+// ray has finished are REFILLED: when fewer than BOUNCE_MIN_LIVE lanes are still walking, the walk pauses (RayWalk::run), the
+// finished lanes claim the next stream positions by rank in the idle ballot, generate their rays and join the walk.
+#define BOUNCE_MIN_LIVE 40
+__global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_refill_kernel(FrameParams P, ViewImages I) {
+    __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
+    ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
+    env.lightIntensity = nullptr; env.lightIndex = nullptr;
+    uint32_t rays = 0;
+    const size_t stride = (size_t)P.width * (size_t)P.height;
+    const uint32_t tiles = tile_count(P), wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t S = P.giSamples, blueNoiseMult = 64u / S;
+    const uint32_t myTiles = blockIdx.x < tiles ? (tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
+    const uint32_t end = myTiles * 64u * S;        // stream positions of this wave: ((tileSeq * 64 + slot) * S + sample)
+    uint32_t next = 0;                              // wave-uniform
+    RayWalk walk; walk.alive = false;
+    SurfaceHit best; best.hit = false; best.key = INFINITY;
+    f3 rayDirection = mk3s(0.0f); size_t recIndex = 0; bool holding = false;     // holding: this lane owns a ray whose record is not written yet
+    for (;;) {
+        // ---- retire finished rays, refill idle lanes ----
+        if (holding && !walk.alive) {
+            uint4 a, b;
+            a.x = __float_as_uint(best.t); a.y = __float_as_uint(best.u); a.z = __float_as_uint(best.v); a.w = best.prim;
+            b.x = __float_as_uint(rayDirection.x); b.y = __float_as_uint(rayDirection.y); b.z = __float_as_uint(rayDirection.z);
+            b.w = best.hit ? best.instance : 0xFFFFFFFFu;
+            I.bounceRecords[recIndex] = a; I.bounceRecords[recIndex + 1] = b;
+            holding = false;
+        }
+        while (next < end) {
+            const unsigned long long idle = __ballot(!holding);
+            if (idle == 0ull) break;
+            if (!holding) {
+                const uint32_t pos = next + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (pos < end) {
+                    const uint32_t smp = pos % S, slot = (pos / S) & 63u, seq = pos / (S * 64u);
+                    const Pixel p = tile_pixel_at(P, blockIdx.x + seq * gridDim.x, wave, slot);
+                    const size_t i = (size_t)p.y * (size_t)P.width + p.x;
+                    if (p.valid && I.instanceId[i] >= 0) {
+                        const float4 pos4 = reinterpret_cast<const float4 *>(I.shadingPosition)[i];
+                        const f3 rayOrigin = mk3(pos4.x, pos4.y, pos4.z), shadingNormal = xyz(load_rgba16f(I.shadingNormal, i));
+                        rayDirection = cos_hemisphere_blue_noise(P, p.x, p.y, P.frameCount + (S - smp) * blueNoiseMult, shadingNormal);
+                        const float oo[3] = { rayOrigin.x, rayOrigin.y, rayOrigin.z }, dd[3] = { rayDirection.x, rayDirection.y, rayDirection.z };
+                        walk.begin(P, oo, dd, RT_RAY_MIN_DISTANCE, RT_RAY_MAX_DISTANCE);
+                        best.hit = false; best.key = INFINITY;
+                        recIndex = ((size_t)(S - smp - 1) * stride + i) * 2;
+                        holding = true; rays++;
+                    }
+                }
+            }
+            next += (uint32_t)__popcll(idle);
+        }
+        if (__ballot(holding) == 0ull) break;
+        // ---- walk until the ray ends or too few lanes are left walking (then refill) ----
+        if (holding)
+            walk.run<BOUNCE_MIN_LIVE>(P, true, env.stk,
+                     [&](float t, float u, float v, uint32_t instance, uint32_t prim, float &tmax) -> bool {      // trace_surface<false>
+                         const float key = t - P.instances[instance].material.depthBias;
+                         if (key < best.key) { best.key = key; best.t = t; best.u = u; best.v = v; best.instance = instance; best.prim = prim; best.hit = true; }
+                         const float lim = key + P.maxDepthBias;
+                         if (lim < tmax) tmax = lim;
+                         return false;
+                     }, env.cnt, next < end);
     }
     flush_env(P, env, PASS_INDIRECT, CTR_INDIRECT, rays);
 }
@@ -844,10 +913,11 @@ hipError_t launch_direct(const FrameParams &P, const ViewImages &I, int cur, boo
     if (lean) LAUNCH_RAY(direct_kernel<false>, P, I, cur);
     LAUNCH_RAY(direct_kernel<true>, P, I, cur);
 }
-hipError_t launch_indirect(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, hipStream_t s) {
+hipError_t launch_indirect(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, bool refill, hipStream_t s) {
     if (klist) LAUNCH_RAY(indirect_kernel<true>, P, I, cur, writeFiltered ? 1 : 0);
     if (P.giSamples == 0 || !I.bounceRecords) LAUNCH_RAY(indirect_kernel<false>, P, I, cur, writeFiltered ? 1 : 0);
-    hipLaunchKernelGGL(bounce_trace_kernel, dim3(RT_GRID_BLOCKS), dim3(RT_BLOCK), 0, s, P, I);
+    if (refill) hipLaunchKernelGGL(bounce_trace_refill_kernel, dim3(RT_GRID_BLOCKS), dim3(RT_BLOCK), 0, s, P, I);
+    else hipLaunchKernelGGL(bounce_trace_plain_kernel, dim3(RT_GRID_BLOCKS), dim3(RT_BLOCK), 0, s, P, I);
     LAUNCH_RAY(bounce_shade_kernel, P, I, cur, writeFiltered ? 1 : 0);
 }
 hipError_t launch_indirect_constant(const FrameParams &P, const ViewImages &I, int cur, hipStream_t s) {

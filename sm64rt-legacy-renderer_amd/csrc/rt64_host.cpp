@@ -136,6 +136,7 @@ static GpuCombiner decode_combiner(uint32_t shaderId) {
 
 struct Options {
     bool countTraversal = false, profilePasses = true, syncPresent = true, alwaysRebuild = false, leanFrames = true;
+    int bounceRefill = -1;        // bounce-ray traversal with wave-ballot refill: 1 on, 0 off, -1 auto (on when the scene has >= 64 Ki triangles)
     int denoiserMode = 1;          // 0 = reference 5x Gaussian, 1 = SVGF
     int maxReflections = 2;        // rt64_view.cpp:60 (inspector-only knob in the reference)
 };
@@ -727,7 +728,11 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         const bool denoiseGI = denoiserEnabled && giSamples > 0;
         if (lean) {}                                                                  // constant ambient folded into Compose
         else if (giSamples == 0) HIP_CHECK(launch_indirect_constant(P, img, cur, s));  // IndirectRayGen.hlsl:135: constant ambient
-        else HIP_CHECK(launch_indirect(P, img, cur, !denoiseGI, klist, s));
+        else {
+            bool refill = dev->opt.bounceRefill == 1;
+            if (dev->opt.bounceRefill < 0) { size_t tri = 0; for (auto &ri : rtInstances) tri += ri.instance->mesh->blasCount; refill = tri >= 65536; }
+            HIP_CHECK(launch_indirect(P, img, cur, !denoiseGI, klist, refill, s));
+        }
         mark(Device::EV_INDIRECT);
         // Refraction / reflection touch only pixels whose primary hit has a refraction / reflection factor (alpha > EPSILON).
         if (anyRefraction) HIP_CHECK(launch_refraction(P, img, klist, s));
@@ -978,6 +983,7 @@ RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, doubl
     else if (k == "profile_passes") d->opt.profilePasses = value != 0.0;
     else if (k == "sync_present") d->opt.syncPresent = value != 0.0;
     else if (k == "denoiser_mode") d->opt.denoiserMode = (int)value;
+    else if (k == "bounce_refill") d->opt.bounceRefill = (int)value;
     else if (k == "lean_frames") d->opt.leanFrames = value != 0.0;                // 0: always write every image of the reference's G-buffer
     else if (k == "always_rebuild") d->opt.alwaysRebuild = value != 0.0;          // upload tables + rebuild the TLAS every frame like the reference
     else if (k == "max_reflections") d->opt.maxReflections = std::max(0, (int)value);

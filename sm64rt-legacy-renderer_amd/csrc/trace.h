@@ -180,6 +180,90 @@ DEV void trace_ray(const FrameParams &P, const float o[3], const float d[3], flo
     }
 }
 
+// RayWalk: the same walk as trace_ray (same operations per ray, kept textually parallel) with its state in a struct so that it
+// can be PAUSED.  RayWalk holds the state of one ray's walk in registers so that a walk can be PAUSED: run() returns either when the ray has
+// finished (alive == false) or -- with MIN_LIVE > 0 -- at a leaf boundary as soon as fewer than MIN_LIVE lanes of the wave are
+// still walking.  The caller then hands fresh rays to the finished lanes and calls run() again (persistent-thread traversal
+// with wave-ballot refill, used for incoherent secondary rays where one long ray would otherwise hold 63 finished lanes).
+struct RayWalk {
+    RaySpace W, R;
+    const GpuNode *nodes; const GpuTri *tris;
+    float tmin, tmax;
+    int sp, blasBase;
+    uint32_t inst, cur;
+    bool cull, alive;
+
+    DEV void begin(const FrameParams &P, const float o[3], const float d[3], float tmin_, float tmax_) {
+        make_ray_space(o, d, W);
+        R = W;
+        nodes = P.tlasNodes; tris = nullptr;
+        tmin = tmin_; tmax = tmax_;
+        sp = 0; blasBase = -1; inst = 0; cull = false; cur = 0;
+        alive = P.instanceCount != 0;
+    }
+
+    DEV bool pop_next(const FrameParams &P, const TraceStack &stk) {
+        if (blasBase >= 0 && sp == blasBase) {          // BLAS exhausted: resume the TLAS walk in world space
+            blasBase = -1; R = W; nodes = P.tlasNodes;
+        }
+        if (sp == 0) return false;
+        cur = stk.pop(sp);
+        return true;
+    }
+
+    template <int MIN_LIVE = 0, class OnHit>
+    DEV void run(const FrameParams &P, bool cullBackFaces, const TraceStack &stk, OnHit &&onHit, TraceCounts &cnt, bool mayPause = false) {
+        while (alive) {
+            // ---- inner nodes ----
+            while (alive && !(cur & RT64_LEAF_BIT)) {
+                const GpuNode nd = load_node(nodes + cur);
+                cnt.nodes++;
+                float tl, tr;
+                const bool hl = box_hit(R, nd.lmin, nd.lmax, tmin, tmax, tl);
+                const bool hr = box_hit(R, nd.rmin, nd.rmax, tmin, tmax, tr);
+                if (hl && hr) {
+                    if (tr < tl) { stk.push(sp, nd.left); cur = nd.right; }
+                    else { stk.push(sp, nd.right); cur = nd.left; }
+                }
+                else if (hl) cur = nd.left;
+                else if (hr) cur = nd.right;
+                else alive = pop_next(P, stk);
+            }
+            if (!alive) break;
+            // ---- leaf ----
+            if (cur != RT64_NO_CHILD) {
+                if (blasBase < 0) {
+                    // TLAS leaf: enter the instance (G8)
+                    inst = load_global(P.tlasIndex + (cur & 0x7FFFFFFFu));
+                    const GpuInstance *in = P.instances + inst;
+                    float oo[3], dd[3];
+                    // p * M with M row-major 4x4: column c of rows 0..3 = M[c], M[4+c], M[8+c], M[12+c]
+                    const float *M = in->worldToObject;
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const float m0 = load_global(M + c), m1 = load_global(M + 4 + c), m2 = load_global(M + 8 + c), m3 = load_global(M + 12 + c);
+                        oo[c] = fmaf(W.o[2], m2, fmaf(W.o[1], m1, fmaf(W.o[0], m0, m3)));
+                        dd[c] = fmaf(W.d[2], m2, fmaf(W.d[1], m1, W.d[0] * m0));
+                    }
+                    make_ray_space(oo, dd, R);
+                    nodes = load_global(&in->nodes); tris = load_global(&in->tris);
+                    cull = cullBackFaces && !(load_global(&in->flags) & GPU_INST_CULL_DISABLE);
+                    blasBase = sp;
+                    cur = 0;
+                    continue;
+                }
+                const GpuTri tri = load_tri(tris + (cur & 0x7FFFFFFFu));
+                cnt.tris++;
+                float t, u, v;
+                if (tri_hit(R, tri, cull, tmin, tmax, t, u, v))
+                    if (onHit(t, u, v, inst, tri.prim, tmax)) { alive = false; return; }
+            }
+            alive = pop_next(P, stk);
+            if (MIN_LIVE > 0 && mayPause && alive && __popcll(__ballot(1)) < MIN_LIVE) return;      // pause: let the caller refill finished lanes
+        }
+    }
+};
+
 // Wave-level add of the per-lane traversal counters into the frame counters (only when instrumentation is on).
 DEV void flush_counts(const FrameParams &P, const TraceCounts &c, int pass) {
     if (!P.countTraversal) return;

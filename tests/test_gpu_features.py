@@ -176,6 +176,21 @@ def test_c3_gi_svgf_denoiser(rt64_lib, sample_data):
     assert roughness(flt) < 0.6 * roughness(raw)
 
 
+def test_c3_bounce_traversal_with_wave_refill_matches_plain_walk(rt64_lib, sample_data):
+    """Option bounce_refill=1: the bounce rays are traced by the persistent walk that refills finished lanes by wave ballot
+    (passes.hip bounce_trace_refill_kernel).  Per-ray arithmetic is unchanged, so the frame equals the oracle's like the plain walk,
+    and with 2 samples per pixel images and traversal counters are bit-identical to the plain walk's."""
+    got, ref, st = _render_pair(rt64_lib, sample_data, frames=4, view_desc=dict(gi_samples=1, denoiser=True), options={"bounce_refill": 1, "denoiser_mode": 1})
+    assert np.array_equal(got["PRIMARY_HIT"], ref["primaryHit"])
+    assert _rmse(got["OUTPUT_RGBA32F"][..., :3], ref["output"][..., :3]) <= 1e-3
+    assert _rmse(got["INDIRECT_LIGHT_FILTERED"][..., :3], ref["filteredIndirect"][..., :3]) <= 2e-3
+    assert st.indirectRays == ref["counters"]["indirectRays"] > 0
+    got1, _, st1 = _render_pair(rt64_lib, sample_data, frames=3, view_desc=dict(gi_samples=2, denoiser=True), options={"bounce_refill": 1, "denoiser_mode": 1})
+    got0, _, st0 = _render_pair(rt64_lib, sample_data, frames=3, view_desc=dict(gi_samples=2, denoiser=True), options={"bounce_refill": 0, "denoiser_mode": 1})
+    assert np.array_equal(got1["INDIRECT_LIGHT_RAW"], got0["INDIRECT_LIGHT_RAW"]) and np.array_equal(got1["OUTPUT_RGBA32F"], got0["OUTPUT_RGBA32F"])
+    assert (st1.nodesVisited, st1.trianglesTested, st1.indirectRays) == (st0.nodesVisited, st0.trianglesTested, st0.indirectRays)
+
+
 def test_c4_refit_of_updatable_mesh(rt64_lib, sample_data):
     """Per-frame vertex animation of an UPDATABLE mesh (rt64_mesh.cpp:129,149-157): SetMesh with unchanged counts refits the BLAS;
     hits stay bit-identical to the oracle's refit."""
