@@ -342,7 +342,7 @@ enum {
 /* Per-frame counters and GPU timings of the last RT64_DrawDevice (milliseconds, HIP events on the device stream). */
 typedef struct {
     unsigned int structSize;           /* caller sets to sizeof(RT64_FRAME_STATS) */
-    unsigned int width, height;        /* render size */
+    unsigned int width, height;        /* render size: lround(screen size x resolutionScale) */
     unsigned int tileY0, tileY1;       /* rows this device rendered */
     unsigned long long primaryRays, shadowRays, indirectRays, reflectionRays, refractionRays;
     unsigned long long nodesVisited, trianglesTested;      /* only when option "count_traversal" = 1 */
@@ -357,6 +357,7 @@ typedef struct {
     unsigned int leanFrame;                 /* 1: images no pass consumed were skipped this frame (produced on readback) */
     /* per-pass split of nodesVisited / trianglesTested (count_traversal = 1) */
     unsigned long long nodesPrimary, trianglesPrimary, nodesDirect, trianglesDirect, nodesIndirect, trianglesIndirect;
+    unsigned int screenWidth, screenHeight; /* back-buffer size; width/height above are the render size (screen x RT64_VIEW_DESC.resolutionScale) */
 } RT64_FRAME_STATS;
 
 #define RT64_EXT_API_LIST(X) \

@@ -90,7 +90,7 @@ struct OScene {
     int matricesValid;
 
     /* images (allocated for width x height) */
-    int imgW, imgH;
+    int imgW, imgH, finalW, finalH;
     uint8_t *finalRGBA8;
     float *outputRGBA32F, *shadingPosition, *shadingNormal, *shadingSpecular, *diffuse;
     int32_t *instanceId;

@@ -56,7 +56,7 @@ class OFrameParams(C.Structure):
                 ("diSamples", C.c_uint), ("giSamples", C.c_uint), ("maxLights", C.c_uint),
                 ("denoiserEnabled", C.c_int), ("denoiserMode", C.c_int),
                 ("motionBlurStrength", C.c_float), ("motionBlurSamples", C.c_uint), ("maxReflections", C.c_int),
-                ("bruteForce", C.c_int), ("cullBehindOpaque", C.c_int), ("threads", C.c_int)]
+                ("bruteForce", C.c_int), ("cullBehindOpaque", C.c_int), ("threads", C.c_int), ("resolutionScale", C.c_float)]
 
 
 _FP = C.POINTER(C.c_float)
@@ -76,7 +76,7 @@ class OFrameResult(C.Structure):
                 ("nodesVisited", C.c_uint64), ("trianglesTested", C.c_uint64),
                 ("nodesVisitedPrimary", C.c_uint64), ("trianglesTestedPrimary", C.c_uint64),
                 ("nodesVisitedShadow", C.c_uint64), ("trianglesTestedShadow", C.c_uint64),
-                ("secondsBuild", C.c_double), ("secondsRender", C.c_double)]
+                ("secondsBuild", C.c_double), ("secondsRender", C.c_double), ("screenWidth", C.c_int), ("screenHeight", C.c_int)]
 
 
 class ONode(C.Structure):
@@ -219,6 +219,8 @@ class OracleScene:
         r = OFrameResult()
         ok = self.L.oracle_render(self.scene, C.byref(p), C.byref(r))
         assert ok
+        screen_w, screen_h = width, height
+        width, height = r.width, r.height            # render size (differs from the screen size with resolutionScale)
         n = width * height
 
         def img(ptr, ch, dt):
@@ -226,7 +228,8 @@ class OracleScene:
             a = a.reshape(height, width, ch) if ch > 1 else a.reshape(height, width)
             return a.astype(dt, copy=False)
         out = {
-            "final": img(r.finalRGBA8, 4, np.uint8), "output": img(r.outputRGBA32F, 4, np.float32),
+            "final": np.ctypeslib.as_array(r.finalRGBA8, shape=(screen_h * screen_w * 4,)).copy().reshape(screen_h, screen_w, 4),
+            "output": img(r.outputRGBA32F, 4, np.float32),
             "shadingPosition": img(r.shadingPosition, 4, np.float32), "shadingNormal": img(r.shadingNormal, 4, np.float32),
             "shadingSpecular": img(r.shadingSpecular, 4, np.float32), "diffuse": img(r.diffuse, 4, np.float32),
             "instanceId": img(r.instanceId, 1, np.int32), "directLight": img(r.directLight, 4, np.float32),

@@ -77,7 +77,7 @@ OScene *oracle_scene_create(void) {
 }
 
 static void free_images(OScene *s) {
-    free(s->finalRGBA8); free(s->outputRGBA32F); free(s->shadingPosition); free(s->shadingNormal); free(s->shadingSpecular);
+    free(s->outputRGBA32F); free(s->shadingPosition); free(s->shadingNormal); free(s->shadingSpecular);
     free(s->diffuse); free(s->instanceId); free(s->reflection); free(s->refraction); free(s->transparent); free(s->viewDirection);
     free(s->flow); free(s->reactiveMask); free(s->lockMask); free(s->primaryHit);
     for (int i = 0; i < 2; i++) {
@@ -88,7 +88,7 @@ static void free_images(OScene *s) {
 
 void oracle_scene_destroy(OScene *s) {
     if (!s) return;
-    free_images(s); free(s->blueNoise); free(s->instances); free(s->rt); obvh_free(&s->tlas); free(s);
+    free_images(s); free(s->finalRGBA8); free(s->blueNoise); free(s->instances); free(s->rt); obvh_free(&s->tlas); free(s);
 }
 
 void oracle_scene_set_desc(OScene *s, const OSceneDesc *d) { s->desc = *d; }
@@ -109,7 +109,6 @@ static void alloc_images(OScene *s, int w, int h) {
     free_images(s);
     size_t n = (size_t)w * (size_t)h;
 #define A4(p) p = (float *)calloc(n * 4, sizeof(float))
-    s->finalRGBA8 = (uint8_t *)calloc(n * 4, 1);
     A4(s->outputRGBA32F); A4(s->shadingPosition); A4(s->shadingNormal); A4(s->shadingSpecular); A4(s->diffuse);
     A4(s->reflection); A4(s->refraction); A4(s->transparent); A4(s->viewDirection);
     s->instanceId = (int32_t *)calloc(n, sizeof(int32_t));
@@ -227,8 +226,8 @@ static void update_view(OScene *s, const OFrameParams *p) {
     }
 }
 
-static void update_global_params(OScene *s, const OFrameParams *p, OShadeCtx *c) {
-    float aspect = (float)p->width / (float)p->height;             /* Device::getAspectRatio, ref:rt64_device.cpp:211 */
+static void update_global_params(OScene *s, const OFrameParams *p, int screenW, int screenH, OShadeCtx *c) {
+    float aspect = (float)screenW / (float)screenH;                /* Device::getAspectRatio, ref:rt64_device.cpp:211 */
     s->view = p->view;
     oracle_perspective_fov_rh(p->fovRadians, aspect, p->nearDist, p->farDist, &s->projection);
     /* ref:rt64_view.cpp:975-990.  On the very first frame the reference's "previous" matrices are uninitialised
@@ -258,8 +257,8 @@ static void update_global_params(OScene *s, const OFrameParams *p, OShadeCtx *c)
     of3 V = v3cross(U, W); { float l = v3len(V); if (l > 0.0f) V = v3(V.x / l, V.y / l, V.z / l); }
     float ulen = focal * tanf(p->fovRadians * 0.5f) * aspect, vlen = focal * tanf(p->fovRadians * 0.5f);
     c->cameraU = v3scale(U, ulen); c->cameraV = v3scale(V, vlen); c->cameraW = W;
-    c->viewportW = (float)p->width; c->viewportH = (float)p->height;
-    c->width = p->width; c->height = p->height; c->screenW = p->width; c->screenH = p->height;
+    c->viewportW = (float)screenW; c->viewportH = (float)screenH;
+    c->width = p->width; c->height = p->height; c->screenW = screenW; c->screenH = screenH;     /* resolution.xy = render size, .zw = screen size (ref:rt64_view.cpp:145-148) */
     c->pixelJitter.x = c->pixelJitter.y = 0.0f;                     /* jitter only with an upscaler, ref:rt64_view.cpp:1273-1281 */
     c->frameCount = s->frameCount; c->diSamples = p->diSamples; c->giSamples = p->giSamples; c->maxLights = p->maxLights;
     c->diReproject = 0;                                             /* DI_REPROJECTION_SUPPORT undefined, ref:rt64_view.cpp:1012-1016 */
@@ -759,7 +758,8 @@ static void pass_compose_post(OScene *s, const OShadeCtx *c, uint32_t px, uint32
     }
     else result = v3(d[0], d[1], d[2]);
     st4(s->outputRGBA32F, i, result.x, result.y, result.z, 1.0f);
-    /* PostProcessPS: motionBlurStrength == 0 -> passthrough of the same texel (render size == screen size). */
+    /* PostProcessPS: motionBlurStrength == 0 and render size == screen size -> passthrough of the same texel. */
+    if (c->separatePost) return;
     s->finalRGBA8[4 * i] = to_unorm8(result.x); s->finalRGBA8[4 * i + 1] = to_unorm8(result.y); s->finalRGBA8[4 * i + 2] = to_unorm8(result.z); s->finalRGBA8[4 * i + 3] = 255;
 }
 
@@ -801,13 +801,73 @@ static void run_pass(OScene *s, OShadeCtx *total, const OFrameParams *p, int cur
     }
 }
 
-int oracle_render(OScene *s, const OFrameParams *p, OFrameResult *out) {
-    if (p->width <= 0 || p->height <= 0 || p->tileY0 < 0 || p->tileY1 > p->height || p->tileY0 >= p->tileY1) return 0;
+/* ---- PostProcessPS as its own pass (resolution scale and / or motion blur), ref:shaders/PostProcessPS.hlsl:13-36 ------------- */
+/* gSampler is the static sampler of ref:rt64_device.cpp:958-973: MIN_MAG_MIP_LINEAR, WRAP.  Filtering follows the texture spec
+ * (texel centres at +0.5, fp32 weights). */
+static int wrapi(int i, int n) { int j = i % n; return j < 0 ? j + n : j; }
+static void sample_linear_wrap(const float *img, int ch, int w, int h, float u, float v, float out[4]) {
+    float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    float x0f = floorf(x), y0f = floorf(y), fx = x - x0f, fy = y - y0f;
+    int x0 = wrapi((int)x0f, w), x1 = wrapi((int)x0f + 1, w), y0 = wrapi((int)y0f, h), y1 = wrapi((int)y0f + 1, h);
+    for (int k = 0; k < ch; k++) {
+        float c00 = img[((size_t)y0 * w + x0) * ch + k], c10 = img[((size_t)y0 * w + x1) * ch + k];
+        float c01 = img[((size_t)y1 * w + x0) * ch + k], c11 = img[((size_t)y1 * w + x1) * ch + k];
+        float top = c00 + fx * (c10 - c00), bot = c01 + fx * (c11 - c01);
+        out[k] = top + fy * (bot - top);
+    }
+}
+static void pass_post(OScene *s, const OFrameParams *p, int rtW, int rtH, int screenW, int screenH) {
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < screenH; y++)
+        for (int x = 0; x < screenW; x++) {
+            float u = ((float)x + 0.5f) / (float)screenW, v = ((float)y + 0.5f) / (float)screenH;      /* FullScreenVS interpolant at the pixel centre */
+            float color[4];
+            int blurred = 0;
+            if (p->motionBlurStrength > 0.0f && p->motionBlurSamples > 0) {
+                float fl[4];
+                sample_linear_wrap(s->flow, 2, rtW, rtH, u, v, fl);
+                float flx = fl[0] / (float)rtW, fly = fl[1] / (float)rtH;
+                float flowLength = sqrtf(flx * flx + fly * fly);
+                if (flowLength > 1e-6f) {
+                    const float sampleStep = p->motionBlurStrength / (float)p->motionBlurSamples;
+                    float sum[3] = { 0.0f, 0.0f, 0.0f }, sumWeight = 0.0f;
+                    float su = u - (flx * p->motionBlurStrength / 2.0f), sv = v - (fly * p->motionBlurStrength / 2.0f);
+                    for (unsigned int k = 0; k < p->motionBlurSamples; k++) {
+                        float uu = su + flx * (float)k * sampleStep, vv = sv + fly * (float)k * sampleStep;
+                        uu = fminf(fmaxf(uu, 0.0f), 1.0f); vv = fminf(fmaxf(vv, 0.0f), 1.0f);
+                        float c4[4];
+                        sample_linear_wrap(s->outputRGBA32F, 4, rtW, rtH, uu, vv, c4);
+                        sum[0] += c4[0] * 1.0f; sum[1] += c4[1] * 1.0f; sum[2] += c4[2] * 1.0f; sumWeight += 1.0f;
+                    }
+                    color[0] = sum[0] / sumWeight; color[1] = sum[1] / sumWeight; color[2] = sum[2] / sumWeight;
+                    blurred = 1;
+                }
+            }
+            if (!blurred) sample_linear_wrap(s->outputRGBA32F, 4, rtW, rtH, u, v, color);
+            uint8_t *f = s->finalRGBA8 + 4 * ((size_t)y * (size_t)screenW + (size_t)x);
+            f[0] = to_unorm8(color[0]); f[1] = to_unorm8(color[1]); f[2] = to_unorm8(color[2]); f[3] = 255;
+        }
+}
+
+int oracle_render(OScene *s, const OFrameParams *pIn, OFrameResult *out) {
+    if (pIn->width <= 0 || pIn->height <= 0 || pIn->tileY0 < 0 || pIn->tileY1 > pIn->height || pIn->tileY0 >= pIn->tileY1) return 0;
+    /* Screen size vs render size (View::createOutputBuffers, ref:rt64_view.cpp:138-139). */
+    const int screenW = pIn->width, screenH = pIn->height;
+    const float scale = pIn->resolutionScale > 0.0f ? pIn->resolutionScale : 1.0f;
+    OFrameParams local = *pIn;
+    local.width = (int)lroundf((float)screenW * scale); local.height = (int)lroundf((float)screenH * scale);
+    if (local.width < 1) local.width = 1;
+    if (local.height < 1) local.height = 1;
+    const int separatePost = local.width != screenW || local.height != screenH || (pIn->motionBlurStrength > 0.0f && pIn->motionBlurSamples > 0);
+    if (separatePost) { local.tileY0 = 0; local.tileY1 = local.height; }       /* the resample reads neighbours: whole frame */
+    const OFrameParams *p = &local;
     double t0 = now_s();
     alloc_images(s, p->width, p->height);
+    if (s->finalW != screenW || s->finalH != screenH) { free(s->finalRGBA8); s->finalRGBA8 = (uint8_t *)calloc((size_t)screenW * (size_t)screenH * 4, 1); s->finalW = screenW; s->finalH = screenH; }
     update_view(s, p);
     OShadeCtx ctx;
-    update_global_params(s, p, &ctx);
+    update_global_params(s, p, screenW, screenH, &ctx);
+    ctx.separatePost = separatePost;
     double t1 = now_s();
     int cur = s->rtSwap;
     size_t n = (size_t)p->width * (size_t)p->height;
@@ -828,15 +888,17 @@ int oracle_render(OScene *s, const OFrameParams *p, OFrameResult *out) {
         }
         else osvgf_filter(s, p, cur);
         run_pass(s, &ctx, p, cur, 5);
+        if (separatePost) pass_post(s, p, p->width, p->height, screenW, screenH);
     }
     else {
-        memset(s->finalRGBA8, 0, n * 4);
-        for (size_t i = 0; i < n; i++) s->finalRGBA8[4 * i + 3] = 255;      /* cleared back buffer, ref:rt64_device.cpp:996-997 */
+        const size_t ns = (size_t)screenW * (size_t)screenH;
+        memset(s->finalRGBA8, 0, ns * 4);
+        for (size_t i = 0; i < ns; i++) s->finalRGBA8[4 * i + 3] = 255;      /* cleared back buffer, ref:rt64_device.cpp:996-997 */
     }
     double t2 = now_s();
     if (out) {
         memset(out, 0, sizeof(*out));
-        out->width = p->width; out->height = p->height;
+        out->width = p->width; out->height = p->height; out->screenWidth = screenW; out->screenHeight = screenH;
         out->finalRGBA8 = s->finalRGBA8; out->outputRGBA32F = s->outputRGBA32F; out->shadingPosition = s->shadingPosition;
         out->shadingNormal = s->shadingNormal; out->shadingSpecular = s->shadingSpecular; out->diffuse = s->diffuse;
         out->instanceId = s->instanceId; out->directLight = s->directLight[cur]; out->indirectLight = s->indirectLight[cur];

@@ -19,6 +19,7 @@ typedef struct {
     float viewportW, viewportH;            /* viewport.zw */
     int width, height;                     /* resolution.xy (render size) */
     int screenW, screenH;                  /* resolution.zw */
+    int separatePost;                      /* PostProcessPS runs as its own pass (resolution scale / motion blur) */
     of2 pixelJitter;
     uint32_t frameCount, diSamples, giSamples, maxLights;
     int giReproject, diReproject, binaryLockMask;

@@ -123,12 +123,15 @@ typedef struct {
     int bruteForce;                               /* 1: test every triangle instead of walking the LBVH */
     int cullBehindOpaque;                         /* 1: shorten tmax behind fully opaque hits (GPU behaviour); 0: visit all (reference) */
     int threads;                                  /* OpenMP threads, 0 = default */
+    /* RT64_VIEW_DESC.resolutionScale (ref:rt64_view.cpp:138-139): width/height above are the SCREEN size, every image except
+     * finalRGBA8 is lround(screen * scale); 0 or 1 = off.  With a scale != 1 (or motion blur) the whole frame is rendered. */
+    float resolutionScale;
 } OFrameParams;
 
 /* Output images of one frame, full-frame row-major arrays owned by the scene (valid until next render). */
 typedef struct {
-    int width, height;
-    const uint8_t *finalRGBA8;                    /* [h][w][4] */
+    int width, height;                            /* render size (all images below except finalRGBA8) */
+    const uint8_t *finalRGBA8;                    /* [screenHeight][screenWidth][4] */
     const float *outputRGBA32F;                   /* [h][w][4] ComposePS */
     const float *shadingPosition, *shadingNormal, *shadingSpecular, *diffuse;   /* [h][w][4], values after storage quantisation */
     const int32_t *instanceId;                    /* [h][w] */
@@ -142,6 +145,7 @@ typedef struct {
     uint64_t nodesVisited, trianglesTested;       /* over all rays of the frame */
     uint64_t nodesVisitedPrimary, trianglesTestedPrimary, nodesVisitedShadow, trianglesTestedShadow;
     double secondsBuild, secondsRender;
+    int screenWidth, screenHeight;                /* size of finalRGBA8 */
 } OFrameResult;
 
 /* ---- API --------------------------------------------------------------------------------------------- */

@@ -875,7 +875,63 @@ __global__ __launch_bounds__(256) void compose_post_kernel(FrameParams P, ViewIm
     }
     else result = xyz(d);
     reinterpret_cast<float4 *>(I.output)[i] = make_float4(result.x, result.y, result.z, 1.0f);
-    store_rgba8(I.final, i, result.x, result.y, result.z, 1.0f);   // PostProcessPS passthrough (motionBlurStrength == 0, render size == screen size)
+    if (!P.separatePost) store_rgba8(I.final, i, result.x, result.y, result.z, 1.0f);   // PostProcessPS passthrough (motionBlurStrength == 0, render size == screen size)
+}
+
+// PostProcessPS.hlsl:13-36 as its own pass: the screen-size back buffer resampled from the render-size output with the static
+// sampler of rt64_device.cpp:958-973 (MIN_MAG_MIP_LINEAR, WRAP), plus the motion-blur gather along gFlow.  Only launched when
+// the render size differs from the screen size (RT64_VIEW_DESC.resolutionScale) or motionBlurStrength > 0.
+DEV int wrapi(int i, int n) { int j = i % n; return j < 0 ? j + n : j; }
+DEV f4 sample_output_linear_wrap(const float *img, int w, int h, float u, float v) {
+    const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    const float x0f = floorf(x), y0f = floorf(y), fx = x - x0f, fy = y - y0f;
+    const int x0 = wrapi((int)x0f, w), x1 = wrapi((int)x0f + 1, w), y0 = wrapi((int)y0f, h), y1 = wrapi((int)y0f + 1, h);
+    const float4 c00 = reinterpret_cast<const float4 *>(img)[(size_t)y0 * w + x0], c10 = reinterpret_cast<const float4 *>(img)[(size_t)y0 * w + x1];
+    const float4 c01 = reinterpret_cast<const float4 *>(img)[(size_t)y1 * w + x0], c11 = reinterpret_cast<const float4 *>(img)[(size_t)y1 * w + x1];
+    f4 r;
+    { const float top = c00.x + fx * (c10.x - c00.x), bot = c01.x + fx * (c11.x - c01.x); r.x = top + fy * (bot - top); }
+    { const float top = c00.y + fx * (c10.y - c00.y), bot = c01.y + fx * (c11.y - c01.y); r.y = top + fy * (bot - top); }
+    { const float top = c00.z + fx * (c10.z - c00.z), bot = c01.z + fx * (c11.z - c01.z); r.z = top + fy * (bot - top); }
+    r.w = 1.0f;
+    return r;
+}
+DEV f2 sample_flow_linear_wrap(const uint16_t *img, int w, int h, float u, float v) {
+    const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    const float x0f = floorf(x), y0f = floorf(y), fx = x - x0f, fy = y - y0f;
+    const int x0 = wrapi((int)x0f, w), x1 = wrapi((int)x0f + 1, w), y0 = wrapi((int)y0f, h), y1 = wrapi((int)y0f + 1, h);
+    auto ld = [&](int xx, int yy) { const uint32_t p = reinterpret_cast<const uint32_t *>(img)[(size_t)yy * w + xx]; f2 r; r.x = f16_bits_to_f32((uint16_t)(p & 0xFFFFu)); r.y = f16_bits_to_f32((uint16_t)(p >> 16)); return r; };
+    const f2 c00 = ld(x0, y0), c10 = ld(x1, y0), c01 = ld(x0, y1), c11 = ld(x1, y1);
+    f2 r;
+    { const float top = c00.x + fx * (c10.x - c00.x), bot = c01.x + fx * (c11.x - c01.x); r.x = top + fy * (bot - top); }
+    { const float top = c00.y + fx * (c10.y - c00.y), bot = c01.y + fx * (c11.y - c01.y); r.y = top + fy * (bot - top); }
+    return r;
+}
+__global__ __launch_bounds__(256) void post_process_kernel(FrameParams P, ViewImages I) {
+    const int sw = (int)P.resolution[2], sh = (int)P.resolution[3];
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= sw || y >= sh) return;
+    const float u = ((float)x + 0.5f) / (float)sw, v = ((float)y + 0.5f) / (float)sh;       // FullScreenVS interpolant at the pixel centre
+    f4 color; bool blurred = false;
+    if (P.motionBlurStrength > 0.0f && P.motionBlurSamples > 0) {
+        const f2 fl = sample_flow_linear_wrap(I.flow, P.width, P.height, u, v);
+        const float flx = fl.x / P.resolution[0], fly = fl.y / P.resolution[1];
+        const float flowLength = sqrtf(flx * flx + fly * fly);
+        if (flowLength > 1e-6f) {
+            const float sampleStep = P.motionBlurStrength / (float)P.motionBlurSamples;
+            float sr = 0.0f, sg = 0.0f, sb = 0.0f, sumWeight = 0.0f;
+            const float su = u - (flx * P.motionBlurStrength / 2.0f), sv = v - (fly * P.motionBlurStrength / 2.0f);
+            for (uint32_t k = 0; k < P.motionBlurSamples; k++) {
+                float uu = su + flx * (float)k * sampleStep, vv = sv + fly * (float)k * sampleStep;
+                uu = fminf(fmaxf(uu, 0.0f), 1.0f); vv = fminf(fmaxf(vv, 0.0f), 1.0f);
+                const f4 c = sample_output_linear_wrap(I.output, P.width, P.height, uu, vv);
+                sr += c.x * 1.0f; sg += c.y * 1.0f; sb += c.z * 1.0f; sumWeight += 1.0f;
+            }
+            color = mk4(sr / sumWeight, sg / sumWeight, sb / sumWeight, 1.0f);
+            blurred = true;
+        }
+    }
+    if (!blurred) color = sample_output_linear_wrap(I.output, P.width, P.height, u, v);
+    store_rgba8(I.final, (size_t)y * (size_t)sw + x, color.x, color.y, color.z, 1.0f);
 }
 
 // IndirectRayGen with giSamples == 0 (IndirectRayGen.hlsl:135): every pixel gets ambientBase + ambientNoGI, history 0.
@@ -889,6 +945,12 @@ __global__ __launch_bounds__(256) void indirect_constant_kernel(FrameParams P, V
 }
 
 __global__ __launch_bounds__(256) void clear_final_kernel(FrameParams P, ViewImages I) {
+    if (P.separatePost) {         // the back buffer has the screen size, the frame is not partitioned
+        const int sw = (int)P.resolution[2], sh = (int)P.resolution[3];
+        const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+        if (x < sw && y < sh) store_rgba8(I.final, (size_t)y * (size_t)sw + x, 0.0f, 0.0f, 0.0f, 1.0f);
+        return;
+    }
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = P.tileY0 + blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= P.width || y >= P.tileY1 || !row_owned(P, y)) return;
     store_rgba8(I.final, (size_t)y * (size_t)P.width + x, 0.0f, 0.0f, 0.0f, 1.0f);   // cleared back buffer, rt64_device.cpp:996-997
@@ -945,8 +1007,14 @@ hipError_t launch_compose_post(const FrameParams &P, const ViewImages &I, int cu
     else hipLaunchKernelGGL(compose_post_kernel<false>, grid, dim3(256), 0, s, P, I, cur);
     return hipGetLastError();
 }
+hipError_t launch_post_process(const FrameParams &P, const ViewImages &I, hipStream_t s) {
+    dim3 grid((unsigned)((int)P.resolution[2] + 31) / 32, (unsigned)((int)P.resolution[3] + 7) / 8);
+    hipLaunchKernelGGL(post_process_kernel, grid, dim3(256), 0, s, P, I);
+    return hipGetLastError();
+}
 hipError_t launch_clear_final(const FrameParams &P, const ViewImages &I, hipStream_t s) {
     dim3 grid((unsigned)(P.width + 31) / 32, (unsigned)(P.tileY1 - P.tileY0 + 7) / 8);
+    if (P.separatePost) grid = dim3((unsigned)((int)P.resolution[2] + 31) / 32, (unsigned)((int)P.resolution[3] + 7) / 8);
     hipLaunchKernelGGL(clear_final_kernel, grid, dim3(256), 0, s, P, I);
     return hipGetLastError();
 }

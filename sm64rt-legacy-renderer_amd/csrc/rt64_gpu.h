@@ -97,6 +97,7 @@ struct FrameParams {
     int32_t tileY0, tileY1;              // row range owned by this device
     int32_t stripRank, stripCount;       // interleaved 16-row strips inside the range (count 1 = all)
     float maxDepthBias;
+    uint32_t separatePost;               // 1: render size != screen size or motion blur on -> PostProcessPS runs as post_process_kernel
     float skyBase[4];                    // ComputeSkyPlaneUV: base u, base v, 0.25 * ratioDivision, 0.25
     uint32_t lightCount, instanceCount, countTraversal;
     const GpuInstance *instances;

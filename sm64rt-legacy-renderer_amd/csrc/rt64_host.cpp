@@ -234,7 +234,9 @@ struct View {
     Mat4 view = mat_identity(), projection = mat_identity(), viewI = mat_identity(), projectionI = mat_identity(), viewProj = mat_identity(), prevViewI = mat_identity(), prevViewProj = mat_identity();
     float fov = 0.0f, nearDist = 0.0f, farDist = 0.0f; bool canReproject = true, matricesValid = false, perspectiveSet = false;
     uint32_t frameCount = 0; bool rtSwap = false, skipReprojection = true;
-    int imgW = 0, imgH = 0;
+    int imgW = 0, imgH = 0;                   // render size: lround(screen * resolutionScale), rt64_view.cpp:138-139
+    int finalW = 0, finalH = 0;               // back buffer = screen size
+    bool separatePost() const { return imgW != finalW || imgH != finalH || (motionBlurStrength > 0.0f && motionBlurSamples > 0); }
     // device images
     ViewImages img = {};
     std::vector<void *> allocations; uint32_t bounceSamples = 0;
@@ -253,7 +255,7 @@ struct View {
     explicit View(Scene *s);
     ~View();
     void releaseImages();
-    void createImages(int w, int h);
+    void createImages(int w, int h, int screenW, int screenH);
     void update();
     void render();
     void fillParams(FrameParams &P);
@@ -451,7 +453,7 @@ Instance::~Instance() { auto &v = scene->instances; v.erase(std::remove(v.begin(
 
 View::View(Scene *s) : scene(s) {
     s->views.push_back(this);
-    createImages(s->device->width, s->device->height);
+    createImages(s->device->width, s->device->height, s->device->width, s->device->height);
 }
 View::~View() {
     auto &v = scene->views; v.erase(std::remove(v.begin(), v.end(), this), v.end());
@@ -459,7 +461,7 @@ View::~View() {
 }
 void View::releaseImages() { for (void *p : allocations) hipFree(p); allocations.clear(); img = ViewImages(); bounceSamples = 0; }
 
-void View::createImages(int w, int h) {       // View::createOutputBuffers, rt64_view.cpp:105-298 (same formats)
+void View::createImages(int w, int h, int screenW, int screenH) {       // View::createOutputBuffers, rt64_view.cpp:105-298 (same formats)
     scene->device->use();
     releaseImages();
     const size_t n = (size_t)w * h;
@@ -478,11 +480,11 @@ void View::createImages(int w, int h) {       // View::createOutputBuffers, rt64
     img.reflection = static_cast<uint16_t *>(alloc(n * 8)); img.refraction = static_cast<uint16_t *>(alloc(n * 8)); img.transparent = static_cast<uint16_t *>(alloc(n * 8));
     img.flow = static_cast<uint16_t *>(alloc(n * 4));
     img.reactiveMask = static_cast<uint8_t *>(alloc(n)); img.lockMask = static_cast<uint8_t *>(alloc(n));
-    img.output = static_cast<float *>(alloc(n * 16)); img.final = static_cast<uint8_t *>(alloc(n * 4));
+    img.output = static_cast<float *>(alloc(n * 16)); img.final = static_cast<uint8_t *>(alloc((size_t)screenW * screenH * 4));
     img.primaryHit = static_cast<uint32_t *>(alloc(n * 16));
     hitInstance.reserve(n);
     HIP_CHECK(hipMemsetAsync(hitInstance.ptr, 0xFF, n * 4, scene->device->stream));
-    imgW = w; imgH = h;
+    imgW = w; imgH = h; finalW = screenW; finalH = screenH;
     skipReprojection = true;                  // rt64_view.cpp:143
     fprintf(stdout, "Render buffer: %dX%d\n", w, h);      // rt64_view.cpp:150
 }
@@ -523,7 +525,13 @@ static bool instance_is_shadow_opaque(const Instance *inst, const GpuCombiner &c
 
 void View::update() {                          // View::update, rt64_view.cpp:1053-1178
     Device *dev = scene->device;
-    if (imgW != dev->width || imgH != dev->height) createImages(dev->width, dev->height);
+    {   // View::createOutputBuffers: render size = lround(screen * resolutionScale) (rt64_view.cpp:138-139)
+        const float scale = resolutionScale > 0.0f ? resolutionScale : 1.0f;
+        const int rw = std::max(1, (int)lroundf((float)dev->width * scale)), rh = std::max(1, (int)lroundf((float)dev->height * scale));
+        if (imgW != rw || imgH != rh || finalW != dev->width || finalH != dev->height) createImages(rw, rh, dev->width, dev->height);
+        if (separatePost() && (dev->stripCount > 1 || dev->tileY0 != 0 || dev->tileY1 != dev->height))
+            throw std::runtime_error("RT64_DrawDevice: resolutionScale != 1 and motion blur resample across rows; they need the whole frame on one device (no RT64_SetDeviceTile / RT64_SetDeviceInterleave).");
+    }
     usedTextures.clear();
     auto textureIndex = [&](Texture *t) -> int {
         if (!t) return -1;
@@ -661,6 +669,8 @@ void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64
     P.binaryLockMask = 1;                                     // rtUpscaleMode != FSR
     P.visualizationMode = 0;
     P.width = imgW; P.height = imgH; P.tileY0 = dev->tileY0; P.tileY1 = dev->tileY1; P.stripRank = dev->stripRank; P.stripCount = dev->stripCount;
+    P.separatePost = separatePost() ? 1u : 0u;
+    if (P.separatePost) { P.tileY0 = 0; P.tileY1 = imgH; P.stripRank = 0; P.stripCount = 1; }       // device rows are screen rows; the render target has its own height
     P.maxDepthBias = maxDepthBias;
     {   // ComputeSkyPlaneUV (BgSky.hlsli:20-52): the view-only part, once per frame
         const float SCREEN_WIDTH = 320.0f, SCREEN_HEIGHT = 240.0f, SKYBOX_WIDTH = 4.0f * SCREEN_WIDTH, SKYBOX_HEIGHT = 4.0f * SCREEN_HEIGHT, PI = 3.14159265f, TWO_PI = PI * 2.0f;
@@ -746,6 +756,7 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         }
         mark(Device::EV_DENOISE);
         HIP_CHECK(launch_compose_post(P, img, cur, lean, s));
+        if (P.separatePost) HIP_CHECK(launch_post_process(P, img, s));
     }
     else {
         leanFrame = false;
@@ -763,7 +774,7 @@ void View::materialise() {
     dev->use();
     HIP_CHECK(launch_primary_shade(lastParams, img, hitInstance.ptr, lastCur, false, false, dev->stream));
     HIP_CHECK(launch_indirect_constant(lastParams, img, lastCur, dev->stream));
-    const size_t rowBytes = (size_t)imgW * 8, off = (size_t)dev->tileY0 * rowBytes, bytes = (size_t)(dev->tileY1 - dev->tileY0) * rowBytes;
+    const size_t rowBytes = (size_t)imgW * 8, off = (size_t)lastParams.tileY0 * rowBytes, bytes = (size_t)(lastParams.tileY1 - lastParams.tileY0) * rowBytes;
     HIP_CHECK(hipMemcpyAsync(reinterpret_cast<uint8_t *>(img.filteredDirect[1]) + off, reinterpret_cast<uint8_t *>(img.directLight[lastCur]) + off, bytes, hipMemcpyDeviceToDevice, dev->stream));
     HIP_CHECK(hipStreamSynchronize(dev->stream));
     leanFrame = false;
@@ -788,6 +799,7 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
 
     RT64_FRAME_STATS st = {};
     st.structSize = sizeof(st); st.width = (unsigned)width; st.height = (unsigned)height; st.tileY0 = (unsigned)tileY0; st.tileY1 = (unsigned)tileY1;
+    st.screenWidth = (unsigned)width; st.screenHeight = (unsigned)height;
     st.msHostWall = std::chrono::duration<float, std::milli>(t1 - t0).count();
     st.stripRank = (unsigned)stripRank; st.stripCount = (unsigned)stripCount; st.rowsRendered = (unsigned)ownedRows();
     bool haveView = false;
@@ -796,6 +808,7 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
         haveView = true;
         st.instanceCount = (unsigned)v->rtInstances.size();
         st.leanFrame = v->leanFrame ? 1u : 0u;
+        st.width = (unsigned)v->imgW; st.height = (unsigned)v->imgH;          // render size ("Render buffer: WxH")
         unsigned tri = 0, nodeBytes = 0, triBytes = 0;
         for (auto &ri : v->rtInstances) { tri += ri.instance->mesh->blasCount; nodeBytes += (unsigned)(std::max<uint32_t>(ri.instance->mesh->blasCount - 1, 1) * sizeof(GpuNode)); triBytes += (unsigned)(ri.instance->mesh->blasCount * sizeof(GpuTri)); }
         st.triangleCount = tri; st.blasNodeBytes = nodeBytes; st.blasTriangleBytes = triBytes;
@@ -873,7 +886,11 @@ static size_t readback(Device *dev, int image, void *dst, size_t dstBytes, bool 
     if (image != RT64_IMAGE_FINAL_RGBA8 && image != RT64_IMAGE_OUTPUT_RGBA32F) v->materialise();
     ImageInfo info; size_t dstPixelBytes;
     if (!image_info(v, image, info, dstPixelBytes)) throw std::runtime_error("RT64_ReadbackDevice: unknown image id.");
-    const size_t rows = (size_t)dev->ownedRows(), w = (size_t)v->imgW, px = rows * w;
+    // Sizes: every image has the render size except the back buffer (screen size); they differ only with resolutionScale != 1,
+    // which renders the whole frame on this device.
+    const bool isFinal = image == RT64_IMAGE_FINAL_RGBA8, scaled = v->imgW != v->finalW || v->imgH != v->finalH;
+    const size_t w = (size_t)(isFinal ? v->finalW : v->imgW);
+    const size_t rows = scaled ? (size_t)(isFinal ? v->finalH : v->imgH) : (size_t)dev->ownedRows(), px = rows * w;
     const size_t need = px * dstPixelBytes;
     if (dstBytes < need) throw std::runtime_error("RT64_ReadbackDevice: destination buffer is too small.");
     const uint8_t *base = static_cast<const uint8_t *>(info.ptr);
@@ -971,9 +988,12 @@ RT64_EXPORT size_t RT64_CopyDeviceImage(RT64_DEVICE *device, int image, void *de
 }
 RT64_EXPORT int RT64_GetDeviceStats(RT64_DEVICE *device, RT64_FRAME_STATS *stats) {
     Device *d = reinterpret_cast<Device *>(device);
-    if (!d || !stats || stats->structSize < sizeof(RT64_FRAME_STATS)) return 0;
-    *stats = d->stats; stats->structSize = sizeof(RT64_FRAME_STATS);
-    if (stats->width == 0) { stats->width = (unsigned)d->width; stats->height = (unsigned)d->height; stats->tileY0 = (unsigned)d->tileY0; stats->tileY1 = (unsigned)d->tileY1; }
+    if (!d || !stats || stats->structSize < 5 * sizeof(unsigned int)) return 0;
+    // The struct only ever grows at its end: a caller built against an older header passes its own (smaller) size and gets that prefix.
+    RT64_FRAME_STATS full = d->stats; full.structSize = sizeof(RT64_FRAME_STATS);
+    if (full.width == 0) { full.width = full.screenWidth = (unsigned)d->width; full.height = full.screenHeight = (unsigned)d->height; full.tileY0 = (unsigned)d->tileY0; full.tileY1 = (unsigned)d->tileY1; }
+    const unsigned int n = stats->structSize < sizeof(RT64_FRAME_STATS) ? stats->structSize : (unsigned int)sizeof(RT64_FRAME_STATS);
+    memcpy(stats, &full, n); stats->structSize = n;
     return 1;
 }
 RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, double value) {

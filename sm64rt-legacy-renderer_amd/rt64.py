@@ -130,7 +130,8 @@ class FRAME_STATS(C.Structure):
                 ("msPrimaryTrace", C.c_float), ("msPrimaryShade", C.c_float),
                 ("stripRank", C.c_uint), ("stripCount", C.c_uint), ("rowsRendered", C.c_uint), ("leanFrame", C.c_uint),
                 ("nodesPrimary", C.c_ulonglong), ("trianglesPrimary", C.c_ulonglong), ("nodesDirect", C.c_ulonglong),
-                ("trianglesDirect", C.c_ulonglong), ("nodesIndirect", C.c_ulonglong), ("trianglesIndirect", C.c_ulonglong)]
+                ("trianglesDirect", C.c_ulonglong), ("nodesIndirect", C.c_ulonglong), ("trianglesIndirect", C.c_ulonglong),
+                ("screenWidth", C.c_uint), ("screenHeight", C.c_uint)]
 
 
 assert C.sizeof(MATERIAL) == 132 and C.sizeof(LIGHT) == 60 and C.sizeof(SCENE_DESC) == 84

@@ -336,8 +336,10 @@ class Rt64Scene:
         dt, ch = rt64.IMAGE_FORMATS[image]
         st = rt64.FRAME_STATS(); st.structSize = C.sizeof(rt64.FRAME_STATS)
         self.lib.GetDeviceStats(self.device, C.byref(st))
-        rows = st.rowsRendered if st.rowsRendered else st.tileY1 - st.tileY0
-        out = np.empty((rows, st.width, ch), dtype=dt)
+        rows, width = (st.rowsRendered if st.rowsRendered else st.tileY1 - st.tileY0), st.width
+        if (st.screenWidth, st.screenHeight) != (st.width, st.height):       # resolutionScale: render size != back-buffer size, whole frame
+            rows, width = (st.screenHeight, st.screenWidth) if image == rt64.IMAGE_FINAL_RGBA8 else (st.height, st.width)
+        out = np.empty((rows, width, ch), dtype=dt)
         n = self.lib.ReadbackDevice(self.device, image, out.ctypes.data, out.nbytes)
         if n != out.nbytes:
             raise RuntimeError(f"RT64_ReadbackDevice(image={image}) returned {n}, expected {out.nbytes}: " + self.lib.last_error())

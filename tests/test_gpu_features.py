@@ -34,7 +34,8 @@ def _render_pair(rt64_lib, data, frames=1, view_desc=None, options=None, per_fra
         if view_desc:
             s.set_view_description(**view_desc)
             kw = dict(diSamples=view_desc.get("di_samples", 0), giSamples=view_desc.get("gi_samples", 0), maxLights=view_desc.get("max_lights", 12),
-                      denoiserEnabled=int(view_desc.get("denoiser", False)))
+                      denoiserEnabled=int(view_desc.get("denoiser", False)), resolutionScale=float(view_desc.get("resolution_scale", 1.0)),
+                      motionBlurStrength=float(view_desc.get("motion_blur", 0.0)))
         for k, v in (options or {}).items():
             assert s.option(k, v)
             if k == "denoiser_mode":
@@ -189,6 +190,37 @@ def test_c3_bounce_traversal_with_wave_refill_matches_plain_walk(rt64_lib, sampl
     got0, _, st0 = _render_pair(rt64_lib, sample_data, frames=3, view_desc=dict(gi_samples=2, denoiser=True), options={"bounce_refill": 0, "denoiser_mode": 1})
     assert np.array_equal(got1["INDIRECT_LIGHT_RAW"], got0["INDIRECT_LIGHT_RAW"]) and np.array_equal(got1["OUTPUT_RGBA32F"], got0["OUTPUT_RGBA32F"])
     assert (st1.nodesVisited, st1.trianglesTested, st1.indirectRays) == (st0.nodesVisited, st0.trianglesTested, st0.indirectRays)
+
+
+def test_resolution_scale_resamples_the_render_target_to_the_screen(rt64_lib, sample_data):
+    """RT64_VIEW_DESC.resolutionScale (rt64_view.cpp:138-139): every image is lround(screen x scale), PostProcessPS.hlsl resamples the
+    composed output to the screen-size back buffer with the LINEAR/WRAP static sampler.  0.75 (upsample) and 1.5 (supersample)."""
+    for scale, (rw, rh) in ((0.75, (240, 135)), (1.5, (480, 270))):
+        got, ref, st = _render_pair(rt64_lib, sample_data, view_desc=dict(resolution_scale=scale))
+        assert (st.width, st.height, st.screenWidth, st.screenHeight) == (rw, rh, W, H)
+        assert got["OUTPUT_RGBA32F"].shape == (rh, rw, 4) and got["FINAL_RGBA8"].shape == (H, W, 4) == ref["final"].shape
+        assert np.array_equal(got["PRIMARY_HIT"], ref["primaryHit"]) and np.array_equal(got["INSTANCE_ID"], ref["instanceId"])
+        assert _rmse(got["OUTPUT_RGBA32F"][..., :3], ref["output"][..., :3]) <= 1e-3
+        assert np.abs(got["FINAL_RGBA8"].astype(np.int32) - ref["final"].astype(np.int32)).max() <= 1
+        assert st.primaryRays == rw * rh == ref["counters"]["primaryRays"]
+
+
+def test_motion_blur_gathers_along_the_flow(rt64_lib, sample_data):
+    """PostProcessPS.hlsl:14-33: with motionBlurStrength > 0 the back buffer averages motionBlurSamples taps of the output along the
+    screen-space motion vector.  The camera strafes between frames so that the flow is not zero."""
+    data = _variant(sample_data, lambda d: None)
+    base = data.view.copy()
+
+    def per_frame(f, s, o):
+        v = base.copy(); v[3, 0] = base[3, 0] - 0.35 * f        # view matrix translation row: camera moves +x
+        data.view = v
+    got, ref, st = _render_pair(rt64_lib, data, frames=3, view_desc=dict(motion_blur=1.0), per_frame=per_frame)
+    assert np.abs(ref["flow"]).max() > 2.0                       # pixels of motion
+    assert _rmse(got["OUTPUT_RGBA32F"][..., :3], ref["output"][..., :3]) <= 1e-3
+    d = np.abs(got["FINAL_RGBA8"].astype(np.int32) - ref["final"].astype(np.int32))
+    assert d.max() <= 2 and (d > 1).mean() < 1e-3
+    sharp = np.clip(np.round(ref["output"][..., :3] * 255.0), 0, 255)
+    assert np.abs(sharp - ref["final"][..., :3]).mean() > 0.5      # the blur changed the picture
 
 
 def test_c4_refit_of_updatable_mesh(rt64_lib, sample_data):
