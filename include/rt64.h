@@ -327,7 +327,8 @@ enum {
     RT64_IMAGE_PRIMARY_HIT = 18,       /* [u32 x4] first-hit record: t bits, u bits, v bits, (instance<<24 | primitive), 0xFFFFFFFF = miss */
     RT64_IMAGE_VIEW_DIRECTION = 19,    /* [f32 x4] */
     RT64_IMAGE_FIRST_INSTANCE_ID = 20, /* [i32]    copy used by GetViewRaytracedInstanceAt           */
-    RT64_IMAGE_COUNT_ = 21
+    RT64_IMAGE_BACKGROUND = 21,        /* [u8 x 4] gBackground: raster background instances, screen size (zeros when there are none) */
+    RT64_IMAGE_COUNT_ = 22
 };
 
 /* Arrays returned by RT64_ReadbackMeshAccel / RT64_ReadbackViewAccel. */

@@ -92,6 +92,7 @@ struct OScene {
     /* images (allocated for width x height) */
     int imgW, imgH, finalW, finalH;
     uint8_t *finalRGBA8;
+    uint8_t *backgroundRGBA8; int bgW, bgH; struct OTexture bgTex;   /* gBackground: raster background instances, screen size */
     float *outputRGBA32F, *shadingPosition, *shadingNormal, *shadingSpecular, *diffuse;
     int32_t *instanceId;
     float *directLight[2], *indirectLight[2], *filteredDirect[2], *filteredIndirect[2];
@@ -122,6 +123,9 @@ void otrace(const OScene *s, const ORay *ray, int bruteForce, OAnyHitFn fn, void
 /* oracle_texture.c */
 void otex_sample_level(const OTexture *t, float u, float v, int level, int filter, int hAddr, int vAddr, float out[4]);
 void otex_sample_grad(const OTexture *t, float u, float v, of2 ddx, of2 ddy, int filter, int hAddr, int vAddr, float out[4]);
+
+/* oracle_raster.c */
+void oraster_draw(const OScene *s, const int *list, int count, uint8_t *target, int w, int h, int y0, int y1, int applyScissorsAndViewports);
 
 /* oracle_render.c / oracle_shade.c */
 int omatrix_inverse_d(const om4 *m, om4 *out);

@@ -46,7 +46,8 @@ class OInstanceDesc(C.Structure):
     _fields_ = [("mesh", C.c_void_p), ("transform", M4), ("previousTransform", M4),
                 ("diffuse", C.c_void_p), ("normal", C.c_void_p), ("specular", C.c_void_p),
                 ("shaderId", C.c_uint32), ("filter", C.c_uint32), ("hAddr", C.c_uint32), ("vAddr", C.c_uint32),
-                ("shaderFlags", C.c_int), ("material", C.c_byte * 132), ("flags", C.c_uint)]
+                ("shaderFlags", C.c_int), ("material", C.c_byte * 132), ("flags", C.c_uint),
+                ("scissorRect", C.c_int * 4), ("viewportRect", C.c_int * 4)]
 
 
 class OFrameParams(C.Structure):
@@ -76,7 +77,8 @@ class OFrameResult(C.Structure):
                 ("nodesVisited", C.c_uint64), ("trianglesTested", C.c_uint64),
                 ("nodesVisitedPrimary", C.c_uint64), ("trianglesTestedPrimary", C.c_uint64),
                 ("nodesVisitedShadow", C.c_uint64), ("trianglesTestedShadow", C.c_uint64),
-                ("secondsBuild", C.c_double), ("secondsRender", C.c_double), ("screenWidth", C.c_int), ("screenHeight", C.c_int)]
+                ("secondsBuild", C.c_double), ("secondsRender", C.c_double), ("screenWidth", C.c_int), ("screenHeight", C.c_int),
+                ("backgroundRGBA8", C.POINTER(C.c_uint8))]
 
 
 class ONode(C.Structure):
@@ -199,6 +201,10 @@ class OracleScene:
         d.shaderId, d.filter, d.hAddr, d.vAddr, d.shaderFlags = s.shader_id, s.shader_filter, s.shader_haddr, s.shader_vaddr, s.shader_flags
         C.memmove(d.material, C.byref(inst.material), 132)
         d.flags = inst.flags
+        for k, v in enumerate(getattr(inst, "scissor", None) or (0, 0, 0, 0)):
+            d.scissorRect[k] = int(v)
+        for k, v in enumerate(getattr(inst, "viewport", None) or (0, 0, 0, 0)):
+            d.viewportRect[k] = int(v)
         return d
 
     def set_instance(self, k, inst):
@@ -241,6 +247,8 @@ class OracleScene:
             "lockMask": img(r.lockMask, 1, np.float32), "depth": img(r.depth, 1, np.float32),
             "primaryHit": img(r.primaryHit, 4, np.uint32),
         }
+        out["background"] = (np.ctypeslib.as_array(r.backgroundRGBA8, shape=(screen_h * screen_w * 4,)).copy().reshape(screen_h, screen_w, 4)
+                             if r.backgroundRGBA8 else None)
         out["counters"] = {k: getattr(r, k) for k in ("primaryRays", "shadowRays", "indirectRays", "reflectionRays", "refractionRays",
                                                       "nodesVisited", "trianglesTested", "nodesVisitedPrimary", "trianglesTestedPrimary",
                                                       "nodesVisitedShadow", "trianglesTestedShadow", "secondsBuild", "secondsRender")}

@@ -88,7 +88,7 @@ static void free_images(OScene *s) {
 
 void oracle_scene_destroy(OScene *s) {
     if (!s) return;
-    free_images(s); free(s->finalRGBA8); free(s->blueNoise); free(s->instances); free(s->rt); obvh_free(&s->tlas); free(s);
+    free_images(s); free(s->finalRGBA8); free(s->backgroundRGBA8); free(s->blueNoise); free(s->instances); free(s->rt); obvh_free(&s->tlas); free(s);
 }
 
 void oracle_scene_set_desc(OScene *s, const OSceneDesc *d) { s->desc = *d; }
@@ -868,6 +868,23 @@ int oracle_render(OScene *s, const OFrameParams *pIn, OFrameResult *out) {
     OShadeCtx ctx;
     update_global_params(s, p, screenW, screenH, &ctx);
     ctx.separatePost = separatePost;
+    /* Raster instances: everything that is not ray traced, background-flagged ones first (View::update, ref:rt64_view.cpp:1138-1147). */
+    int *bgList = (int *)malloc(sizeof(int) * (size_t)(s->instanceCount + 1)), *fgList = (int *)malloc(sizeof(int) * (size_t)(s->instanceCount + 1));
+    int bgCount = 0, fgCount = 0;
+    for (int i = 0; i < s->instanceCount; i++) {
+        const OInstanceDesc *d = &s->instances[i];
+        if (!d->mesh || !d->diffuse) continue;
+        if ((d->mesh->flags & 0x1) && d->mesh->bvh.count > 0) continue;
+        if (d->flags & 0x1) bgList[bgCount++] = i; else fgList[fgCount++] = i;       /* RT64_INSTANCE_RASTER_BACKGROUND */
+    }
+    if (bgCount > 0) {      /* gBackground: cleared to 0, background instances without their scissors / viewports (ref:rt64_view.cpp:1298-1319) */
+        if (s->bgW != screenW || s->bgH != screenH) { free(s->backgroundRGBA8); s->backgroundRGBA8 = (uint8_t *)malloc((size_t)screenW * (size_t)screenH * 4); s->bgW = screenW; s->bgH = screenH; }
+        memset(s->backgroundRGBA8, 0, (size_t)screenW * (size_t)screenH * 4);
+        oraster_draw(s, bgList, bgCount, s->backgroundRGBA8, screenW, screenH, 0, screenH, 0);
+        memset(&s->bgTex, 0, sizeof(s->bgTex));
+        s->bgTex.mips = 1; s->bgTex.w[0] = screenW; s->bgTex.h[0] = screenH; s->bgTex.rgba[0] = s->backgroundRGBA8;
+        ctx.background = &s->bgTex;
+    }
     double t1 = now_s();
     int cur = s->rtSwap;
     size_t n = (size_t)p->width * (size_t)p->height;
@@ -894,11 +911,17 @@ int oracle_render(OScene *s, const OFrameParams *pIn, OFrameResult *out) {
         const size_t ns = (size_t)screenW * (size_t)screenH;
         memset(s->finalRGBA8, 0, ns * 4);
         for (size_t i = 0; i < ns; i++) s->finalRGBA8[4 * i + 3] = 255;      /* cleared back buffer, ref:rt64_device.cpp:996-997 */
+        /* Without ray-traced content nothing covers the background instances on the back buffer (ref:rt64_view.cpp:1292-1296). */
+        oraster_draw(s, bgList, bgCount, s->finalRGBA8, screenW, screenH, separatePost ? 0 : pIn->tileY0, separatePost ? screenH : pIn->tileY1, 1);
     }
+    /* Foreground instances over the finished frame (ref:rt64_view.cpp:1657-1661). */
+    oraster_draw(s, fgList, fgCount, s->finalRGBA8, screenW, screenH, separatePost ? 0 : pIn->tileY0, separatePost ? screenH : pIn->tileY1, 1);
+    free(bgList); free(fgList);
     double t2 = now_s();
     if (out) {
         memset(out, 0, sizeof(*out));
         out->width = p->width; out->height = p->height; out->screenWidth = screenW; out->screenHeight = screenH;
+        out->backgroundRGBA8 = bgCount > 0 ? s->backgroundRGBA8 : NULL;
         out->finalRGBA8 = s->finalRGBA8; out->outputRGBA32F = s->outputRGBA32F; out->shadingPosition = s->shadingPosition;
         out->shadingNormal = s->shadingNormal; out->shadingSpecular = s->shadingSpecular; out->diffuse = s->diffuse;
         out->instanceId = s->instanceId; out->directLight = s->directLight[cur]; out->indirectLight = s->indirectLight[cur];

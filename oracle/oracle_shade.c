@@ -366,6 +366,16 @@ static float alpha_formula(const OCombiner *cc, const VertexData *vd, of4 t0, of
     return (alpha_input(c[0], vd, t0, t1) - alpha_input(c[1], vd, t0, t1)) * alpha_input(c[2], vd, t0, t1) + alpha_input(c[3], vd, t0, t1);
 }
 
+/* Pixel shader of the raster pipeline, ref:private/rt64_shader.cpp:363-387: texVal1 is the constant (1,0,1,1) there. */
+void oshade_raster_pixel(const OCombiner *cc, const of4 inputs[4], of4 texVal0, float out[4]) {
+    VertexData vd; memset(&vd, 0, sizeof(vd));
+    for (int i = 0; i < 4; i++) vd.input[i] = inputs[i];
+    of4 t1 = { 1.0f, 0.0f, 1.0f, 1.0f }, result;
+    if (!cc->color_alpha_same && cc->opt_alpha) { result = color_formula(cc, 0, 1, &vd, texVal0, t1); result.w = alpha_formula(cc, &vd, texVal0, t1); }
+    else result = color_formula(cc, cc->opt_alpha, cc->opt_alpha, &vd, texVal0, t1);
+    out[0] = result.x; out[1] = result.y; out[2] = result.z; out[3] = result.w;
+}
+
 /* ---- surface any-hit, ref:rt64_shader.cpp:444-581 -------------------------------------------------------------- */
 
 int oshade_surface_anyhit(const OShadeCtx *c, const OHit *hit, of3 rayDirW, ORayDiff payloadDiff, uint32_t px, uint32_t py, OHitRecord *rec) {

@@ -40,6 +40,7 @@ of3 oshade_cos_hemisphere_blue_noise(const OShadeCtx *c, uint32_t px, uint32_t p
 void oshade_compute_ray_diffs(of3 nonNormDir, of3 right, of3 up, of2 viewportDims, of3 *dDdx, of3 *dDdy);
 of4 oshade_sample_sky_2d(const OShadeCtx *c, of2 screenUV);
 of4 oshade_sample_sky_plane(const OShadeCtx *c, of3 rayDirection);
+void oshade_raster_pixel(const OCombiner *cc, const of4 inputs[4], of4 texVal0, float out[4]);
 of3 oshade_sample_background_2d(const OShadeCtx *c, of2 screenUV);
 of3 oshade_sample_background_envmap(const OShadeCtx *c, of3 rayDirection);
 of4 oshade_fog_from_camera(const OShadeCtx *c, uint32_t instanceId, of3 position);

@@ -105,6 +105,7 @@ typedef struct {
     int shaderFlags;                              /* RT64_SHADER_* */
     OMaterial material;
     unsigned int flags;                           /* RT64_INSTANCE_* */
+    int scissorRect[4], viewportRect[4];          /* RT64_RECT x, y, w, h (origin bottom-left, ref:rt64_view.cpp:1114-1136); w or h <= 0 = unset */
 } OInstanceDesc;
 
 typedef struct {
@@ -146,6 +147,7 @@ typedef struct {
     uint64_t nodesVisitedPrimary, trianglesTestedPrimary, nodesVisitedShadow, trianglesTestedShadow;
     double secondsBuild, secondsRender;
     int screenWidth, screenHeight;                /* size of finalRGBA8 */
+    const uint8_t *backgroundRGBA8;               /* [screenHeight][screenWidth][4]: gBackground (raster background instances), NULL when there are none */
 } OFrameResult;
 
 /* ---- API --------------------------------------------------------------------------------------------- */

@@ -48,6 +48,14 @@ hipError_t launch_compose_post(const FrameParams &P, const ViewImages &I, int cu
 hipError_t launch_post_process(const FrameParams &P, const ViewImages &I, hipStream_t s);      // PostProcessPS as its own pass (resolution scale / motion blur)
 hipError_t launch_clear_final(const FrameParams &P, const ViewImages &I, hipStream_t s);
 
+// ---- raster.hip ----------------------------------------------------------------------------------------------------
+size_t raster_tri_bytes(uint32_t triTotal);       // setup records of a draw list
+// Triangle setup of a draw list for a w x h target, rows [y0, y1); `apply` = drawInstances' applyScissorsAndViewports (rt64_view.cpp:1225).
+hipError_t launch_raster_setup(const GpuRasterInstance *instances, uint32_t instanceCount, uint32_t triTotal, void *tris, int w, int h, int y0, int y1, bool apply, hipStream_t s);
+// Shade + blend the list, in order, into the RGBA8 target; `bounds` = pixel rectangle [x0, y0, x1, y1) the list can touch.
+hipError_t launch_raster_draw(const GpuRasterInstance *instances, const void *tris, uint32_t triTotal, const GpuTexture *textures, uint8_t *target,
+                              int w, int y0, int y1, const int bounds[4], int stripRank, int stripCount, hipStream_t s);
+
 // ---- svgf.hip ------------------------------------------------------------------------------------------------------
 // variance estimate + 5 a-trous iterations over the GI buffer; result in filteredIndirect[1]
 hipError_t launch_svgf(const ViewImages &I, int cur, int width, int height, hipStream_t s);

@@ -220,14 +220,13 @@ __global__ __launch_bounds__(RT_BLOCK, SHADE_WAVES) void primary_shade_kernel(Fr
         float reflA = 0.0f, refrA = 0.0f;
 
         f2 screenUV; screenUV.x = ((float)px + P.pixelJitter[0]) / (float)P.width; screenUV.y = ((float)py + P.pixelJitter[1]) / (float)P.height;
-        f3 bgColor = sample_background_2d(P, screenUV);
-        f4 skyColor = sample_sky_2d(P, screenUV);
+        // The background / sky colour only enters through `bgColor * resColor.a` after the resolve loop: it is fetched there, and
+        // only by pixels that are not fully covered (PrimaryRayGen.hlsl:47-53 samples up front; same values, fewer fetches).
         f2 prevBgPos, curBgPos; prevBgPos.x = prevBgPos.y = curBgPos.x = curBgPos.y = 0.0f;
         if (FULL) {
             f3 bgPosition = rayOrigin + rayDirection * RT_RAY_MAX_DISTANCE;
             prevBgPos = world_to_screen(P.prevViewProj, bgPosition); curBgPos = world_to_screen(P.viewProj, bgPosition);
         }
-        bgColor = lerp3(bgColor, xyz(skyColor), skyColor.w);
 
         RayDiff rayDiff;
         rayDiff.dOdx = mk3s(0.0f); rayDiff.dOdy = mk3s(0.0f); rayDiff.dDdx = mk3s(0.0f); rayDiff.dDdy = mk3s(0.0f);
@@ -302,7 +301,12 @@ __global__ __launch_bounds__(RT_BLOCK, SHADE_WAVES) void primary_shade_kernel(Fr
             if (resColor.w <= RT_EPSILON) break;
         }
         resReactiveMask += fmaxf(resTransparent.x, fmaxf(resTransparent.y, resTransparent.z));
-        resColor.x += bgColor.x * resColor.w; resColor.y += bgColor.y * resColor.w; resColor.z += bgColor.z * resColor.w;
+        if (resColor.w != 0.0f) {
+            const f4 skyColor = sample_sky_2d(P, screenUV);
+            // lerp(background, sky, 1) is the sky itself up to one rounding of (sky - bg) + bg: skip the gBackground fetch under an opaque sky
+            f3 bgColor = skyColor.w >= 1.0f ? xyz(skyColor) : lerp3(sample_background_2d(P, screenUV), xyz(skyColor), skyColor.w);
+            resColor.x += bgColor.x * resColor.w; resColor.y += bgColor.y * resColor.w; resColor.z += bgColor.z * resColor.w;
+        }
         resColor.w = 1.0f - resColor.w;
 
         if (FULL) {

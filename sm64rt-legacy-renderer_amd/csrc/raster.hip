@@ -1,0 +1,171 @@
+// raster.hip -- raster (HUD / background) instance pass: software rasteriser + the generated raster pixel shader.
+//
+// Replaces the D3D12 graphics pipeline the reference draws its non-ray-traced instances with
+// (/root/reference/src/rt64lib/private/rt64_shader.cpp:312-442 generateRasterGroup: pass-through vertex shader, pixel shader =
+// diffuse texture sample + colour combiner, SRC_ALPHA / INV_SRC_ALPHA blending, no depth, no culling;
+// private/rt64_view.cpp:1225-1254 drawInstances, :1292-1319 background pass + gBackground, :1657-1661 foreground pass).
+// The rasteriser is fixed-function hardware there; here it follows the Direct3D 11 rules as the "Raster spec" S0-S8 written out
+// in oracle/oracle_raster.c (24.8 fixed-point vertices, int64 edge functions, top-left rule, perspective-correct attributes,
+// blending in the target's RGBA8 storage triangle by triangle).  Coverage is integer arithmetic: bit-exact with the oracle.
+//
+// MI355X shape: raster_setup_kernel turns every triangle of a draw list into a 96-byte record (one thread per triangle);
+// raster_draw_kernel runs one thread per target pixel (32x2 pixels per wave), walks the records IN DRAW ORDER -- the record
+// address is wave-uniform, so records arrive through scalar loads and a triangle whose bounding box misses the wave's 32x2
+// pixels costs a few SALU instructions -- and keeps the destination pixel in registers until the list is exhausted
+// (one read + one write of the target per pixel, however many layers blend).  HUD lists are hundreds of triangles; no binning.
+#include <algorithm>
+#include "kernels.h"
+#include "shade.h"
+
+namespace {
+
+struct RasterTri {                 // 96 bytes
+    int32_t X[3], Y[3];            // 24.8 fixed point, orientation normalised (area2 > 0)
+    float rw[3];
+    uint32_t vtx[3];               // vertex numbers in the same (possibly swapped) order
+    int32_t px0, py0, px1, py1;    // pixel bounding box clipped to the scissor; px0 > px1 = nothing to draw
+    uint32_t inst;
+    uint32_t pad[7];
+};
+
+__global__ __launch_bounds__(256) void raster_setup_kernel(const GpuRasterInstance *instances, uint32_t instanceCount, uint32_t triTotal,
+                                                           RasterTri *tris, int w, int h, int y0, int y1, int apply) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= triTotal) return;
+    uint32_t lo = 0, hi = instanceCount - 1;                                  // last instance with firstTri <= t
+    while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (instances[mid].firstTri <= t) lo = mid; else hi = mid - 1; }
+    const GpuRasterInstance &in = instances[lo];
+    const uint32_t tri = t - in.firstTri;
+    RasterTri r; memset(&r, 0, sizeof(r));
+    r.inst = lo; r.px0 = 1; r.px1 = 0; r.py0 = 1; r.py1 = 0;
+    float vpX = 0.0f, vpY = 0.0f, vpW = (float)w, vpH = (float)h;
+    int scL = 0, scT = 0, scR = w, scB = h;
+    if (apply) {                                                               // rt64_view.cpp:1114-1136
+        if (in.scissorRect[2] > 0 && in.scissorRect[3] > 0) { scL = in.scissorRect[0]; scT = h - in.scissorRect[1] - in.scissorRect[3]; scR = in.scissorRect[0] + in.scissorRect[2]; scB = h - in.scissorRect[1]; }
+        if (in.viewportRect[2] > 0 && in.viewportRect[3] > 0) { vpX = (float)in.viewportRect[0]; vpY = (float)(h - in.viewportRect[1] - in.viewportRect[3]); vpW = (float)in.viewportRect[2]; vpH = (float)in.viewportRect[3]; }
+    }
+    scL = max(scL, 0); scT = max(scT, y0); scR = min(scR, w); scB = min(scB, y1);
+    bool ok = true;
+    int64_t X[3], Y[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint32_t v = in.indices[3 * tri + k];
+        const float *p = reinterpret_cast<const float *>(in.vertices + (size_t)v * in.vertexStride);
+        const float px = p[0], py = p[1], pw = p[3];
+        if (!(pw > 0.0f)) ok = false;                                                                      // S0
+        const float rw = 1.0f / pw;
+        const float xs = ((px * rw) * 0.5f + 0.5f) * vpW + vpX, ys = (0.5f - (py * rw) * 0.5f) * vpH + vpY;     // S1
+        const float xf = xs * 256.0f, yf = ys * 256.0f;
+        if (!(fabsf(xf) <= 4194304.0f) || !(fabsf(yf) <= 4194304.0f)) ok = false;                          // S2
+        X[k] = ok ? (int64_t)__float2int_rn(xf) : 0; Y[k] = ok ? (int64_t)__float2int_rn(yf) : 0;
+        r.rw[k] = rw; r.vtx[k] = v;
+    }
+    int64_t area2 = (X[1] - X[0]) * (Y[2] - Y[0]) - (Y[1] - Y[0]) * (X[2] - X[0]);                          // S3
+    if (area2 == 0) ok = false;
+    if (area2 < 0) {
+        int64_t tx = X[1]; X[1] = X[2]; X[2] = tx; int64_t ty = Y[1]; Y[1] = Y[2]; Y[2] = ty;
+        float tr = r.rw[1]; r.rw[1] = r.rw[2]; r.rw[2] = tr; uint32_t tv = r.vtx[1]; r.vtx[1] = r.vtx[2]; r.vtx[2] = tv;
+    }
+    if (ok) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { r.X[k] = (int32_t)X[k]; r.Y[k] = (int32_t)Y[k]; }
+        const int64_t minX = min(X[0], min(X[1], X[2])), maxX = max(X[0], max(X[1], X[2])), minY = min(Y[0], min(Y[1], Y[2])), maxY = max(Y[0], max(Y[1], Y[2]));
+        r.px0 = max((int)(minX >> 8), scL); r.px1 = min((int)(maxX >> 8), scR - 1);
+        r.py0 = max((int)(minY >> 8), scT); r.py1 = min((int)(maxY >> 8), scB - 1);
+    }
+    tris[t] = r;
+}
+
+DEV int64_t edge_fn(const RasterTri &t, int a, int b, int64_t px, int64_t py) {
+    return (int64_t)(t.X[b] - t.X[a]) * (py - (int64_t)t.Y[a]) - (int64_t)(t.Y[b] - t.Y[a]) * (px - (int64_t)t.X[a]);
+}
+DEV bool edge_in(const RasterTri &t, int a, int b, int64_t e) {               // S4: top-left rule, y down
+    if (e > 0) return true;
+    if (e < 0) return false;
+    const int dx = t.X[b] - t.X[a], dy = t.Y[b] - t.Y[a];
+    return dy < 0 || (dy == 0 && dx > 0);
+}
+struct Weights { float q0, q1, q2, qs; };
+DEV Weights weights_at(const RasterTri &t, float area, int64_t px, int64_t py) {      // S6
+    const float l0 = (float)edge_fn(t, 1, 2, px, py) / area, l1 = (float)edge_fn(t, 2, 0, px, py) / area, l2 = (float)edge_fn(t, 0, 1, px, py) / area;
+    Weights w; w.q0 = l0 * t.rw[0]; w.q1 = l1 * t.rw[1]; w.q2 = l2 * t.rw[2]; w.qs = (w.q0 + w.q1) + w.q2;
+    return w;
+}
+DEV float interp(const Weights &w, float a0, float a1, float a2) { return ((w.q0 * a0 + w.q1 * a1) + w.q2 * a2) / w.qs; }
+
+__global__ __launch_bounds__(256) void raster_draw_kernel(const GpuRasterInstance *__restrict__ instances, const RasterTri *__restrict__ tris, uint32_t triTotal,
+                                                          const GpuTexture *__restrict__ textures, uint8_t *target, int w, int y0, int y1, int gx0, int gy0, int stripRank, int stripCount) {
+    const int bx = (int)blockIdx.x + gx0, by = (int)blockIdx.y + gy0;
+    const int x = bx * 32 + (threadIdx.x & 31), y = y0 + by * 8 + (threadIdx.x >> 5);
+    const bool inside = x < w && y < y1 && (((y - y0) / 16) % stripCount) == stripRank;
+    // wave-uniform pixel rectangle of this wave: 32 x 2
+    const int wx0 = bx * 32, wx1 = wx0 + 31, wy0 = __builtin_amdgcn_readfirstlane(y0 + by * 8 + (int)((threadIdx.x >> 6) * 2)), wy1 = wy0 + 1;
+    uint32_t dstBits = 0; bool loaded = false, dirty = false;
+    const size_t i = (size_t)y * (size_t)w + (size_t)x;
+    for (uint32_t n = 0; n < triTotal; n++) {
+        const RasterTri &t = tris[n];
+        if (t.px0 > wx1 || t.px1 < wx0 || t.py0 > wy1 || t.py1 < wy0) continue;          // uniform: scalar compares
+        if (!inside || x < t.px0 || x > t.px1 || y < t.py0 || y > t.py1) continue;
+        const int64_t cx = (int64_t)x * 256 + 128, cy = (int64_t)y * 256 + 128;
+        const int64_t e12 = edge_fn(t, 1, 2, cx, cy), e20 = edge_fn(t, 2, 0, cx, cy), e01 = edge_fn(t, 0, 1, cx, cy);
+        if (!edge_in(t, 1, 2, e12) || !edge_in(t, 2, 0, e20) || !edge_in(t, 0, 1, e01)) continue;
+        const GpuRasterInstance &in = instances[t.inst];
+        const GpuCombiner cc = in.cc;
+        const float area = (float)(e12 + e20 + e01);                                      // = area2 (the three edge functions sum to it)
+        const Weights wq = weights_at(t, area, cx, cy);
+        const uint8_t *v0 = in.vertices + (size_t)t.vtx[0] * in.vertexStride, *v1 = in.vertices + (size_t)t.vtx[1] * in.vertexStride, *v2 = in.vertices + (size_t)t.vtx[2] * in.vertexStride;
+        VertexData vd;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            vd.input[k] = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (k < cc.inputCount) {
+                const float *a0 = reinterpret_cast<const float *>(v0 + cc.inputOffset[k]), *a1 = reinterpret_cast<const float *>(v1 + cc.inputOffset[k]), *a2 = reinterpret_cast<const float *>(v2 + cc.inputOffset[k]);
+                vd.input[k].x = interp(wq, a0[0], a1[0], a2[0]); vd.input[k].y = interp(wq, a0[1], a1[1], a2[1]); vd.input[k].z = interp(wq, a0[2], a1[2], a2[2]);
+                vd.input[k].w = cc.optAlpha ? interp(wq, a0[3], a1[3], a2[3]) : interp(wq, 1.0f, 1.0f, 1.0f);        // VS: float4(iInput, 1)
+            }
+        }
+        f4 texVal0 = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (cc.useTex0 && in.texDiffuse >= 0) {
+            const float *u0 = reinterpret_cast<const float *>(v0 + cc.uvOffset), *u1 = reinterpret_cast<const float *>(v1 + cc.uvOffset), *u2 = reinterpret_cast<const float *>(v2 + cc.uvOffset);
+            const float u = interp(wq, u0[0], u1[0], u2[0]), v = interp(wq, u0[1], u1[1], u2[1]);
+            const Weights wx = weights_at(t, area, cx + 256, cy), wy = weights_at(t, area, cx, cy + 256);         // S7
+            f2 ddx, ddy;
+            ddx.x = interp(wx, u0[0], u1[0], u2[0]) - u; ddx.y = interp(wx, u0[1], u1[1], u2[1]) - v;
+            ddy.x = interp(wy, u0[0], u1[0], u2[0]) - u; ddy.y = interp(wy, u0[1], u1[1], u2[1]) - v;
+            texVal0 = tex_sample_grad(textures[in.texDiffuse], u, v, ddx, ddy, in.filter, in.hAddr, in.vAddr);
+        }
+        const f4 t1 = mk4(1.0f, 0.0f, 1.0f, 1.0f);                                       // rt64_shader.cpp:377 (TODO in the reference)
+        f4 src;
+        if (!cc.colorAlphaSame && cc.optAlpha) { src = color_formula(cc, false, true, vd, texVal0, t1); src.w = alpha_formula(cc, vd, texVal0, t1); }
+        else src = color_formula(cc, cc.optAlpha, cc.optAlpha, vd, texVal0, t1);
+        src.x = src.x > 0.0f ? fminf(src.x, 1.0f) : 0.0f; src.y = src.y > 0.0f ? fminf(src.y, 1.0f) : 0.0f;       // S8
+        src.z = src.z > 0.0f ? fminf(src.z, 1.0f) : 0.0f; src.w = src.w > 0.0f ? fminf(src.w, 1.0f) : 0.0f;
+        if (!loaded) { dstBits = reinterpret_cast<const uint32_t *>(target)[i]; loaded = true; }
+        const float dr = from_unorm8((uint8_t)(dstBits & 0xFF)), dg = from_unorm8((uint8_t)((dstBits >> 8) & 0xFF)), db = from_unorm8((uint8_t)((dstBits >> 16) & 0xFF)), da = from_unorm8((uint8_t)(dstBits >> 24));
+        const float ia = 1.0f - src.w;
+        dstBits = (uint32_t)to_unorm8(src.x * src.w + dr * ia) | ((uint32_t)to_unorm8(src.y * src.w + dg * ia) << 8)
+                | ((uint32_t)to_unorm8(src.z * src.w + db * ia) << 16) | ((uint32_t)to_unorm8(src.w + da * ia) << 24);
+        dirty = true;
+    }
+    if (dirty) reinterpret_cast<uint32_t *>(target)[i] = dstBits;
+}
+
+}  // namespace
+
+size_t raster_tri_bytes(uint32_t triTotal) { return (size_t)triTotal * sizeof(RasterTri); }
+
+hipError_t launch_raster_setup(const GpuRasterInstance *instances, uint32_t instanceCount, uint32_t triTotal, void *tris, int w, int h, int y0, int y1, bool apply, hipStream_t s) {
+    if (instanceCount == 0 || triTotal == 0) return hipSuccess;
+    hipLaunchKernelGGL(raster_setup_kernel, dim3((triTotal + 255) / 256), dim3(256), 0, s, instances, instanceCount, triTotal, static_cast<RasterTri *>(tris), w, h, y0, y1, apply ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_raster_draw(const GpuRasterInstance *instances, const void *tris, uint32_t triTotal, const GpuTexture *textures, uint8_t *target,
+                              int w, int y0, int y1, const int bounds[4], int stripRank, int stripCount, hipStream_t s) {
+    // grid over the list's bounding rectangle, aligned to the 32 x 8 block shape (rows relative to y0 keep the strip arithmetic)
+    const int gx0 = bounds[0] / 32, gx1 = (bounds[2] + 31) / 32, gy0 = (std::max(bounds[1], y0) - y0) / 8, gy1 = (std::min(bounds[3], y1) - y0 + 7) / 8;
+    if (triTotal == 0 || gx1 <= gx0 || gy1 <= gy0) return hipSuccess;
+    hipLaunchKernelGGL(raster_draw_kernel, dim3((unsigned)(gx1 - gx0), (unsigned)(gy1 - gy0)), dim3(256), 0, s, instances, static_cast<const RasterTri *>(tris), triTotal, textures,
+                       target, w, y0, y1, gx0, gy0, stripRank, stripCount);
+    return hipGetLastError();
+}

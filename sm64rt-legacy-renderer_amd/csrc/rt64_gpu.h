@@ -80,6 +80,19 @@ struct alignas(16) GpuInstance {
     uint32_t meshVersion;                // bumps on every RT64_SetMesh: part of the frame-table cache key
 };
 
+// One raster (non-ray-traced) instance of the frame, draw order: background list, then foreground list (rt64_view.cpp:1138-1147).
+struct alignas(16) GpuRasterInstance {
+    const uint8_t *vertices;             // vertex buffer as passed to RT64_SetMesh (position float4 at offset 0 = clip space)
+    const uint32_t *indices;
+    uint32_t vertexStride, triCount;
+    uint32_t firstTri;                   // prefix sum of triCount inside its list
+    GpuCombiner cc;
+    int32_t texDiffuse;
+    uint32_t filter, hAddr, vAddr;
+    int32_t scissorRect[4], viewportRect[4];     // RT64_RECT x, y, w, h (origin bottom-left); w or h <= 0 = unset
+    uint32_t meshVersion;
+};
+
 // Constant block of one frame (reference: GlobalParams.hlsli:8-43 / rt64_view.cpp:961-1028), passed by value.
 struct FrameParams {
     float view[16], viewI[16], prevViewI[16], projection[16], projectionI[16], viewProj[16], prevViewProj[16];
@@ -97,6 +110,7 @@ struct FrameParams {
     int32_t tileY0, tileY1;              // row range owned by this device
     int32_t stripRank, stripCount;       // interleaved 16-row strips inside the range (count 1 = all)
     float maxDepthBias;
+    GpuTexture background;               // gBackground: raster background target (screen size RGBA8); texels == nullptr: no background instances
     uint32_t separatePost;               // 1: render size != screen size or motion blur on -> PostProcessPS runs as post_process_kernel
     float skyBase[4];                    // ComputeSkyPlaneUV: base u, base v, 0.25 * ratioDivision, 0.25
     uint32_t lightCount, instanceCount, countTraversal;

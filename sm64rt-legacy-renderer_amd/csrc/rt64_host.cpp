@@ -243,6 +243,17 @@ struct View {
     DevArray<int32_t> hitInstance;
     // per-frame tables
     std::vector<RenderInstance> rtInstances, rasterBg, rasterFg;
+    // raster pass (raster.hip): device tables of the two lists, triangle setup records, gBackground target
+    struct RasterList {
+        DevArray<GpuRasterInstance> table; DevArray<uint8_t> tris;      // device instance table + triangle setup records
+        std::vector<uint8_t> uploaded;                                   // bytes of the table the records were built from (cache key)
+        uint32_t triTotal = 0; int w = 0, h = 0, y0 = 0, y1 = 0; bool apply = false, ready = false, changed = false;
+        int bounds[4] = { 0, 0, 0, 0 };                                  // conservative pixel rectangle [x0, y0, x1, y1) the list can touch
+    };
+    RasterList rasterBgEnv, rasterBgScreen, rasterFgScreen;             // bg -> gBackground (no scissors), bg -> back buffer, fg -> back buffer
+    DevArray<uint8_t> background; int backgroundW = 0, backgroundH = 0;
+    void prepareRasterList(const std::vector<RenderInstance> &list, RasterList &rl, int w, int h, int y0, int y1, bool apply);
+    void drawRasterList(RasterList &rl, uint8_t *target);
     std::vector<Texture *> usedTextures;
     DevArray<GpuInstance> dInstances; DevArray<GpuTexture> dTextures; DevArray<RT64_LIGHT> dLights;
     DevArray<GpuNode> tlasNodes; DevArray<uint32_t> tlasIndex, tlasMorton, tlasLeafParent; DevArray<BlasHeader> tlasHeader; DevArray<uint8_t> tlasScratch;
@@ -523,6 +534,61 @@ static bool instance_is_shadow_opaque(const Instance *inst, const GpuCombiner &c
     return lo >= 0.0f && inst->material.shadowAlphaMultiplier * lo >= 0.999f;
 }
 
+// Build (or reuse) the device table and the triangle setup records of one raster draw list.  The records only depend on the
+// table bytes, the target size, the row range and the scissor mode: an unchanged HUD costs nothing here after its first frame.
+void View::prepareRasterList(const std::vector<RenderInstance> &list, RasterList &rl, int w, int h, int y0, int y1, bool apply) {
+    rl.changed = false;
+    if (list.empty()) { rl.triTotal = 0; rl.ready = false; rl.uploaded.clear(); return; }
+    Device *dev = scene->device;
+    std::vector<GpuRasterInstance> hst(list.size());
+    uint32_t triTotal = 0;
+    float bx0 = INFINITY, by0 = INFINITY, bx1 = -INFINITY, by1 = -INFINITY;
+    for (size_t i = 0; i < list.size(); i++) {
+        Instance *inst = list[i].instance;
+        GpuRasterInstance &g = hst[i];
+        memset(&g, 0, sizeof(g));
+        g.vertices = inst->mesh->vertices.ptr; g.indices = inst->mesh->indices.ptr;
+        g.vertexStride = (uint32_t)inst->mesh->vertexStride; g.triCount = (uint32_t)inst->mesh->indexCount / 3; g.firstTri = triTotal;
+        g.cc = inst->shader->cc;
+        g.texDiffuse = inst->diffuse->currentIndex; g.filter = inst->shader->filter; g.hAddr = inst->shader->hAddr; g.vAddr = inst->shader->vAddr;
+        g.scissorRect[0] = inst->scissorRect.x; g.scissorRect[1] = inst->scissorRect.y; g.scissorRect[2] = inst->scissorRect.w; g.scissorRect[3] = inst->scissorRect.h;
+        g.viewportRect[0] = inst->viewportRect.x; g.viewportRect[1] = inst->viewportRect.y; g.viewportRect[2] = inst->viewportRect.w; g.viewportRect[3] = inst->viewportRect.h;
+        g.meshVersion = inst->mesh->version;
+        // the raster input layout reads position float4 + the attributes the combiner uses (rt64_shader.cpp:389-398)
+        if (g.cc.vertexSize > inst->mesh->vertexStride || inst->mesh->vertexStride < 16) throw std::runtime_error("Raster instance mesh vertex stride is smaller than the layout its shader reads.");
+        triTotal += g.triCount;
+        // conservative screen bounds of the instance (same transform as raster spec S1, +-1 pixel)
+        float vpX = 0.0f, vpY = 0.0f, vpW = (float)w, vpH = (float)h;
+        if (apply && inst->viewportRect.w > 0 && inst->viewportRect.h > 0) { vpX = (float)inst->viewportRect.x; vpY = (float)(h - inst->viewportRect.y - inst->viewportRect.h); vpW = (float)inst->viewportRect.w; vpH = (float)inst->viewportRect.h; }
+        for (int v = 0; v < inst->mesh->vertexCount; v++) {
+            float p[4]; memcpy(p, inst->mesh->hostVertices.data() + (size_t)v * inst->mesh->vertexStride, 16);
+            if (!(p[3] > 0.0f)) continue;
+            const float rw = 1.0f / p[3], xs = ((p[0] * rw) * 0.5f + 0.5f) * vpW + vpX, ys = (0.5f - (p[1] * rw) * 0.5f) * vpH + vpY;
+            bx0 = std::min(bx0, xs); bx1 = std::max(bx1, xs); by0 = std::min(by0, ys); by1 = std::max(by1, ys);
+        }
+    }
+    const size_t bytes = hst.size() * sizeof(GpuRasterInstance);
+    const bool same = rl.ready && rl.uploaded.size() == bytes && memcmp(rl.uploaded.data(), hst.data(), bytes) == 0 &&
+                      rl.w == w && rl.h == h && rl.y0 == y0 && rl.y1 == y1 && rl.apply == apply && !dev->opt.alwaysRebuild;
+    if (same) return;
+    rl.table.reserve(hst.size()); rl.tris.reserve(std::max<size_t>(raster_tri_bytes(triTotal), 16));
+    uint8_t *stage = static_cast<uint8_t *>(dev->staging(bytes));
+    memcpy(stage, hst.data(), bytes);
+    HIP_CHECK(hipMemcpyAsync(rl.table.ptr, stage, bytes, hipMemcpyHostToDevice, dev->stream));
+    HIP_CHECK(hipStreamSynchronize(dev->stream));                // the staging buffer is shared with the frame tables
+    rl.uploaded.assign(reinterpret_cast<uint8_t *>(hst.data()), reinterpret_cast<uint8_t *>(hst.data()) + bytes);
+    rl.triTotal = triTotal; rl.w = w; rl.h = h; rl.y0 = y0; rl.y1 = y1; rl.apply = apply; rl.ready = true; rl.changed = true;
+    rl.bounds[0] = std::max(0, (int)std::floor(std::min(bx0, 1e9f)) - 1); rl.bounds[1] = std::max(y0, (int)std::floor(std::min(by0, 1e9f)) - 1);
+    rl.bounds[2] = std::min(w, (int)std::ceil(std::max(bx1, -1e9f)) + 2); rl.bounds[3] = std::min(y1, (int)std::ceil(std::max(by1, -1e9f)) + 2);
+    HIP_CHECK(launch_raster_setup(rl.table.ptr, (uint32_t)hst.size(), triTotal, rl.tris.ptr, w, h, y0, y1, apply, dev->stream));
+}
+
+void View::drawRasterList(RasterList &rl, uint8_t *target) {
+    if (!rl.ready || rl.triTotal == 0) return;
+    Device *dev = scene->device;
+    HIP_CHECK(launch_raster_draw(rl.table.ptr, rl.tris.ptr, rl.triTotal, dTextures.ptr, target, rl.w, rl.y0, rl.y1, rl.bounds, dev->stripRank, dev->stripCount, dev->stream));
+}
+
 void View::update() {                          // View::update, rt64_view.cpp:1053-1178
     Device *dev = scene->device;
     {   // View::createOutputBuffers: render size = lround(screen * resolutionScale) (rt64_view.cpp:138-139)
@@ -623,6 +689,21 @@ void View::update() {                          // View::update, rt64_view.cpp:10
         }
         uploadedTables.assign(stage, stage + tableBytes);
     }
+    // Raster lists (background first, then foreground; rt64_view.cpp:1138-1147).  They are a handful of HUD instances: uploaded every frame.
+    {
+        const bool whole = separatePost();                     // the back buffer is screen size; device rows are screen rows
+        const int sy0 = whole ? 0 : dev->tileY0, sy1 = whole ? finalH : dev->tileY1;
+        prepareRasterList(rasterBg, rasterBgEnv, finalW, finalH, 0, finalH, false);               // gBackground: every rank needs all of it (env-map lookups)
+        prepareRasterList(rtInstances.empty() ? rasterBg : std::vector<RenderInstance>(), rasterBgScreen, finalW, finalH, sy0, sy1, true);
+        prepareRasterList(rasterFg, rasterFgScreen, finalW, finalH, sy0, sy1, true);
+        if (!rasterBg.empty() && (backgroundW != finalW || backgroundH != finalH)) { background.reserve((size_t)finalW * finalH * 4); backgroundW = finalW; backgroundH = finalH; rasterBgEnv.changed = true; }
+        if (rasterBgEnv.ready && rasterBgEnv.changed) {        // gBackground: cleared to 0, drawn without scissors / viewports (rt64_view.cpp:1298-1319)
+            HIP_CHECK(hipMemsetAsync(background.ptr, 0, (size_t)finalW * finalH * 4, dev->stream));
+            const int sr = dev->stripRank, sc = dev->stripCount; dev->stripRank = 0; dev->stripCount = 1;
+            drawRasterList(rasterBgEnv, background.ptr);
+            dev->stripRank = sr; dev->stripCount = sc;
+        }
+    }
     for (Texture *t : usedTextures) t->currentIndex = -1;
 }
 
@@ -670,6 +751,8 @@ void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64
     P.visualizationMode = 0;
     P.width = imgW; P.height = imgH; P.tileY0 = dev->tileY0; P.tileY1 = dev->tileY1; P.stripRank = dev->stripRank; P.stripCount = dev->stripCount;
     P.separatePost = separatePost() ? 1u : 0u;
+    memset(&P.background, 0, sizeof(P.background));
+    if (rasterBgEnv.ready) { P.background.texels = background.ptr; P.background.width = (uint32_t)backgroundW; P.background.height = (uint32_t)backgroundH; P.background.mips = 1; }
     if (P.separatePost) { P.tileY0 = 0; P.tileY1 = imgH; P.stripRank = 0; P.stripCount = 1; }       // device rows are screen rows; the render target has its own height
     P.maxDepthBias = maxDepthBias;
     {   // ComputeSkyPlaneUV (BgSky.hlsli:20-52): the view-only part, once per frame
@@ -762,7 +845,9 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         leanFrame = false;
         mark(Device::EV_PRIMARY_TRACE); mark(Device::EV_PRIMARY); mark(Device::EV_DIRECT); mark(Device::EV_INDIRECT); mark(Device::EV_REFL); mark(Device::EV_DENOISE);
         HIP_CHECK(launch_clear_final(P, img, s));
+        drawRasterList(rasterBgScreen, img.final);           // nothing ray traced covers the background instances (rt64_view.cpp:1292-1296)
     }
+    drawRasterList(rasterFgScreen, img.final);               // foreground instances over the finished frame (rt64_view.cpp:1657-1661)
     // End of frame (rt64_view.cpp:1663-1667)
     rtSwap = !rtSwap; skipReprojection = false; frameCount++;
 }
@@ -883,6 +968,14 @@ static size_t readback(Device *dev, int image, void *dst, size_t dstBytes, bool 
     dev->use();
     View *v = first_view(dev);
     if (!v) throw std::runtime_error("RT64_ReadbackDevice: the device has no view.");
+    if (image == RT64_IMAGE_BACKGROUND) {        // gBackground: whole screen on every device; zeros when the frame had no background instance
+        const size_t need = (size_t)v->finalW * v->finalH * 4;
+        if (dstBytes < need) throw std::runtime_error("RT64_ReadbackDevice: destination buffer is too small.");
+        if (!v->rasterBgEnv.ready) { if (toDevice) HIP_CHECK(hipMemsetAsync(dst, 0, need, dev->stream)); else memset(dst, 0, need); }
+        else HIP_CHECK(hipMemcpyAsync(dst, v->background.ptr, need, toDevice ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, dev->stream));
+        HIP_CHECK(hipStreamSynchronize(dev->stream));
+        return need;
+    }
     if (image != RT64_IMAGE_FINAL_RGBA8 && image != RT64_IMAGE_OUTPUT_RGBA32F) v->materialise();
     ImageInfo info; size_t dstPixelBytes;
     if (!image_info(v, image, info, dstPixelBytes)) throw std::runtime_error("RT64_ReadbackDevice: unknown image id.");

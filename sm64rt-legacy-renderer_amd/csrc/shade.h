@@ -128,9 +128,17 @@ DEV f4 sample_sky_plane(const FrameParams &P, f3 rayDirection) {                
     f2 uv = fake_envmap_uv(rayDirection, P.skyYawOffset);
     return sky_finish(P, tex_sample_level(P.textures[P.skyPlaneTexIndex], uv.x, uv.y, 0, 1, 0, 0));
 }
-// gBackground (raster background target, rt64_view.cpp:1296-1319): no raster pass yet -> transparent black.
-DEV f3 sample_background_2d(const FrameParams &, f2) { return mk3s(0.0f); }
-DEV f3 sample_background_envmap(const FrameParams &, f3) { return mk3s(0.0f); }
+// gBackground: the raster background instances drawn into a screen-size RGBA8 target (rt64_view.cpp:1296-1319, raster.hip),
+// sampled with the static LINEAR / WRAP sampler (BgSky.hlsli:89-95).  No background instance => transparent black.
+DEV f3 sample_background_2d(const FrameParams &P, f2 screenUV) {
+    if (!P.background.texels) return mk3s(0.0f);
+    return xyz(tex_sample_level(P.background, screenUV.x, screenUV.y, 0, 1, 0, 0));
+}
+DEV f3 sample_background_envmap(const FrameParams &P, f3 rayDirection) {
+    if (!P.background.texels) return mk3s(0.0f);
+    const f2 uv = fake_envmap_uv(rayDirection, 0.0f);
+    return xyz(tex_sample_level(P.background, uv.x, uv.y, 0, 1, 0, 0));
+}
 
 DEV f4 fog_from_camera(const FrameParams &P, const RT64_MATERIAL &m, f3 position) {    // Fog.hlsli:5-18
     f4 clip = mul4(P.viewProj, mk4(position.x, position.y, position.z, 1.0f));

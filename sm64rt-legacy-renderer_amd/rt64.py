@@ -26,7 +26,7 @@ ACCEL_NODES, ACCEL_TRIANGLES, ACCEL_SORTED_INDEX, ACCEL_MORTON, ACCEL_HEADER = r
  IMAGE_INSTANCE_ID, IMAGE_DIRECT_LIGHT_RAW, IMAGE_DIRECT_LIGHT_FILTERED, IMAGE_INDIRECT_LIGHT_RAW,
  IMAGE_INDIRECT_LIGHT_FILTERED, IMAGE_REFLECTION, IMAGE_REFRACTION, IMAGE_TRANSPARENT, IMAGE_FLOW,
  IMAGE_REACTIVE_MASK, IMAGE_LOCK_MASK, IMAGE_DEPTH, IMAGE_OUTPUT_RGBA32F, IMAGE_PRIMARY_HIT,
- IMAGE_VIEW_DIRECTION, IMAGE_FIRST_INSTANCE_ID) = range(21)
+ IMAGE_VIEW_DIRECTION, IMAGE_FIRST_INSTANCE_ID, IMAGE_BACKGROUND) = range(22)
 
 # image id -> (numpy dtype string, channels)
 IMAGE_FORMATS = {
@@ -36,7 +36,7 @@ IMAGE_FORMATS = {
     IMAGE_INDIRECT_LIGHT_FILTERED: ("f4", 4), IMAGE_REFLECTION: ("f4", 4), IMAGE_REFRACTION: ("f4", 4),
     IMAGE_TRANSPARENT: ("f4", 4), IMAGE_FLOW: ("f4", 2), IMAGE_REACTIVE_MASK: ("f4", 1), IMAGE_LOCK_MASK: ("f4", 1),
     IMAGE_DEPTH: ("f4", 1), IMAGE_OUTPUT_RGBA32F: ("f4", 4), IMAGE_PRIMARY_HIT: ("u4", 4),
-    IMAGE_VIEW_DIRECTION: ("f4", 4), IMAGE_FIRST_INSTANCE_ID: ("i4", 1),
+    IMAGE_VIEW_DIRECTION: ("f4", 4), IMAGE_FIRST_INSTANCE_ID: ("i4", 1), IMAGE_BACKGROUND: ("u1", 4),
 }
 
 

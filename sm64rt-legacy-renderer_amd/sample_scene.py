@@ -57,6 +57,8 @@ class InstanceData:
     specular: Optional[int]
     material: rt64.MATERIAL
     flags: int = 0
+    scissor: Optional[tuple] = None  # RT64_RECT (x, y, w, h), origin bottom-left; None = unset
+    viewport: Optional[tuple] = None
 
 
 @dataclass
@@ -312,6 +314,10 @@ class Rt64Scene:
         d.shader = self.shader
         d.material = inst.material
         d.flags = inst.flags
+        if inst.scissor:
+            d.scissorRect = rt64.RECT(*[int(v) for v in inst.scissor])
+        if inst.viewport:
+            d.viewportRect = rt64.RECT(*[int(v) for v in inst.viewport])
         self.lib.SetInstanceDescription(self.instances[k], d)
 
     def set_view_description(self, di_samples=0, gi_samples=0, max_lights=12, denoiser=False, resolution_scale=1.0, motion_blur=0.0):
@@ -338,7 +344,9 @@ class Rt64Scene:
         self.lib.GetDeviceStats(self.device, C.byref(st))
         rows, width = (st.rowsRendered if st.rowsRendered else st.tileY1 - st.tileY0), st.width
         if (st.screenWidth, st.screenHeight) != (st.width, st.height):       # resolutionScale: render size != back-buffer size, whole frame
-            rows, width = (st.screenHeight, st.screenWidth) if image == rt64.IMAGE_FINAL_RGBA8 else (st.height, st.width)
+            rows, width = (st.screenHeight, st.screenWidth) if image in (rt64.IMAGE_FINAL_RGBA8, rt64.IMAGE_BACKGROUND) else (st.height, st.width)
+        if image == rt64.IMAGE_BACKGROUND:
+            rows, width = st.screenHeight, st.screenWidth                      # always the whole screen, on every device
         out = np.empty((rows, width, ch), dtype=dt)
         n = self.lib.ReadbackDevice(self.device, image, out.ctypes.data, out.nbytes)
         if n != out.nbytes:

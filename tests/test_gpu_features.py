@@ -24,7 +24,7 @@ def _variant(sample_data, fn):
     return d
 
 
-def _render_pair(rt64_lib, data, frames=1, view_desc=None, options=None, per_frame=None):
+def _render_pair(rt64_lib, data, frames=1, view_desc=None, options=None, per_frame=None, extra_images=(), images=None):
     from sm64rt_legacy_renderer_amd import rt64, sample_scene
     from oracle import oracle_py
     s = sample_scene.Rt64Scene(rt64_lib, data, W, H, hip_device=0)
@@ -46,8 +46,9 @@ def _render_pair(rt64_lib, data, frames=1, view_desc=None, options=None, per_fra
                 per_frame(f, s, o)
             s.draw()
             ref = o.render(W, H, **kw)
-        got = {k: s.readback(getattr(rt64, "IMAGE_" + k)) for k in ("OUTPUT_RGBA32F", "FINAL_RGBA8", "INSTANCE_ID", "PRIMARY_HIT", "DIFFUSE",
-                                                                    "DIRECT_LIGHT_RAW", "INDIRECT_LIGHT_RAW", "INDIRECT_LIGHT_FILTERED", "REFLECTION", "REFRACTION", "TRANSPARENT")}
+        names = images or (("OUTPUT_RGBA32F", "FINAL_RGBA8", "INSTANCE_ID", "PRIMARY_HIT", "DIFFUSE", "DIRECT_LIGHT_RAW", "INDIRECT_LIGHT_RAW",
+                            "INDIRECT_LIGHT_FILTERED", "REFLECTION", "REFRACTION", "TRANSPARENT") + tuple(extra_images))
+        got = {k: s.readback(getattr(rt64, "IMAGE_" + k)) for k in names}
         st = s.stats()
         return got, ref, st
     finally:
