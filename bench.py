@@ -59,6 +59,7 @@ def parse_args():
     ap.add_argument("--always-rebuild", action="store_true", help="upload the frame tables and rebuild the TLAS every frame (the reference's behaviour)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU-staged rehearsal of the N>1 path")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a 1-GPU box: every rank renders on device 0")
+    ap.add_argument("--force-gather", action="store_true", help="rehearsal: run the N > 1 code path (enqueued frames + pipelined RCCL gather) with a world of 1")
     ap.add_argument("--cpu-baseline-height", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = all)")
     return ap.parse_args()
 
@@ -82,12 +83,17 @@ def main():
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    G = N > 1 or args.force_gather           # the gather path (always on for N > 1)
     dist = None
-    if N > 1:
+    if G:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            if N == 1:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+                dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend="gloo")
     comm_device = "cuda" if args.backend == "nccl" else "cpu" 
@@ -127,30 +133,46 @@ def main():
     if args.gi_samples or args.denoiser:
         scene.set_view_description(gi_samples=args.gi_samples, denoiser=args.denoiser)
 
-    max_rows = tiles.max_owned_rows(H, N)
-    local = torch.zeros(max_rows * W * 4, dtype=torch.uint8, device="cuda")
+    # N > 1: frames are ENQUEUED (sync_present = 0) on the renderer's stream, the strips are copied into a gather slot on the same
+    # stream, and the RCCL gather of frame k runs beside the rendering of frame k+1 (two slots).  Everything is complete at the
+    # closing barrier + synchronize, which is inside the timed region.
+    pipelined = G and args.backend == "nccl"
+    ext_stream = torch.cuda.ExternalStream(lib.GetDeviceStream(scene.device)) if pipelined else None
+    gatherer = tiles.FrameGatherer(H, W, rank, N, comm_device, stream=ext_stream) if G else None
+    staging = torch.zeros(tiles.strips_per_rank(H, N) * 16 * W * 4, dtype=torch.uint8, device="cuda") if (G and not pipelined) else None
+    local = torch.zeros(max(tiles.max_owned_rows(H, N), 1) * W * 4, dtype=torch.uint8, device="cuda")
     my_bytes = tiles.owned_rows(H, rank, N) * W * 4
 
-    def fetch():
-        n = lib.CopyDeviceImage(scene.device, rt64.IMAGE_FINAL_RGBA8, local.data_ptr(), local.numel())
+    def fetch(dst):
+        n = lib.CopyDeviceImage(scene.device, rt64.IMAGE_FINAL_RGBA8, dst.data_ptr(), dst.numel())
         if n != my_bytes:
             raise RuntimeError("RT64_CopyDeviceImage returned %d, expected %d: %s" % (n, my_bytes, lib.last_error()))
 
     frame_no = [0]
+    step_no = [0]
 
     def step():
         if anim is not None:
             frame_no[0] += 1
             scene.set_mesh(scene.meshes[0], anim[frame_no[0] % len(anim)], data.meshes[0].indices)
-        scene.draw()                 # returns after the frame is complete in the device's back buffer (HBM)
-        if N == 1:
-            return None              # single GPU: the back buffer IS the composited frame, nothing to gather
-        fetch()
-        return tiles.gather_frame(local if comm_device == "cuda" else local.cpu(), H, W, rank, N)
+        if not G:
+            scene.draw()             # returns after the frame is complete in the device's back buffer (HBM): nothing to gather
+            return None
+        slot = step_no[0] % 2
+        step_no[0] += 1
+        gatherer.wait(slot)          # the gather that last read this slot (two frames ago) is ordered before the refill
+        scene.draw()
+        if pipelined:
+            fetch(gatherer.local(slot))
+        else:                        # gloo rehearsal: CPU-staged
+            fetch(staging)
+            gatherer.local(slot).copy_(staging)
+        gatherer.submit(slot)
+        return slot
 
     def barrier():
         torch.cuda.synchronize()
-        if N > 1:
+        if G:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -175,20 +197,37 @@ def main():
         dist.all_reduce(t)
         rays_total = int(t.item())
 
+    if pipelined:
+        scene.option("sync_present", 0)      # RT64_DrawDevice enqueues; ordering is on the renderer's stream from here on
     for _ in range(args.warmup):
         step()
     acc = dict(trace=0.0, shade=0.0, direct=0.0, indirect=0.0, compose=0.0, build=0.0, total=0.0, denoise=0.0, reflect=0.0)
-    barrier()
-    t0 = time.perf_counter()
-    frame = None
-    for _ in range(args.steps):
-        frame = step()
+
+    def add_stats():
         s = scene.stats()
         acc["trace"] += s.msPrimaryTrace; acc["shade"] += s.msPrimaryShade; acc["direct"] += s.msDirect
         acc["indirect"] += s.msIndirect; acc["compose"] += s.msComposePost; acc["build"] += s.msBuild; acc["total"] += s.msTotal
         acc["denoise"] += s.msDenoise; acc["reflect"] += s.msReflectRefract
     barrier()
+    t0 = time.perf_counter()
+    last_slot = None
+    for _ in range(args.steps):
+        last_slot = step()
+        if not G:
+            add_stats()              # HIP-event timings of the frame that just finished (the frame is synchronous at N = 1)
+    enqueue_ms = (time.perf_counter() - t0) * 1e3 / args.steps      # host time per step before the closing barrier (= frame time when frames are synchronous)
+    barrier()
     elapsed = time.perf_counter() - t0
+    stat_frames = args.steps
+    gathered_checksum = None
+    if G and rank == 0:              # the frame assembled on rank 0 by the gather of the last timed step
+        gathered_checksum = int(gatherer.frame(last_slot).to(torch.int64).sum().item())
+    if G:                            # per-kernel timings of this rank's strips from a few untimed frames (reading them synchronises)
+        stat_frames = 10
+        for _ in range(stat_frames):
+            step()
+            add_stats()
+        barrier()
     if N > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -197,7 +236,7 @@ def main():
     value = rays_total / (elapsed / args.steps) / 1e6
 
     if rank == 0:
-        K = float(args.steps)
+        K = float(stat_frames)
         kms = {k: v / K for k, v in acc.items()}
         my_pixels = tiles.owned_rows(H, 0, N) * W
         kernels = {
@@ -243,17 +282,21 @@ def main():
                 "partition": "interleaved 16-row strips x%d + RCCL gather of RGBA8" % N if N > 1 else "single GPU"},
             "roofline": roofline,
         }
+        if G:
+            result["pipeline"] = {"frames": "enqueued (sync_present=0), 2 gather slots" if pipelined else "synchronous, CPU-staged gather (rehearsal)",
+                                  "host_ms_per_step": round(enqueue_ms, 5)}
         if N == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(data, W, H, args.cpu_baseline_height)
-        if N == 1:
-            fetch()
+        if not G:
+            fetch(local)
             frame = local[:H * W * 4]
-        if frame is not None:
             result["frame_checksum"] = int(frame.to(torch.int64).sum().item())
+        else:
+            result["frame_checksum"] = gathered_checksum
         print(json.dumps(result), flush=True)
 
     scene.close()
-    if N > 1:
+    if G:
         dist.barrier()
         dist.destroy_process_group()
 

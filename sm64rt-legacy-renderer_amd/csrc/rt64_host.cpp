@@ -136,6 +136,7 @@ static GpuCombiner decode_combiner(uint32_t shaderId) {
 
 struct Options {
     bool countTraversal = false, profilePasses = true, syncPresent = true, alwaysRebuild = false, leanFrames = true;
+    bool spinPresent = true;      // RT64_DrawDevice waits for the frame by polling the stream (0: blocking hipStreamSynchronize)
     int bounceRefill = -1;        // bounce-ray traversal with wave-ballot refill: 1 on, 0 off, -1 auto (on when the scene has >= 64 Ki triangles)
     int denoiserMode = 1;          // 0 = reference 5x Gaussian, 1 = SVGF
     int maxReflections = 2;        // rt64_view.cpp:60 (inspector-only knob in the reference)
@@ -149,13 +150,17 @@ struct Device {
     int stripRank = 0, stripCount = 1;
     std::vector<Scene *> scenes;
     Options opt;
-    RT64_FRAME_STATS stats = {};
+    RT64_FRAME_STATS stats = {}; bool statsPending = false, statsHaveView = false;
+    double hostUpdateUs = 0.0, hostRenderUs = 0.0, hostStageUs[16] = {}, hostEventUs = 0.0; unsigned long long hostFrames = 0;      // host-side cost of View::update / View::render (RT64_HOST_TIMING=1 prints them)
+    void finishStats();
     DevArray<uint32_t> spillStack;
     DevArray<unsigned long long> counters;
     DevArray<uint8_t> blueNoise;
     uint8_t *pinned = nullptr; size_t pinnedBytes = 0;
     enum { EV_BEGIN, EV_BUILD, EV_PRIMARY_TRACE, EV_PRIMARY, EV_DIRECT, EV_INDIRECT, EV_REFL, EV_DENOISE, EV_END, EV_COUNT };
     hipEvent_t events[EV_COUNT] = {};
+    // A mark with no GPU work since the previous mark reuses that mark's event: every hipEventRecord is a barrier packet (~4 us of GPU idle).
+    int eventAlias[EV_COUNT] = {}; int lastMark = EV_BEGIN; bool workSinceMark = false;
 
     Device(int w, int h, int dev);
     ~Device();
@@ -321,6 +326,8 @@ Device::Device(int w, int h, int dev) {
 Device::~Device() {
     hipSetDevice(hipDevice);
     hipStreamSynchronize(stream);
+    if (getenv("RT64_HOST_TIMING") && hostFrames) fprintf(stderr, "RT64 host timing: %llu frames, View::update %.1f us, View::render %.1f us per frame\n", hostFrames, hostUpdateUs / (double)hostFrames, hostRenderUs / (double)hostFrames);
+    if (getenv("RT64_HOST_TIMING") && hostFrames) { fprintf(stderr, "  launch host us by stage (up to each event mark):"); for (int i = 0; i < 16; i++) if (hostStageUs[i] > 0.0) fprintf(stderr, " [%d] %.1f", i, hostStageUs[i] / (double)hostFrames); fprintf(stderr, "  event records %.1f\n", hostEventUs / (double)hostFrames); }
     auto scenesCopy = scenes;
     for (Scene *s : scenesCopy) delete s;                 // rt64_device.cpp:97-100
     for (auto &ev : events) if (ev) hipEventDestroy(ev);
@@ -587,6 +594,7 @@ void View::drawRasterList(RasterList &rl, uint8_t *target) {
     if (!rl.ready || rl.triTotal == 0) return;
     Device *dev = scene->device;
     HIP_CHECK(launch_raster_draw(rl.table.ptr, rl.tris.ptr, rl.triTotal, dTextures.ptr, target, rl.w, rl.y0, rl.y1, rl.bounds, dev->stripRank, dev->stripCount, dev->stream));
+    dev->workSinceMark = true;
 }
 
 void View::update() {                          // View::update, rt64_view.cpp:1053-1178
@@ -677,6 +685,7 @@ void View::update() {                          // View::update, rt64_view.cpp:10
         if (instBytes) HIP_CHECK(hipMemcpyAsync(dInstances.ptr, hInst, instBytes, hipMemcpyHostToDevice, dev->stream));
         if (texBytes) HIP_CHECK(hipMemcpyAsync(dTextures.ptr, hTex, texBytes, hipMemcpyHostToDevice, dev->stream));
         if (lightBytes) HIP_CHECK(hipMemcpyAsync(dLights.ptr, hLights, lightBytes, hipMemcpyHostToDevice, dev->stream));
+        if (!dev->opt.syncPresent) HIP_CHECK(hipStreamSynchronize(dev->stream));      // frames are enqueued without a host wait: the staging buffer must be drained before its next use
         // TLAS: full rebuild (rt64_view.cpp:412-452 rebuilds every frame, updateOnly = false).
         if (nInst) {
             const uint32_t n = (uint32_t)nInst;
@@ -688,6 +697,7 @@ void View::update() {                          // View::update, rt64_view.cpp:10
             HIP_CHECK(lbvh_launch(a, dev->stream));
         }
         uploadedTables.assign(stage, stage + tableBytes);
+        dev->workSinceMark = true;
     }
     // Raster lists (background first, then foreground; rt64_view.cpp:1138-1147).  They are a handful of HUD instances: uploaded every frame.
     {
@@ -784,7 +794,18 @@ void View::render() {                          // View::render, rt64_view.cpp:11
     Device *dev = scene->device;
     hipStream_t s = dev->stream;
     const bool prof = dev->opt.profilePasses;
-    auto mark = [&](int ev) { if (prof) HIP_CHECK(hipEventRecord(dev->events[ev], s)); };
+    static const bool hostTiming = getenv("RT64_HOST_TIMING") != nullptr;
+    auto hostPrev = std::chrono::steady_clock::now();
+    auto mark = [&](int ev) {
+        if (hostTiming) { auto now = std::chrono::steady_clock::now(); dev->hostStageUs[ev] += std::chrono::duration<double, std::micro>(now - hostPrev).count(); hostPrev = now; }
+        if (prof) {
+            if (dev->workSinceMark) { HIP_CHECK(hipEventRecord(dev->events[ev], s)); dev->eventAlias[ev] = ev; }
+            else dev->eventAlias[ev] = dev->eventAlias[dev->lastMark];
+            dev->lastMark = ev; dev->workSinceMark = false;
+        }
+        if (hostTiming) { auto now = std::chrono::steady_clock::now(); dev->hostEventUs += std::chrono::duration<double, std::micro>(now - hostPrev).count(); hostPrev = now; }
+    };
+    auto L = [&](hipError_t e) { HIP_CHECK(e); dev->workSinceMark = true; };       // a launch between two marks
     if (!perspectiveSet) throw std::runtime_error("RT64_DrawDevice: RT64_SetViewPerspective was never called (fov must be > 0).");
     FrameParams P;
     fillParams(P);
@@ -806,45 +827,45 @@ void View::render() {                          // View::render, rt64_view.cpp:11
             img.bounceRecords = static_cast<uint4 *>(a); bounceSamples = giSamples;
         }
         const bool klist = anyNonOpaque;
-        HIP_CHECK(launch_primary_trace(P, img, hitInstance.ptr, klist, s));
+        L(launch_primary_trace(P, img, hitInstance.ptr, klist, s));
         mark(Device::EV_PRIMARY_TRACE);
         // Lean frame: nothing downstream reads the view direction, the reflection / refraction / transparent accumulators,
         // motion vectors, upscaler masks or a GI buffer -> skip those stores (and the matching loads in Compose).
         const bool lean = dev->opt.leanFrames && !anyNonOpaque && !anyReflection && !anyRefraction && !anyFog && giSamples == 0 && motionBlurStrength <= 0.0f;
         leanFrame = lean; lastParams = P; lastCur = cur;
-        HIP_CHECK(launch_primary_shade(P, img, hitInstance.ptr, cur, anyNonOpaque, lean, s));
+        L(launch_primary_shade(P, img, hitInstance.ptr, cur, anyNonOpaque, lean, s));
         mark(Device::EV_PRIMARY);
         // DirectRayGen also writes the "filtered" copy: DI denoising is compiled out in the reference (rt64_view.cpp:1438-1463),
         // so rtFilteredDirectLight[1] is always a plain copy of the raw accumulation.
-        HIP_CHECK(launch_direct(P, img, cur, lean, s));
+        L(launch_direct(P, img, cur, lean, s));
         mark(Device::EV_DIRECT);
         const bool denoiseGI = denoiserEnabled && giSamples > 0;
         if (lean) {}                                                                  // constant ambient folded into Compose
-        else if (giSamples == 0) HIP_CHECK(launch_indirect_constant(P, img, cur, s));  // IndirectRayGen.hlsl:135: constant ambient
+        else if (giSamples == 0) L(launch_indirect_constant(P, img, cur, s));  // IndirectRayGen.hlsl:135: constant ambient
         else {
             bool refill = dev->opt.bounceRefill == 1;
             if (dev->opt.bounceRefill < 0) { size_t tri = 0; for (auto &ri : rtInstances) tri += ri.instance->mesh->blasCount; refill = tri >= 65536; }
-            HIP_CHECK(launch_indirect(P, img, cur, !denoiseGI, klist, refill, s));
+            L(launch_indirect(P, img, cur, !denoiseGI, klist, refill, s));
         }
         mark(Device::EV_INDIRECT);
         // Refraction / reflection touch only pixels whose primary hit has a refraction / reflection factor (alpha > EPSILON).
-        if (anyRefraction) HIP_CHECK(launch_refraction(P, img, klist, s));
-        if (anyReflection) for (int r = 0; r < dev->opt.maxReflections; r++) HIP_CHECK(launch_reflection(P, img, klist, s));
+        if (anyRefraction) L(launch_refraction(P, img, klist, s));
+        if (anyReflection) for (int r = 0; r < dev->opt.maxReflections; r++) L(launch_reflection(P, img, klist, s));
         mark(Device::EV_REFL);
-        if (denoiseGI && dev->opt.denoiserMode == 1) HIP_CHECK(launch_svgf(img, cur, imgW, imgH, s));
+        if (denoiseGI && dev->opt.denoiserMode == 1) L(launch_svgf(img, cur, imgW, imgH, s));
         else if (denoiseGI) {
-            HIP_CHECK(hipMemcpyAsync(img.filteredIndirect[0], img.indirectLight[cur], n * 8, hipMemcpyDeviceToDevice, s));
+            L(hipMemcpyAsync(img.filteredIndirect[0], img.indirectLight[cur], n * 8, hipMemcpyDeviceToDevice, s));
             for (int k = 0; k < 5; k++)            // rt64_view.cpp:1512-1530
-                HIP_CHECK(launch_gaussian(img.filteredIndirect[k % 2], img.filteredIndirect[(k % 2) ^ 1], imgW, imgH, 0, imgH, s));
+                L(launch_gaussian(img.filteredIndirect[k % 2], img.filteredIndirect[(k % 2) ^ 1], imgW, imgH, 0, imgH, s));
         }
         mark(Device::EV_DENOISE);
-        HIP_CHECK(launch_compose_post(P, img, cur, lean, s));
-        if (P.separatePost) HIP_CHECK(launch_post_process(P, img, s));
+        L(launch_compose_post(P, img, cur, lean, s));
+        if (P.separatePost) L(launch_post_process(P, img, s));
     }
     else {
         leanFrame = false;
         mark(Device::EV_PRIMARY_TRACE); mark(Device::EV_PRIMARY); mark(Device::EV_DIRECT); mark(Device::EV_INDIRECT); mark(Device::EV_REFL); mark(Device::EV_DENOISE);
-        HIP_CHECK(launch_clear_final(P, img, s));
+        L(launch_clear_final(P, img, s));
         drawRasterList(rasterBgScreen, img.final);           // nothing ray traced covers the background instances (rt64_view.cpp:1292-1296)
     }
     drawRasterList(rasterFgScreen, img.final);               // foreground instances over the finished frame (rt64_view.cpp:1657-1661)
@@ -875,11 +896,24 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
     if (tileY1 > height) tileY1 = height;
     if (tileY0 >= tileY1) { tileY0 = 0; tileY1 = height; }
     if (opt.countTraversal) HIP_CHECK(hipMemsetAsync(counters.ptr, 0, counters.bytes(), stream));
-    if (opt.profilePasses) HIP_CHECK(hipEventRecord(events[EV_BEGIN], stream));
+    if (opt.profilePasses) { HIP_CHECK(hipEventRecord(events[EV_BEGIN], stream)); eventAlias[EV_BEGIN] = EV_BEGIN; lastMark = EV_BEGIN; workSinceMark = false; }
+    auto tu0 = std::chrono::steady_clock::now();
     for (Scene *sc : scenes) for (View *v : sc->views) v->update();
+    auto tu1 = std::chrono::steady_clock::now();
     for (Scene *sc : scenes) for (View *v : sc->views) v->render();
-    if (opt.profilePasses) HIP_CHECK(hipEventRecord(events[EV_END], stream));
-    HIP_CHECK(hipStreamSynchronize(stream));                      // postRender: Present + waitForGPU (:1006-1025)
+    auto tu2 = std::chrono::steady_clock::now();
+    hostUpdateUs += std::chrono::duration<double, std::micro>(tu1 - tu0).count(); hostRenderUs += std::chrono::duration<double, std::micro>(tu2 - tu1).count(); hostFrames++;
+    if (opt.profilePasses) { HIP_CHECK(hipEventRecord(events[EV_END], stream)); eventAlias[EV_END] = EV_END; }
+    // postRender: Present + waitForGPU (:1006-1025).  Option sync_present = 0 turns RT64_DrawDevice into "enqueue the frame": the
+    // host returns at once and orders its own work behind the frame on RT64_GetDeviceStream (pipelined multi-GPU gather in bench.py).
+    if (opt.syncPresent) {
+        if (opt.spinPresent) {       // poll instead of sleeping on the completion signal: the render thread is back ~10 us sooner
+            hipError_t q;
+            while ((q = hipStreamQuery(stream)) == hipErrorNotReady) { __builtin_ia32_pause(); }
+            HIP_CHECK(q);
+        }
+        else HIP_CHECK(hipStreamSynchronize(stream));
+    }
     auto t1 = std::chrono::steady_clock::now();
 
     RT64_FRAME_STATS st = {};
@@ -899,8 +933,19 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
         st.triangleCount = tri; st.blasNodeBytes = nodeBytes; st.blasTriangleBytes = triBytes;
         st.tlasNodeBytes = (unsigned)(std::max<size_t>(v->rtInstances.size() ? v->rtInstances.size() - 1 : 0, 1) * sizeof(GpuNode));
     }
+    stats = st; statsHaveView = haveView; statsPending = true;
+    if (opt.syncPresent) finishStats();
+}
+
+// Timings and counters of the last frame: they need the frame to have finished on the GPU (lazy when sync_present = 0).
+void Device::finishStats() {
+    if (!statsPending) return;
+    statsPending = false;
+    RT64_FRAME_STATS st = stats;
+    const bool haveView = statsHaveView;
+    if (!opt.syncPresent) HIP_CHECK(hipStreamSynchronize(stream));
     if (opt.profilePasses && haveView) {
-        auto ms = [&](int a, int b) { float v = 0.0f; hipEventElapsedTime(&v, events[a], events[b]); return v; };
+        auto ms = [&](int a, int b) { float v = 0.0f; if (eventAlias[a] != eventAlias[b]) hipEventElapsedTime(&v, events[eventAlias[a]], events[eventAlias[b]]); return v; };
         st.msTotal = ms(EV_BEGIN, EV_END); st.msBuild = ms(EV_BEGIN, EV_BUILD); st.msPrimary = ms(EV_BUILD, EV_PRIMARY);
         st.msPrimaryTrace = ms(EV_BUILD, EV_PRIMARY_TRACE); st.msPrimaryShade = ms(EV_PRIMARY_TRACE, EV_PRIMARY);
         st.msDirect = ms(EV_PRIMARY, EV_DIRECT); st.msIndirect = ms(EV_DIRECT, EV_INDIRECT); st.msReflectRefract = ms(EV_INDIRECT, EV_REFL);
@@ -1011,7 +1056,7 @@ static size_t readback(Device *dev, int image, void *dst, size_t dstBytes, bool 
     if (toDevice) {
         if (info.kind != 0 || image == RT64_IMAGE_PRIMARY_HIT) throw std::runtime_error("RT64_CopyDeviceImage: only images stored in their API element type can be copied device-to-device.");
         gather(dst, hipMemcpyDeviceToDevice, base, (size_t)info.srcBytes);
-        HIP_CHECK(hipStreamSynchronize(dev->stream));
+        if (dev->opt.syncPresent) HIP_CHECK(hipStreamSynchronize(dev->stream));      // sync_present = 0: the copy is ordered on RT64_GetDeviceStream like the frame
         return need;
     }
     if (info.kind == 0 && image != RT64_IMAGE_PRIMARY_HIT) { gather(dst, hipMemcpyDeviceToHost, base, (size_t)info.srcBytes); HIP_CHECK(hipStreamSynchronize(dev->stream)); return need; }
@@ -1083,6 +1128,7 @@ RT64_EXPORT int RT64_GetDeviceStats(RT64_DEVICE *device, RT64_FRAME_STATS *stats
     Device *d = reinterpret_cast<Device *>(device);
     if (!d || !stats || stats->structSize < 5 * sizeof(unsigned int)) return 0;
     // The struct only ever grows at its end: a caller built against an older header passes its own (smaller) size and gets that prefix.
+    d->use(); d->finishStats();
     RT64_FRAME_STATS full = d->stats; full.structSize = sizeof(RT64_FRAME_STATS);
     if (full.width == 0) { full.width = full.screenWidth = (unsigned)d->width; full.height = full.screenHeight = (unsigned)d->height; full.tileY0 = (unsigned)d->tileY0; full.tileY1 = (unsigned)d->tileY1; }
     const unsigned int n = stats->structSize < sizeof(RT64_FRAME_STATS) ? stats->structSize : (unsigned int)sizeof(RT64_FRAME_STATS);
@@ -1097,6 +1143,7 @@ RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, doubl
     else if (k == "sync_present") d->opt.syncPresent = value != 0.0;
     else if (k == "denoiser_mode") d->opt.denoiserMode = (int)value;
     else if (k == "bounce_refill") d->opt.bounceRefill = (int)value;
+    else if (k == "spin_present") d->opt.spinPresent = value != 0.0;
     else if (k == "lean_frames") d->opt.leanFrames = value != 0.0;                // 0: always write every image of the reference's G-buffer
     else if (k == "always_rebuild") d->opt.alwaysRebuild = value != 0.0;          // upload tables + rebuild the TLAS every frame like the reference
     else if (k == "max_reflections") d->opt.maxReflections = std::max(0, (int)value);

@@ -294,6 +294,7 @@ class Rt64Scene:
             self.set_mesh(h, m.vertices, m.indices)
             self.meshes.append(h)
         self.instances = []
+        self._desc_cache = {}
         for inst in data.instances:
             h = lib.CreateInstance(self.scene)
             self.instances.append(h)
@@ -304,7 +305,7 @@ class Rt64Scene:
         v = np.ascontiguousarray(vertices); i = np.ascontiguousarray(indices, dtype=np.uint32)
         self.lib.SetMesh(handle, v.ctypes.data, len(v), v.dtype.itemsize, i.ctypes.data, len(i))
 
-    def set_instance(self, k, inst: InstanceData):
+    def _instance_desc(self, inst: InstanceData):
         d = rt64.INSTANCE_DESC()
         d.mesh = self.meshes[inst.mesh]
         d.transform = rt64.MATRIX4.from_rows(inst.transform); d.previousTransform = rt64.MATRIX4.from_rows(inst.previous_transform)
@@ -318,7 +319,11 @@ class Rt64Scene:
             d.scissorRect = rt64.RECT(*[int(v) for v in inst.scissor])
         if inst.viewport:
             d.viewportRect = rt64.RECT(*[int(v) for v in inst.viewport])
-        self.lib.SetInstanceDescription(self.instances[k], d)
+        return d
+
+    def set_instance(self, k, inst: InstanceData):
+        self._desc_cache.pop(k, None)
+        self.lib.SetInstanceDescription(self.instances[k], self._instance_desc(inst))
 
     def set_view_description(self, di_samples=0, gi_samples=0, max_lights=12, denoiser=False, resolution_scale=1.0, motion_blur=0.0):
         v = rt64.VIEW_DESC()
@@ -329,12 +334,20 @@ class Rt64Scene:
         self.lib.SetViewDescription(self.view, v)
 
     def draw(self, can_reproject=True):
-        """One WM_PAINT of main.cpp:97-134."""
+        """One WM_PAINT of main.cpp:97-134: SetViewPerspective, SetInstanceDescription of the sphere, SetSceneLights, DrawDevice.
+        The ctypes descriptors are rebuilt only when the scene description object they came from changed (host-side overhead
+        of the harness, not of the library)."""
         d = self.data
-        self.lib.SetViewPerspective(self.view, rt64.MATRIX4.from_rows(d.view), d.fov, d.near, d.far, can_reproject)
-        k = next((i for i, inst in enumerate(d.instances) if inst.name == "sphere"), None)
-        if k is not None:
-            self.set_instance(k, d.instances[k])                                                       # main.cpp:129
+        if getattr(self, "_view_src", None) is not d.view:
+            self._view_src, self._view_m = d.view, rt64.MATRIX4.from_rows(d.view)
+        self.lib.SetViewPerspective(self.view, self._view_m, d.fov, d.near, d.far, can_reproject)
+        k = getattr(self, "_sphere_k", -2)
+        if k == -2:
+            k = self._sphere_k = next((i for i, inst in enumerate(d.instances) if inst.name == "sphere"), -1)
+        if k >= 0:
+            if self._desc_cache.get(k, (None,))[0] is not d.instances[k]:
+                self._desc_cache[k] = (d.instances[k], self._instance_desc(d.instances[k]))
+            self.lib.SetInstanceDescription(self.instances[k], self._desc_cache[k][1])                # main.cpp:129
         self.lib.SetSceneLights(self.scene, self._lights, len(d.lights))
         self.lib.DrawDevice(self.device, 1, 1000.0 / 60.0)
 

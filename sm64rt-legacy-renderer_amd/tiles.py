@@ -80,3 +80,82 @@ def gather_frame(local, height, width, rank, count, group=None, fast=True):
         return assemble_fast(bucket, height, width, count) if fast else assemble(bucket, height, width, count)
     dist.gather(local, None, dst=0, group=group)
     return None
+
+
+def strips_per_rank(height, count):
+    """Largest number of 16-row strips one rank owns."""
+    full = (height + STRIP - 1) // STRIP
+    return (full + count - 1) // count
+
+
+class FrameGatherer:
+    """Pipelined gather of the composited framebuffer: rank r fills `local(slot)` with its packed strips, `submit(slot)` starts ONE
+    asynchronous collective (dist.gather to rank 0 == RCCL send/recv over xGMI) and, on rank 0, one strided copy that de-interleaves
+    the strips into the frame; `wait(slot)` orders the caller's stream behind both before the slot is reused.  With two slots the
+    gather of frame k overlaps the rendering of frame k+1.
+
+    Layout: every rank's buffer is [K][16 rows][W][4] with K = strips_per_rank (unused strips stay empty), so the bucket on rank 0 is
+    [N][K][S] and the frame, padded to N*K strips, is bucket.transpose(0, 1): strip k of rank r is frame strip k*N + r.
+    `stream` (a torch.cuda.Stream, e.g. the renderer's stream wrapped in torch.cuda.ExternalStream) is the stream the local buffer
+    is produced on; None = the current stream / CPU tensors (gloo rehearsal)."""
+
+    def __init__(self, height, width, rank, count, device, group=None, slots=2, stream=None):
+        import torch
+        self.height, self.width, self.rank, self.count, self.group, self.stream = height, width, rank, count, group, stream
+        self.k = strips_per_rank(height, count)
+        self.strip_elems = STRIP * width * 4
+        n = self.k * self.strip_elems
+        self.locals = [torch.zeros(n, dtype=torch.uint8, device=device) for _ in range(slots)]
+        self.work = [None] * slots
+        self.frames = [None] * slots
+        if rank == 0:
+            self.buckets = [torch.empty((count, n), dtype=torch.uint8, device=device) for _ in range(slots)]
+            self.padded = [torch.empty((self.k * count, self.strip_elems), dtype=torch.uint8, device=device) for _ in range(slots)]
+        self.side = torch.cuda.Stream(device=device) if (stream is not None) else None      # assembly runs beside the renderer's stream
+
+    def local(self, slot):
+        return self.locals[slot]
+
+    def owned_bytes(self):
+        return owned_rows(self.height, self.rank, self.count) * self.width * 4
+
+    def submit(self, slot):
+        import torch
+        import torch.distributed as dist
+        ctx = torch.cuda.stream(self.stream) if self.stream is not None else _Null()
+        with ctx:                                   # the collective is ordered behind whatever produced locals[slot] on this stream
+            if self.rank == 0:
+                self.work[slot] = dist.gather(self.locals[slot], list(self.buckets[slot].unbind(0)), dst=0, group=self.group, async_op=True)
+            else:
+                self.work[slot] = dist.gather(self.locals[slot], None, dst=0, group=self.group, async_op=True)
+        if self.rank == 0:
+            ctx = torch.cuda.stream(self.side) if self.side is not None else _Null()
+            with ctx:
+                self.work[slot].wait()              # stream-level wait on CUDA tensors, blocking on CPU tensors
+                self.padded[slot].view(self.k, self.count, self.strip_elems).copy_(self.buckets[slot].view(self.count, self.k, self.strip_elems).transpose(0, 1))
+                self.frames[slot] = self.padded[slot].view(-1)[:self.height * self.width * 4].view(self.height, self.width, 4)
+
+    def wait(self, slot):
+        """Before refilling locals[slot]: the collective that reads it (and rank 0's assembly of it) must have run."""
+        import torch
+        w = self.work[slot]
+        if w is None:
+            return
+        ctx = torch.cuda.stream(self.stream) if self.stream is not None else _Null()
+        with ctx:
+            w.wait()
+            if self.side is not None:
+                torch.cuda.current_stream().wait_stream(self.side)
+        self.work[slot] = None
+
+    def frame(self, slot):
+        """Rank 0: the assembled frame of the last submit(slot) (valid after wait(slot) / a device synchronise)."""
+        return self.frames[slot]
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

@@ -56,13 +56,26 @@ def _worker(rank, world, init_file, h, w, out_file):
             assert np.array_equal(full.numpy(), frame)
         else:
             assert full is None
+    # pipelined gatherer (bench.py's N > 1 path): two slots, frames that differ per step, submit / wait in flight order
+    g = tiles.FrameGatherer(h, w, rank, world, "cpu")
+    assert g.local(0).numel() == tiles.strips_per_rank(h, world) * 16 * w * 4 >= mine.size == g.owned_bytes()
+    for step in range(5):
+        slot = step % 2
+        g.wait(slot)
+        shifted = np.roll(frame, step, axis=1)
+        part = np.concatenate([shifted[a:b].reshape(-1) for a, b in tiles.strip_ranges(h, rank, world)])
+        g.local(slot)[:part.size] = torch.from_numpy(part)
+        g.submit(slot)
+        if rank == 0:
+            g.wait(slot)                      # CPU tensors: the collective has completed here
+            assert np.array_equal(g.frame(slot).numpy(), shifted)
     dist.barrier()
     if rank == 0:
         open(out_file, "w").write("ok")
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("h,w", [(270, 32), (1080, 8)])
+@pytest.mark.parametrize("h,w", [(270, 32), (1080, 8), (40, 8)])
 def test_gather_frame_gloo_world2(h, w):
     torch = pytest.importorskip("torch")
     import torch.multiprocessing as mp
