@@ -242,9 +242,13 @@ def main():
         kernels = {
             "primary_trace": (kms["trace"], my_pixels * PRIMARY_TRACE_PIXEL_B + NODE_B * counts["nodesPrimary"] + TRI_B * counts["trisPrimary"]),
             "primary_shade": (kms["shade"], my_pixels * (PRIMARY_SHADE_PIXEL_LEAN_B if lean else PRIMARY_SHADE_PIXEL_B) + hit_pixels * PRIMARY_SHADE_HIT_B + (my_pixels - hit_pixels) * PRIMARY_SHADE_MISS_B),
-            "direct": (kms["direct"], my_pixels * (DIRECT_PIXEL_B + (0 if lean else 8)) + hit_pixels * DIRECT_HIT_B + NODE_B * counts["nodesDirect"] + TRI_B * counts["trisDirect"] + 4 * counts["shadow"]),
-            "compose_post": (kms["compose"], my_pixels * (COMPOSE_PIXEL_LEAN_B if lean else COMPOSE_PIXEL_B)),
+            "direct": (kms["direct"], my_pixels * (DIRECT_PIXEL_B + (0 if lean else 8)) + hit_pixels * DIRECT_HIT_B + NODE_B * counts["nodesDirect"] + TRI_B * counts["trisDirect"] + 4 * counts["shadow"]
+                       + (my_pixels * COMPOSE_PIXEL_LEAN_B if lean else 0)),          # lean frame: direct_kernel<false> composes the pixel itself
         }
+        if not lean:
+            kernels["compose_post"] = (kms["compose"], my_pixels * COMPOSE_PIXEL_B)
+        else:
+            kernels["raster_fg"] = (kms["compose"], 0)                                  # what is left after the last ray pass: the HUD draw
         if args.gi_samples:
             kernels["indirect"] = (kms["indirect"], my_pixels * 12 + hit_pixels * 24 + NODE_B * counts["nodesIndirect"] + TRI_B * counts["trisIndirect"])
         if args.denoiser:

@@ -351,6 +351,23 @@ DEV float history_weight(const FrameParams &P, const ViewImages &I, size_t i, ui
     return expf(-weightDepth) * weightNormal;
 }
 
+// ComposePS + PostProcessPS of a LEAN frame for one pixel (same arithmetic as compose_post_kernel<true>): everything it reads is
+// the pixel's own diffuse colour and direct light, so DirectRayGen's kernel finishes the pixel instead of a separate launch
+// (one kernel boundary less per frame: ~11 us of kernel + the inter-kernel gap and cache refill).
+DEV void compose_lean_pixel(const FrameParams &P, const ViewImages &I, size_t i, f3 directStored) {
+    f4 d = load_rgba8(I.diffuse, i);
+    f3 result;
+    if (d.w > RT_EPSILON) {
+        f3 diffuse = xyz(d);
+        f3 indirect = mk3(q_f16(P.ambientBaseColor[0] + P.ambientNoGIColor[0]), q_f16(P.ambientBaseColor[1] + P.ambientNoGIColor[1]), q_f16(P.ambientBaseColor[2] + P.ambientNoGIColor[2]));
+        result = diffuse * (directStored + indirect);
+        result = lerp3(diffuse, result, d.w);
+    }
+    else result = xyz(d);
+    reinterpret_cast<float4 *>(I.output)[i] = make_float4(result.x, result.y, result.z, 1.0f);
+    if (!P.separatePost) store_rgba8(I.final, i, result.x, result.y, result.z, 1.0f);
+}
+
 template <bool FULL>
 __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void direct_kernel(FrameParams P, ViewImages I, int cur) {
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
@@ -365,7 +382,12 @@ __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void direct_kernel(FramePar
         const uint32_t px = p.x, py = p.y;
         const size_t i = (size_t)py * (size_t)P.width + px;
         const int instanceId = I.instanceId[i];
-        if (instanceId < 0) { store_rgba16f(I.directLight[cur], i, 1.0f, 1.0f, 1.0f, 0.0f); if (FULL) store_rgba16f(I.filteredDirect[1], i, 1.0f, 1.0f, 1.0f, 0.0f); continue; }
+        if (instanceId < 0) {
+            store_rgba16f(I.directLight[cur], i, 1.0f, 1.0f, 1.0f, 0.0f);
+            if (FULL) store_rgba16f(I.filteredDirect[1], i, 1.0f, 1.0f, 1.0f, 0.0f);
+            else compose_lean_pixel(P, I, i, mk3s(1.0f));
+            continue;
+        }
         f3 o, rayDirection; f2 ndc;
         primary_ray(P, px, py, o, rayDirection, ndc);
         const float4 pos4 = reinterpret_cast<const float4 *>(I.shadingPosition)[i];
@@ -388,6 +410,7 @@ __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void direct_kernel(FramePar
         newDirect = lerp3(newDirect, resDirect, s_rcp(historyLength));
         store_rgba16f(I.directLight[cur], i, newDirect.x, newDirect.y, newDirect.z, historyLength);
         if (FULL) store_rgba16f(I.filteredDirect[1], i, newDirect.x, newDirect.y, newDirect.z, historyLength);
+        else compose_lean_pixel(P, I, i, mk3(q_f16(newDirect.x), q_f16(newDirect.y), q_f16(newDirect.z)));      // Compose reads the RGBA16F value
     }
     flush_env(P, env, PASS_DIRECT, CTR_PRIMARY, 0);
 }

@@ -156,7 +156,7 @@ struct Device {
     DevArray<uint32_t> spillStack;
     DevArray<unsigned long long> counters;
     DevArray<uint8_t> blueNoise;
-    uint8_t *pinned = nullptr; size_t pinnedBytes = 0;
+    uint8_t *pinned[2] = { nullptr, nullptr }; size_t pinnedBytes[2] = { 0, 0 };
     enum { EV_BEGIN, EV_BUILD, EV_PRIMARY_TRACE, EV_PRIMARY, EV_DIRECT, EV_INDIRECT, EV_REFL, EV_DENOISE, EV_END, EV_COUNT };
     hipEvent_t events[EV_COUNT] = {};
     // A mark with no GPU work since the previous mark reuses that mark's event: every hipEventRecord is a barrier packet (~4 us of GPU idle).
@@ -165,13 +165,16 @@ struct Device {
     Device(int w, int h, int dev);
     ~Device();
     void use() const { HIP_CHECK(hipSetDevice(hipDevice)); }
-    void *staging(size_t bytes) {
-        if (bytes > pinnedBytes) {
-            if (pinned) hipHostFree(pinned);
-            pinnedBytes = std::max(bytes, (size_t)1 << 20);
-            HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&pinned), pinnedBytes, hipHostMallocDefault));
+    // Pinned upload buffers.  An async copy out of a pool must have completed before the pool is written again: pool 0 carries the
+    // frame tables (drained by the end-of-frame wait) and the synchronous mesh / texture uploads, pool 1 the raster lists, which are
+    // staged in the same View::update right after the frame tables were queued.
+    void *staging(size_t bytes, int pool = 0) {
+        if (bytes > pinnedBytes[pool]) {
+            if (pinned[pool]) { HIP_CHECK(hipStreamSynchronize(stream)); hipHostFree(pinned[pool]); }
+            pinnedBytes[pool] = std::max(bytes, (size_t)1 << 20);
+            HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&pinned[pool]), pinnedBytes[pool], hipHostMallocDefault));
         }
-        return pinned;
+        return pinned[pool];
     }
     void draw(int vsyncInterval, float deltaTimeMs);
     float aspect() const { return (float)width / (float)height; }
@@ -331,7 +334,7 @@ Device::~Device() {
     auto scenesCopy = scenes;
     for (Scene *s : scenesCopy) delete s;                 // rt64_device.cpp:97-100
     for (auto &ev : events) if (ev) hipEventDestroy(ev);
-    if (pinned) hipHostFree(pinned);
+    for (auto *p : pinned) if (p) hipHostFree(p);
     if (stream) hipStreamDestroy(stream);
 }
 
@@ -579,7 +582,7 @@ void View::prepareRasterList(const std::vector<RenderInstance> &list, RasterList
                       rl.w == w && rl.h == h && rl.y0 == y0 && rl.y1 == y1 && rl.apply == apply && !dev->opt.alwaysRebuild;
     if (same) return;
     rl.table.reserve(hst.size()); rl.tris.reserve(std::max<size_t>(raster_tri_bytes(triTotal), 16));
-    uint8_t *stage = static_cast<uint8_t *>(dev->staging(bytes));
+    uint8_t *stage = static_cast<uint8_t *>(dev->staging(bytes, 1));
     memcpy(stage, hst.data(), bytes);
     HIP_CHECK(hipMemcpyAsync(rl.table.ptr, stage, bytes, hipMemcpyHostToDevice, dev->stream));
     HIP_CHECK(hipStreamSynchronize(dev->stream));                // the staging buffer is shared with the frame tables
@@ -859,7 +862,7 @@ void View::render() {                          // View::render, rt64_view.cpp:11
                 L(launch_gaussian(img.filteredIndirect[k % 2], img.filteredIndirect[(k % 2) ^ 1], imgW, imgH, 0, imgH, s));
         }
         mark(Device::EV_DENOISE);
-        L(launch_compose_post(P, img, cur, lean, s));
+        if (!lean) L(launch_compose_post(P, img, cur, false, s));       // a lean frame is composed by direct_kernel<false> itself
         if (P.separatePost) L(launch_post_process(P, img, s));
     }
     else {
