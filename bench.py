@@ -32,13 +32,14 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 NODE_B, TRI_B = 64, 48
 PRIMARY_TRACE_PIXEL_B = 16 + 4                 # hit record (t,u,v,prim) + instance id written per primary ray
 PRIMARY_SHADE_PIXEL_B = 20 + 94                # hit record read + 15 G-buffer images written (90 B/px + first-instance copy)
-PRIMARY_SHADE_PIXEL_LEAN_B = 20 + 52           # lean frame: position, normals x2, specular, diffuse, instance id, depth only
+PRIMARY_SHADE_PIXEL_LEAN_B = 20 + 8            # lean frame, every pixel: hit record read + diffuse and instance id written
+PRIMARY_SHADE_HIT_LEAN_B = 16 + 8 + 8          # lean frame, hit pixels only: position, normal, specular written
 PRIMARY_SHADE_HIT_B = 3 * 52 + 4 * 16 * 4      # 3 vertices of the sample layout + 4 bilinear fetches x 4 texels x 4 B
 PRIMARY_SHADE_MISS_B = 16                      # one bilinear sky fetch
 DIRECT_PIXEL_B = 4 + 8                         # instance id read + RGBA16F light written
 DIRECT_HIT_B = 16 + 8 + 8                      # position + normal + specular read for lit pixels
 COMPOSE_PIXEL_B = 44 + 16 + 4                  # compose reads 44 B, writes 16 B; post writes 4 B (fused: output not re-read)
-COMPOSE_PIXEL_LEAN_B = 12 + 16 + 4             # lean frame: diffuse + direct light read
+COMPOSE_PIXEL_LEAN_B = 4 + 16 + 4              # lean frame, inside direct_kernel: diffuse read, output + back buffer written
 
 
 def parse_args():
@@ -241,7 +242,7 @@ def main():
         my_pixels = tiles.owned_rows(H, 0, N) * W
         kernels = {
             "primary_trace": (kms["trace"], my_pixels * PRIMARY_TRACE_PIXEL_B + NODE_B * counts["nodesPrimary"] + TRI_B * counts["trisPrimary"]),
-            "primary_shade": (kms["shade"], my_pixels * (PRIMARY_SHADE_PIXEL_LEAN_B if lean else PRIMARY_SHADE_PIXEL_B) + hit_pixels * PRIMARY_SHADE_HIT_B + (my_pixels - hit_pixels) * PRIMARY_SHADE_MISS_B),
+            "primary_shade": (kms["shade"], my_pixels * (PRIMARY_SHADE_PIXEL_LEAN_B if lean else PRIMARY_SHADE_PIXEL_B) + hit_pixels * (PRIMARY_SHADE_HIT_B + (PRIMARY_SHADE_HIT_LEAN_B if lean else 0)) + (my_pixels - hit_pixels) * PRIMARY_SHADE_MISS_B),
             "direct": (kms["direct"], my_pixels * (DIRECT_PIXEL_B + (0 if lean else 8)) + hit_pixels * DIRECT_HIT_B + NODE_B * counts["nodesDirect"] + TRI_B * counts["trisDirect"] + 4 * counts["shadow"]
                        + (my_pixels * COMPOSE_PIXEL_LEAN_B if lean else 0)),          # lean frame: direct_kernel<false> composes the pixel itself
         }

@@ -313,9 +313,12 @@ __global__ __launch_bounds__(RT_BLOCK, SHADE_WAVES) void primary_shade_kernel(Fr
             store_rgba16f(I.reflection, i, 0.0f, 0.0f, 0.0f, reflA);
             store_rgba16f(I.refraction, i, 0.0f, 0.0f, 0.0f, refrA);
         }
-        reinterpret_cast<float4 *>(I.shadingPosition)[i] = make_float4(resPosition.x, resPosition.y, resPosition.z, 0.0f);
-        store_rgba16f(I.shadingNormal, i, resNormal.x, resNormal.y, resNormal.z, 0.0f);
-        store_rgba16f(I.shadingSpecular, i, resSpecular.x, resSpecular.y, resSpecular.z, 0.0f);
+        // Lean frame: DirectRayGen reads position / normal / specular only where a surface was hit, so miss pixels skip those stores.
+        if (FULL || resInstanceId >= 0) {
+            reinterpret_cast<float4 *>(I.shadingPosition)[i] = make_float4(resPosition.x, resPosition.y, resPosition.z, 0.0f);
+            store_rgba16f(I.shadingNormal, i, resNormal.x, resNormal.y, resNormal.z, 0.0f);
+            store_rgba16f(I.shadingSpecular, i, resSpecular.x, resSpecular.y, resSpecular.z, 0.0f);
+        }
         store_rgba8(I.diffuse, i, resColor.x, resColor.y, resColor.z, resColor.w);
         I.instanceId[i] = resInstanceId;
         if (FULL) {
@@ -325,8 +328,10 @@ __global__ __launch_bounds__(RT_BLOCK, SHADE_WAVES) void primary_shade_kernel(Fr
             I.reactiveMask[i] = to_unorm8(fminf(resReactiveMask, 0.9f));
             I.lockMask[i] = to_unorm8(P.binaryLockMask ? (resLockMask >= 0.5f ? 1.0f : 0.0f) : fminf(resLockMask, 1.0f));
         }
-        store_rgba16f(I.normal[cur], i, resNormal.x, resNormal.y, resNormal.z, 0.0f);
-        I.depth[cur][i] = resDepth;
+        if (FULL) {                                                 // history guides of the temporal / SVGF passes: no consumer on a lean frame
+            store_rgba16f(I.normal[cur], i, resNormal.x, resNormal.y, resNormal.z, 0.0f);
+            I.depth[cur][i] = resDepth;
+        }
     }
     flush_env(P, env, PASS_PRIMARY_SHADE, CTR_PRIMARY, 0);
 }

@@ -480,7 +480,7 @@ View::~View() {
     auto &v = scene->views; v.erase(std::remove(v.begin(), v.end(), this), v.end());
     releaseImages();
 }
-void View::releaseImages() { for (void *p : allocations) hipFree(p); allocations.clear(); img = ViewImages(); bounceSamples = 0; }
+void View::releaseImages() { for (void *p : allocations) hipFree(p); allocations.clear(); img = ViewImages(); bounceSamples = 0; leanFrame = false; }
 
 void View::createImages(int w, int h, int screenW, int screenH) {       // View::createOutputBuffers, rt64_view.cpp:105-298 (same formats)
     scene->device->use();
@@ -810,6 +810,11 @@ void View::render() {                          // View::render, rt64_view.cpp:11
     };
     auto L = [&](hipError_t e) { HIP_CHECK(e); dev->workSinceMark = true; };       // a launch between two marks
     if (!perspectiveSet) throw std::runtime_error("RT64_DrawDevice: RT64_SetViewPerspective was never called (fov must be > 0).");
+    // Lean frame: nothing downstream reads the view direction, the reflection / refraction / transparent accumulators, motion
+    // vectors, upscaler masks, history guides or a GI buffer.  A full frame after lean ones reads the previous frame's guides and
+    // history (temporal reprojection), so what that lean frame skipped is produced first, while its hit records still exist.
+    const bool leanNow = !rtInstances.empty() && dev->opt.leanFrames && !anyNonOpaque && !anyReflection && !anyRefraction && !anyFog && giSamples == 0 && motionBlurStrength <= 0.0f;
+    if (leanFrame && !leanNow) materialise();
     FrameParams P;
     fillParams(P);
     const int cur = rtSwap ? 1 : 0;
@@ -832,9 +837,7 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         const bool klist = anyNonOpaque;
         L(launch_primary_trace(P, img, hitInstance.ptr, klist, s));
         mark(Device::EV_PRIMARY_TRACE);
-        // Lean frame: nothing downstream reads the view direction, the reflection / refraction / transparent accumulators,
-        // motion vectors, upscaler masks or a GI buffer -> skip those stores (and the matching loads in Compose).
-        const bool lean = dev->opt.leanFrames && !anyNonOpaque && !anyReflection && !anyRefraction && !anyFog && giSamples == 0 && motionBlurStrength <= 0.0f;
+        const bool lean = leanNow;
         leanFrame = lean; lastParams = P; lastCur = cur;
         L(launch_primary_shade(P, img, hitInstance.ptr, cur, anyNonOpaque, lean, s));
         mark(Device::EV_PRIMARY);

@@ -224,6 +224,33 @@ def test_motion_blur_gathers_along_the_flow(rt64_lib, sample_data):
     assert np.abs(sharp - ref["final"][..., :3]).mean() > 0.5      # the blur changed the picture
 
 
+def test_full_frame_after_lean_frames_sees_a_complete_previous_frame(rt64_lib, sample_data):
+    """Lean frames (giSamples = 0) skip the history guides and the GI buffer.  When the host then turns GI + denoiser on, the first
+    full frame reprojects from the previous one (IndirectRayGen.hlsl:43-56): the library produces what the lean frame skipped before
+    it renders, so the sequence matches the oracle, which writes every image every frame."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    from oracle import oracle_py
+    s = sample_scene.Rt64Scene(rt64_lib, sample_data, W, H, hip_device=0)
+    o = oracle_py.OracleScene(sample_data)
+    try:
+        kw = {}
+        for f in range(5):
+            if f == 2:
+                s.set_view_description(gi_samples=1, denoiser=True)
+                kw = dict(giSamples=1, denoiserEnabled=1, denoiserMode=1)
+            s.draw()
+            assert bool(s.stats().leanFrame) == (f < 2)
+            ref = o.render(W, H, **kw)
+        got_out, got_gi = s.readback(rt64.IMAGE_OUTPUT_RGBA32F), s.readback(rt64.IMAGE_INDIRECT_LIGHT_FILTERED)
+        raw = s.readback(rt64.IMAGE_INDIRECT_LIGHT_RAW)
+        assert _rmse(got_out[..., :3], ref["output"][..., :3]) <= 1e-3
+        assert _rmse(got_gi[..., :3], ref["filteredIndirect"][..., :3]) <= 2e-3
+        hit = ref["instanceId"] >= 0
+        assert np.abs(raw[..., 3][hit] - ref["indirectLight"][..., 3][hit]).max() < 0.51      # history length: 3 GI frames on static pixels
+    finally:
+        s.close(); o.close()
+
+
 def test_c4_refit_of_updatable_mesh(rt64_lib, sample_data):
     """Per-frame vertex animation of an UPDATABLE mesh (rt64_mesh.cpp:129,149-157): SetMesh with unchanged counts refits the BLAS;
     hits stay bit-identical to the oracle's refit."""
