@@ -992,7 +992,16 @@ __global__ __launch_bounds__(256) void clear_final_kernel(FrameParams P, ViewIma
 
 size_t rt_stack_spill_bytes() { return (size_t)RT_GRID_BLOCKS * RT_BLOCK * RT_STACK_SPILL * sizeof(uint32_t); }
 
-#define LAUNCH_RAY(kernel, ...) do { hipLaunchKernelGGL(kernel, dim3(RT_GRID_BLOCKS), dim3(RT_BLOCK), 0, s, __VA_ARGS__); return hipGetLastError(); } while (0)
+// Grid of a ray kernel: one persistent workgroup per CU slot (RT_GRID_BLOCKS), or one per tile when the device's share of the
+// frame has fewer tiles than that (small frames, a 1/8 strip share): workgroups without a tile only cost launch time.
+static unsigned rt_grid(const FrameParams &P) {
+    const unsigned all = (unsigned)(P.tileY1 - P.tileY0 + 15) / 16;
+    const unsigned strips = all > (unsigned)P.stripRank ? (all - (unsigned)P.stripRank + (unsigned)P.stripCount - 1) / (unsigned)P.stripCount : 0u;
+    const unsigned tilesSquare = (unsigned)((P.width + 15) / 16) * strips, tilesRows = (unsigned)((P.width + 31) / 32) * strips * 2u;
+    const unsigned tiles = tilesSquare > tilesRows ? tilesSquare : tilesRows;
+    return tiles < 1u ? 1u : (tiles < (unsigned)RT_GRID_BLOCKS ? tiles : (unsigned)RT_GRID_BLOCKS);
+}
+#define LAUNCH_RAY(kernel, ...) do { hipLaunchKernelGGL(kernel, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, __VA_ARGS__); return hipGetLastError(); } while (0)
 
 hipError_t launch_primary_trace(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, bool klist, hipStream_t s) {
     if (klist) LAUNCH_RAY(primary_trace_kernel<true>, P, I, hitInstance);
@@ -1010,8 +1019,8 @@ hipError_t launch_direct(const FrameParams &P, const ViewImages &I, int cur, boo
 hipError_t launch_indirect(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, bool refill, hipStream_t s) {
     if (klist) LAUNCH_RAY(indirect_kernel<true>, P, I, cur, writeFiltered ? 1 : 0);
     if (P.giSamples == 0 || !I.bounceRecords) LAUNCH_RAY(indirect_kernel<false>, P, I, cur, writeFiltered ? 1 : 0);
-    if (refill) hipLaunchKernelGGL(bounce_trace_refill_kernel, dim3(RT_GRID_BLOCKS), dim3(RT_BLOCK), 0, s, P, I);
-    else hipLaunchKernelGGL(bounce_trace_plain_kernel, dim3(RT_GRID_BLOCKS), dim3(RT_BLOCK), 0, s, P, I);
+    if (refill) hipLaunchKernelGGL(bounce_trace_refill_kernel, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
+    else hipLaunchKernelGGL(bounce_trace_plain_kernel, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
     LAUNCH_RAY(bounce_shade_kernel, P, I, cur, writeFiltered ? 1 : 0);
 }
 hipError_t launch_indirect_constant(const FrameParams &P, const ViewImages &I, int cur, hipStream_t s) {
