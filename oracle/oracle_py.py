@@ -160,8 +160,9 @@ class OracleScene:
         self.scene = L.oracle_scene_create()
         self._keep = []
         L.oracle_scene_set_desc(self.scene, C.addressof(data.desc))
-        arr = (type(data.lights[0]) * len(data.lights))(*data.lights)
-        L.oracle_scene_set_lights(self.scene, C.addressof(arr), len(data.lights))
+        if data.lights:
+            arr = (type(data.lights[0]) * len(data.lights))(*data.lights)
+            L.oracle_scene_set_lights(self.scene, C.addressof(arr), len(data.lights))
         bn = np.ascontiguousarray(data.bluenoise)
         L.oracle_scene_set_bluenoise(self.scene, bn.ctypes.data)
         self.textures = []

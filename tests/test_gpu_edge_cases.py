@@ -1,0 +1,151 @@
+"""Edge cases of the render path through the C ABI: ragged and tiny frame sizes, resizes, empty scenes, degenerate geometry,
+light-count limits, object lifetime.  Parity bars as in test_gpu_parity.py (geometry bit-exact, shading within tolerance)."""
+import copy
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from test_gpu_features import _variant, _rmse
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(rt64_lib, data, w, h, frames=1, **kw):
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    from oracle import oracle_py
+    s = sample_scene.Rt64Scene(rt64_lib, data, w, h, hip_device=0)
+    o = oracle_py.OracleScene(data)
+    try:
+        s.option("count_traversal", 1)
+        for _ in range(frames):
+            s.draw()
+            ref = o.render(w, h, **kw)
+        got = {k: s.readback(getattr(rt64, "IMAGE_" + k)) for k in ("OUTPUT_RGBA32F", "FINAL_RGBA8", "PRIMARY_HIT", "INSTANCE_ID")}
+        return got, ref, s.stats()
+    finally:
+        s.close(); o.close()
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (7, 3), (17, 16), (123, 77), (33, 200)])
+def test_ragged_frame_sizes(rt64_lib, sample_data, w, h):
+    """Sizes that are not multiples of the 16x16 / 32x8 tiles, down to a single pixel."""
+    got, ref, st = _pair(rt64_lib, sample_data, w, h)
+    assert got["PRIMARY_HIT"].shape == (h, w, 4)
+    assert np.array_equal(got["PRIMARY_HIT"], ref["primaryHit"]) and np.array_equal(got["INSTANCE_ID"], ref["instanceId"])
+    assert _rmse(got["OUTPUT_RGBA32F"][..., :3], ref["output"][..., :3]) <= 1e-3
+    assert np.abs(got["FINAL_RGBA8"].astype(np.int32) - ref["final"].astype(np.int32)).max() <= 1
+    assert st.primaryRays == w * h == ref["counters"]["primaryRays"] and st.shadowRays == ref["counters"]["shadowRays"]
+    assert (st.nodesVisited, st.trianglesTested) == (ref["counters"]["nodesVisited"], ref["counters"]["trianglesTested"])
+
+
+def test_resize_between_frames_recreates_the_images(rt64_lib, sample_data):
+    """RT64_SetDeviceSize stands in for a window resize (rt64_device.cpp:1039): the next frame has the new size and no stale history."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    from oracle import oracle_py
+    s = sample_scene.Rt64Scene(rt64_lib, sample_data, 160, 90, hip_device=0)
+    try:
+        s.draw()
+        assert s.readback(rt64.IMAGE_FINAL_RGBA8).shape == (90, 160, 4)
+        rt64_lib.SetDeviceSize(s.device, 208, 120)
+        s.draw()
+        out = s.readback(rt64.IMAGE_OUTPUT_RGBA32F)
+        hit = s.readback(rt64.IMAGE_PRIMARY_HIT)
+    finally:
+        s.close()
+    o = oracle_py.OracleScene(sample_data)
+    try:
+        ref = o.render(208, 120)
+    finally:
+        o.close()
+    assert out.shape == (120, 208, 4) and np.array_equal(hit, ref["primaryHit"])
+    assert _rmse(out[..., :3], ref["output"][..., :3]) <= 1e-3
+
+
+def test_scene_without_instances_and_without_lights(rt64_lib, sample_data):
+    """No instance at all: the cleared back buffer (rt64_device.cpp:996-997).  No light: only ambient + eye light remain."""
+    def empty(d):
+        d.instances = []
+    got, ref, st = _pair(rt64_lib, _variant(sample_data, empty), 64, 48)
+    assert st.primaryRays == 0 and (got["FINAL_RGBA8"] == np.array([0, 0, 0, 255], dtype=np.uint8)).all()
+    assert np.array_equal(got["FINAL_RGBA8"], ref["final"])
+
+    def dark(d):
+        d.lights = []
+    got, ref, st = _pair(rt64_lib, _variant(sample_data, dark), 96, 54)
+    assert np.array_equal(got["PRIMARY_HIT"], ref["primaryHit"]) and st.shadowRays == 0 == ref["counters"]["shadowRays"]
+    assert _rmse(got["OUTPUT_RGBA32F"][..., :3], ref["output"][..., :3]) <= 1e-3
+
+
+def test_single_triangle_and_degenerate_triangles(rt64_lib, sample_data):
+    """A one-triangle ray-traced mesh (LBVH with n = 1: root with one leaf and RT64_NO_CHILD) and a mesh with zero-area and
+    duplicate triangles next to valid ones."""
+    from sm64rt_legacy_renderer_amd import sample_scene
+
+    def mod(d):
+        one = np.zeros(3, dtype=sample_scene.VERTEX_DTYPE)
+        one["position"] = [(-2.0, 0.2, 3.0, 1.0), (2.0, 0.2, 3.0, 1.0), (0.0, 3.0, 3.0, 1.0)]
+        one["normal"] = (0.0, 0.0, 1.0); one["uv"] = [(0, 0), (1, 0), (0, 1)]; one["input1"] = 1.0
+        d.meshes.append(sample_scene.MeshData("one", d.meshes[0].flags, one, np.array([0, 1, 2], dtype=np.uint32)))
+        deg = np.zeros(6, dtype=sample_scene.VERTEX_DTYPE)
+        deg["position"] = [(3.0, 0.1, 2.0, 1.0), (5.0, 0.1, 2.0, 1.0), (4.0, 2.0, 2.0, 1.0), (3.0, 0.1, 2.0, 1.0), (3.0, 0.1, 2.0, 1.0), (4.0, 1.0, 2.0, 1.0)]
+        deg["normal"] = (0.0, 0.0, 1.0); deg["input1"] = 1.0
+        idx = np.array([0, 1, 2, 3, 4, 5, 0, 0, 0, 0, 1, 2, 0, 1, 1], dtype=np.uint32)     # valid, zero-area (two equal corners), point, duplicate, line
+        d.meshes.append(sample_scene.MeshData("deg", d.meshes[0].flags, deg, idx))
+        for m in (len(d.meshes) - 2, len(d.meshes) - 1):
+            i = copy.copy(d.instances[1]); i.mesh = m; i.material = sample_scene.copy_material(d.instances[1].material); i.name = "extra%d" % m
+            i.flags = 2                                                   # both faces
+            d.instances.append(i)
+    got, ref, st = _pair(rt64_lib, _variant(sample_data, mod), 160, 90)
+    assert np.array_equal(got["PRIMARY_HIT"], ref["primaryHit"])
+    assert set(np.unique(got["INSTANCE_ID"])) >= {2, 3}                   # both extra instances are visible
+    assert (st.nodesVisited, st.trianglesTested) == (ref["counters"]["nodesVisited"], ref["counters"]["trianglesTested"])
+    assert _rmse(got["OUTPUT_RGBA32F"][..., :3], ref["output"][..., :3]) <= 1e-3
+
+
+def test_more_lights_than_the_shader_keeps(rt64_lib, sample_data):
+    """RT64_SetSceneLights with more than MAX_LIGHTS (16, Lights.hlsli:25) entries and maxLights = 4: the random selection without
+    replacement (Lights.hlsli:115-168) picks the same lights on both sides."""
+    from sm64rt_legacy_renderer_amd import rt64
+
+    def mod(d):
+        base = d.lights[0]
+        ls = []
+        for k in range(24):
+            l = rt64.LIGHT(); C.memmove(C.byref(l), C.byref(base), C.sizeof(rt64.LIGHT))
+            l.position = rt64.VECTOR3(-12.0 + k, 6.0 + (k % 3), 4.0 - (k % 5)); l.diffuseColor = rt64.VECTOR3(0.2 + 0.03 * k, 0.5, 0.9 - 0.03 * k)
+            ls.append(l)
+        d.lights = ls
+    from test_gpu_features import _render_pair
+    got, ref, st = _render_pair(rt64_lib, _variant(sample_data, mod), view_desc=dict(max_lights=4))
+    assert np.array_equal(got["PRIMARY_HIT"], ref["primaryHit"])
+    assert st.shadowRays == ref["counters"]["shadowRays"] > 0
+    dd = np.abs(got["DIRECT_LIGHT_RAW"][..., :3] - ref["directLight"][..., :3]).max(axis=2)
+    assert (dd > 1e-2).mean() < 2e-3
+
+
+def test_destroying_an_instance_and_a_view_between_frames(rt64_lib, sample_data):
+    """Object lifetime through the ABI: DestroyInstance removes it from the next frame; a second view / scene can be created and
+    destroyed without disturbing the first (rt64_scene.cpp:43-51)."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    from oracle import oracle_py
+    s = sample_scene.Rt64Scene(rt64_lib, sample_data, 128, 72, hip_device=0)
+    try:
+        s.draw()
+        extra_scene = rt64_lib.CreateScene(s.device); extra_view = rt64_lib.CreateView(extra_scene)
+        rt64_lib.DestroyView(extra_view); rt64_lib.DestroyScene(extra_scene)
+        k = next(i for i, inst in enumerate(sample_data.instances) if inst.name == "sphere")
+        rt64_lib.DestroyInstance(s.instances[k]); s.instances[k] = None; s._sphere_k = -1
+        s.draw()
+        ids = s.readback(rt64.IMAGE_INSTANCE_ID)
+        hit = s.readback(rt64.IMAGE_PRIMARY_HIT)
+    finally:
+        s.instances = [h for h in s.instances if h]
+        s.close()
+    d = _variant(sample_data, lambda dd: None); d.instances = [i for i in d.instances if i.name != "sphere"]
+    o = oracle_py.OracleScene(d)
+    try:
+        ref = o.render(128, 72)
+    finally:
+        o.close()
+    assert np.array_equal(hit, ref["primaryHit"]) and set(np.unique(ids)) == {-1, 0}
