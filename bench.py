@@ -137,8 +137,14 @@ def main():
     # N > 1: frames are ENQUEUED (sync_present = 0) on the renderer's stream, the strips are copied into a gather slot on the same
     # stream, and the RCCL gather of frame k runs beside the rendering of frame k+1 (two slots).  Everything is complete at the
     # closing barrier + synchronize, which is inside the timed region.
-    pipelined = G and args.backend == "nccl"
-    ext_stream = torch.cuda.ExternalStream(lib.GetDeviceStream(scene.device)) if pipelined else None
+    pipelined = G and args.backend == "nccl" and os.environ.get("RT64_BENCH_PIPELINE", "1") != "0"
+    ext_stream = None
+    if pipelined:
+        try:
+            ext_stream = torch.cuda.ExternalStream(lib.GetDeviceStream(scene.device))
+        except Exception as e:       # keep measuring: synchronous frames + blocking gather (same result, no overlap)
+            print("bench.py: renderer stream not usable from torch (%r): synchronous gather" % (e,), file=sys.stderr)
+            pipelined = False
     gatherer = tiles.FrameGatherer(H, W, rank, N, comm_device, stream=ext_stream) if G else None
     staging = torch.zeros(tiles.strips_per_rank(H, N) * 16 * W * 4, dtype=torch.uint8, device="cuda") if (G and not pipelined) else None
     local = torch.zeros(max(tiles.max_owned_rows(H, N), 1) * W * 4, dtype=torch.uint8, device="cuda")
