@@ -130,9 +130,22 @@ def main():
             if inst.name == "floor":
                 inst.material.reflectionFactor = 0.3
     scene = sample_scene.Rt64Scene(lib, data, W, H, hip_device=local_rank)
-    scene.set_interleave(rank, N)
+    # Partition: interleaved 16-row strips balance sky against geometry; a frame with GI + denoiser filters across rows, so it is
+    # cut into contiguous bands and the library renders each band with the filter's halo (no mid-frame exchange).
+    # Rays of one whole frame (the unit of `value`): counted once on every rank before the frame is partitioned, so that rows a
+    # rank renders redundantly (denoiser halo) never inflate the throughput.
     if args.gi_samples or args.denoiser:
         scene.set_view_description(gi_samples=args.gi_samples, denoiser=args.denoiser)
+    scene.option("count_traversal", 1)
+    scene.draw()
+    st_full = scene.stats()
+    rays_total = int(st_full.primaryRays + st_full.shadowRays + st_full.indirectRays + st_full.reflectionRays + st_full.refractionRays)
+    scene.option("count_traversal", 0)
+    use_bands = N > 1 and args.gi_samples > 0 and args.denoiser
+    if use_bands:
+        scene.set_tile(*tiles.band_range(H, rank, N))
+    else:
+        scene.set_interleave(rank, N)
 
     # N > 1: frames are ENQUEUED (sync_present = 0) on the renderer's stream, the strips are copied into a gather slot on the same
     # stream, and the RCCL gather of frame k runs beside the rendering of frame k+1 (two slots).  Everything is complete at the
@@ -145,10 +158,10 @@ def main():
         except Exception as e:       # keep measuring: synchronous frames + blocking gather (same result, no overlap)
             print("bench.py: renderer stream not usable from torch (%r): synchronous gather" % (e,), file=sys.stderr)
             pipelined = False
-    gatherer = tiles.FrameGatherer(H, W, rank, N, comm_device, stream=ext_stream) if G else None
-    staging = torch.zeros(tiles.strips_per_rank(H, N) * 16 * W * 4, dtype=torch.uint8, device="cuda") if (G and not pipelined) else None
+    gatherer = tiles.FrameGatherer(H, W, rank, N, comm_device, stream=ext_stream, bands=use_bands) if G else None
+    staging = torch.zeros(max(tiles.strips_per_rank(H, N) * 16, tiles.band_rows(H, N)) * W * 4, dtype=torch.uint8, device="cuda") if (G and not pipelined) else None
     local = torch.zeros(max(tiles.max_owned_rows(H, N), 1) * W * 4, dtype=torch.uint8, device="cuda")
-    my_bytes = tiles.owned_rows(H, rank, N) * W * 4
+    my_bytes = gatherer.owned_bytes() if G else H * W * 4
 
     def fetch(dst):
         n = lib.CopyDeviceImage(scene.device, rt64.IMAGE_FINAL_RGBA8, dst.data_ptr(), dst.numel())
@@ -173,7 +186,7 @@ def main():
             fetch(gatherer.local(slot))
         else:                        # gloo rehearsal: CPU-staged
             fetch(staging)
-            gatherer.local(slot).copy_(staging)
+            gatherer.local(slot).copy_(staging[:gatherer.local(slot).numel()])
         gatherer.submit(slot)
         return slot
 
@@ -197,12 +210,6 @@ def main():
     lean = bool(st.leanFrame)
     hit_pixels = int((scene.readback(rt64.IMAGE_FIRST_INSTANCE_ID) >= 0).sum())
     scene.option("count_traversal", 0)
-    rays_local = counts["primary"] + counts["shadow"] + counts["indirect"] + counts["reflection"]
-    rays_total = rays_local
-    if N > 1:
-        t = torch.tensor([rays_local], dtype=torch.float64, device=comm_device)
-        dist.all_reduce(t)
-        rays_total = int(t.item())
 
     if pipelined:
         scene.option("sync_present", 0)      # RT64_DrawDevice enqueues; ordering is on the renderer's stream from here on
@@ -245,7 +252,7 @@ def main():
     if rank == 0:
         K = float(stat_frames)
         kms = {k: v / K for k, v in acc.items()}
-        my_pixels = tiles.owned_rows(H, 0, N) * W
+        my_pixels = (tiles.band_range(H, 0, N)[1] if use_bands else tiles.owned_rows(H, 0, N)) * W
         kernels = {
             "primary_trace": (kms["trace"], my_pixels * PRIMARY_TRACE_PIXEL_B + NODE_B * counts["nodesPrimary"] + TRI_B * counts["trisPrimary"]),
             "primary_shade": (kms["shade"], my_pixels * (PRIMARY_SHADE_PIXEL_LEAN_B if lean else PRIMARY_SHADE_PIXEL_B) + hit_pixels * (PRIMARY_SHADE_HIT_B + (PRIMARY_SHADE_HIT_LEAN_B if lean else 0)) + (my_pixels - hit_pixels) * PRIMARY_SHADE_MISS_B),
@@ -290,7 +297,7 @@ def main():
                 args.config, W, H, "" if not (args.gi_samples or args.subdiv or args.floor_grid > 1) else " [gi=%d denoiser=%d subdiv=%d floor_grid=%d]" % (
                     args.gi_samples, int(args.denoiser), args.subdiv, args.floor_grid)),
                 "rays_per_frame": int(rays_total), "width": W, "height": H,
-                "partition": "interleaved 16-row strips x%d + RCCL gather of RGBA8" % N if N > 1 else "single GPU"},
+                "partition": ("%s x%d + RCCL gather of RGBA8" % ("contiguous bands with denoiser halo" if use_bands else "interleaved 16-row strips", N)) if N > 1 else "single GPU"},
             "roofline": roofline,
         }
         if G:

@@ -58,4 +58,6 @@ hipError_t launch_raster_draw(const GpuRasterInstance *instances, const void *tr
 
 // ---- svgf.hip ------------------------------------------------------------------------------------------------------
 // variance estimate + 5 a-trous iterations over the GI buffer; result in filteredIndirect[1]
-hipError_t launch_svgf(const ViewImages &I, int cur, int width, int height, hipStream_t s);
+#define SVGF_HALO_ROWS 66            // rows of neighbourhood the SVGF result of a row depends on (62 a-trous + 3 variance + 1 gradient)
+#define GAUSSIAN_HALO_ROWS 5         // five 3x3 passes
+hipError_t launch_svgf(const ViewImages &I, int cur, int width, int height, int y0, int y1, hipStream_t s);

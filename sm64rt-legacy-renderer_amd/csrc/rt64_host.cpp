@@ -835,34 +835,44 @@ void View::render() {                          // View::render, rt64_view.cpp:11
             img.bounceRecords = static_cast<uint4 *>(a); bounceSamples = giSamples;
         }
         const bool klist = anyNonOpaque;
-        L(launch_primary_trace(P, img, hitInstance.ptr, klist, s));
+        // Image-tile partition with a spatial filter downstream: the GI denoiser reads a neighbourhood of every row this device
+        // owns (SVGF: 66 rows, the reference's five 3x3 Gaussians: 5), so the passes that feed it -- primary visibility, G-buffer,
+        // GI bounce -- also cover a halo above and below the device's rows.  Pixel-local passes (direct light, reflection,
+        // refraction, compose) stay on the owned rows.  The halo rows are recomputed, not exchanged: no mid-frame collective.
+        const bool denoiseGI = denoiserEnabled && giSamples > 0;
+        FrameParams X = P;                                        // X: owned rows + halo
+        if (denoiseGI && !P.separatePost && (P.tileY0 > 0 || P.tileY1 < imgH || P.stripCount > 1)) {
+            if (P.stripCount > 1) throw std::runtime_error("RT64_DrawDevice: a frame with GI + denoiser filters across rows; partition it into contiguous bands (RT64_SetDeviceTile), not interleaved strips.");
+            const int halo = dev->opt.denoiserMode == 1 ? SVGF_HALO_ROWS : GAUSSIAN_HALO_ROWS;
+            X.tileY0 = std::max(0, P.tileY0 - halo); X.tileY1 = std::min(imgH, P.tileY1 + halo);
+        }
+        L(launch_primary_trace(X, img, hitInstance.ptr, klist, s));
         mark(Device::EV_PRIMARY_TRACE);
         const bool lean = leanNow;
         leanFrame = lean; lastParams = P; lastCur = cur;
-        L(launch_primary_shade(P, img, hitInstance.ptr, cur, anyNonOpaque, lean, s));
+        L(launch_primary_shade(X, img, hitInstance.ptr, cur, anyNonOpaque, lean, s));
         mark(Device::EV_PRIMARY);
         // DirectRayGen also writes the "filtered" copy: DI denoising is compiled out in the reference (rt64_view.cpp:1438-1463),
         // so rtFilteredDirectLight[1] is always a plain copy of the raw accumulation.
         L(launch_direct(P, img, cur, lean, s));
         mark(Device::EV_DIRECT);
-        const bool denoiseGI = denoiserEnabled && giSamples > 0;
         if (lean) {}                                                                  // constant ambient folded into Compose
         else if (giSamples == 0) L(launch_indirect_constant(P, img, cur, s));  // IndirectRayGen.hlsl:135: constant ambient
         else {
             bool refill = dev->opt.bounceRefill == 1;
             if (dev->opt.bounceRefill < 0) { size_t tri = 0; for (auto &ri : rtInstances) tri += ri.instance->mesh->blasCount; refill = tri >= 65536; }
-            L(launch_indirect(P, img, cur, !denoiseGI, klist, refill, s));
+            L(launch_indirect(X, img, cur, !denoiseGI, klist, refill, s));
         }
         mark(Device::EV_INDIRECT);
         // Refraction / reflection touch only pixels whose primary hit has a refraction / reflection factor (alpha > EPSILON).
         if (anyRefraction) L(launch_refraction(P, img, klist, s));
         if (anyReflection) for (int r = 0; r < dev->opt.maxReflections; r++) L(launch_reflection(P, img, klist, s));
         mark(Device::EV_REFL);
-        if (denoiseGI && dev->opt.denoiserMode == 1) L(launch_svgf(img, cur, imgW, imgH, s));
+        if (denoiseGI && dev->opt.denoiserMode == 1) L(launch_svgf(img, cur, imgW, imgH, X.tileY0, X.tileY1, s));
         else if (denoiseGI) {
             L(hipMemcpyAsync(img.filteredIndirect[0], img.indirectLight[cur], n * 8, hipMemcpyDeviceToDevice, s));
             for (int k = 0; k < 5; k++)            // rt64_view.cpp:1512-1530
-                L(launch_gaussian(img.filteredIndirect[k % 2], img.filteredIndirect[(k % 2) ^ 1], imgW, imgH, 0, imgH, s));
+                L(launch_gaussian(img.filteredIndirect[k % 2], img.filteredIndirect[(k % 2) ^ 1], imgW, imgH, X.tileY0, X.tileY1, s));
         }
         mark(Device::EV_DENOISE);
         if (!lean) L(launch_compose_post(P, img, cur, false, s));       // a lean frame is composed by direct_kernel<false> itself

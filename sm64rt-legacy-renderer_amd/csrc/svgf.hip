@@ -32,9 +32,9 @@ DEV float grad_z(const float *depth, int x, int y, int w, int h) {
 }
 
 __global__ __launch_bounds__(256) void svgf_variance_kernel(const uint16_t *color, const float *moments, const int32_t *instanceId, const uint16_t *normal,
-                                                            const float *depth, uint16_t *out, int w, int h) {
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
-    if (x >= w || y >= h) return;
+                                                            const float *depth, uint16_t *out, int w, int h, int y0, int y1) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = y0 + blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= w || y >= y1) return;
     const size_t i = (size_t)y * w + x;
     const f4 c = load_rgba16f(color, i);
     float var = 0.0f;
@@ -81,9 +81,9 @@ DEV float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 #define LOG2E 1.44269504088896f
 
 // guide record of every pixel (svgf_variance_kernel fills it for the frame)
-__global__ __launch_bounds__(256) void svgf_guide_kernel(const int32_t *instanceId, const uint16_t *normal, const float *depth, uint4 *guide, int w, int h) {
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
-    if (x >= w || y >= h) return;
+__global__ __launch_bounds__(256) void svgf_guide_kernel(const int32_t *instanceId, const uint16_t *normal, const float *depth, uint4 *guide, int w, int h, int y0, int y1) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = y0 + blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= w || y >= y1) return;
     const size_t i = (size_t)y * w + x;
     const uint2 n = reinterpret_cast<const uint2 *>(normal)[i];
     uint4 g;
@@ -93,11 +93,11 @@ __global__ __launch_bounds__(256) void svgf_guide_kernel(const int32_t *instance
 }
 
 #define ATROUS_ROWS 4
-__global__ __launch_bounds__(256, 3) void svgf_atrous_kernel(const uint2 *__restrict__ in, uint2 *__restrict__ out, const uint4 *__restrict__ guide, int w, int h, int step) {
+__global__ __launch_bounds__(256, 3) void svgf_atrous_kernel(const uint2 *__restrict__ in, uint2 *__restrict__ out, const uint4 *__restrict__ guide, int w, int h, int step, int y0, int y1) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int t = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int yb = (t / step) * (ATROUS_ROWS * step) + (t % step);          // this lane filters rows yb + j*step, j = 0..3
-    if (x >= w || yb >= h) return;
+    const int yb = y0 + (t / step) * (ATROUS_ROWS * step) + (t % step);     // this lane filters rows yb + j*step, j = 0..3, inside [y0, y1)
+    if (x >= w || yb >= y1) return;
 
     f4 c[ATROUS_ROWS]; f3 np[ATROUS_ROWS]; float zp[ATROUS_ROWS], lp[ATROUS_ROWS], kl[ATROUS_ROWS], gzc[ATROUS_ROWS];
     bool live[ATROUS_ROWS];
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256, 3) void svgf_atrous_kernel(const uint2 *__rest
         const int y = yb + j * step;
         live[j] = false; sw[j] = sr[j] = sg[j] = sb[j] = sv[j] = 0.0f;
         c[j] = mk4(0.0f, 0.0f, 0.0f, 0.0f); np[j] = mk3s(0.0f); zp[j] = lp[j] = kl[j] = gzc[j] = 0.0f;
-        if (y >= h) continue;
+        if (y >= y1) continue;
         const size_t i = (size_t)y * w + x;
         c[j] = unpack_rgba16f(in[i]);
         const GuideRec g = unpack_guide(guide[i]);
@@ -201,16 +201,21 @@ __global__ __launch_bounds__(256, 3) void svgf_atrous_kernel(const uint2 *__rest
 
 }  // namespace
 
-hipError_t launch_svgf(const ViewImages &I, int cur, int width, int height, hipStream_t s) {
-    dim3 grid((unsigned)(width + 31) / 32, (unsigned)(height + 7) / 8);
-    hipLaunchKernelGGL(svgf_guide_kernel, grid, dim3(256), 0, s, I.instanceId, I.normal[cur], I.depth[cur], I.svgfGuide, width, height);
-    hipLaunchKernelGGL(svgf_variance_kernel, grid, dim3(256), 0, s, I.indirectLight[cur], I.moments[cur], I.instanceId, I.normal[cur], I.depth[cur], I.filteredIndirect[0], width, height);
+// Rows [y0, y1) are filtered (an image-tile partition passes its rows + SVGF_HALO_ROWS on each side: the five iterations reach
+// 2 * (1 + 2 + 4 + 8 + 16) = 62 rows, the 7x7 variance estimate 3, the depth gradient 1).  Taps may fall outside [y0, y1) but
+// inside the frame: they only reach output rows that are themselves farther than the halo from the rows the device owns.
+hipError_t launch_svgf(const ViewImages &I, int cur, int width, int height, int y0, int y1, hipStream_t s) {
+    if (y1 <= y0) return hipSuccess;
+    const int rows = y1 - y0;
+    dim3 grid((unsigned)(width + 31) / 32, (unsigned)(rows + 7) / 8);
+    hipLaunchKernelGGL(svgf_guide_kernel, grid, dim3(256), 0, s, I.instanceId, I.normal[cur], I.depth[cur], I.svgfGuide, width, height, y0, y1);
+    hipLaunchKernelGGL(svgf_variance_kernel, grid, dim3(256), 0, s, I.indirectLight[cur], I.moments[cur], I.instanceId, I.normal[cur], I.depth[cur], I.filteredIndirect[0], width, height, y0, y1);
     for (int k = 0; k < 5; k++) {
         const int step = 1 << k;
-        const unsigned laneRows = (unsigned)((height + ATROUS_ROWS * step - 1) / (ATROUS_ROWS * step)) * (unsigned)step;     // lanes per column
+        const unsigned laneRows = (unsigned)((rows + ATROUS_ROWS * step - 1) / (ATROUS_ROWS * step)) * (unsigned)step;     // lanes per column
         dim3 agrid((unsigned)(width + 63) / 64, (laneRows + 3) / 4);
         hipLaunchKernelGGL(svgf_atrous_kernel, agrid, dim3(256), 0, s, reinterpret_cast<const uint2 *>(I.filteredIndirect[k % 2]),
-                           reinterpret_cast<uint2 *>(I.filteredIndirect[(k % 2) ^ 1]), I.svgfGuide, width, height, step);
+                           reinterpret_cast<uint2 *>(I.filteredIndirect[(k % 2) ^ 1]), I.svgfGuide, width, height, step, y0, y1);
     }
     return hipGetLastError();
 }

@@ -374,6 +374,10 @@ class Rt64Scene:
     def set_interleave(self, rank, count):
         self.lib.SetDeviceInterleave(self.device, rank, count)
 
+    def set_tile(self, y0, y1):
+        """Contiguous band of rows [y0, y1) (frames with GI + denoiser partition this way: the library adds the filter's halo)."""
+        self.lib.SetDeviceTile(self.device, int(y0), int(y1))
+
     def option(self, key, value):
         return self.lib.SetDeviceOption(self.device, key.encode(), float(value))
 

@@ -82,6 +82,16 @@ def gather_frame(local, height, width, rank, count, group=None, fast=True):
     return None
 
 
+def band_rows(height, count):
+    """Rows of one contiguous band when the frame is cut into `count` bands (the last one may be shorter)."""
+    return (height + count - 1) // count
+
+
+def band_range(height, rank, count):
+    b = band_rows(height, count)
+    return min(rank * b, height), min((rank + 1) * b, height)
+
+
 def strips_per_rank(height, count):
     """Largest number of 16-row strips one rank owns."""
     full = (height + STRIP - 1) // STRIP
@@ -99,24 +109,30 @@ class FrameGatherer:
     `stream` (a torch.cuda.Stream, e.g. the renderer's stream wrapped in torch.cuda.ExternalStream) is the stream the local buffer
     is produced on; None = the current stream / CPU tensors (gloo rehearsal)."""
 
-    def __init__(self, height, width, rank, count, device, group=None, slots=2, stream=None):
+    def __init__(self, height, width, rank, count, device, group=None, slots=2, stream=None, bands=False):
         import torch
         self.height, self.width, self.rank, self.count, self.group, self.stream = height, width, rank, count, group, stream
+        self.bands = bands                          # contiguous bands of band_rows(height, count) rows instead of interleaved strips
         self.k = strips_per_rank(height, count)
         self.strip_elems = STRIP * width * 4
         n = self.k * self.strip_elems
+        if bands:
+            n = band_rows(height, count) * width * 4
         self.locals = [torch.zeros(n, dtype=torch.uint8, device=device) for _ in range(slots)]
         self.work = [None] * slots
         self.frames = [None] * slots
         if rank == 0:
             self.buckets = [torch.empty((count, n), dtype=torch.uint8, device=device) for _ in range(slots)]
-            self.padded = [torch.empty((self.k * count, self.strip_elems), dtype=torch.uint8, device=device) for _ in range(slots)]
+            self.padded = [None if bands else torch.empty((self.k * count, self.strip_elems), dtype=torch.uint8, device=device) for _ in range(slots)]
         self.side = torch.cuda.Stream(device=device) if (stream is not None) else None      # assembly runs beside the renderer's stream
 
     def local(self, slot):
         return self.locals[slot]
 
     def owned_bytes(self):
+        if self.bands:
+            a, b = band_range(self.height, self.rank, self.count)
+            return (b - a) * self.width * 4
         return owned_rows(self.height, self.rank, self.count) * self.width * 4
 
     def submit(self, slot):
@@ -132,8 +148,11 @@ class FrameGatherer:
             ctx = torch.cuda.stream(self.side) if self.side is not None else _Null()
             with ctx:
                 self.work[slot].wait()              # stream-level wait on CUDA tensors, blocking on CPU tensors
-                self.padded[slot].view(self.k, self.count, self.strip_elems).copy_(self.buckets[slot].view(self.count, self.k, self.strip_elems).transpose(0, 1))
-                self.frames[slot] = self.padded[slot].view(-1)[:self.height * self.width * 4].view(self.height, self.width, 4)
+                if self.bands:                      # rank r's band is rows [r*B, (r+1)*B): the bucket, flattened, IS the frame
+                    self.frames[slot] = self.buckets[slot].view(-1)[:self.height * self.width * 4].view(self.height, self.width, 4)
+                else:
+                    self.padded[slot].view(self.k, self.count, self.strip_elems).copy_(self.buckets[slot].view(self.count, self.k, self.strip_elems).transpose(0, 1))
+                    self.frames[slot] = self.padded[slot].view(-1)[:self.height * self.width * 4].view(self.height, self.width, 4)
 
     def wait(self, slot):
         """Before refilling locals[slot]: the collective that reads it (and rank 0's assembly of it) must have run."""

@@ -251,6 +251,34 @@ def test_full_frame_after_lean_frames_sees_a_complete_previous_frame(rt64_lib, s
         s.close(); o.close()
 
 
+def test_band_partition_with_denoiser_halo_equals_the_whole_frame(rt64_lib, sample_data):
+    """Image-tile partition of a GI + SVGF frame: every device renders its band plus the filter's halo and the bands, put
+    together, are bit-identical to the frame one device renders alone -- for the SVGF denoiser and for the reference's Gaussian passes."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    bands = [(0, 70), (70, 131), (131, H)]                       # ragged on purpose: not multiples of the 16-row tiles
+    for mode in (1, 0):
+        whole = sample_scene.Rt64Scene(rt64_lib, sample_data, W, H, hip_device=0)
+        parts = [sample_scene.Rt64Scene(rt64_lib, sample_data, W, H, hip_device=0) for _ in bands]
+        try:
+            for s in [whole] + parts:
+                s.set_view_description(gi_samples=1, denoiser=True)
+                assert s.option("denoiser_mode", mode)
+            for s, (a, b) in zip(parts, bands):
+                s.set_tile(a, b)
+            parts[1].option("count_traversal", 1)
+            for f in range(4):
+                for s in [whole] + parts:
+                    s.draw()
+            for image in (rt64.IMAGE_OUTPUT_RGBA32F, rt64.IMAGE_FINAL_RGBA8, rt64.IMAGE_INDIRECT_LIGHT_FILTERED):
+                full = whole.readback(image)
+                tiled = np.concatenate([s.readback(image) for s in parts], axis=0)
+                assert tiled.shape == full.shape and np.array_equal(tiled, full), (mode, image)
+            assert parts[1].stats().primaryRays == (min(H, 131 + (66 if mode else 5)) - max(0, 70 - (66 if mode else 5))) * W      # band + halo
+        finally:
+            for s in [whole] + parts:
+                s.close()
+
+
 def test_c4_refit_of_updatable_mesh(rt64_lib, sample_data):
     """Per-frame vertex animation of an UPDATABLE mesh (rt64_mesh.cpp:129,149-157): SetMesh with unchanged counts refits the BLAS;
     hits stay bit-identical to the oracle's refit."""

@@ -69,6 +69,19 @@ def _worker(rank, world, init_file, h, w, out_file):
         if rank == 0:
             g.wait(slot)                      # CPU tensors: the collective has completed here
             assert np.array_equal(g.frame(slot).numpy(), shifted)
+    # contiguous bands (frames with GI + denoiser): rank r owns rows [r*B, (r+1)*B), the gathered bucket is the frame itself
+    gb = tiles.FrameGatherer(h, w, rank, world, "cpu", bands=True)
+    a, b = tiles.band_range(h, rank, world)
+    assert gb.owned_bytes() == (b - a) * w * 4 and gb.local(0).numel() == tiles.band_rows(h, world) * w * 4
+    for step in range(3):
+        slot = step % 2
+        gb.wait(slot)
+        shifted = np.roll(frame, step, axis=0)
+        gb.local(slot)[:(b - a) * w * 4] = torch.from_numpy(np.ascontiguousarray(shifted[a:b]).reshape(-1))
+        gb.submit(slot)
+        if rank == 0:
+            gb.wait(slot)
+            assert np.array_equal(gb.frame(slot).numpy(), shifted)
     dist.barrier()
     if rank == 0:
         open(out_file, "w").write("ok")
