@@ -40,7 +40,7 @@ struct BlasHeader {
 
 struct GpuTexture {
     const uint8_t *texels;           // RGBA8, mips packed back to back
-    uint32_t width, height, mips, pad;
+    uint32_t width, height, mips, pow2;  // pow2: width and height are powers of two (every mip then is): wrap / mirror by mask
     uint32_t mipOffset[RT64_MAX_MIPS];   // in texels
 };
 

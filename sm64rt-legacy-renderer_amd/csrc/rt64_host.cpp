@@ -675,7 +675,8 @@ void View::update() {                          // View::update, rt64_view.cpp:10
     for (size_t i = 0; i < nTex; i++) {
         Texture *t = usedTextures[i];
         GpuTexture &g = hTex[i];
-        g.texels = t->texels.ptr; g.width = (uint32_t)t->width; g.height = (uint32_t)t->height; g.mips = (uint32_t)t->mips; g.pad = 0;
+        g.texels = t->texels.ptr; g.width = (uint32_t)t->width; g.height = (uint32_t)t->height; g.mips = (uint32_t)t->mips;
+        g.pow2 = ((t->width & (t->width - 1)) == 0 && (t->height & (t->height - 1)) == 0) ? 1u : 0u;
         memcpy(g.mipOffset, t->mipOffset, sizeof(g.mipOffset));
     }
     if (nLights) memcpy(hLights, scene->lights.data(), lightBytes);
@@ -765,7 +766,7 @@ void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64
     P.width = imgW; P.height = imgH; P.tileY0 = dev->tileY0; P.tileY1 = dev->tileY1; P.stripRank = dev->stripRank; P.stripCount = dev->stripCount;
     P.separatePost = separatePost() ? 1u : 0u;
     memset(&P.background, 0, sizeof(P.background));
-    if (rasterBgEnv.ready) { P.background.texels = background.ptr; P.background.width = (uint32_t)backgroundW; P.background.height = (uint32_t)backgroundH; P.background.mips = 1; }
+    if (rasterBgEnv.ready) { P.background.texels = background.ptr; P.background.width = (uint32_t)backgroundW; P.background.height = (uint32_t)backgroundH; P.background.mips = 1; P.background.pow2 = ((backgroundW & (backgroundW - 1)) == 0 && (backgroundH & (backgroundH - 1)) == 0) ? 1u : 0u; }
     if (P.separatePost) { P.tileY0 = 0; P.tileY1 = imgH; P.stripRank = 0; P.stripCount = 1; }       // device rows are screen rows; the render target has its own height
     P.maxDepthBias = maxDepthBias;
     {   // ComputeSkyPlaneUV (BgSky.hlsli:20-52): the view-only part, once per frame

@@ -13,10 +13,18 @@
 
 // ---- texel store -------------------------------------------------------------------------------------------------
 
-DEV int tex_address(int i, int n, uint32_t mode) {
+// Texel address under the sampler's addressing mode.  POW2 (both sizes of the texture are powers of two -- GpuTexture::pow2, the
+// usual case): wrap / mirror need a mask, not the ~20-instruction integer remainder (same result for every i, negative ones included).
+template <bool POW2> DEV int tex_address(int i, int n, uint32_t mode) {
     if (mode == 2) return i < 0 ? 0 : (i >= n ? n - 1 : i);                 // CLAMP
-    if (mode == 1) { int p = 2 * n, j = i % p; if (j < 0) j += p; return j < n ? j : p - 1 - j; }   // MIRROR
-    int j = i % n; if (j < 0) j += n;                                        // WRAP
+    if (mode == 1) {                                                         // MIRROR
+        const int p = 2 * n;
+        int j;
+        if (POW2) j = i & (p - 1); else { j = i % p; if (j < 0) j += p; }
+        return j < n ? j : p - 1 - j;
+    }
+    if (POW2) return i & (n - 1);                                            // WRAP
+    int j = i % n; if (j < 0) j += n;
     return j;
 }
 
@@ -27,17 +35,18 @@ DEV f4 tex_texel(const GpuTexture &t, uint32_t level, int x, int y, int w) {
     return mk4((float)(v & 0xFF) * k, (float)((v >> 8) & 0xFF) * k, (float)((v >> 16) & 0xFF) * k, (float)(v >> 24) * k);
 }
 
-DEV f4 tex_sample_level(const GpuTexture &t, float u, float v, uint32_t level, uint32_t filter, uint32_t hAddr, uint32_t vAddr) {
+template <bool POW2>
+DEV f4 tex_sample_level_impl(const GpuTexture &t, float u, float v, uint32_t level, uint32_t filter, uint32_t hAddr, uint32_t vAddr) {
     int w = max((int)(t.width >> level), 1), h = max((int)(t.height >> level), 1);
     if (filter == 0) {
-        int x = tex_address((int)floorf(u * (float)w), w, hAddr), y = tex_address((int)floorf(v * (float)h), h, vAddr);
+        int x = tex_address<POW2>((int)floorf(u * (float)w), w, hAddr), y = tex_address<POW2>((int)floorf(v * (float)h), h, vAddr);
         return tex_texel(t, level, x, y, w);
     }
     float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
     float x0f = floorf(x), y0f = floorf(y);
     float fx = x - x0f, fy = y - y0f;
-    int x0 = tex_address((int)x0f, w, hAddr), x1 = tex_address((int)x0f + 1, w, hAddr);
-    int y0 = tex_address((int)y0f, h, vAddr), y1 = tex_address((int)y0f + 1, h, vAddr);
+    int x0 = tex_address<POW2>((int)x0f, w, hAddr), x1 = tex_address<POW2>((int)x0f + 1, w, hAddr);
+    int y0 = tex_address<POW2>((int)y0f, h, vAddr), y1 = tex_address<POW2>((int)y0f + 1, h, vAddr);
     f4 c00 = tex_texel(t, level, x0, y0, w), c10 = tex_texel(t, level, x1, y0, w), c01 = tex_texel(t, level, x0, y1, w), c11 = tex_texel(t, level, x1, y1, w);
     f4 r;
     { float top = c00.x + fx * (c10.x - c00.x), bot = c01.x + fx * (c11.x - c01.x); r.x = top + fy * (bot - top); }
@@ -45,6 +54,9 @@ DEV f4 tex_sample_level(const GpuTexture &t, float u, float v, uint32_t level, u
     { float top = c00.z + fx * (c10.z - c00.z), bot = c01.z + fx * (c11.z - c01.z); r.z = top + fy * (bot - top); }
     { float top = c00.w + fx * (c10.w - c00.w), bot = c01.w + fx * (c11.w - c01.w); r.w = top + fy * (bot - top); }
     return r;
+}
+DEV f4 tex_sample_level(const GpuTexture &t, float u, float v, uint32_t level, uint32_t filter, uint32_t hAddr, uint32_t vAddr) {
+    return t.pow2 ? tex_sample_level_impl<true>(t, u, v, level, filter, hAddr, vAddr) : tex_sample_level_impl<false>(t, u, v, level, filter, hAddr, vAddr);
 }
 
 DEV f4 tex_sample_grad(const GpuTexture &t, float u, float v, f2 ddx, f2 ddy, uint32_t filter, uint32_t hAddr, uint32_t vAddr) {
