@@ -816,11 +816,16 @@ static void sample_linear_wrap(const float *img, int ch, int w, int h, float u, 
         out[k] = top + fy * (bot - top);
     }
 }
-static void pass_post(OScene *s, const OFrameParams *p, int rtW, int rtH, int screenW, int screenH) {
+/* `vp` = viewport (x, y, w, h) and `sc` = scissor (left, top, right, bottom) the full-screen triangle is drawn with: the screen unless
+ * the first ray-traced instance carries its own rectangles (ref:rt64_view.cpp:1258-1271,1624-1626). */
+static void pass_post(OScene *s, const OFrameParams *p, int rtW, int rtH, int screenW, int screenH, const float vp[4], const int sc[4]) {
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < screenH; y++)
         for (int x = 0; x < screenW; x++) {
-            float u = ((float)x + 0.5f) / (float)screenW, v = ((float)y + 0.5f) / (float)screenH;      /* FullScreenVS interpolant at the pixel centre */
+            float cx = (float)x + 0.5f, cy = (float)y + 0.5f;
+            if (x < sc[0] || x >= sc[2] || y < sc[1] || y >= sc[3]) continue;
+            if (!(cx >= vp[0]) || !(cx < vp[0] + vp[2]) || !(cy >= vp[1]) || !(cy < vp[1] + vp[3])) continue;
+            float u = (cx - vp[0]) / vp[2], v = (cy - vp[1]) / vp[3];                                  /* FullScreenVS interpolant at the pixel centre */
             float color[4];
             int blurred = 0;
             if (p->motionBlurStrength > 0.0f && p->motionBlurSamples > 0) {
@@ -858,7 +863,24 @@ int oracle_render(OScene *s, const OFrameParams *pIn, OFrameResult *out) {
     local.width = (int)lroundf((float)screenW * scale); local.height = (int)lroundf((float)screenH * scale);
     if (local.width < 1) local.width = 1;
     if (local.height < 1) local.height = 1;
-    const int separatePost = local.width != screenW || local.height != screenH || (pIn->motionBlurStrength > 0.0f && pIn->motionBlurSamples > 0);
+    int separatePost = local.width != screenW || local.height != screenH || (pIn->motionBlurStrength > 0.0f && pIn->motionBlurSamples > 0);
+    /* Viewport / scissor of the ray-traced content: the rectangles of the first ray-traced instance, when it has any (ref:rt64_view.cpp:1258-1271). */
+    float rtVp[4] = { 0.0f, 0.0f, (float)screenW, (float)screenH };
+    int rtSc[4] = { 0, 0, screenW, screenH }, rtRect = 0;
+    for (int i = 0; i < s->instanceCount; i++) {
+        const OInstanceDesc *d = &s->instances[i];
+        if (!d->mesh || !d->diffuse || !((d->mesh->flags & 0x1) && d->mesh->bvh.count > 0)) continue;
+        if (d->scissorRect[2] > 0 && d->scissorRect[3] > 0) {
+            rtSc[0] = d->scissorRect[0]; rtSc[1] = screenH - d->scissorRect[1] - d->scissorRect[3]; rtSc[2] = d->scissorRect[0] + d->scissorRect[2]; rtSc[3] = screenH - d->scissorRect[1];
+            rtRect = 1;
+        }
+        if (d->viewportRect[2] > 0 && d->viewportRect[3] > 0) {
+            rtVp[0] = (float)d->viewportRect[0]; rtVp[1] = (float)(screenH - d->viewportRect[1] - d->viewportRect[3]); rtVp[2] = (float)d->viewportRect[2]; rtVp[3] = (float)d->viewportRect[3];
+            rtRect = 1;
+        }
+        break;
+    }
+    if (rtRect) separatePost = 1;
     if (separatePost) { local.tileY0 = 0; local.tileY1 = local.height; }       /* the resample reads neighbours: whole frame */
     const OFrameParams *p = &local;
     double t0 = now_s();
@@ -868,6 +890,7 @@ int oracle_render(OScene *s, const OFrameParams *pIn, OFrameResult *out) {
     OShadeCtx ctx;
     update_global_params(s, p, screenW, screenH, &ctx);
     ctx.separatePost = separatePost;
+    ctx.viewportW = rtVp[2]; ctx.viewportH = rtVp[3];                 /* gParams.viewport.zw, ref:rt64_view.cpp:1283-1286 */
     /* Raster instances: everything that is not ray traced, background-flagged ones first (View::update, ref:rt64_view.cpp:1138-1147). */
     int *bgList = (int *)malloc(sizeof(int) * (size_t)(s->instanceCount + 1)), *fgList = (int *)malloc(sizeof(int) * (size_t)(s->instanceCount + 1));
     int bgCount = 0, fgCount = 0;
@@ -905,7 +928,13 @@ int oracle_render(OScene *s, const OFrameParams *pIn, OFrameResult *out) {
         }
         else osvgf_filter(s, p, cur);
         run_pass(s, &ctx, p, cur, 5);
-        if (separatePost) pass_post(s, p, p->width, p->height, screenW, screenH);
+        if (rtRect) {       /* the ray-traced picture covers only its rectangle: cleared buffer + background instances show around it (ref:rt64_view.cpp:1292-1296) */
+            const size_t ns = (size_t)screenW * (size_t)screenH;
+            memset(s->finalRGBA8, 0, ns * 4);
+            for (size_t i = 0; i < ns; i++) s->finalRGBA8[4 * i + 3] = 255;
+            oraster_draw(s, bgList, bgCount, s->finalRGBA8, screenW, screenH, 0, screenH, 1);
+        }
+        if (separatePost) pass_post(s, p, p->width, p->height, screenW, screenH, rtVp, rtSc);
     }
     else {
         const size_t ns = (size_t)screenW * (size_t)screenH;

@@ -942,7 +942,11 @@ __global__ __launch_bounds__(256) void post_process_kernel(FrameParams P, ViewIm
     const int sw = (int)P.resolution[2], sh = (int)P.resolution[3];
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= sw || y >= sh) return;
-    const float u = ((float)x + 0.5f) / (float)sw, v = ((float)y + 0.5f) / (float)sh;       // FullScreenVS interpolant at the pixel centre
+    // viewport + scissor of the full-screen triangle: the screen, or the rectangles of the first ray-traced instance (rt64_view.cpp:1258-1271,1624-1626)
+    const float cx = (float)x + 0.5f, cy = (float)y + 0.5f;
+    if (x < P.rtScissor[0] || x >= P.rtScissor[2] || y < P.rtScissor[1] || y >= P.rtScissor[3]) return;
+    if (!(cx >= P.rtViewport[0]) || !(cx < P.rtViewport[0] + P.rtViewport[2]) || !(cy >= P.rtViewport[1]) || !(cy < P.rtViewport[1] + P.rtViewport[3])) return;
+    const float u = (cx - P.rtViewport[0]) / P.rtViewport[2], v = (cy - P.rtViewport[1]) / P.rtViewport[3];       // FullScreenVS interpolant at the pixel centre
     f4 color; bool blurred = false;
     if (P.motionBlurStrength > 0.0f && P.motionBlurSamples > 0) {
         const f2 fl = sample_flow_linear_wrap(I.flow, P.width, P.height, u, v);

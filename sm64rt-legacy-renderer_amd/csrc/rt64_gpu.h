@@ -111,6 +111,7 @@ struct FrameParams {
     int32_t stripRank, stripCount;       // interleaved 16-row strips inside the range (count 1 = all)
     float maxDepthBias;
     GpuTexture background;               // gBackground: raster background target (screen size RGBA8); texels == nullptr: no background instances
+    float rtViewport[4]; int32_t rtScissor[4];   // rectangle the ray-traced picture is drawn into (x, y, w, h / left, top, right, bottom; screen pixels)
     uint32_t separatePost;               // 1: render size != screen size or motion blur on -> PostProcessPS runs as post_process_kernel
     float skyBase[4];                    // ComputeSkyPlaneUV: base u, base v, 0.25 * ratioDivision, 0.25
     uint32_t lightCount, instanceCount, countTraversal;

@@ -244,7 +244,9 @@ struct View {
     uint32_t frameCount = 0; bool rtSwap = false, skipReprojection = true;
     int imgW = 0, imgH = 0;                   // render size: lround(screen * resolutionScale), rt64_view.cpp:138-139
     int finalW = 0, finalH = 0;               // back buffer = screen size
-    bool separatePost() const { return imgW != finalW || imgH != finalH || (motionBlurStrength > 0.0f && motionBlurSamples > 0); }
+    // rectangle of the ray-traced picture: the first ray-traced instance's scissor / viewport when it has any (rt64_view.cpp:1258-1271)
+    float rtViewport[4] = { 0, 0, 0, 0 }; int rtScissor[4] = { 0, 0, 0, 0 }; bool rtRect = false;
+    bool separatePost() const { return rtRect || imgW != finalW || imgH != finalH || (motionBlurStrength > 0.0f && motionBlurSamples > 0); }
     // device images
     ViewImages img = {};
     std::vector<void *> allocations; uint32_t bounceSamples = 0;
@@ -606,8 +608,6 @@ void View::update() {                          // View::update, rt64_view.cpp:10
         const float scale = resolutionScale > 0.0f ? resolutionScale : 1.0f;
         const int rw = std::max(1, (int)lroundf((float)dev->width * scale)), rh = std::max(1, (int)lroundf((float)dev->height * scale));
         if (imgW != rw || imgH != rh || finalW != dev->width || finalH != dev->height) createImages(rw, rh, dev->width, dev->height);
-        if (separatePost() && (dev->stripCount > 1 || dev->tileY0 != 0 || dev->tileY1 != dev->height))
-            throw std::runtime_error("RT64_DrawDevice: resolutionScale != 1 and motion blur resample across rows; they need the whole frame on one device (no RT64_SetDeviceTile / RT64_SetDeviceInterleave).");
     }
     usedTextures.clear();
     auto textureIndex = [&](Texture *t) -> int {
@@ -626,6 +626,18 @@ void View::update() {                          // View::update, rt64_view.cpp:10
         else if (inst->flags & RT64_INSTANCE_RASTER_BACKGROUND) rasterBg.push_back(ri);
         else rasterFg.push_back(ri);
     }
+    {
+        const int sw = dev->width, sh = dev->height;
+        rtViewport[0] = 0.0f; rtViewport[1] = 0.0f; rtViewport[2] = (float)sw; rtViewport[3] = (float)sh;
+        rtScissor[0] = 0; rtScissor[1] = 0; rtScissor[2] = sw; rtScissor[3] = sh; rtRect = false;
+        if (!rtInstances.empty()) {
+            const Instance *i0 = rtInstances[0].instance;
+            if (i0->scissorRect.w > 0 && i0->scissorRect.h > 0) { rtScissor[0] = i0->scissorRect.x; rtScissor[1] = sh - i0->scissorRect.y - i0->scissorRect.h; rtScissor[2] = i0->scissorRect.x + i0->scissorRect.w; rtScissor[3] = sh - i0->scissorRect.y; rtRect = true; }
+            if (i0->viewportRect.w > 0 && i0->viewportRect.h > 0) { rtViewport[0] = (float)i0->viewportRect.x; rtViewport[1] = (float)(sh - i0->viewportRect.y - i0->viewportRect.h); rtViewport[2] = (float)i0->viewportRect.w; rtViewport[3] = (float)i0->viewportRect.h; rtRect = true; }
+        }
+    }
+    if (separatePost() && (dev->stripCount > 1 || dev->tileY0 != 0 || dev->tileY1 != dev->height))
+        throw std::runtime_error("RT64_DrawDevice: resolutionScale != 1, motion blur and a viewport / scissor on the ray-traced picture resample across rows; they need the whole frame on one device (no RT64_SetDeviceTile / RT64_SetDeviceInterleave).");
     if (usedTextures.size() > 512) throw std::runtime_error("More than 512 textures in one frame (SRV_TEXTURES_MAX).");
 
     // Tables: instances (transforms rt64_view.cpp:348-376, materials :388-410), textures, lights -> one staged upload.
@@ -708,7 +720,7 @@ void View::update() {                          // View::update, rt64_view.cpp:10
         const bool whole = separatePost();                     // the back buffer is screen size; device rows are screen rows
         const int sy0 = whole ? 0 : dev->tileY0, sy1 = whole ? finalH : dev->tileY1;
         prepareRasterList(rasterBg, rasterBgEnv, finalW, finalH, 0, finalH, false);               // gBackground: every rank needs all of it (env-map lookups)
-        prepareRasterList(rtInstances.empty() ? rasterBg : std::vector<RenderInstance>(), rasterBgScreen, finalW, finalH, sy0, sy1, true);
+        prepareRasterList((rtInstances.empty() || rtRect) ? rasterBg : std::vector<RenderInstance>(), rasterBgScreen, finalW, finalH, sy0, sy1, true);
         prepareRasterList(rasterFg, rasterFgScreen, finalW, finalH, sy0, sy1, true);
         if (!rasterBg.empty() && (backgroundW != finalW || backgroundH != finalH)) { background.reserve((size_t)finalW * finalH * 4); backgroundW = finalW; backgroundH = finalH; rasterBgEnv.changed = true; }
         if (rasterBgEnv.ready && rasterBgEnv.changed) {        // gBackground: cleared to 0, drawn without scissors / viewports (rt64_view.cpp:1298-1319)
@@ -752,7 +764,7 @@ void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64
     const float ulen = focal * tanf(fov * 0.5f) * aspect, vlen_ = focal * tanf(fov * 0.5f);
     U = U * ulen; V = V * vlen_;
     P.cameraU[0] = U.x; P.cameraU[1] = U.y; P.cameraU[2] = U.z; P.cameraV[0] = V.x; P.cameraV[1] = V.y; P.cameraV[2] = V.z; P.cameraW[0] = W.x; P.cameraW[1] = W.y; P.cameraW[2] = W.z;
-    P.viewport[0] = 0.0f; P.viewport[1] = 0.0f; P.viewport[2] = (float)dev->width; P.viewport[3] = (float)dev->height;
+    for (int k = 0; k < 4; k++) { P.viewport[k] = rtViewport[k]; P.rtViewport[k] = rtViewport[k]; P.rtScissor[k] = rtScissor[k]; }      // gParams.viewport = rtViewport (rt64_view.cpp:1283-1286)
     P.resolution[0] = (float)imgW; P.resolution[1] = (float)imgH; P.resolution[2] = (float)dev->width; P.resolution[3] = (float)dev->height;
     P.pixelJitter[0] = P.pixelJitter[1] = 0.0f;              // jitter only with an upscaler (:1273-1281)
     P.motionBlurStrength = motionBlurStrength; P.motionBlurSamples = motionBlurSamples;
@@ -877,6 +889,10 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         }
         mark(Device::EV_DENOISE);
         if (!lean) L(launch_compose_post(P, img, cur, false, s));       // a lean frame is composed by direct_kernel<false> itself
+        if (rtRect) {            // the ray-traced picture covers only its rectangle: cleared buffer + background instances show around it (rt64_view.cpp:1292-1296)
+            L(launch_clear_final(P, img, s));
+            drawRasterList(rasterBgScreen, img.final);
+        }
         if (P.separatePost) L(launch_post_process(P, img, s));
     }
     else {

@@ -110,3 +110,19 @@ def test_raster_only_scene_draws_background_then_foreground_on_the_cleared_buffe
     _final_close(got, ref, max_step=1, frac=1e-3)
     assert (ref["final"][..., :3].max(axis=2) > 0).sum() > 200                  # both HUD triangles are on screen
     assert np.array_equal(got["BACKGROUND"][..., 3] > 0, ref["background"][..., 3] > 0)
+
+
+def test_ray_traced_picture_in_the_first_instances_viewport_and_scissor(rt64_lib, sample_data):
+    """The first ray-traced instance's rectangles confine the ray-traced picture (rt64_view.cpp:1258-1271,1624-1626): it is drawn with
+    that viewport (squeezed into it) and scissor; around it the cleared back buffer and the background instances stay visible."""
+    def mod(d):
+        d.instances[1].viewport = (30, 20, 260, 140)             # the sphere: first ray-traced instance in scene order
+        d.instances[1].scissor = (50, 30, 200, 100)
+    got, ref, st = _render_pair(rt64_lib, _variant(sample_data, mod), extra_images=("BACKGROUND",))
+    assert np.array_equal(got["PRIMARY_HIT"], ref["primaryHit"])
+    assert _rmse(got["OUTPUT_RGBA32F"][..., :3], ref["output"][..., :3]) <= 1e-3          # sky UV uses the viewport's aspect (gParams.viewport.zw)
+    _final_close(got, ref)
+    f = ref["final"]
+    inside = np.zeros((H, W), dtype=bool); inside[H - 30 - 100:H - 30, 50:250] = True
+    assert (f[~inside][:, :3].max(axis=1) == 0).mean() > 0.9                             # outside the scissor: cleared buffer (+ the HUD triangles)
+    assert (f[inside][:, :3].max(axis=1) > 0).mean() > 0.99                              # inside: the squeezed picture
