@@ -27,6 +27,7 @@ size_t lbvh_small_lds_bytes(uint32_t n);
 size_t lbvh_large_scratch_bytes(uint32_t n);
 hipError_t lbvh_launch(const LbvhArgs &args, hipStream_t stream);
 hipError_t lbvh_launch_large(const LbvhArgs &args, hipStream_t stream);
+hipError_t lbvh_launch_batch(const LbvhArgs *deviceArgs, uint32_t count, uint32_t maxN, hipStream_t stream);   // one workgroup per tree, n <= LBVH_SMALL_MAX each
 
 // ---- bc7.hip ------------------------------------------------------------------------------------------------------
 // Decode `blocksX * blocksY` BC7 blocks into an RGBA8 image of width x height texels.

@@ -84,8 +84,7 @@ DEV int delta64(const uint32_t *key, const uint32_t *val, int n, int i, int j) {
 }
 
 // LDS carve (uint32 words): keyA[n] valA[n] keyB[n] valB[n] parentLeaf[n] parentNode[n] counters[n] scratch[64]
-__global__ __launch_bounds__(LBVH_THREADS) void lbvh_small_kernel(LbvhArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+DEV void lbvh_small_body(const LbvhArgs &a, uint32_t *lds) {
     const uint32_t n = a.n, tid = threadIdx.x, T = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6;
     uint32_t *keyA = lds, *valA = lds + n, *keyB = lds + 2 * n, *valB = lds + 3 * n;
@@ -272,6 +271,19 @@ __global__ __launch_bounds__(LBVH_THREADS) void lbvh_small_kernel(LbvhArgs a) {
     }
 }
 
+__global__ __launch_bounds__(LBVH_THREADS) void lbvh_small_kernel(LbvhArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    lbvh_small_body(a, lds);
+}
+
+// One workgroup per tree: the meshes a host updated between two frames (RT64_SetMesh records them, RT64_DrawDevice builds them
+// together -- the reference executes its recorded uploads and BLAS builds at the next frame too, rt64_device.cpp:979-983).
+__global__ __launch_bounds__(LBVH_THREADS) void lbvh_small_batch_kernel(const LbvhArgs *args) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const LbvhArgs a = args[blockIdx.x];
+    lbvh_small_body(a, lds);
+}
+
 }  // namespace
 
 size_t lbvh_small_lds_bytes(uint32_t n) { return ((size_t)7 * n + 64) * sizeof(uint32_t); }
@@ -291,6 +303,21 @@ hipError_t lbvh_launch(const LbvhArgs &args, hipStream_t stream) {
         return hipGetLastError();
     }
     return lbvh_launch_large(args, stream);
+}
+
+// `count` trees of at most `maxN` <= LBVH_SMALL_MAX leaves each, argument blocks in device memory.
+hipError_t lbvh_launch_batch(const LbvhArgs *deviceArgs, uint32_t count, uint32_t maxN, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    if (maxN == 0 || maxN > LBVH_SMALL_MAX) return hipErrorInvalidValue;
+    static bool attrSet = false;
+    if (!attrSet) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lbvh_small_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lbvh_small_lds_bytes(LBVH_SMALL_MAX));
+        if (e != hipSuccess) return e;
+        attrSet = true;
+    }
+    const uint32_t threads = maxN >= LBVH_THREADS ? LBVH_THREADS : ((maxN + 63u) / 64u) * 64u;
+    hipLaunchKernelGGL(lbvh_small_batch_kernel, dim3(count), dim3(threads), lbvh_small_lds_bytes(maxN), stream, deviceArgs);
+    return hipGetLastError();
 }
 
 // ---- large trees (n > LBVH_SMALL_MAX) -----------------------------------------------------------------------------------------

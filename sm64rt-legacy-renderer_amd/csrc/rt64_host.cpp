@@ -176,6 +176,25 @@ struct Device {
         }
         return pinned[pool];
     }
+    // Upload ring (pinned): RT64_SetMesh stages its arrays here and queues the copies without waiting; a wrap-around drains the
+    // stream first, so a region is never rewritten while a copy may still read it.
+    uint8_t *ring = nullptr; size_t ringBytes = 0, ringHead = 0;
+    void *ringAlloc(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (bytes > ringBytes) {
+            HIP_CHECK(hipStreamSynchronize(stream));
+            if (ring) hipHostFree(ring);
+            ringBytes = std::max(bytes * 2, (size_t)32 << 20); ringHead = 0;
+            HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ring), ringBytes, hipHostMallocDefault));
+        }
+        if (ringHead + bytes > ringBytes) { HIP_CHECK(hipStreamSynchronize(stream)); ringHead = 0; }
+        void *p = ring + ringHead; ringHead += bytes;
+        return p;
+    }
+    // Meshes whose BLAS has to be (re)built or refitted: recorded by RT64_SetMesh, executed together by flushMeshBuilds() at the
+    // next frame (or before anything else reads a BLAS) -- small trees in ONE launch, one workgroup each.
+    std::vector<Mesh *> dirtyMeshes; DevArray<LbvhArgs> buildArgs;
+    void flushMeshBuilds();
     void draw(int vsyncInterval, float deltaTimeMs);
     float aspect() const { return (float)width / (float)height; }
     // Rows of [tileY0, tileY1) in strips stripRank, stripRank + stripCount, ... (16 rows each).
@@ -207,6 +226,8 @@ struct Mesh {
     DevArray<GpuNode> nodes; DevArray<GpuTri> tris; DevArray<BlasHeader> header;
     DevArray<uint32_t> sortedIndex, morton, leafParent; DevArray<uint8_t> buildScratch;
     uint32_t blasCount = 0;                            // leaves of the current BLAS (0 = none)
+    bool buildPending = false, pendingRefit = false;   // RT64_SetMesh recorded a build / refit that Device::flushMeshBuilds has not run yet
+    ~Mesh();
     uint32_t version = 0;
     std::map<int, std::pair<float, float>> alphaBounds; uint32_t alphaBoundsVersion = 0;
     Mesh(Device *d, int f) : device(d), flags(f) {}
@@ -337,6 +358,7 @@ Device::~Device() {
     for (Scene *s : scenesCopy) delete s;                 // rt64_device.cpp:97-100
     for (auto &ev : events) if (ev) hipEventDestroy(ev);
     for (auto *p : pinned) if (p) hipHostFree(p);
+    if (ring) hipHostFree(ring);
     if (stream) hipStreamDestroy(stream);
 }
 
@@ -416,7 +438,8 @@ void Mesh::set(const void *vertexArray, int vcount, int vstride, const unsigned 
     const size_t vbytes = (size_t)vcount * vstride, ibytes = (size_t)icount * 4;
     hostVertices.assign(static_cast<const uint8_t *>(vertexArray), static_cast<const uint8_t *>(vertexArray) + vbytes);
     vertices.reserve(vbytes); indices.reserve((size_t)icount);
-    uint8_t *stage = static_cast<uint8_t *>(device->staging(vbytes + ibytes));
+    // rt64_mesh.cpp:53,96: the arrays are copied during the call; the device copies are queued behind them on the stream.
+    uint8_t *stage = static_cast<uint8_t *>(device->ringAlloc(vbytes + ibytes));
     memcpy(stage, vertexArray, vbytes); memcpy(stage + vbytes, indexArray, ibytes);
     HIP_CHECK(hipMemcpyAsync(vertices.ptr, stage, vbytes, hipMemcpyHostToDevice, device->stream));
     HIP_CHECK(hipMemcpyAsync(indices.ptr, stage + vbytes, ibytes, hipMemcpyHostToDevice, device->stream));
@@ -426,19 +449,46 @@ void Mesh::set(const void *vertexArray, int vcount, int vstride, const unsigned 
         const uint32_t n = (uint32_t)icount / 3;
         if (n == 0) throw std::runtime_error("RT64_SetMesh: a ray-traced mesh needs at least one triangle.");
         const bool refit = (flags & RT64_MESH_RAYTRACE_UPDATABLE) && sameShape && blasCount == n;   // rt64_mesh.cpp:129,149-157
+        // A refit keeps the topology of the tree that exists (or is about to exist, if its build is still pending).
+        pendingRefit = buildPending ? (pendingRefit && refit) : refit;
         nodes.reserve(std::max<size_t>(n - 1, 1)); tris.reserve(n); header.reserve(1);
         sortedIndex.reserve(n); morton.reserve(n); leafParent.reserve(n);
-        LbvhArgs a = {};
-        a.mode = LBVH_MODE_TRIANGLES; a.refit = refit ? 1 : 0; a.n = n;
-        a.vertices = vertices.ptr; a.vertexStride = (uint32_t)vstride; a.indices = indices.ptr;
-        a.nodes = nodes.ptr; a.tris = tris.ptr; a.header = header.ptr; a.sortedIndex = sortedIndex.ptr; a.morton = morton.ptr; a.leafParent = leafParent.ptr;
-        if (n > LBVH_SMALL_MAX) { buildScratch.reserve(lbvh_large_scratch_bytes(n)); a.scratch = buildScratch.ptr; a.scratchBytes = buildScratch.bytes(); }
-        HIP_CHECK(lbvh_launch(a, device->stream));
+        if (n > LBVH_SMALL_MAX) buildScratch.reserve(lbvh_large_scratch_bytes(n));
         blasCount = n;
+        if (!buildPending) { buildPending = true; device->dirtyMeshes.push_back(this); }
     }
-    // The staging buffer is reused by the next upload: drain the copies (uploads are rare next to frames; the
-    // reference records them on the open command list and executes them at the next preRender, rt64_device.cpp:979-983).
-    HIP_CHECK(hipStreamSynchronize(device->stream));
+}
+
+Mesh::~Mesh() {
+    if (buildPending) { auto &d = device->dirtyMeshes; d.erase(std::remove(d.begin(), d.end(), this), d.end()); }
+}
+
+// The recorded BLAS work of every mesh set since the last frame (the reference executes its upload command list the same way at the
+// next preRender, rt64_device.cpp:979-983).
+void Device::flushMeshBuilds() {
+    if (dirtyMeshes.empty()) return;
+    use();
+    std::vector<LbvhArgs> small; uint32_t maxN = 0;
+    for (Mesh *m : dirtyMeshes) {
+        LbvhArgs a = {};
+        a.mode = LBVH_MODE_TRIANGLES; a.refit = m->pendingRefit ? 1 : 0; a.n = m->blasCount;
+        a.vertices = m->vertices.ptr; a.vertexStride = (uint32_t)m->vertexStride; a.indices = m->indices.ptr;
+        a.nodes = m->nodes.ptr; a.tris = m->tris.ptr; a.header = m->header.ptr; a.sortedIndex = m->sortedIndex.ptr; a.morton = m->morton.ptr; a.leafParent = m->leafParent.ptr;
+        if (a.n > LBVH_SMALL_MAX) { a.scratch = m->buildScratch.ptr; a.scratchBytes = m->buildScratch.bytes(); HIP_CHECK(lbvh_launch_large(a, stream)); }
+        else { small.push_back(a); maxN = std::max(maxN, a.n); }
+        m->buildPending = false; m->pendingRefit = false;
+    }
+    dirtyMeshes.clear();
+    if (small.size() == 1) HIP_CHECK(lbvh_launch(small[0], stream));
+    else if (!small.empty()) {
+        const size_t bytes = small.size() * sizeof(LbvhArgs);
+        buildArgs.reserve(small.size());
+        void *stage = ringAlloc(bytes);
+        memcpy(stage, small.data(), bytes);
+        HIP_CHECK(hipMemcpyAsync(buildArgs.ptr, stage, bytes, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(lbvh_launch_batch(buildArgs.ptr, (uint32_t)small.size(), maxN, stream));
+    }
+    workSinceMark = true;
 }
 
 std::pair<float, float> Mesh::inputAlphaBounds(int offset) {
@@ -931,6 +981,7 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
     if (opt.countTraversal) HIP_CHECK(hipMemsetAsync(counters.ptr, 0, counters.bytes(), stream));
     if (opt.profilePasses) { HIP_CHECK(hipEventRecord(events[EV_BEGIN], stream)); eventAlias[EV_BEGIN] = EV_BEGIN; lastMark = EV_BEGIN; workSinceMark = false; }
     auto tu0 = std::chrono::steady_clock::now();
+    flushMeshBuilds();
     for (Scene *sc : scenes) for (View *v : sc->views) v->update();
     auto tu1 = std::chrono::steady_clock::now();
     for (Scene *sc : scenes) for (View *v : sc->views) v->render();
@@ -1309,6 +1360,7 @@ static size_t accel_readback(Device *dev, int what, uint32_t n, const GpuNode *n
 RT64_EXPORT size_t RT64_ReadbackMeshAccel(RT64_MESH *meshPtr, int what, void *dst, size_t dstBytes) {
     RT64_TRY
     Mesh *m = reinterpret_cast<Mesh *>(meshPtr); if (!m) throw std::runtime_error("RT64_ReadbackMeshAccel: NULL mesh.");
+    m->device->flushMeshBuilds();
     return accel_readback(m->device, what, m->blasCount, m->nodes.ptr, m->tris.ptr, m->sortedIndex.ptr, m->morton.ptr, m->header.ptr, dst, dstBytes);
     RT64_CATCH(0)
 }

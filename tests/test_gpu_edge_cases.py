@@ -149,3 +149,57 @@ def test_destroying_an_instance_and_a_view_between_frames(rt64_lib, sample_data)
     finally:
         o.close()
     assert np.array_equal(hit, ref["primaryHit"]) and set(np.unique(ids)) == {-1, 0}
+
+
+def test_many_meshes_set_between_frames_build_in_one_batch(rt64_lib, sample_data):
+    """RT64_SetMesh records the BLAS work, RT64_DrawDevice runs it for all meshes together (one workgroup per small tree, large trees on
+    the multi-kernel path); a mesh set twice before a frame, refits of UPDATABLE meshes and rebuilds after a size change all end in the
+    tree the oracle builds."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    from oracle import oracle_py
+    rng = np.random.default_rng(3)
+
+    def blob(cx, cz, n_tri, r=0.35):
+        v = np.zeros(3 * n_tri, dtype=sample_scene.VERTEX_DTYPE)
+        c = np.array([cx, 0.6, cz]) + rng.normal(0, r, size=(n_tri, 1, 3))
+        p = c + rng.normal(0, 0.12, size=(n_tri, 3, 3))
+        v["position"][:, :3] = p.reshape(-1, 3).astype(np.float32); v["position"][:, 3] = 1.0
+        v["normal"] = (0.0, 1.0, 0.0); v["input1"] = 1.0; v["uv"] = rng.random((3 * n_tri, 2)).astype(np.float32)
+        return v, np.arange(3 * n_tri, dtype=np.uint32)
+
+    def mod(d):
+        sizes = [1, 2, 7, 64, 300, 1024, 1500, 4096, 5000] + [int(x) for x in rng.integers(3, 200, size=24)]
+        for k, n in enumerate(sizes):
+            v, i = blob(-6.0 + 1.5 * (k % 9), -2.0 + 1.5 * (k // 9), n)
+            d.meshes.append(sample_scene.MeshData("blob%d" % k, rt64.MESH_RAYTRACE_ENABLED | (rt64.MESH_RAYTRACE_UPDATABLE if k % 2 else 0), v, i))
+            inst = copy.copy(d.instances[1]); inst.mesh = len(d.meshes) - 1; inst.material = sample_scene.copy_material(d.instances[1].material)
+            inst.name = "blob%d" % k; inst.flags = 2
+            d.instances.append(inst)
+    data = _variant(sample_data, mod)
+    s = sample_scene.Rt64Scene(rt64_lib, data, 160, 90, hip_device=0)
+    o = oracle_py.OracleScene(data)
+    try:
+        s.option("count_traversal", 1)
+        first = len(sample_data.meshes)
+        for frame in range(3):
+            for k in range(first, len(data.meshes)):
+                m = data.meshes[k]
+                if frame == 0:
+                    continue
+                v = m.vertices.copy()
+                if (k + frame) % 3 == 0:                                   # same shape: refit when UPDATABLE, rebuild otherwise
+                    v["position"][:, 1] += np.float32(0.05 * frame)
+                    s.set_mesh(s.meshes[k], v, m.indices); o.set_mesh(o.meshes[k], v, m.indices)
+                elif (k + frame) % 3 == 1 and len(m.indices) >= 6:        # fewer triangles: rebuild; set twice before the frame
+                    keep = (len(m.indices) // 3 - 1) * 3
+                    s.set_mesh(s.meshes[k], v, m.indices); o.set_mesh(o.meshes[k], v, m.indices)
+                    s.set_mesh(s.meshes[k], v[:keep], m.indices[:keep]); o.set_mesh(o.meshes[k], v[:keep], m.indices[:keep])
+            s.draw()
+            ref = o.render(160, 90)
+        hit = s.readback(rt64.IMAGE_PRIMARY_HIT)
+        st = s.stats()
+        assert np.array_equal(hit, ref["primaryHit"])
+        assert (st.nodesVisited, st.trianglesTested) == (ref["counters"]["nodesVisited"], ref["counters"]["trianglesTested"])
+        assert len(np.unique(s.readback(rt64.IMAGE_INSTANCE_ID))) > 12
+    finally:
+        s.close(); o.close()
