@@ -41,6 +41,12 @@ for mode, flagmask in (("refit (UPDATABLE, same shape)", None), ("rebuild (verte
         t2 = time.perf_counter()
         t_set += t1 - t0; t_draw += t2 - t1
     st = scene.stats()
-    print("%d meshes x %d triangles, %s: SetMesh calls %.3f ms/frame, DrawDevice %.3f ms/frame (GPU %.3f ms, of which builds %.3f ms)" % (
-        M, T, mode, t_set * 1e3 / K, t_draw * 1e3 / K, st.msTotal, st.msBuild))
+    print("%d meshes x %d triangles, %s: SetMesh calls %.3f ms/frame, DrawDevice %.3f ms/frame (GPU %.3f ms: builds %.3f, trace %.3f, shade %.3f, direct %.3f)" % (
+        M, T, mode, t_set * 1e3 / K, t_draw * 1e3 / K, st.msTotal, st.msBuild, st.msPrimaryTrace, st.msPrimaryShade, st.msDirect))
+scene.option("count_traversal", 1); scene.draw(); st = scene.stats()
+print("static frame: nodes/primary ray %.2f, tris/primary ray %.2f, nodes/shadow ray %.2f; lean %d" % (st.nodesPrimary / max(st.primaryRays, 1), st.trianglesPrimary / max(st.primaryRays, 1), st.nodesDirect / max(st.shadowRays, 1), st.leanFrame))
+scene.option("count_traversal", 0)
+for _ in range(3): scene.draw()
+st = scene.stats()
+print("static frame (tables cached): GPU %.3f ms: build %.3f trace %.3f shade %.3f direct %.3f" % (st.msTotal, st.msBuild, st.msPrimaryTrace, st.msPrimaryShade, st.msDirect))
 scene.close()
