@@ -223,12 +223,11 @@ def main():
         acc["indirect"] += s.msIndirect; acc["compose"] += s.msComposePost; acc["build"] += s.msBuild; acc["total"] += s.msTotal
         acc["denoise"] += s.msDenoise; acc["reflect"] += s.msReflectRefract
     barrier()
+    scene.option("reset_accum", 1)   # the library sums the HIP-event timings of every frame from here on; read once after the loop
     t0 = time.perf_counter()
     last_slot = None
     for _ in range(args.steps):
         last_slot = step()
-        if not G:
-            add_stats()              # HIP-event timings of the frame that just finished (the frame is synchronous at N = 1)
     enqueue_ms = (time.perf_counter() - t0) * 1e3 / args.steps      # host time per step before the closing barrier (= frame time when frames are synchronous)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -236,6 +235,11 @@ def main():
     gathered_checksum = None
     if G and rank == 0:              # the frame assembled on rank 0 by the gather of the last timed step
         gathered_checksum = int(gatherer.frame(last_slot).to(torch.int64).sum().item())
+    if not G:                        # N = 1: every timed frame was measured live with HIP events inside the library
+        s = scene.stats()
+        assert s.accumFrames == args.steps, (s.accumFrames, args.steps)
+        acc.update(trace=s.accumMsPrimaryTrace, shade=s.accumMsPrimaryShade, direct=s.accumMsDirect, indirect=s.accumMsIndirect, compose=s.accumMsComposePost,
+                   build=s.accumMsBuild, total=s.accumMsTotal, denoise=s.accumMsDenoise, reflect=s.accumMsReflectRefract)
     if G:                            # per-kernel timings of this rank's strips from a few untimed frames (reading them synchronises)
         stat_frames = 10
         for _ in range(stat_frames):

@@ -359,6 +359,10 @@ typedef struct {
     /* per-pass split of nodesVisited / trianglesTested (count_traversal = 1) */
     unsigned long long nodesPrimary, trianglesPrimary, nodesDirect, trianglesDirect, nodesIndirect, trianglesIndirect;
     unsigned int screenWidth, screenHeight; /* back-buffer size; width/height above are the render size (screen x RT64_VIEW_DESC.resolutionScale) */
+    /* Sums of the per-frame timings above over every frame since RT64_SetDeviceOption("reset_accum", 1): a host that times many
+       frames reads them once instead of calling RT64_GetDeviceStats inside its frame loop. */
+    unsigned int accumFrames;
+    float accumMsTotal, accumMsBuild, accumMsPrimaryTrace, accumMsPrimaryShade, accumMsDirect, accumMsIndirect, accumMsReflectRefract, accumMsDenoise, accumMsComposePost;
 } RT64_FRAME_STATS;
 
 #define RT64_EXT_API_LIST(X) \

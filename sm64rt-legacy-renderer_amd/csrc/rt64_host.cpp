@@ -150,7 +150,7 @@ struct Device {
     int stripRank = 0, stripCount = 1;
     std::vector<Scene *> scenes;
     Options opt;
-    RT64_FRAME_STATS stats = {}; bool statsPending = false, statsHaveView = false;
+    RT64_FRAME_STATS stats = {}, accum = {}; bool statsPending = false, statsHaveView = false;
     double hostUpdateUs = 0.0, hostRenderUs = 0.0, hostStageUs[16] = {}, hostEventUs = 0.0; unsigned long long hostFrames = 0;      // host-side cost of View::update / View::render (RT64_HOST_TIMING=1 prints them)
     void finishStats();
     DevArray<uint32_t> spillStack;
@@ -1034,7 +1034,13 @@ void Device::finishStats() {
         st.msPrimaryTrace = ms(EV_BUILD, EV_PRIMARY_TRACE); st.msPrimaryShade = ms(EV_PRIMARY_TRACE, EV_PRIMARY);
         st.msDirect = ms(EV_PRIMARY, EV_DIRECT); st.msIndirect = ms(EV_DIRECT, EV_INDIRECT); st.msReflectRefract = ms(EV_INDIRECT, EV_REFL);
         st.msDenoise = ms(EV_REFL, EV_DENOISE); st.msComposePost = ms(EV_DENOISE, EV_END);
+        accum.accumFrames++; accum.accumMsTotal += st.msTotal; accum.accumMsBuild += st.msBuild; accum.accumMsPrimaryTrace += st.msPrimaryTrace;
+        accum.accumMsPrimaryShade += st.msPrimaryShade; accum.accumMsDirect += st.msDirect; accum.accumMsIndirect += st.msIndirect;
+        accum.accumMsReflectRefract += st.msReflectRefract; accum.accumMsDenoise += st.msDenoise; accum.accumMsComposePost += st.msComposePost;
     }
+    st.accumFrames = accum.accumFrames; st.accumMsTotal = accum.accumMsTotal; st.accumMsBuild = accum.accumMsBuild; st.accumMsPrimaryTrace = accum.accumMsPrimaryTrace;
+    st.accumMsPrimaryShade = accum.accumMsPrimaryShade; st.accumMsDirect = accum.accumMsDirect; st.accumMsIndirect = accum.accumMsIndirect;
+    st.accumMsReflectRefract = accum.accumMsReflectRefract; st.accumMsDenoise = accum.accumMsDenoise; st.accumMsComposePost = accum.accumMsComposePost;
     if (opt.countTraversal) {
         unsigned long long c[CTR_COUNT];
         HIP_CHECK(hipMemcpy(c, counters.ptr, sizeof(c), hipMemcpyDeviceToHost));
@@ -1228,6 +1234,7 @@ RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, doubl
     else if (k == "denoiser_mode") d->opt.denoiserMode = (int)value;
     else if (k == "bounce_refill") d->opt.bounceRefill = (int)value;
     else if (k == "spin_present") d->opt.spinPresent = value != 0.0;
+    else if (k == "reset_accum") { d->finishStats(); d->accum = RT64_FRAME_STATS(); }
     else if (k == "lean_frames") d->opt.leanFrames = value != 0.0;                // 0: always write every image of the reference's G-buffer
     else if (k == "always_rebuild") d->opt.alwaysRebuild = value != 0.0;          // upload tables + rebuild the TLAS every frame like the reference
     else if (k == "max_reflections") d->opt.maxReflections = std::max(0, (int)value);

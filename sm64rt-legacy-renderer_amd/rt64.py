@@ -131,7 +131,10 @@ class FRAME_STATS(C.Structure):
                 ("stripRank", C.c_uint), ("stripCount", C.c_uint), ("rowsRendered", C.c_uint), ("leanFrame", C.c_uint),
                 ("nodesPrimary", C.c_ulonglong), ("trianglesPrimary", C.c_ulonglong), ("nodesDirect", C.c_ulonglong),
                 ("trianglesDirect", C.c_ulonglong), ("nodesIndirect", C.c_ulonglong), ("trianglesIndirect", C.c_ulonglong),
-                ("screenWidth", C.c_uint), ("screenHeight", C.c_uint)]
+                ("screenWidth", C.c_uint), ("screenHeight", C.c_uint), ("accumFrames", C.c_uint),
+                ("accumMsTotal", C.c_float), ("accumMsBuild", C.c_float), ("accumMsPrimaryTrace", C.c_float), ("accumMsPrimaryShade", C.c_float),
+                ("accumMsDirect", C.c_float), ("accumMsIndirect", C.c_float), ("accumMsReflectRefract", C.c_float), ("accumMsDenoise", C.c_float),
+                ("accumMsComposePost", C.c_float)]
 
 
 assert C.sizeof(MATERIAL) == 132 and C.sizeof(LIGHT) == 60 and C.sizeof(SCENE_DESC) == 84
