@@ -27,6 +27,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+HBM_TRIAD_GBS = 4689.0         # measured on the box with tools/micro/triad.hip (stream triad, 3 x 1 GiB; device-to-device copy: 5146 GB/s)
 
 # Algorithmic bytes (DESIGN.md "Kernels and rooflines"): a BVH node record is 64 B, a triangle record 48 B.
 NODE_B, TRI_B = 64, 48
@@ -286,6 +287,7 @@ def main():
                 traffic = None
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "measured_triad_GBps": HBM_TRIAD_GBS, "frac_of_triad": round(achieved / HBM_TRIAD_GBS, 4),
                     "algorithmic_bytes_per_launch": int(d_bytes), "ms_per_launch": round(d_ms, 5),
                     "kernels": {k: {"ms": round(v[0], 5), "alg_bytes": int(v[1]), "GBps": round(v[1] / (v[0] * 1e-3) / 1e9, 2) if v[0] > 0 else 0.0} for k, v in kernels.items()},
                     "lean_frame": lean, "frame_gpu_ms": round(kms["total"], 5), "build_ms": round(kms["build"], 5),
@@ -337,9 +339,14 @@ def cpu_baseline(data, W, H, rows):
             rays += c["primaryRays"] + c["shadowRays"] + c["indirectRays"]
             secs += c["secondsRender"]; build += c["secondsBuild"]; frames += 1
         dt = time.perf_counter() - t0
+        cpu = "unknown CPU"
+        try:
+            cpu = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+        except Exception:
+            pass
         return {"value": round(rays / secs / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-                "sample": "%d frames of the same C2 workload at %dx%d (%d rows), %d rays, %.2f s render + %.3f s BVH build" % (
-                    frames, W, H, (tile[1] if tile else H), rays, secs, build),
+                "sample": "%d frames of the same C2 workload at %dx%d (%d rows), %d rays, %.2f s render + %.3f s BVH build; %d OpenMP threads on %s (%d logical CPUs)" % (
+                    frames, W, H, (tile[1] if tile else H), rays, secs, build, threads, cpu, os.cpu_count() or 0),
                 "ms_per_frame": round(dt * 1e3 / frames, 1)}
     finally:
         ora.close()
