@@ -509,6 +509,8 @@ DEV f3 compute_lights_random(const FrameParams &P, ShadeEnv &env, uint32_t px, u
             if (li > RT_EPSILON) { sInt[sCount * RT_BLOCK] = li; sIdx[sCount * RT_BLOCK] = (uint8_t)l; total += li; sCount++; }
         }
     }
+    if (sCount == 1 && maxLightCount >= 1)       // one candidate: it is chosen whatever the random number is, with probability 1 (randomRange / cInt = total / total)
+        return compute_light(P, env, px, py, sIdx[0], rayDirection, m, position, normal, specular, checkShadows);
     float randomRange = total;
     uint32_t lCount = sCount < maxLightCount ? sCount : maxLightCount;
     bool useProbability = lCount == 1;
