@@ -507,12 +507,45 @@ __global__ __launch_bounds__(RT_BLOCK, 3) void indirect_kernel(FrameParams P, Vi
 // The one-kernel form above (bounce traversal + any-hit + texturing + light pick + shadow traversal) is 71 KB of code at 237
 // VGPRs: it overflows the 64 KB instruction cache two CUs share and runs at 2 waves/SIMD.  When every instance is provably opaque
 // (rule O1: the hit list degenerates to the closest hit) the pass splits like the primary pass does:
-//   bounce_trace_kernel  : bounce direction + closest-hit traversal only -> 32-byte record per (sample, pixel)
-//                          { t, u, v, primitive | dir.xyz, instance }
-//   bounce_shade_kernel  : surface any-hit on the recorded hit, sky, light pick + shadow ray, temporal accumulation, moments.
-// Same arithmetic in the same order as indirect_kernel<false>; the records only carry values across the launch boundary.
+//   bounce_trace_{plain,refill}_kernel : bounce direction + closest-hit traversal only -> 32-byte record per (sample, pixel)
+//                          { t, u, v, primitive | dir.xyz, instance }, ray ids compacted into hit / miss lists (wave ballot)
+//   bounce_hit_kernel / bounce_miss_kernel : sample radiance of the listed rays (surface any-hit + light pick + shadow ray / sky)
+//   bounce_resolve_kernel : per pixel: temporal accumulation over the samples, moments, stores.
+// Same arithmetic in the same order as indirect_kernel<false>; records and results only carry values across launch boundaries.
+// Wave-ballot compaction of the bounce rays by outcome: every traced ray appends its id (sample * pixels + pixel) to the hit list or
+// to the miss list of ITS WORKGROUP (a private segment of the list arrays): one LDS atomic per wave and list, rank inside the ballot
+// gives the slot, no global atomics (two chip-wide counters saturate at ~90 appends/us).  The shading kernels below run with the same
+// grid, workgroup b on the segments of workgroup b: lanes that shade a surface and trace a shadow ray are no longer interleaved with
+// lanes that only look up the sky (the one-kernel form ran at 30 % VALU lane utilisation).
+struct BounceSegments { uint32_t perBlock; };        // list entries reserved per workgroup and list
+DEV uint32_t bounce_segment_size(const FrameParams &P) {
+    const uint32_t tiles = tile_count(P);
+    return ((tiles + gridDim.x - 1) / gridDim.x) * RT_BLOCK * P.giSamples;
+}
+// called by the lanes that hold a finished ray (any subset of the wave); ldsCount = the workgroup's two running counts
+DEV void bounce_append(const ViewImages &I, uint32_t *ldsCount, uint32_t segment, size_t missBase, bool hit, uint32_t id) {
+    const unsigned long long hm = __ballot(hit), mm = __ballot(!hit);
+    const uint32_t lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)(hm | mm)) - 1;
+    uint32_t hbase = 0, mbase = 0;
+    if ((int)lane == leader) {
+        if (hm) hbase = atomicAdd(&ldsCount[0], (uint32_t)__popcll(hm));
+        if (mm) mbase = atomicAdd(&ldsCount[1], (uint32_t)__popcll(mm));
+    }
+    hbase = __shfl(hbase, leader, 64); mbase = __shfl(mbase, leader, 64);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const size_t seg = (size_t)blockIdx.x * segment;
+    if (hit) I.bounceLists[seg + hbase + (uint32_t)__popcll(hm & below)] = id;
+    else I.bounceLists[missBase + seg + mbase + (uint32_t)__popcll(mm & below)] = id;
+}
+DEV size_t bounce_miss_base(const FrameParams &P, uint32_t segment) { return (size_t)gridDim.x * segment; }
+
 __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kernel(FrameParams P, ViewImages I) {
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
+    __shared__ uint32_t ldsCount[2];
+    if (threadIdx.x < 2) ldsCount[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t segment = bounce_segment_size(P); const size_t missBase = bounce_miss_base(P, segment);
     ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
     env.lightIntensity = nullptr; env.lightIndex = nullptr;
     uint32_t rays = 0;
@@ -539,8 +572,11 @@ __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kern
             b.w = best.hit ? best.instance : 0xFFFFFFFFu;
             uint4 *rec = I.bounceRecords + ((size_t)(smp - 1) * stride + i) * 2;
             rec[0] = a; rec[1] = b;
+            bounce_append(I, ldsCount, segment, missBase, best.hit, (uint32_t)((size_t)(smp - 1) * stride + i));
         }
     }
+    __syncthreads();
+    if (threadIdx.x < 2) I.bounceCounts[2 * blockIdx.x + threadIdx.x] = ldsCount[threadIdx.x];
     flush_env(P, env, PASS_INDIRECT, CTR_INDIRECT, rays);
 }
 
@@ -551,6 +587,10 @@ __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kern
 #define BOUNCE_MIN_LIVE 40
 __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_refill_kernel(FrameParams P, ViewImages I) {
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
+    __shared__ uint32_t ldsCount[2];
+    if (threadIdx.x < 2) ldsCount[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t segment = bounce_segment_size(P); const size_t missBase = bounce_miss_base(P, segment);
     ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
     env.lightIntensity = nullptr; env.lightIndex = nullptr;
     uint32_t rays = 0;
@@ -571,6 +611,7 @@ __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_refill_ker
             b.x = __float_as_uint(rayDirection.x); b.y = __float_as_uint(rayDirection.y); b.z = __float_as_uint(rayDirection.z);
             b.w = best.hit ? best.instance : 0xFFFFFFFFu;
             I.bounceRecords[recIndex] = a; I.bounceRecords[recIndex + 1] = b;
+            bounce_append(I, ldsCount, segment, missBase, best.hit, (uint32_t)(recIndex / 2));
             holding = false;
         }
         while (next < end) {
@@ -608,10 +649,23 @@ __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_refill_ker
                          return false;
                      }, env.cnt, next < end);
     }
+    __syncthreads();
+    if (threadIdx.x < 2) I.bounceCounts[2 * blockIdx.x + threadIdx.x] = ldsCount[threadIdx.x];
     flush_env(P, env, PASS_INDIRECT, CTR_INDIRECT, rays);
 }
 
-__global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void bounce_shade_kernel(FrameParams P, ViewImages I, int cur, int writeFiltered) {
+// ---- IndirectRayGen shading on the compacted lists ---------------------------------------------------------------------------------
+// bounce_hit_kernel   : one list entry per lane: surface any-hit on the recorded hit, light pick + shadow ray -> sample radiance
+// bounce_miss_kernel  : one list entry per lane: sky / background environment lookup                          -> sample radiance
+// bounce_resolve_kernel: per pixel, samples in the reference's order: temporal accumulation, luminance moments, stores.
+// Per-sample arithmetic and its order are those of indirect_kernel<false>.
+DEV f3 bounce_sky_term(const FrameParams &P, f3 rayDirection) {
+    f3 bgColor = sample_background_envmap(P, rayDirection);
+    f4 sky = sample_sky_plane(P, rayDirection);
+    return lerp3(bgColor, xyz(sky), sky.w);
+}
+
+__global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void bounce_hit_kernel(FrameParams P, ViewImages I) {
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -619,70 +673,90 @@ __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void bounce_shade_kernel(Fr
     env.lightIntensity = ldsLightIntensity + threadIdx.x; env.lightIndex = ldsLightIndex + threadIdx.x;
     const f3 ambientBase = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]);
     const f3 ambient = ambientBase + mk3(P.ambientNoGIColor[0], P.ambientNoGIColor[1], P.ambientNoGIColor[2]);
-    const size_t stride = (size_t)P.width * (size_t)P.height;
-    const uint32_t tiles = tile_count(P);
-    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        Pixel p = tile_pixel(P, tile);
-        if (!p.valid) continue;
-        const uint32_t px = p.x, py = p.y;
-        const size_t i = (size_t)py * (size_t)P.width + px;
-        if (I.instanceId[i] < 0) {
-            store_rgba16f(I.indirectLight[cur], i, ambient.x, ambient.y, ambient.z, 0.0f);
-            reinterpret_cast<float2 *>(I.moments[cur])[i] = make_float2(0.0f, 0.0f);
-            if (writeFiltered) store_rgba16f(I.filteredIndirect[1], i, ambient.x, ambient.y, ambient.z, 0.0f);
-            continue;
-        }
+    const uint32_t stride = (uint32_t)P.width * (uint32_t)P.height;
+    const uint32_t segment = bounce_segment_size(P), n = I.bounceCounts[2 * blockIdx.x];      // the segment bounce_trace's workgroup blockIdx.x filled
+    for (uint32_t e = threadIdx.x; e < n; e += RT_BLOCK) {
+        const uint32_t id = I.bounceLists[(size_t)blockIdx.x * segment + e], i = id % stride;
+        const uint32_t px = i % (uint32_t)P.width, py = i / (uint32_t)P.width;
+        const uint4 a = I.bounceRecords[(size_t)id * 2], b = I.bounceRecords[(size_t)id * 2 + 1];
+        const f3 rayDirection = mk3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
         const float4 pos4 = reinterpret_cast<const float4 *>(I.shadingPosition)[i];
-        const f3 rayOrigin = mk3(pos4.x, pos4.y, pos4.z), shadingNormal = xyz(load_rgba16f(I.shadingNormal, i));
-        f3 newIndirect = mk3s(0.0f); float historyLength = 0.0f;
-        float2 prevM = make_float2(0.0f, 0.0f); float sumL = 0.0f, sumL2 = 0.0f;
-        if (P.giReproject) {
-            long j; float w = history_weight(P, I, i, px, py, shadingNormal, cur, j);
-            f4 prevAccum = j >= 0 ? load_rgba16f(I.indirectLight[cur ^ 1], (size_t)j) : mk4(0, 0, 0, 0);
-            if (j >= 0) prevM = reinterpret_cast<const float2 *>(I.moments[cur ^ 1])[j];
-            newIndirect = xyz(prevAccum); historyLength = prevAccum.w * w;
-        }
-        for (uint32_t smp = P.giSamples; smp > 0; smp--) {
-            const uint4 *rec = I.bounceRecords + ((size_t)(smp - 1) * stride + i) * 2;
-            const uint4 a = rec[0], b = rec[1];
-            const f3 rayDirection = mk3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
-            RayDiff rd; rd.dOdx = rd.dOdy = rd.dDdx = rd.dDdy = mk3s(0.0f);
-            f3 bgColor = sample_background_envmap(P, rayDirection);
-            f4 sky = sample_sky_plane(P, rayDirection);
-            bgColor = lerp3(bgColor, xyz(sky), sky.w);
-            f3 resPosition = mk3s(0.0f), resNormal = mk3s(0.0f), resSpecular = mk3s(0.0f); f4 resColor = mk4(0, 0, 0, 1); int resInstanceId = -1;
-            HitRecord r;
-            if (b.w != 0xFFFFFFFFu && surface_anyhit(P, b.w, a.w, __uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), rayDirection, rd, px, py, r)) {
-                f4 hitColor = r.color;
-                float alphaContrib = resColor.w * hitColor.w;
-                if (alphaContrib >= RT_EPSILON) {
-                    const RT64_MATERIAL &m = P.instances[r.instanceId].material;
-                    resPosition = rayOrigin + rayDirection * (r.dist + m.depthBias);
-                    resNormal = r.normal; resSpecular = ld_v3(m.specularColor) * r.specular;
-                    resColor.x += hitColor.x * alphaContrib; resColor.y += hitColor.y * alphaContrib; resColor.z += hitColor.z * alphaContrib;
-                    resColor.w *= (1.0f - hitColor.w);
-                    resInstanceId = (int)r.instanceId;
-                }
+        const f3 rayOrigin = mk3(pos4.x, pos4.y, pos4.z);
+        RayDiff rd; rd.dOdx = rd.dOdy = rd.dDdx = rd.dDdy = mk3s(0.0f);
+        f3 resPosition = mk3s(0.0f), resNormal = mk3s(0.0f), resSpecular = mk3s(0.0f); f4 resColor = mk4(0, 0, 0, 1); int resInstanceId = -1;
+        HitRecord r;
+        if (surface_anyhit(P, b.w, a.w, __uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), rayDirection, rd, px, py, r)) {
+            f4 hitColor = r.color;
+            float alphaContrib = resColor.w * hitColor.w;
+            if (alphaContrib >= RT_EPSILON) {
+                const RT64_MATERIAL &m = P.instances[r.instanceId].material;
+                resPosition = rayOrigin + rayDirection * (r.dist + m.depthBias);
+                resNormal = r.normal; resSpecular = ld_v3(m.specularColor) * r.specular;
+                resColor.x += hitColor.x * alphaContrib; resColor.y += hitColor.y * alphaContrib; resColor.z += hitColor.z * alphaContrib;
+                resColor.w *= (1.0f - hitColor.w);
+                resInstanceId = (int)r.instanceId;
             }
-            f3 resIndirect = ambientBase;
-            if (resInstanceId >= 0) {
-                f3 directLight = compute_lights_random(P, env, px, py, rayDirection, (uint32_t)resInstanceId, resPosition, resNormal, resSpecular, 1, true) + ld_v3(P.instances[resInstanceId].material.selfLight);
-                f3 indirectLight = ((xyz(resColor) * (1.0f - resColor.w)) * (ambient + directLight)) * P.giDiffuseStrength;
-                resIndirect = resIndirect + indirectLight;
-            }
-            resIndirect = resIndirect + bgColor * (P.giSkyStrength * resColor.w);
-            historyLength = fminf(historyLength + 1.0f, 64.0f);
-            newIndirect = lerp3(newIndirect, resIndirect, s_rcp(historyLength));
-            { const float l = 0.2126f * resIndirect.x + 0.7152f * resIndirect.y + 0.0722f * resIndirect.z; sumL += l; sumL2 += l * l; }
         }
-        store_rgba16f(I.indirectLight[cur], i, newIndirect.x, newIndirect.y, newIndirect.z, historyLength);
-        {
-            const float nS = (float)P.giSamples, alphaM = fminf(nS / historyLength, 1.0f);
-            reinterpret_cast<float2 *>(I.moments[cur])[i] = make_float2(lerpf(prevM.x, sumL / nS, alphaM), lerpf(prevM.y, sumL2 / nS, alphaM));
+        f3 resIndirect = ambientBase;
+        if (resInstanceId >= 0) {
+            f3 directLight = compute_lights_random(P, env, px, py, rayDirection, (uint32_t)resInstanceId, resPosition, resNormal, resSpecular, 1, true) + ld_v3(P.instances[resInstanceId].material.selfLight);
+            f3 indirectLight = ((xyz(resColor) * (1.0f - resColor.w)) * (ambient + directLight)) * P.giDiffuseStrength;
+            resIndirect = resIndirect + indirectLight;
         }
-        if (writeFiltered) store_rgba16f(I.filteredIndirect[1], i, newIndirect.x, newIndirect.y, newIndirect.z, historyLength);
+        if (resColor.w != 0.0f) resIndirect = resIndirect + bounce_sky_term(P, rayDirection) * (P.giSkyStrength * resColor.w);
+        else resIndirect = resIndirect + mk3s(0.0f) * (P.giSkyStrength * resColor.w);
+        I.bounceResults[id] = make_float4(resIndirect.x, resIndirect.y, resIndirect.z, 0.0f);
     }
     flush_env(P, env, PASS_INDIRECT, CTR_INDIRECT, 0);
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void bounce_miss_kernel(FrameParams P, ViewImages I) {
+    const f3 ambientBase = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]);
+    const uint32_t segment = bounce_segment_size(P), n = I.bounceCounts[2 * blockIdx.x + 1];
+    const size_t base = bounce_miss_base(P, segment) + (size_t)blockIdx.x * segment;
+    for (uint32_t e = threadIdx.x; e < n; e += RT_BLOCK) {
+        const uint32_t id = I.bounceLists[base + e];
+        const uint4 b = I.bounceRecords[(size_t)id * 2 + 1];
+        const f3 rayDirection = mk3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
+        const f3 resIndirect = ambientBase + bounce_sky_term(P, rayDirection) * (P.giSkyStrength * 1.0f);
+        I.bounceResults[id] = make_float4(resIndirect.x, resIndirect.y, resIndirect.z, 0.0f);
+    }
+}
+
+__global__ __launch_bounds__(256) void bounce_resolve_kernel(FrameParams P, ViewImages I, int cur, int writeFiltered) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = P.tileY0 + blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= P.width || y >= P.tileY1 || !row_owned(P, y)) return;
+    const uint32_t px = (uint32_t)x, py = (uint32_t)y;
+    const size_t i = (size_t)py * (size_t)P.width + px, stride = (size_t)P.width * (size_t)P.height;
+    if (I.instanceId[i] < 0) {
+        const float ax = P.ambientBaseColor[0] + P.ambientNoGIColor[0], ay = P.ambientBaseColor[1] + P.ambientNoGIColor[1], az = P.ambientBaseColor[2] + P.ambientNoGIColor[2];
+        store_rgba16f(I.indirectLight[cur], i, ax, ay, az, 0.0f);
+        reinterpret_cast<float2 *>(I.moments[cur])[i] = make_float2(0.0f, 0.0f);
+        if (writeFiltered) store_rgba16f(I.filteredIndirect[1], i, ax, ay, az, 0.0f);
+        return;
+    }
+    const f3 shadingNormal = xyz(load_rgba16f(I.shadingNormal, i));
+    f3 newIndirect = mk3s(0.0f); float historyLength = 0.0f;
+    float2 prevM = make_float2(0.0f, 0.0f); float sumL = 0.0f, sumL2 = 0.0f;
+    if (P.giReproject) {
+        long j; float w = history_weight(P, I, i, px, py, shadingNormal, cur, j);
+        f4 prevAccum = j >= 0 ? load_rgba16f(I.indirectLight[cur ^ 1], (size_t)j) : mk4(0, 0, 0, 0);
+        if (j >= 0) prevM = reinterpret_cast<const float2 *>(I.moments[cur ^ 1])[j];
+        newIndirect = xyz(prevAccum); historyLength = prevAccum.w * w;
+    }
+    for (uint32_t smp = P.giSamples; smp > 0; smp--) {
+        const float4 v = I.bounceResults[(size_t)(smp - 1) * stride + i];
+        const f3 resIndirect = mk3(v.x, v.y, v.z);
+        historyLength = fminf(historyLength + 1.0f, 64.0f);
+        newIndirect = lerp3(newIndirect, resIndirect, s_rcp(historyLength));
+        { const float l = 0.2126f * resIndirect.x + 0.7152f * resIndirect.y + 0.0722f * resIndirect.z; sumL += l; sumL2 += l * l; }
+    }
+    store_rgba16f(I.indirectLight[cur], i, newIndirect.x, newIndirect.y, newIndirect.z, historyLength);
+    {
+        const float nS = (float)P.giSamples, alphaM = fminf(nS / historyLength, 1.0f);
+        reinterpret_cast<float2 *>(I.moments[cur])[i] = make_float2(lerpf(prevM.x, sumL / nS, alphaM), lerpf(prevM.y, sumL2 / nS, alphaM));
+    }
+    if (writeFiltered) store_rgba16f(I.filteredIndirect[1], i, newIndirect.x, newIndirect.y, newIndirect.z, historyLength);
 }
 
 DEV f3 hlsl_refract(f3 i, f3 n, float eta) {
@@ -1025,7 +1099,12 @@ hipError_t launch_indirect(const FrameParams &P, const ViewImages &I, int cur, b
     if (P.giSamples == 0 || !I.bounceRecords) LAUNCH_RAY(indirect_kernel<false>, P, I, cur, writeFiltered ? 1 : 0);
     if (refill) hipLaunchKernelGGL(bounce_trace_refill_kernel, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
     else hipLaunchKernelGGL(bounce_trace_plain_kernel, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
-    LAUNCH_RAY(bounce_shade_kernel, P, I, cur, writeFiltered ? 1 : 0);
+    // same grid for the three kernels: workgroup b shades the segments workgroup b of bounce_trace filled (lengths stay on the device)
+    hipLaunchKernelGGL(bounce_hit_kernel, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
+    hipLaunchKernelGGL(bounce_miss_kernel, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
+    dim3 grid((unsigned)(P.width + 31) / 32, (unsigned)(P.tileY1 - P.tileY0 + 7) / 8);
+    hipLaunchKernelGGL(bounce_resolve_kernel, grid, dim3(256), 0, s, P, I, cur, writeFiltered ? 1 : 0);
+    return hipGetLastError();
 }
 hipError_t launch_indirect_constant(const FrameParams &P, const ViewImages &I, int cur, hipStream_t s) {
     dim3 grid((unsigned)(P.width + 31) / 32, (unsigned)(P.tileY1 - P.tileY0 + 7) / 8);

@@ -142,7 +142,9 @@ struct ViewImages {
     uint8_t *final;                      // RGBA8 back buffer
     uint32_t *primaryHit;                // RGBA32UI: t, u, v bits, instance << 24 | primitive
     float *moments[2];                   // SVGF: RG32F luminance moments
-    uint4 *bounceRecords;                // IndirectRayGen wavefront pair: 2 x uint4 per (GI sample, pixel), sized for bounceSamples
+    uint4 *bounceRecords;                // IndirectRayGen wavefront: 2 x uint4 per (GI sample, pixel), sized for bounceSamples
+    uint32_t *bounceLists, *bounceCounts; // ids of the traced rays compacted by outcome: [0, cap) hits, [cap, 2 cap) misses; counts[2]
+    float4 *bounceResults;               // radiance of every (GI sample, pixel)
     uint4 *svgfGuide;                    // SVGF: 16-B guide record per pixel (normal 3 x f16, valid, depth, depth gradient)
     // Per-pixel sorted hit list (k-buffer), [RT64_MAX_HIT_QUERIES + 1][pixels]; allocated only while some instance is not
     // provably opaque.  The reference keeps 17 x 34 B per pixel for every frame (rt64_view.cpp:237-241).

@@ -896,6 +896,13 @@ void View::render() {                          // View::render, rt64_view.cpp:11
             void *a = nullptr;
             HIP_CHECK(hipMalloc(&a, (size_t)giSamples * n * 2 * sizeof(uint4))); allocations.push_back(a);
             img.bounceRecords = static_cast<uint4 *>(a); bounceSamples = giSamples;
+            void *l = nullptr, *c = nullptr, *r = nullptr;
+            // per-workgroup list segments: ceil(tiles / grid) tiles of 256 pixels each -> at most n + grid * 256 entries per list and sample
+            const size_t tilesAll = (size_t)((imgW + 15) / 16) * (size_t)((imgH + 15) / 16);
+            HIP_CHECK(hipMalloc(&l, (size_t)giSamples * (tilesAll + RT_GRID_BLOCKS) * 256 * 2 * sizeof(uint32_t))); allocations.push_back(l);
+            HIP_CHECK(hipMalloc(&c, (size_t)RT_GRID_BLOCKS * 2 * sizeof(uint32_t))); allocations.push_back(c);
+            HIP_CHECK(hipMalloc(&r, (size_t)giSamples * n * sizeof(float4))); allocations.push_back(r);
+            img.bounceLists = static_cast<uint32_t *>(l); img.bounceCounts = static_cast<uint32_t *>(c); img.bounceResults = static_cast<float4 *>(r);
         }
         const bool klist = anyNonOpaque;
         // Image-tile partition with a spatial filter downstream: the GI denoiser reads a neighbourhood of every row this device
