@@ -10,12 +10,13 @@
 //              (sigma_l = 4 x sqrt of the 3x3-Gaussian-filtered variance); variance filtered with squared weights.
 // Images between iterations are RGBA16F (rgb = colour, a = variance) in the reference's filter ping-pong buffers.
 //
-// MI355X shape.  The variance kernel also packs what the edge stops need into one 16-byte guide record per pixel (normal 3 x f16,
-// valid flag, depth f32, depth gradient f32) so a tap costs two loads (8 B colour + 16 B guide) instead of four.  The a-trous
-// kernel is register-blocked: a lane filters FOUR rows spaced by the step (y, y+s, y+2s, y+3s), so the 8 x 5 taps it fetches
-// serve 4 outputs -- 10 fetched taps per pixel instead of 25, which moves the kernel from the L1 return path (64 B/clk/CU) to
-// the VALU.  Per (tap, pixel) pair the three edge stops collapse into ONE v_exp_f32:
+// MI355X shape.  A guide kernel packs what the edge stops need into one 16-byte record per pixel (normal 3 x f16, valid flag,
+// depth f32, depth gradient f32) so a tap costs two loads (8 B colour + 16 B guide) instead of four.  Per (tap, pixel) pair the three
+// edge stops collapse into ONE v_exp_f32:
 //     w = h * exp2(128 log2(max(0, n.n')) - log2e (|dz| / (gz dist + 1e-8) + |dl| / phi_l)).
+// The a-trous kernel can register-block ATROUS_ROWS output rows spaced by the step per lane (8 x 5 fetched taps serve 4 outputs: 10
+// taps per pixel instead of 25).  Measured at 1080p (five iterations + guide + variance): 4 rows 0.240 ms (133 VGPRs, 3 waves/SIMD),
+// 2 rows 0.223 ms, 1 row 0.210 ms (68 VGPRs, 7 waves/SIMD): the pass is latency-bound and occupancy beats tap reuse, so 1 it is.
 // Sky pixels (56 % of the sample frame) copy through.
 #include "kernels.h"
 #include "device_math.h"
@@ -92,8 +93,8 @@ __global__ __launch_bounds__(256) void svgf_guide_kernel(const int32_t *instance
     guide[i] = g;
 }
 
-#define ATROUS_ROWS 4
-__global__ __launch_bounds__(256, 3) void svgf_atrous_kernel(const uint2 *__restrict__ in, uint2 *__restrict__ out, const uint4 *__restrict__ guide, int w, int h, int step, int y0, int y1) {
+#define ATROUS_ROWS 1
+__global__ __launch_bounds__(256, 6) void svgf_atrous_kernel(const uint2 *__restrict__ in, uint2 *__restrict__ out, const uint4 *__restrict__ guide, int w, int h, int step, int y0, int y1) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int t = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int yb = y0 + (t / step) * (ATROUS_ROWS * step) + (t % step);     // this lane filters rows yb + j*step, j = 0..3, inside [y0, y1)
