@@ -200,6 +200,8 @@ def main():
     # --- instrumented frame (untimed): ray / node / triangle counts of this rank's strips ---
     if args.always_rebuild:
         scene.option("always_rebuild", 1)
+    if os.environ.get("RT64_LDS_CACHE"):
+        scene.option("lds_cache", int(os.environ["RT64_LDS_CACHE"]))
     if os.environ.get("RT64_BOUNCE_REFILL"):
         scene.option("bounce_refill", int(os.environ["RT64_BOUNCE_REFILL"]))
     scene.option("count_traversal", 1)

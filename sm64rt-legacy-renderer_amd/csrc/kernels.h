@@ -34,6 +34,7 @@ hipError_t lbvh_launch_batch(const LbvhArgs *deviceArgs, uint32_t count, uint32_
 hipError_t bc7_decode_launch(const uint8_t *blocks, uint8_t *rgba, uint32_t width, uint32_t height, hipStream_t stream);
 
 // ---- passes.hip ---------------------------------------------------------------------------------------------------
+#define RT_CACHE_MAX_WORDS 1536       // LDS scene cache: at most 24 KB next to the 24 KB of traversal stacks (3 workgroups per CU)
 #define RT_GRID_BLOCKS 2048           // persistent grid of every ray kernel (8 workgroups of 256 per CU)
 size_t rt_stack_spill_bytes();        // bytes of FrameParams::traversalStack
 

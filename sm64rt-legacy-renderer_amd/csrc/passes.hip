@@ -58,7 +58,44 @@ DEV TraceStack make_stack(const FrameParams &P, uint32_t *ldsStack) {
     TraceStack s;
     s.lds = ldsStack + threadIdx.x;
     s.spill = P.traversalStack + ((size_t)blockIdx.x * RT_BLOCK + threadIdx.x) * RT_STACK_SPILL;
+    s.cache = nullptr; s.ldsEntries = RT_STACK_LDS;
     return s;
+}
+
+// LDS scene cache, filled once per workgroup (all threads call it; ends with a barrier).  Layout in 16-byte words:
+//   [0, 4m)            one 64-byte record per TLAS leaf slot: (M[c], M[4+c], M[8+c], M[12+c]) for c = 0..2 of worldToObject, then
+//                      (instance | flags << 16, word offset of its BLAS nodes, tris pointer lo, hi)
+//   [4m, 4m + 4 nT)    TLAS nodes, nT = max(m - 1, 1)
+//   [cacheNodeOffset)  the BLAS nodes of every instance (offsets assigned by View::update)
+// The host enables it (FrameParams::cacheWords != 0) when all of that is at most RT_CACHE_MAX_WORDS: small scenes, like the sample.
+DEV void fill_scene_cache(const FrameParams &P, u32x4_lds *cache) {
+    const uint32_t m = P.cacheInstances, T = blockDim.x, tid = threadIdx.x;
+    typedef const u32x4 __attribute__((address_space(1))) *G4;
+    for (uint32_t k = tid; k < m; k += T) {
+        const uint32_t inst = P.tlasIndex[k];
+        const GpuInstance &in = P.instances[inst];
+        const float *M = in.worldToObject;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            u32x4_lds w; w.x = __float_as_uint(M[c]); w.y = __float_as_uint(M[4 + c]); w.z = __float_as_uint(M[8 + c]); w.w = __float_as_uint(M[12 + c]);
+            cache[4 * k + c] = w;
+        }
+        const uint64_t tp = reinterpret_cast<uint64_t>(in.tris);
+        u32x4_lds info; info.x = inst | (in.flags << 16); info.y = in.cacheNodeOffset; info.z = (uint32_t)tp; info.w = (uint32_t)(tp >> 32);
+        cache[4 * k + 3] = info;
+    }
+    {
+        const uint32_t words = 4u * (m > 1 ? m - 1 : 1u);
+        G4 src = reinterpret_cast<G4>(reinterpret_cast<uintptr_t>(P.tlasNodes));
+        for (uint32_t t = tid; t < words; t += T) cache[4 * m + t] = src[t];
+    }
+    for (uint32_t k = 0; k < m; k++) {                       // uniform: every thread walks the same instance list
+        const GpuInstance &in = P.instances[P.tlasIndex[k]];
+        const uint32_t words = 4u * (in.triCount > 1 ? in.triCount - 1 : 1u), off = in.cacheNodeOffset;
+        G4 src = reinterpret_cast<G4>(reinterpret_cast<uintptr_t>(in.nodes));
+        for (uint32_t t = tid; t < words; t += T) cache[off + t] = src[t];
+    }
+    __syncthreads();
 }
 
 DEV void flush_env(const FrameParams &P, const ShadeEnv &env, int pass, int rayCounter, uint32_t rays) {
@@ -79,14 +116,14 @@ DEV void flush_env(const FrameParams &P, const ShadeEnv &env, int pass, int rayC
 //                  rt64_shader.cpp:547-581 (a hit that lands in slot 15 commits tmax; nhits keeps counting).
 struct SurfaceHit { float key, t, u, v; uint32_t instance, prim; bool hit; };
 
-template <bool KLIST>
+template <bool KLIST, bool CACHED = false>
 DEV uint32_t trace_surface(const FrameParams &P, ShadeEnv &env, const ViewImages &I, size_t pixel, f3 o, f3 d, const RayDiff &rayDiff,
                            uint32_t px, uint32_t py, SurfaceHit &best) {
     float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
     best.hit = false; best.key = INFINITY;
     uint32_t nhits = 0;
     const size_t stride = (size_t)P.width * (size_t)P.height;
-    trace_ray(P, oo, dd, RT_RAY_MIN_DISTANCE, RT_RAY_MAX_DISTANCE, true, env.stk,
+    trace_ray<CACHED>(P, oo, dd, RT_RAY_MIN_DISTANCE, RT_RAY_MAX_DISTANCE, true, env.stk,
               [&](float t, float u, float v, uint32_t instance, uint32_t prim, float &tmax) -> bool {
                   const GpuInstance &in = P.instances[instance];
                   const float key = t - in.material.depthBias;
@@ -139,14 +176,17 @@ DEV bool surface_record(const FrameParams &P, const ViewImages &I, size_t pixel,
 #endif
 // ---- primary visibility --------------------------------------------------------------------------------------------------
 
-template <bool KLIST>
+template <bool KLIST, bool CACHED = false>
 __global__ __launch_bounds__(RT_BLOCK, KLIST ? 2 : TRACE_WAVES) void primary_trace_kernel(FrameParams P, ViewImages I, int32_t *hitInstance) {
-    __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
+    __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED : RT_STACK_LDS) * RT_BLOCK];
+    extern __shared__ u32x4_lds dynLds[];
+    if (CACHED) fill_scene_cache(P, dynLds);
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
     env.lightIntensity = ldsLightIntensity + threadIdx.x; env.lightIndex = ldsLightIndex + threadIdx.x;
     env.lightIntensity = nullptr; env.lightIndex = nullptr;
+    if (CACHED) { env.stk.cache = dynLds; env.stk.ldsEntries = RT_STACK_LDS_CACHED; }
     uint32_t rays = 0;
     const uint32_t tiles = tile_count(P);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
@@ -162,7 +202,7 @@ __global__ __launch_bounds__(RT_BLOCK, KLIST ? 2 : TRACE_WAVES) void primary_tra
             compute_ray_diffs((cU * ndc.x + cV * ndc.y) + cW, cU, cV, P.resolution[2], P.resolution[3], rayDiff.dDdx, rayDiff.dDdy);
         }
         SurfaceHit h;
-        const uint32_t nhits = trace_surface<KLIST>(P, env, I, i, o, d, rayDiff, p.x, p.y, h);
+        const uint32_t nhits = trace_surface<KLIST, CACHED>(P, env, I, i, o, d, rayDiff, p.x, p.y, h);
         rays++;
         uint4 rec;
         if (KLIST) {
@@ -373,13 +413,26 @@ DEV void compose_lean_pixel(const FrameParams &P, const ViewImages &I, size_t i,
     if (!P.separatePost) store_rgba8(I.final, i, result.x, result.y, result.z, 1.0f);
 }
 
-template <bool FULL>
+// CACHED variants of the ray kernels keep the scene cache and the light-selection columns in dynamic LDS:
+//   [scene cache: P.cacheWords x 16 B][light intensities: slots x RT_BLOCK floats][light indices: slots x RT_BLOCK bytes], slots = min(lights, 16) + 1
+DEV uint32_t light_slots(const FrameParams &P) { return (P.lightCount < RT64_MAX_LIGHTS ? P.lightCount : (uint32_t)RT64_MAX_LIGHTS) + 1u; }
+DEV void cached_env(const FrameParams &P, ShadeEnv &env, u32x4_lds *dynLds) {
+    fill_scene_cache(P, dynLds);
+    env.stk.cache = dynLds; env.stk.ldsEntries = RT_STACK_LDS_CACHED;
+    float *li = reinterpret_cast<float *>(dynLds + P.cacheWords);
+    env.lightIntensity = li + threadIdx.x;
+    env.lightIndex = reinterpret_cast<uint8_t *>(li + light_slots(P) * RT_BLOCK) + threadIdx.x;
+}
+
+template <bool FULL, bool CACHED = false>
 __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void direct_kernel(FrameParams P, ViewImages I, int cur) {
-    __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
-    __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
-    __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
+    __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED : RT_STACK_LDS) * RT_BLOCK];
+    __shared__ float ldsLightIntensity[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
+    __shared__ uint8_t ldsLightIndex[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
+    extern __shared__ u32x4_lds dynLds[];
     ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
     env.lightIntensity = ldsLightIntensity + threadIdx.x; env.lightIndex = ldsLightIndex + threadIdx.x;
+    if (CACHED) cached_env(P, env, dynLds);
     const uint32_t tiles = tile_count<DIRECT_TILE>(P);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         Pixel p = tile_pixel<DIRECT_TILE>(P, tile);
@@ -404,7 +457,7 @@ __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void direct_kernel(FramePar
             newDirect = xyz(prevAccum); historyLength = prevAccum.w * w;
         }
         const RT64_MATERIAL &m = P.instances[instanceId].material;
-        f3 resDirect = compute_lights_random(P, env, px, py, rayDirection, (uint32_t)instanceId, position, normal, specular, P.maxLights, true);
+        f3 resDirect = compute_lights_random<CACHED>(P, env, px, py, rayDirection, (uint32_t)instanceId, position, normal, specular, P.maxLights, true);
         resDirect = resDirect + ld_v3(m.selfLight);
         float eyeLambert = fmaxf(dot3(normal, -rayDirection), 0.0f);
         f3 eyeReflected = reflect3(rayDirection, normal);
@@ -540,14 +593,18 @@ DEV void bounce_append(const ViewImages &I, uint32_t *ldsCount, uint32_t segment
 }
 DEV size_t bounce_miss_base(const FrameParams &P, uint32_t segment) { return (size_t)gridDim.x * segment; }
 
+template <bool CACHED>
 __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kernel(FrameParams P, ViewImages I) {
-    __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
+    __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED : RT_STACK_LDS) * RT_BLOCK];
     __shared__ uint32_t ldsCount[2];
+    extern __shared__ u32x4_lds dynLds[];
     if (threadIdx.x < 2) ldsCount[threadIdx.x] = 0;
+    if (CACHED) fill_scene_cache(P, dynLds);
     __syncthreads();
     const uint32_t segment = bounce_segment_size(P); const size_t missBase = bounce_miss_base(P, segment);
     ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
     env.lightIntensity = nullptr; env.lightIndex = nullptr;
+    if (CACHED) { env.stk.cache = dynLds; env.stk.ldsEntries = RT_STACK_LDS_CACHED; }
     uint32_t rays = 0;
     const size_t stride = (size_t)P.width * (size_t)P.height;
     const uint32_t tiles = tile_count(P);
@@ -564,7 +621,7 @@ __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kern
             const f3 rayDirection = cos_hemisphere_blue_noise(P, px, py, P.frameCount + smp * blueNoiseMult, shadingNormal);
             RayDiff rd; rd.dOdx = rd.dOdy = rd.dDdx = rd.dDdy = mk3s(0.0f);
             SurfaceHit best;
-            trace_surface<false>(P, env, I, i, rayOrigin, rayDirection, rd, px, py, best);
+            trace_surface<false, CACHED>(P, env, I, i, rayOrigin, rayDirection, rd, px, py, best);
             rays++;
             uint4 a, b;
             a.x = __float_as_uint(best.t); a.y = __float_as_uint(best.u); a.z = __float_as_uint(best.v); a.w = best.prim;
@@ -665,12 +722,15 @@ DEV f3 bounce_sky_term(const FrameParams &P, f3 rayDirection) {
     return lerp3(bgColor, xyz(sky), sky.w);
 }
 
+template <bool CACHED>
 __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void bounce_hit_kernel(FrameParams P, ViewImages I) {
-    __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
-    __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
-    __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
+    __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED : RT_STACK_LDS) * RT_BLOCK];
+    __shared__ float ldsLightIntensity[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
+    __shared__ uint8_t ldsLightIndex[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
+    extern __shared__ u32x4_lds dynLds[];
     ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
     env.lightIntensity = ldsLightIntensity + threadIdx.x; env.lightIndex = ldsLightIndex + threadIdx.x;
+    if (CACHED) cached_env(P, env, dynLds);
     const f3 ambientBase = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]);
     const f3 ambient = ambientBase + mk3(P.ambientNoGIColor[0], P.ambientNoGIColor[1], P.ambientNoGIColor[2]);
     const uint32_t stride = (uint32_t)P.width * (uint32_t)P.height;
@@ -699,7 +759,7 @@ __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void bounce_hit_kernel(Fram
         }
         f3 resIndirect = ambientBase;
         if (resInstanceId >= 0) {
-            f3 directLight = compute_lights_random(P, env, px, py, rayDirection, (uint32_t)resInstanceId, resPosition, resNormal, resSpecular, 1, true) + ld_v3(P.instances[resInstanceId].material.selfLight);
+            f3 directLight = compute_lights_random<CACHED>(P, env, px, py, rayDirection, (uint32_t)resInstanceId, resPosition, resNormal, resSpecular, 1, true) + ld_v3(P.instances[resInstanceId].material.selfLight);
             f3 indirectLight = ((xyz(resColor) * (1.0f - resColor.w)) * (ambient + directLight)) * P.giDiffuseStrength;
             resIndirect = resIndirect + indirectLight;
         }
@@ -1080,9 +1140,16 @@ static unsigned rt_grid(const FrameParams &P) {
     return tiles < 1u ? 1u : (tiles < (unsigned)RT_GRID_BLOCKS ? tiles : (unsigned)RT_GRID_BLOCKS);
 }
 #define LAUNCH_RAY(kernel, ...) do { hipLaunchKernelGGL(kernel, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, __VA_ARGS__); return hipGetLastError(); } while (0)
+// dynamic LDS of a CACHED kernel: scene cache, plus the light-selection columns when the kernel picks lights
+static size_t cached_lds_bytes(const FrameParams &P, bool lights) {
+    const size_t slots = (P.lightCount < RT64_MAX_LIGHTS ? P.lightCount : (uint32_t)RT64_MAX_LIGHTS) + 1u;
+    return (size_t)P.cacheWords * 16 + (lights ? (slots * RT_BLOCK * 5 + 15) / 16 * 16 : 0);
+}
+#define LAUNCH_RAY_LDS(kernel, bytes, ...) do { hipLaunchKernelGGL(kernel, dim3(rt_grid(P)), dim3(RT_BLOCK), bytes, s, __VA_ARGS__); return hipGetLastError(); } while (0)
 
 hipError_t launch_primary_trace(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, bool klist, hipStream_t s) {
     if (klist) LAUNCH_RAY(primary_trace_kernel<true>, P, I, hitInstance);
+    if (P.cacheWords) LAUNCH_RAY_LDS((primary_trace_kernel<false, true>), cached_lds_bytes(P, false), P, I, hitInstance);
     LAUNCH_RAY(primary_trace_kernel<false>, P, I, hitInstance);
 }
 hipError_t launch_primary_shade(const FrameParams &P, const ViewImages &I, const int32_t *hitInstance, int cur, bool transparentLighting, bool lean, hipStream_t s) {
@@ -1091,6 +1158,10 @@ hipError_t launch_primary_shade(const FrameParams &P, const ViewImages &I, const
     LAUNCH_RAY((primary_shade_kernel<false, false, true>), P, I, hitInstance, cur);
 }
 hipError_t launch_direct(const FrameParams &P, const ViewImages &I, int cur, bool lean, hipStream_t s) {
+    if (P.cacheWords) {
+        if (lean) LAUNCH_RAY_LDS((direct_kernel<false, true>), cached_lds_bytes(P, true), P, I, cur);
+        LAUNCH_RAY_LDS((direct_kernel<true, true>), cached_lds_bytes(P, true), P, I, cur);
+    }
     if (lean) LAUNCH_RAY(direct_kernel<false>, P, I, cur);
     LAUNCH_RAY(direct_kernel<true>, P, I, cur);
 }
@@ -1098,9 +1169,11 @@ hipError_t launch_indirect(const FrameParams &P, const ViewImages &I, int cur, b
     if (klist) LAUNCH_RAY(indirect_kernel<true>, P, I, cur, writeFiltered ? 1 : 0);
     if (P.giSamples == 0 || !I.bounceRecords) LAUNCH_RAY(indirect_kernel<false>, P, I, cur, writeFiltered ? 1 : 0);
     if (refill) hipLaunchKernelGGL(bounce_trace_refill_kernel, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
-    else hipLaunchKernelGGL(bounce_trace_plain_kernel, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
+    else if (P.cacheWords) hipLaunchKernelGGL(bounce_trace_plain_kernel<true>, dim3(rt_grid(P)), dim3(RT_BLOCK), cached_lds_bytes(P, false), s, P, I);
+    else hipLaunchKernelGGL(bounce_trace_plain_kernel<false>, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
     // same grid for the three kernels: workgroup b shades the segments workgroup b of bounce_trace filled (lengths stay on the device)
-    hipLaunchKernelGGL(bounce_hit_kernel, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
+    if (P.cacheWords) hipLaunchKernelGGL(bounce_hit_kernel<true>, dim3(rt_grid(P)), dim3(RT_BLOCK), cached_lds_bytes(P, true), s, P, I);
+    else hipLaunchKernelGGL(bounce_hit_kernel<false>, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
     hipLaunchKernelGGL(bounce_miss_kernel, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
     dim3 grid((unsigned)(P.width + 31) / 32, (unsigned)(P.tileY1 - P.tileY0 + 7) / 8);
     hipLaunchKernelGGL(bounce_resolve_kernel, grid, dim3(256), 0, s, P, I, cur, writeFiltered ? 1 : 0);

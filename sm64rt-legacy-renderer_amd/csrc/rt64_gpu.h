@@ -78,6 +78,7 @@ struct alignas(16) GpuInstance {
     uint32_t flags;
     uint32_t triCount;
     uint32_t meshVersion;                // bumps on every RT64_SetMesh: part of the frame-table cache key
+    uint32_t cacheNodeOffset;            // LDS scene cache: where this instance's BLAS nodes start, in 16-byte words (FrameParams::cacheWords != 0)
 };
 
 // One raster (non-ray-traced) instance of the frame, draw order: background list, then foreground list (rt64_view.cpp:1138-1147).
@@ -112,6 +113,9 @@ struct FrameParams {
     float maxDepthBias;
     GpuTexture background;               // gBackground: raster background target (screen size RGBA8); texels == nullptr: no background instances
     float rtViewport[4]; int32_t rtScissor[4];   // rectangle the ray-traced picture is drawn into (x, y, w, h / left, top, right, bottom; screen pixels)
+    // LDS scene cache (trace.h): when the TLAS + every BLAS node array + one 64-byte record per instance fit in LDS next to the
+    // traversal stacks, the ray kernels copy them in once per workgroup and walk from there.  cacheWords = size in 16-byte words, 0 = off.
+    uint32_t cacheWords, cacheInstances;
     uint32_t separatePost;               // 1: render size != screen size or motion blur on -> PostProcessPS runs as post_process_kernel
     float skyBase[4];                    // ComputeSkyPlaneUV: base u, base v, 0.25 * ratioDivision, 0.25
     uint32_t lightCount, instanceCount, countTraversal;

@@ -136,6 +136,7 @@ static GpuCombiner decode_combiner(uint32_t shaderId) {
 
 struct Options {
     bool countTraversal = false, profilePasses = true, syncPresent = true, alwaysRebuild = false, leanFrames = true;
+    bool ldsCache = true;         // small scenes: BVH nodes + instance records cached in LDS by the ray kernels (0: always walk from HBM/L2)
     bool spinPresent = true;      // RT64_DrawDevice waits for the frame by polling the stream (0: blocking hipStreamSynchronize)
     int bounceRefill = -1;        // bounce-ray traversal with wave-ballot refill: 1 on, 0 off, -1 auto (on when the scene has >= 64 Ki triangles)
     int denoiserMode = 1;          // 0 = reference 5x Gaussian, 1 = SVGF
@@ -267,6 +268,7 @@ struct View {
     int finalW = 0, finalH = 0;               // back buffer = screen size
     // rectangle of the ray-traced picture: the first ray-traced instance's scissor / viewport when it has any (rt64_view.cpp:1258-1271)
     float rtViewport[4] = { 0, 0, 0, 0 }; int rtScissor[4] = { 0, 0, 0, 0 }; bool rtRect = false;
+    uint32_t cacheWords = 0;                   // LDS scene cache size in 16-byte words (0: the scene does not fit / option lds_cache = 0)
     bool separatePost() const { return rtRect || imgW != finalW || imgH != finalH || (motionBlurStrength > 0.0f && motionBlurSamples > 0); }
     // device images
     ViewImages img = {};
@@ -697,6 +699,15 @@ void View::update() {                          // View::update, rt64_view.cpp:10
     GpuInstance *hInst = reinterpret_cast<GpuInstance *>(stage);
     GpuTexture *hTex = reinterpret_cast<GpuTexture *>(stage + instBytes);
     RT64_LIGHT *hLights = reinterpret_cast<RT64_LIGHT *>(stage + instBytes + texBytes);
+    // LDS scene cache (trace.h): instance records + TLAS nodes + every BLAS node array, if that is small enough to sit next to the
+    // traversal stacks of a workgroup.  Offsets are in 16-byte words.
+    std::vector<uint32_t> cacheOffset(nInst, 0);
+    cacheWords = 0;
+    if (dev->opt.ldsCache && nInst >= 1 && nInst <= 16) {
+        uint64_t words = 4 * nInst + 4 * std::max<size_t>(nInst - 1, 1);
+        for (size_t i = 0; i < nInst; i++) { cacheOffset[i] = (uint32_t)words; words += 4ull * std::max<uint32_t>(rtInstances[i].instance->mesh->blasCount - 1, 1); }
+        if (words <= RT_CACHE_MAX_WORDS) cacheWords = (uint32_t)words;
+    }
     maxDepthBias = nInst ? -INFINITY : 0.0f;
     anyNonOpaque = anyReflection = anyRefraction = anyFog = false;
     for (size_t i = 0; i < nInst; i++) {
@@ -727,6 +738,7 @@ void View::update() {                          // View::update, rt64_view.cpp:10
         if (instance_is_shadow_opaque(inst, g.cc)) g.flags |= GPU_INST_SHADOW_OPAQUE;
         g.triCount = mesh->blasCount;
         g.meshVersion = mesh->version;
+        g.cacheNodeOffset = cacheWords ? cacheOffset[i] : 0u;
         if (g.cc.vertexSize > mesh->vertexStride) throw std::runtime_error("Instance mesh vertex stride is smaller than the layout its shader reads.");
         maxDepthBias = std::max(maxDepthBias, inst->material.depthBias);
         if (!(g.flags & GPU_INST_OPAQUE)) anyNonOpaque = true;
@@ -826,6 +838,7 @@ void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64
     P.binaryLockMask = 1;                                     // rtUpscaleMode != FSR
     P.visualizationMode = 0;
     P.width = imgW; P.height = imgH; P.tileY0 = dev->tileY0; P.tileY1 = dev->tileY1; P.stripRank = dev->stripRank; P.stripCount = dev->stripCount;
+    P.cacheWords = cacheWords; P.cacheInstances = cacheWords ? (uint32_t)rtInstances.size() : 0u;
     P.separatePost = separatePost() ? 1u : 0u;
     memset(&P.background, 0, sizeof(P.background));
     if (rasterBgEnv.ready) { P.background.texels = background.ptr; P.background.width = (uint32_t)backgroundW; P.background.height = (uint32_t)backgroundH; P.background.mips = 1; P.background.pow2 = ((backgroundW & (backgroundW - 1)) == 0 && (backgroundH & (backgroundH - 1)) == 0) ? 1u : 0u; }
@@ -1241,6 +1254,7 @@ RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, doubl
     else if (k == "denoiser_mode") d->opt.denoiserMode = (int)value;
     else if (k == "bounce_refill") d->opt.bounceRefill = (int)value;
     else if (k == "spin_present") d->opt.spinPresent = value != 0.0;
+    else if (k == "lds_cache") d->opt.ldsCache = value != 0.0;
     else if (k == "reset_accum") { d->finishStats(); d->accum = RT64_FRAME_STATS(); }
     else if (k == "lean_frames") d->opt.leanFrames = value != 0.0;                // 0: always write every image of the reference's G-buffer
     else if (k == "always_rebuild") d->opt.alwaysRebuild = value != 0.0;          // upload tables + rebuild the TLAS every frame like the reference

@@ -430,11 +430,12 @@ struct ShadeEnv {                // per-lane traversal resources handed down to 
     uint8_t *lightIndex;         // LDS, [RT64_MAX_LIGHTS + 1][RT_BLOCK]
 };
 
+template <bool CACHED = false>
 DEV float trace_shadow(const FrameParams &P, ShadeEnv &env, f3 origin, f3 dir, float tmin, float tmax, uint32_t px, uint32_t py) {   // :27-52
     float o[3] = { origin.x, origin.y, origin.z }, d[3] = { dir.x, dir.y, dir.z };
     float shadowHit = 1.0f;
     env.shadowRays++;
-    trace_ray(P, o, d, tmin, tmax, false /* SKIP_BACKFACE_SHADOWS undefined */, env.stk,
+    trace_ray<CACHED>(P, o, d, tmin, tmax, false /* SKIP_BACKFACE_SHADOWS undefined */, env.stk,
               [&](float, float u, float v, uint32_t instance, uint32_t prim, float &) -> bool {
                   if (P.instances[instance].flags & GPU_INST_SHADOW_OPAQUE) { shadowHit = 0.0f; return true; }   // payload.shadowHit = 0 (:661)
                   float a = shadow_anyhit_alpha(P, instance, prim, u, v, px, py);
@@ -457,6 +458,7 @@ DEV float light_intensity_simple(const RT64_LIGHT &L, f3 position, f3 normal, fl
     return f * (L.diffuseColor.x + L.diffuseColor.y + L.diffuseColor.z);
 }
 
+template <bool CACHED = false>
 DEV f3 compute_light(const FrameParams &P, ShadeEnv &env, uint32_t px, uint32_t py, uint32_t lightIndex, f3 rayDirection,
                      const RT64_MATERIAL &m, f3 position, f3 normal, f3 specular, bool checkShadows) {   // :67-113
     const RT64_LIGHT &L = P.lights[lightIndex];
@@ -482,7 +484,7 @@ DEV f3 compute_light(const FrameParams &P, ShadeEnv &env, uint32_t px, uint32_t 
         float sampleLambert = lerpf(NdotL, 1.0f, m.ignoreNormalFactor) * sampleIntensityFactor;
         float sampleShadow = 1.0f;
         if (checkShadows)
-            sampleShadow = trace_shadow(P, env, position, sampleDirection, RT_RAY_MIN_DISTANCE + m.shadowRayBias, sampleDistance - L.shadowOffset, px, py);
+            sampleShadow = trace_shadow<CACHED>(P, env, position, sampleDirection, RT_RAY_MIN_DISTANCE + m.shadowRayBias, sampleDistance - L.shadowOffset, px, py);
         float sp = s_pow(fmaxf(saturatef(dot3(reflectedLight, -rayDirection) * sampleIntensityFactor), 0.0f), m.specularExponent);
         const float rs = s_rcp((float)maxSamples);
         lLambert += sampleLambert * rs;
@@ -494,6 +496,7 @@ DEV f3 compute_light(const FrameParams &P, ShadeEnv &env, uint32_t px, uint32_t 
     return r * lShadow;
 }
 
+template <bool CACHED = false>
 DEV f3 compute_lights_random(const FrameParams &P, ShadeEnv &env, uint32_t px, uint32_t py, f3 rayDirection, uint32_t instanceId,
                              f3 position, f3 normal, f3 specular, uint32_t maxLightCount, bool checkShadows) {   // :115-168
     f3 result = mk3s(0.0f);
@@ -510,7 +513,7 @@ DEV f3 compute_lights_random(const FrameParams &P, ShadeEnv &env, uint32_t px, u
         }
     }
     if (sCount == 1 && maxLightCount >= 1)       // one candidate: it is chosen whatever the random number is, with probability 1 (randomRange / cInt = total / total)
-        return compute_light(P, env, px, py, sIdx[0], rayDirection, m, position, normal, specular, checkShadows);
+        return compute_light<CACHED>(P, env, px, py, sIdx[0], rayDirection, m, position, normal, specular, checkShadows);
     float randomRange = total;
     uint32_t lCount = sCount < maxLightCount ? sCount : maxLightCount;
     bool useProbability = lCount == 1;
@@ -521,7 +524,7 @@ DEV f3 compute_lights_random(const FrameParams &P, ShadeEnv &env, uint32_t px, u
         float cInt = sInt[chosen * RT_BLOCK]; uint32_t cIdx = sIdx[chosen * RT_BLOCK];
         float invProbability = useProbability ? s_div(randomRange, cInt) : 1.0f;
         sInt[chosen * RT_BLOCK] = 0.0f; randomRange -= cInt;
-        result = result + compute_light(P, env, px, py, cIdx, rayDirection, m, position, normal, specular, checkShadows) * invProbability;
+        result = result + compute_light<CACHED>(P, env, px, py, cIdx, rayDirection, m, position, normal, specular, checkShadows) * invProbability;
     }
     return result;
 }

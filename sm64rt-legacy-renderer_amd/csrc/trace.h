@@ -21,8 +21,8 @@
 
 #define RT_BLOCK 256                 // threads per workgroup of every ray kernel
 #define RT_STACK_LDS 24
-#define RT_STACK_SPILL 72
-#define RT_STACK_MAX (RT_STACK_LDS + RT_STACK_SPILL)
+#define RT_STACK_SPILL 84               // entries per lane in the HBM slab behind the LDS entries
+#define RT_STACK_LDS_CACHED 12           // kernels that also hold the LDS scene cache: the cached scenes are small, their trees shallow
 
 struct RaySpace { float o[3], d[3], inv[3], oi[3]; };
 
@@ -65,18 +65,22 @@ DEV bool tri_hit(const RaySpace &r, const GpuTri &tri, bool cull, float tmin, fl
     return true;
 }
 
+typedef uint32_t u32x4_lds __attribute__((ext_vector_type(4)));      // a 16-byte word of the LDS scene cache
+
 struct TraceStack {
     uint32_t *lds;        // &ldsStack[threadIdx.x], stride RT_BLOCK
     uint32_t *spill;      // per-lane slab of RT_STACK_SPILL entries
+    const u32x4_lds *cache;   // LDS scene cache (see fill_scene_cache), nullptr when the scene does not fit
+    int ldsEntries;       // entries of this lane's stack that live in LDS (RT_STACK_LDS or RT_STACK_LDS_CACHED)
     DEV void push(int &sp, uint32_t v) const {
-        if (sp < RT_STACK_LDS) lds[sp * RT_BLOCK] = v;
-        else if (sp < RT_STACK_MAX) spill[sp - RT_STACK_LDS] = v;
+        if (sp < ldsEntries) lds[sp * RT_BLOCK] = v;
+        else if (sp < ldsEntries + RT_STACK_SPILL) spill[sp - ldsEntries] = v;
         else return;      // deeper than any tree this builder produces for n < 2^20 leaves, m < 2^13 instances
         sp++;
     }
     DEV uint32_t pop(int &sp) const {
         sp--;
-        return sp < RT_STACK_LDS ? lds[sp * RT_BLOCK] : spill[sp - RT_STACK_LDS];
+        return sp < ldsEntries ? lds[sp * RT_BLOCK] : spill[sp - ldsEntries];
     }
 };
 
@@ -109,7 +113,17 @@ DEV GpuTri load_tri(const GpuTri *p) {                            // 3 x global_
 // lanes process their leaf together (ray/triangle test, or the object-space switch at a TLAS leaf).  Lanes never execute the
 // node path and the leaf path in the same trip, which is what a one-ray-per-lane walk loses most to on wave64.  The order of
 // operations of each individual ray is unchanged (R3), so hits and visit counts stay bit-identical to the scalar tracer.
-template <class OnHit>
+//
+// CACHED: the scene's nodes and per-instance records sit in LDS (stk.cache, layout in fill_scene_cache): a node visit and an
+// instance entry are ds_read_b128s (~100 cycles) instead of dependent global loads (~1 us each under load); only triangles still come
+// from HBM/L2.  Same data, same arithmetic, same order: results and visit counts are unchanged.
+DEV GpuNode load_node_lds(const u32x4_lds *q) {
+    union { u32x4_lds w[4]; GpuNode n; } u;
+    u.w[0] = q[0]; u.w[1] = q[1]; u.w[2] = q[2]; u.w[3] = q[3];
+    return u.n;
+}
+
+template <bool CACHED = false, class OnHit>
 DEV void trace_ray(const FrameParams &P, const float o[3], const float d[3], float tmin, float tmax, bool cullBackFaces,
                    const TraceStack &stk, OnHit &&onHit, TraceCounts &cnt) {
     if (P.instanceCount == 0) return;
@@ -117,6 +131,8 @@ DEV void trace_ray(const FrameParams &P, const float o[3], const float d[3], flo
     make_ray_space(o, d, W);
     R = W;
     const GpuNode *nodes = P.tlasNodes;
+    const uint32_t tlasOff = 4u * P.cacheInstances;          // CACHED: node arrays are addressed by their word offset in the cache
+    uint32_t nodeOff = tlasOff;
     const GpuTri *tris = nullptr;
     int sp = 0, blasBase = -1;
     uint32_t inst = 0;
@@ -125,7 +141,7 @@ DEV void trace_ray(const FrameParams &P, const float o[3], const float d[3], flo
     bool alive = true;
     auto popNext = [&]() -> bool {
         if (blasBase >= 0 && sp == blasBase) {          // BLAS exhausted: resume the TLAS walk in world space
-            blasBase = -1; R = W; nodes = P.tlasNodes;
+            blasBase = -1; R = W; nodes = P.tlasNodes; nodeOff = tlasOff;
         }
         if (sp == 0) return false;
         cur = stk.pop(sp);
@@ -134,7 +150,7 @@ DEV void trace_ray(const FrameParams &P, const float o[3], const float d[3], flo
     while (alive) {
         // ---- inner nodes ----
         while (alive && !(cur & RT64_LEAF_BIT)) {
-            const GpuNode nd = load_node(nodes + cur);
+            const GpuNode nd = CACHED ? load_node_lds(stk.cache + nodeOff + 4u * cur) : load_node(nodes + cur);
             cnt.nodes++;
             float tl, tr;
             const bool hl = box_hit(R, nd.lmin, nd.lmax, tmin, tmax, tl);
@@ -152,20 +168,38 @@ DEV void trace_ray(const FrameParams &P, const float o[3], const float d[3], flo
         if (cur != RT64_NO_CHILD) {
             if (blasBase < 0) {
                 // TLAS leaf: enter the instance (G8)
-                inst = load_global(P.tlasIndex + (cur & 0x7FFFFFFFu));
-                const GpuInstance *in = P.instances + inst;
                 float oo[3], dd[3];
-                // p * M with M row-major 4x4: column c of rows 0..3 = M[c], M[4+c], M[8+c], M[12+c]
-                const float *M = in->worldToObject;
+                uint32_t flags;
+                if (CACHED) {
+                    // 64-byte record of leaf slot `cur`: three words (M[c], M[4+c], M[8+c], M[12+c]), then (instance | flags << 16, node offset, tris pointer)
+                    const u32x4_lds *rec = stk.cache + 4u * (cur & 0x7FFFFFFFu);
+                    const u32x4_lds info = rec[3];
 #pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    const float m0 = load_global(M + c), m1 = load_global(M + 4 + c), m2 = load_global(M + 8 + c), m3 = load_global(M + 12 + c);
-                    oo[c] = fmaf(W.o[2], m2, fmaf(W.o[1], m1, fmaf(W.o[0], m0, m3)));
-                    dd[c] = fmaf(W.d[2], m2, fmaf(W.d[1], m1, W.d[0] * m0));
+                    for (int c = 0; c < 3; c++) {
+                        const u32x4_lds mw = rec[c];
+                        const float m0 = __uint_as_float(mw.x), m1 = __uint_as_float(mw.y), m2 = __uint_as_float(mw.z), m3 = __uint_as_float(mw.w);
+                        oo[c] = fmaf(W.o[2], m2, fmaf(W.o[1], m1, fmaf(W.o[0], m0, m3)));
+                        dd[c] = fmaf(W.d[2], m2, fmaf(W.d[1], m1, W.d[0] * m0));
+                    }
+                    inst = info.x & 0xFFFFu; flags = info.x >> 16; nodeOff = info.y;
+                    tris = reinterpret_cast<const GpuTri *>(((uint64_t)info.w << 32) | (uint64_t)info.z);
+                }
+                else {
+                    inst = load_global(P.tlasIndex + (cur & 0x7FFFFFFFu));
+                    const GpuInstance *in = P.instances + inst;
+                    // p * M with M row-major 4x4: column c of rows 0..3 = M[c], M[4+c], M[8+c], M[12+c]
+                    const float *M = in->worldToObject;
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const float m0 = load_global(M + c), m1 = load_global(M + 4 + c), m2 = load_global(M + 8 + c), m3 = load_global(M + 12 + c);
+                        oo[c] = fmaf(W.o[2], m2, fmaf(W.o[1], m1, fmaf(W.o[0], m0, m3)));
+                        dd[c] = fmaf(W.d[2], m2, fmaf(W.d[1], m1, W.d[0] * m0));
+                    }
+                    nodes = load_global(&in->nodes); tris = load_global(&in->tris);
+                    flags = load_global(&in->flags);
                 }
                 make_ray_space(oo, dd, R);
-                nodes = load_global(&in->nodes); tris = load_global(&in->tris);
-                cull = cullBackFaces && !(load_global(&in->flags) & GPU_INST_CULL_DISABLE);
+                cull = cullBackFaces && !(flags & GPU_INST_CULL_DISABLE);
                 blasBase = sp;
                 cur = 0;
                 continue;
