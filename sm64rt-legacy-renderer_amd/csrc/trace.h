@@ -22,7 +22,7 @@
 #define RT_BLOCK 256                 // threads per workgroup of every ray kernel
 #define RT_STACK_LDS 24
 #define RT_STACK_SPILL 84               // entries per lane in the HBM slab behind the LDS entries
-#define RT_STACK_LDS_CACHED 12           // kernels that also hold the LDS scene cache: the cached scenes are small, their trees shallow
+#define RT_STACK_LDS_CACHED 8            // kernels that also hold the LDS scene cache: the cached scenes are small, their trees shallow
 
 struct RaySpace { float o[3], d[3], inv[3], oi[3]; };
 
