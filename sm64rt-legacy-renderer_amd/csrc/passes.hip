@@ -64,7 +64,7 @@ DEV TraceStack make_stack(const FrameParams &P, uint32_t *ldsStack) {
 
 // LDS scene cache, filled once per workgroup (all threads call it; ends with a barrier).  Layout in 16-byte words:
 //   [0, 4m)            one 64-byte record per TLAS leaf slot: (M[c], M[4+c], M[8+c], M[12+c]) for c = 0..2 of worldToObject, then
-//                      (instance | flags << 16, word offset of its BLAS nodes, tris pointer lo, hi)
+//                      (instance | flags << 8 | word offset of its BLAS nodes << 16, depth bias, tris pointer lo, hi)
 //   [4m, 4m + 4 nT)    TLAS nodes, nT = max(m - 1, 1)
 //   [cacheNodeOffset)  the BLAS nodes of every instance (offsets assigned by View::update)
 // The host enables it (FrameParams::cacheWords != 0) when all of that is at most RT_CACHE_MAX_WORDS: small scenes, like the sample.
@@ -81,7 +81,7 @@ DEV void fill_scene_cache(const FrameParams &P, u32x4_lds *cache) {
             cache[4 * k + c] = w;
         }
         const uint64_t tp = reinterpret_cast<uint64_t>(in.tris);
-        u32x4_lds info; info.x = inst | (in.flags << 16); info.y = in.cacheNodeOffset; info.z = (uint32_t)tp; info.w = (uint32_t)(tp >> 32);
+        u32x4_lds info; info.x = inst | ((in.flags & 0xFFu) << 8) | (in.cacheNodeOffset << 16); info.y = __float_as_uint(in.material.depthBias); info.z = (uint32_t)tp; info.w = (uint32_t)(tp >> 32);
         cache[4 * k + 3] = info;
     }
     {
@@ -124,9 +124,9 @@ DEV uint32_t trace_surface(const FrameParams &P, ShadeEnv &env, const ViewImages
     uint32_t nhits = 0;
     const size_t stride = (size_t)P.width * (size_t)P.height;
     trace_ray<CACHED>(P, oo, dd, RT_RAY_MIN_DISTANCE, RT_RAY_MAX_DISTANCE, true, env.stk,
-              [&](float t, float u, float v, uint32_t instance, uint32_t prim, float &tmax) -> bool {
+              [&](float t, float u, float v, uint32_t instance, uint32_t prim, float &tmax, uint32_t instFlags, float instDepthBias) -> bool {
                   const GpuInstance &in = P.instances[instance];
-                  const float key = t - in.material.depthBias;
+                  const float key = t - instDepthBias;
                   if (!KLIST) {
                       if (key < best.key) { best.key = key; best.t = t; best.u = u; best.v = v; best.instance = instance; best.prim = prim; best.hit = true; }
                   }
@@ -149,7 +149,7 @@ DEV uint32_t trace_surface(const FrameParams &P, ShadeEnv &env, const ViewImages
                           ++nhits;
                           if (hi == RT64_MAX_HIT_QUERIES - 1 && t < tmax) tmax = t;      // not IgnoreHit(): the hit is committed
                       }
-                      if (!(in.flags & GPU_INST_OPAQUE)) return false;
+                      if (!(instFlags & GPU_INST_OPAQUE)) return false;
                   }
                   const float lim = key + P.maxDepthBias;
                   if (lim < tmax) tmax = lim;

@@ -436,8 +436,8 @@ DEV float trace_shadow(const FrameParams &P, ShadeEnv &env, f3 origin, f3 dir, f
     float shadowHit = 1.0f;
     env.shadowRays++;
     trace_ray<CACHED>(P, o, d, tmin, tmax, false /* SKIP_BACKFACE_SHADOWS undefined */, env.stk,
-              [&](float, float u, float v, uint32_t instance, uint32_t prim, float &) -> bool {
-                  if (P.instances[instance].flags & GPU_INST_SHADOW_OPAQUE) { shadowHit = 0.0f; return true; }   // payload.shadowHit = 0 (:661)
+              [&](float, float u, float v, uint32_t instance, uint32_t prim, float &, uint32_t instFlags, float) -> bool {
+                  if (instFlags & GPU_INST_SHADOW_OPAQUE) { shadowHit = 0.0f; return true; }   // payload.shadowHit = 0 (:661)
                   float a = shadow_anyhit_alpha(P, instance, prim, u, v, px, py);
                   if (a < 0.0f) return false;
                   shadowHit = fmaxf(shadowHit - a, 0.0f);

@@ -107,7 +107,8 @@ DEV GpuTri load_tri(const GpuTri *p) {                            // 3 x global_
     return u.t;
 }
 
-// OnHit: bool operator()(float t, float u, float v, uint32_t instance, uint32_t prim, float &tmax) -> true = end search.
+// OnHit: bool operator()(float t, float u, float v, uint32_t instance, uint32_t prim, float &tmax, uint32_t instanceFlags,
+//                        float instanceDepthBias) -> true = end search.   (RayWalk::run below keeps the six-argument form.)
 //
 // Loop shape ("while-while"): the wave first walks inner nodes until every live lane holds a leaf (or has finished), then all
 // lanes process their leaf together (ray/triangle test, or the object-space switch at a TLAS leaf).  Lanes never execute the
@@ -135,7 +136,8 @@ DEV void trace_ray(const FrameParams &P, const float o[3], const float d[3], flo
     uint32_t nodeOff = tlasOff;
     const GpuTri *tris = nullptr;
     int sp = 0, blasBase = -1;
-    uint32_t inst = 0;
+    uint32_t inst = 0, instFlags = 0;
+    float instDepthBias = 0.0f;            // of the instance being walked: handed to the hit handler (no table lookup per hit)
     bool cull = false;
     uint32_t cur = 0;
     bool alive = true;
@@ -171,7 +173,7 @@ DEV void trace_ray(const FrameParams &P, const float o[3], const float d[3], flo
                 float oo[3], dd[3];
                 uint32_t flags;
                 if (CACHED) {
-                    // 64-byte record of leaf slot `cur`: three words (M[c], M[4+c], M[8+c], M[12+c]), then (instance | flags << 16, node offset, tris pointer)
+                    // 64-byte record of leaf slot `cur`: three words (M[c], M[4+c], M[8+c], M[12+c]), then (instance | flags << 8 | node offset << 16, depth bias, tris pointer)
                     const u32x4_lds *rec = stk.cache + 4u * (cur & 0x7FFFFFFFu);
                     const u32x4_lds info = rec[3];
 #pragma unroll
@@ -181,7 +183,7 @@ DEV void trace_ray(const FrameParams &P, const float o[3], const float d[3], flo
                         oo[c] = fmaf(W.o[2], m2, fmaf(W.o[1], m1, fmaf(W.o[0], m0, m3)));
                         dd[c] = fmaf(W.d[2], m2, fmaf(W.d[1], m1, W.d[0] * m0));
                     }
-                    inst = info.x & 0xFFFFu; flags = info.x >> 16; nodeOff = info.y;
+                    inst = info.x & 0xFFu; flags = (info.x >> 8) & 0xFFu; nodeOff = info.x >> 16; instDepthBias = __uint_as_float(info.y);
                     tris = reinterpret_cast<const GpuTri *>(((uint64_t)info.w << 32) | (uint64_t)info.z);
                 }
                 else {
@@ -196,9 +198,10 @@ DEV void trace_ray(const FrameParams &P, const float o[3], const float d[3], flo
                         dd[c] = fmaf(W.d[2], m2, fmaf(W.d[1], m1, W.d[0] * m0));
                     }
                     nodes = load_global(&in->nodes); tris = load_global(&in->tris);
-                    flags = load_global(&in->flags);
+                    flags = load_global(&in->flags); instDepthBias = load_global(&in->material.depthBias);
                 }
                 make_ray_space(oo, dd, R);
+                instFlags = flags;
                 cull = cullBackFaces && !(flags & GPU_INST_CULL_DISABLE);
                 blasBase = sp;
                 cur = 0;
@@ -208,7 +211,7 @@ DEV void trace_ray(const FrameParams &P, const float o[3], const float d[3], flo
             cnt.tris++;
             float t, u, v;
             if (tri_hit(R, tri, cull, tmin, tmax, t, u, v))
-                if (onHit(t, u, v, inst, tri.prim, tmax)) return;
+                if (onHit(t, u, v, inst, tri.prim, tmax, instFlags, instDepthBias)) return;
         }
         alive = popNext();
     }
