@@ -203,3 +203,43 @@ def test_many_meshes_set_between_frames_build_in_one_batch(rt64_lib, sample_data
         assert len(np.unique(s.readback(rt64.IMAGE_INSTANCE_ID))) > 12
     finally:
         s.close(); o.close()
+
+
+def test_five_thousand_instances_use_the_large_tlas_builder(rt64_lib, sample_data):
+    """More than 4096 ray-traced instances: the TLAS goes through the multi-kernel LBVH path (radix sort over instance boxes) and is
+    bit-identical to the oracle's; the frame's hits and traversal counters follow."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    from oracle import oracle_py
+    rng = np.random.default_rng(9)
+
+    def mod(d):
+        tri = np.zeros(3, dtype=sample_scene.VERTEX_DTYPE)
+        tri["position"] = [(-0.06, 0.0, 0.0, 1.0), (0.06, 0.0, 0.0, 1.0), (0.0, 0.1, 0.0, 1.0)]
+        tri["normal"] = (0.0, 0.0, 1.0); tri["input1"] = 1.0; tri["uv"] = [(0, 0), (1, 0), (0, 1)]
+        d.meshes.append(sample_scene.MeshData("chip", rt64.MESH_RAYTRACE_ENABLED, tri, np.array([0, 1, 2], dtype=np.uint32)))
+        base = d.instances[1]
+        for k in range(5000):
+            inst = copy.copy(base); inst.mesh = len(d.meshes) - 1; inst.material = sample_scene.copy_material(base.material); inst.name = "chip%d" % k
+            t = np.eye(4, dtype=np.float32)
+            t[3, :3] = (rng.uniform(-7, 7), rng.uniform(0.1, 4.5), rng.uniform(-3, 5))
+            inst.transform = t; inst.previous_transform = t; inst.flags = 2
+            d.instances.append(inst)
+    data = _variant(sample_data, mod)
+    s = sample_scene.Rt64Scene(rt64_lib, data, 160, 90, hip_device=0)
+    o = oracle_py.OracleScene(data)
+    try:
+        s.option("count_traversal", 1)
+        s.draw()
+        ref = o.render(160, 90)
+        assert s.stats().instanceCount == 5002
+        hit = s.readback(rt64.IMAGE_PRIMARY_HIT)
+        assert np.array_equal(hit, ref["primaryHit"])
+        st = s.stats()
+        assert (st.nodesVisited, st.trianglesTested) == (ref["counters"]["nodesVisited"], ref["counters"]["trianglesTested"])
+        nodes = np.empty(5001 * 64, dtype=np.uint8)
+        n = rt64_lib.ReadbackViewAccel(s.view, rt64.ACCEL_NODES, nodes.ctypes.data, nodes.nbytes)
+        assert n == nodes.nbytes
+        tl = oracle_py.bvh_to_numpy(o.L.oracle_scene_tlas(o.scene))
+        assert np.array_equal(nodes.view(np.uint8), tl["nodes"].view(np.uint8).reshape(-1))
+    finally:
+        s.close(); o.close()
