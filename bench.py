@@ -62,6 +62,7 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU-staged rehearsal of the N>1 path")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a 1-GPU box: every rank renders on device 0")
     ap.add_argument("--force-gather", action="store_true", help="rehearsal: run the N > 1 code path (enqueued frames + pipelined RCCL gather) with a world of 1")
+    ap.add_argument("--pretend-ranks", type=int, default=0, help="diagnosis on a 1-GPU box: render only rank 0's share of a P-way partition, frames enqueued, no gather; `value` is then NOT a throughput of the whole frame")
     ap.add_argument("--cpu-baseline-height", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = all)")
     return ap.parse_args()
 
@@ -143,7 +144,12 @@ def main():
     rays_total = int(st_full.primaryRays + st_full.shadowRays + st_full.indirectRays + st_full.reflectionRays + st_full.refractionRays)
     scene.option("count_traversal", 0)
     use_bands = N > 1 and args.gi_samples > 0 and args.denoiser
-    if use_bands:
+    PR = args.pretend_ranks if (N == 1 and not G) else 0
+    if PR > 1 and args.gi_samples > 0 and args.denoiser:
+        scene.set_tile(*tiles.band_range(H, 0, PR))
+    elif PR > 1:
+        scene.set_interleave(0, PR)
+    elif use_bands:
         scene.set_tile(*tiles.band_range(H, rank, N))
     else:
         scene.set_interleave(rank, N)
@@ -163,6 +169,8 @@ def main():
     staging = torch.zeros(max(tiles.strips_per_rank(H, N) * 16, tiles.band_rows(H, N)) * W * 4, dtype=torch.uint8, device="cuda") if (G and not pipelined) else None
     local = torch.zeros(max(tiles.max_owned_rows(H, N), 1) * W * 4, dtype=torch.uint8, device="cuda")
     my_bytes = gatherer.owned_bytes() if G else H * W * 4
+    if PR > 1:
+        my_bytes = ((tiles.band_range(H, 0, PR)[1] - tiles.band_range(H, 0, PR)[0]) if (args.gi_samples > 0 and args.denoiser) else tiles.owned_rows(H, 0, PR)) * W * 4
 
     def fetch(dst):
         n = lib.CopyDeviceImage(scene.device, rt64.IMAGE_FINAL_RGBA8, dst.data_ptr(), dst.numel())
@@ -202,6 +210,8 @@ def main():
         scene.option("always_rebuild", 1)
     if os.environ.get("RT64_LDS_CACHE"):
         scene.option("lds_cache", int(os.environ["RT64_LDS_CACHE"]))
+    if os.environ.get("RT64_FUSED_LEAN"):
+        scene.option("fused_lean", int(os.environ["RT64_FUSED_LEAN"]))
     if os.environ.get("RT64_BOUNCE_REFILL"):
         scene.option("bounce_refill", int(os.environ["RT64_BOUNCE_REFILL"]))
     scene.option("count_traversal", 1)
@@ -214,7 +224,7 @@ def main():
     hit_pixels = int((scene.readback(rt64.IMAGE_FIRST_INSTANCE_ID) >= 0).sum())
     scene.option("count_traversal", 0)
 
-    if pipelined:
+    if pipelined or PR > 1:
         scene.option("sync_present", 0)      # RT64_DrawDevice enqueues; ordering is on the renderer's stream from here on
     for _ in range(args.warmup):
         step()
@@ -238,12 +248,12 @@ def main():
     gathered_checksum = None
     if G and rank == 0:              # the frame assembled on rank 0 by the gather of the last timed step
         gathered_checksum = int(gatherer.frame(last_slot).to(torch.int64).sum().item())
-    if not G:                        # N = 1: every timed frame was measured live with HIP events inside the library
+    if not G and PR <= 1:            # N = 1: every timed frame was measured live with HIP events inside the library
         s = scene.stats()
         assert s.accumFrames == args.steps, (s.accumFrames, args.steps)
         acc.update(trace=s.accumMsPrimaryTrace, shade=s.accumMsPrimaryShade, direct=s.accumMsDirect, indirect=s.accumMsIndirect, compose=s.accumMsComposePost,
                    build=s.accumMsBuild, total=s.accumMsTotal, denoise=s.accumMsDenoise, reflect=s.accumMsReflectRefract)
-    if G:                            # per-kernel timings of this rank's strips from a few untimed frames (reading them synchronises)
+    if G or PR > 1:                  # per-kernel timings of this rank's strips from a few untimed frames (reading them synchronises)
         stat_frames = 10
         for _ in range(stat_frames):
             step()
@@ -260,6 +270,8 @@ def main():
         K = float(stat_frames)
         kms = {k: v / K for k, v in acc.items()}
         my_pixels = (tiles.band_range(H, 0, N)[1] if use_bands else tiles.owned_rows(H, 0, N)) * W
+        if PR > 1:
+            my_pixels = my_bytes // 4
         kernels = {
             "primary_trace": (kms["trace"], my_pixels * PRIMARY_TRACE_PIXEL_B + NODE_B * counts["nodesPrimary"] + TRI_B * counts["trisPrimary"]),
             "primary_shade": (kms["shade"], my_pixels * (PRIMARY_SHADE_PIXEL_LEAN_B if lean else PRIMARY_SHADE_PIXEL_B) + hit_pixels * (PRIMARY_SHADE_HIT_B + (PRIMARY_SHADE_HIT_LEAN_B if lean else 0)) + (my_pixels - hit_pixels) * PRIMARY_SHADE_MISS_B),
@@ -305,7 +317,7 @@ def main():
                 args.config, W, H, "" if not (args.gi_samples or args.subdiv or args.floor_grid > 1) else " [gi=%d denoiser=%d subdiv=%d floor_grid=%d]" % (
                     args.gi_samples, int(args.denoiser), args.subdiv, args.floor_grid)),
                 "rays_per_frame": int(rays_total), "width": W, "height": H,
-                "partition": ("%s x%d + RCCL gather of RGBA8" % ("contiguous bands with denoiser halo" if use_bands else "interleaved 16-row strips", N)) if N > 1 else "single GPU"},
+                "partition": ("DIAGNOSIS: rank 0's share of a %d-way partition only, no gather" % PR) if PR > 1 else ("%s x%d + RCCL gather of RGBA8" % ("contiguous bands with denoiser halo" if use_bands else "interleaved 16-row strips", N)) if N > 1 else "single GPU"},
             "roofline": roofline,
         }
         if G:

@@ -56,8 +56,8 @@ DEV bool row_owned(const FrameParams &P, int y) { return (((y - P.tileY0) / 16) 
 
 DEV TraceStack make_stack(const FrameParams &P, uint32_t *ldsStack) {
     TraceStack s;
-    s.lds = ldsStack + threadIdx.x;
-    s.spill = P.traversalStack + ((size_t)blockIdx.x * RT_BLOCK + threadIdx.x) * RT_STACK_SPILL;
+    s.lds = (LdsU32Ptr)(ldsStack + threadIdx.x);
+    s.spill = (GlobalU32Ptr)(P.traversalStack + ((size_t)blockIdx.x * RT_BLOCK + threadIdx.x) * RT_STACK_SPILL);
     s.cache = nullptr; s.ldsEntries = RT_STACK_LDS;
     return s;
 }
@@ -160,6 +160,17 @@ DEV uint32_t trace_surface(const FrameParams &P, ShadeEnv &env, const ViewImages
 
 // Entry `hit` of the list as a shaded record (the any-hit program runs here, on coherent data, instead of during traversal).
 // Reads beyond the 17 allocated slots return an empty record like an out-of-bounds typed UAV load.
+// Entry `hit` of the pixel's sorted list as (instance, primitive, t, u, v), without running the any-hit program.
+template <bool KLIST>
+DEV bool surface_entry(const FrameParams &P, const ViewImages &I, size_t pixel, uint32_t hit, const SurfaceHit &best, SurfaceHit &e) {
+    if (!KLIST) { e = best; return true; }
+    if (hit > RT64_MAX_HIT_QUERIES) return false;
+    const size_t stride = (size_t)P.width * (size_t)P.height;
+    const uint4 a = I.klistA[(size_t)hit * stride + pixel];
+    const uint2 b = I.klistB[(size_t)hit * stride + pixel];
+    e.instance = b.y; e.prim = a.w; e.t = __uint_as_float(b.x); e.u = __uint_as_float(a.y); e.v = __uint_as_float(a.z); e.hit = true; e.key = __uint_as_float(a.x);
+    return true;
+}
 template <bool KLIST>
 DEV bool surface_record(const FrameParams &P, const ViewImages &I, size_t pixel, uint32_t hit, const SurfaceHit &best, f3 dir,
                         const RayDiff &rayDiff, uint32_t px, uint32_t py, HitRecord &r) {
@@ -239,6 +250,120 @@ __global__ __launch_bounds__(RT_BLOCK, KLIST ? 2 : TRACE_WAVES) void primary_tra
 // FULL = false ("lean" frame): no pass of this frame consumes the view direction, reflection / refraction / transparent
 // accumulators, motion vectors or upscaler masks, so they are not written (42 of 94 bytes per pixel); RT64_ReadbackDevice
 // re-runs the FULL variant on demand (View::materialise in rt64_host.cpp).
+// What PrimaryRayGen resolves for one pixel (the values its image stores take).
+struct PrimaryResolve {
+    f3 position, normal, specular, transparent;
+    f4 color;
+    float flowX, flowY, reactiveMask, lockMask, depth, reflA, refrA;
+    int instanceId;
+};
+
+// PrimaryRayGen.hlsl:47-196 for one pixel whose visibility is already known (`best` / the k-buffer): the resolve loop over the
+// sorted hits + the background term.  Shared by primary_shade_kernel (hit records from HBM) and lean_frame_kernel (hit in registers).
+template <bool TRANSPARENT_LIGHT, bool KLIST, bool FULL>
+DEV void resolve_primary(const FrameParams &P, const ViewImages &I, ShadeEnv &env, uint32_t px, uint32_t py, size_t i, f3 rayOrigin, f3 rayDirection, f2 d,
+                         const SurfaceHit &best, uint32_t nhits, PrimaryResolve &R) {
+    f3 cU = mk3(P.cameraU[0], P.cameraU[1], P.cameraU[2]), cV = mk3(P.cameraV[0], P.cameraV[1], P.cameraV[2]), cW = mk3(P.cameraW[0], P.cameraW[1], P.cameraW[2]);
+    f3 nonNormRayDir = (cU * d.x + cV * d.y) + cW;
+    float reflA = 0.0f, refrA = 0.0f;
+
+    f2 screenUV; screenUV.x = ((float)px + P.pixelJitter[0]) / (float)P.width; screenUV.y = ((float)py + P.pixelJitter[1]) / (float)P.height;
+    // The background / sky colour only enters through `bgColor * resColor.a` after the resolve loop: it is fetched there, and
+    // only by pixels that are not fully covered (PrimaryRayGen.hlsl:47-53 samples up front; same values, fewer fetches).
+    f2 prevBgPos, curBgPos; prevBgPos.x = prevBgPos.y = curBgPos.x = curBgPos.y = 0.0f;
+    if (FULL) {
+        f3 bgPosition = rayOrigin + rayDirection * RT_RAY_MAX_DISTANCE;
+        prevBgPos = world_to_screen(P.prevViewProj, bgPosition); curBgPos = world_to_screen(P.viewProj, bgPosition);
+    }
+
+    RayDiff rayDiff;
+    rayDiff.dOdx = mk3s(0.0f); rayDiff.dOdy = mk3s(0.0f); rayDiff.dDdx = mk3s(0.0f); rayDiff.dDdy = mk3s(0.0f);
+
+    f3 resPosition = mk3s(0.0f), resNormal = -rayDirection, resSpecular = mk3s(0.0f), resTransparent = mk3s(0.0f), resTransparentLight = mk3s(0.0f);
+    bool resTransparentLightComputed = false;
+    f4 resColor = mk4(0, 0, 0, 1);
+    float resFlowX = (curBgPos.x - prevBgPos.x) * (float)P.width, resFlowY = (curBgPos.y - prevBgPos.y) * (float)P.height;
+    float resReactiveMask = 0.0f, resLockMask = 0.0f, resDepth = 1.0f;
+    int resInstanceId = -1;
+    const f3 ambient = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]) + mk3(P.ambientNoGIColor[0], P.ambientNoGIColor[1], P.ambientNoGIColor[2]);
+
+    if (nhits) compute_ray_diffs(nonNormRayDir, cU, cV, P.resolution[2], P.resolution[3], rayDiff.dDdx, rayDiff.dDdy);
+    for (uint32_t hit = 0; hit < nhits; hit++) {
+        SurfaceHit e;
+        if (!surface_entry<KLIST>(P, I, i, hit, best, e)) continue;
+        bool covered = false;
+        // one pass per distinct instance among the wave's lanes: the any-hit program and the material run on scalar registers
+        waterfall(e.instance, [&](uint32_t instanceId) {
+        const InstView iv = inst_view(P, instanceId);
+        HitRecord r;
+        if (!surface_anyhit_view(P, iv, instanceId, e.prim, e.t, e.u, e.v, rayDirection, rayDiff, px, py, r)) return;
+        f4 hitColor = r.color;
+        float alphaContrib = resColor.w * hitColor.w;
+        if (alphaContrib >= RT_EPSILON) {
+            const RT64_MATERIAL &m = iv.material;
+            resLockMask += m.lockMask * alphaContrib;
+            bool usesLighting = m.lightGroupMaskBits > 0;
+            bool applyLighting = usesLighting && (hitColor.w > RT_APPLY_LIGHTS_MINIMUM_ALPHA);
+            f3 vertexPosition = rayOrigin + rayDirection * (r.dist + m.depthBias);
+            f3 vertexNormal = r.normal;
+            f3 specular = ld_v3(m.specularColor) * r.specular;
+            bool storeHit = false;
+            if (m.fogEnabled) {
+                f4 fog = fog_from_camera(P, m, vertexPosition);
+                resTransparent = resTransparent + xyz(fog) * (fog.w * alphaContrib);
+                alphaContrib *= (1.0f - fog.w);
+            }
+            if (m.reflectionFactor > RT_EPSILON) {
+                float fresnelAmount = fresnel_reflect_amount(vertexNormal, rayDirection, m.reflectionFactor, m.reflectionFresnelFactor);
+                float reflectAmount = fresnelAmount * alphaContrib;
+                reflA = reflectAmount;
+                alphaContrib *= (1.0f - fresnelAmount);
+                storeHit = true;
+                resLockMask += reflectAmount;
+            }
+            f3 resColorAdd = xyz(hitColor) * alphaContrib;
+            if (applyLighting) {
+                storeHit = true;
+                resColor.x += resColorAdd.x; resColor.y += resColorAdd.y; resColor.z += resColorAdd.z;
+            }
+            else if (TRANSPARENT_LIGHT && usesLighting) {
+                if (!resTransparentLightComputed) {
+                    resTransparentLight = compute_lights_random(P, env, px, py, rayDirection, instanceId, vertexPosition, vertexNormal, specular, 1, true);
+                    resTransparentLightComputed = true;
+                }
+                resTransparent = resTransparent + resColorAdd * ((ambient + ld_v3(m.selfLight)) + resTransparentLight);
+            }
+            else resTransparent = resTransparent + resColorAdd * (ambient + ld_v3(m.selfLight));
+            resColor.w *= (1.0f - hitColor.w);
+            if (m.refractionFactor > RT_EPSILON) { storeHit = true; refrA = resColor.w; resColor.w = 0.0f; }
+            if (storeHit && resInstanceId < 0) {
+                f2 prevPos, curPos; prevPos.x = prevPos.y = curPos.x = curPos.y = 0.0f;
+                if (FULL) { prevPos = world_to_screen(P.prevViewProj, vertexPosition - r.flow); curPos = world_to_screen(P.viewProj, vertexPosition); }
+                resPosition = vertexPosition; resNormal = vertexNormal; resSpecular = specular; resInstanceId = (int)instanceId;
+                resFlowX = (curPos.x - prevPos.x) * (float)P.width; resFlowY = (curPos.y - prevPos.y) * (float)P.height;
+                if (FULL) {
+                    f4 projPos = mul4(P.viewProj, mk4(vertexPosition.x, vertexPosition.y, vertexPosition.z, 1.0f));
+                    resDepth = s_div(projPos.z, projPos.w);
+                }
+            }
+        }
+        if (resColor.w <= RT_EPSILON) covered = true;
+        });
+        if (covered) break;
+    }
+    resReactiveMask += fmaxf(resTransparent.x, fmaxf(resTransparent.y, resTransparent.z));
+    if (resColor.w != 0.0f) {
+        const f4 skyColor = sample_sky_2d(P, screenUV);
+        // lerp(background, sky, 1) is the sky itself up to one rounding of (sky - bg) + bg: skip the gBackground fetch under an opaque sky
+        f3 bgColor = skyColor.w >= 1.0f ? xyz(skyColor) : lerp3(sample_background_2d(P, screenUV), xyz(skyColor), skyColor.w);
+        resColor.x += bgColor.x * resColor.w; resColor.y += bgColor.y * resColor.w; resColor.z += bgColor.z * resColor.w;
+    }
+    resColor.w = 1.0f - resColor.w;
+    R.position = resPosition; R.normal = resNormal; R.specular = resSpecular; R.transparent = resTransparent; R.color = resColor;
+    R.flowX = resFlowX; R.flowY = resFlowY; R.reactiveMask = resReactiveMask; R.lockMask = resLockMask; R.depth = resDepth; R.reflA = reflA; R.refrA = refrA;
+    R.instanceId = resInstanceId;
+}
+
 template <bool TRANSPARENT_LIGHT, bool KLIST, bool FULL>
 __global__ __launch_bounds__(RT_BLOCK, SHADE_WAVES) void primary_shade_kernel(FrameParams P, ViewImages I, const int32_t *hitInstance, int cur) {
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
@@ -254,30 +379,7 @@ __global__ __launch_bounds__(RT_BLOCK, SHADE_WAVES) void primary_shade_kernel(Fr
         const size_t i = (size_t)py * (size_t)P.width + px;
         f3 rayOrigin, rayDirection; f2 d;
         primary_ray(P, px, py, rayOrigin, rayDirection, d);
-        f3 cU = mk3(P.cameraU[0], P.cameraU[1], P.cameraU[2]), cV = mk3(P.cameraV[0], P.cameraV[1], P.cameraV[2]), cW = mk3(P.cameraW[0], P.cameraW[1], P.cameraW[2]);
-        f3 nonNormRayDir = (cU * d.x + cV * d.y) + cW;
         if (FULL) store_rgba16f(I.viewDirection, i, rayDirection.x, rayDirection.y, rayDirection.z, 0.0f);
-        float reflA = 0.0f, refrA = 0.0f;
-
-        f2 screenUV; screenUV.x = ((float)px + P.pixelJitter[0]) / (float)P.width; screenUV.y = ((float)py + P.pixelJitter[1]) / (float)P.height;
-        // The background / sky colour only enters through `bgColor * resColor.a` after the resolve loop: it is fetched there, and
-        // only by pixels that are not fully covered (PrimaryRayGen.hlsl:47-53 samples up front; same values, fewer fetches).
-        f2 prevBgPos, curBgPos; prevBgPos.x = prevBgPos.y = curBgPos.x = curBgPos.y = 0.0f;
-        if (FULL) {
-            f3 bgPosition = rayOrigin + rayDirection * RT_RAY_MAX_DISTANCE;
-            prevBgPos = world_to_screen(P.prevViewProj, bgPosition); curBgPos = world_to_screen(P.viewProj, bgPosition);
-        }
-
-        RayDiff rayDiff;
-        rayDiff.dOdx = mk3s(0.0f); rayDiff.dOdy = mk3s(0.0f); rayDiff.dDdx = mk3s(0.0f); rayDiff.dDdy = mk3s(0.0f);
-
-        f3 resPosition = mk3s(0.0f), resNormal = -rayDirection, resSpecular = mk3s(0.0f), resTransparent = mk3s(0.0f), resTransparentLight = mk3s(0.0f);
-        bool resTransparentLightComputed = false;
-        f4 resColor = mk4(0, 0, 0, 1);
-        float resFlowX = (curBgPos.x - prevBgPos.x) * (float)P.width, resFlowY = (curBgPos.y - prevBgPos.y) * (float)P.height;
-        float resReactiveMask = 0.0f, resLockMask = 0.0f, resDepth = 1.0f;
-        int resInstanceId = -1;
-        const f3 ambient = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]) + mk3(P.ambientNoGIColor[0], P.ambientNoGIColor[1], P.ambientNoGIColor[2]);
 
         const uint4 hrec = reinterpret_cast<const uint4 *>(I.primaryHit)[i];
         const int hInst = hitInstance[i];
@@ -285,92 +387,31 @@ __global__ __launch_bounds__(RT_BLOCK, SHADE_WAVES) void primary_shade_kernel(Fr
         best.hit = hInst >= 0; best.instance = (uint32_t)hInst; best.prim = hrec.w;
         best.t = __uint_as_float(hrec.x); best.u = __uint_as_float(hrec.y); best.v = __uint_as_float(hrec.z);
         const uint32_t nhits = KLIST ? I.klistCount[i] : (hInst >= 0 ? 1u : 0u);
-        if (nhits) compute_ray_diffs(nonNormRayDir, cU, cV, P.resolution[2], P.resolution[3], rayDiff.dDdx, rayDiff.dDdy);
-        for (uint32_t hit = 0; hit < nhits; hit++) {
-            HitRecord r;
-            if (!surface_record<KLIST>(P, I, i, hit, best, rayDirection, rayDiff, px, py, r)) continue;
-            f4 hitColor = r.color;
-            float alphaContrib = resColor.w * hitColor.w;
-            if (alphaContrib >= RT_EPSILON) {
-                const uint32_t instanceId = r.instanceId;
-                const RT64_MATERIAL &m = P.instances[instanceId].material;
-                resLockMask += m.lockMask * alphaContrib;
-                bool usesLighting = m.lightGroupMaskBits > 0;
-                bool applyLighting = usesLighting && (hitColor.w > RT_APPLY_LIGHTS_MINIMUM_ALPHA);
-                f3 vertexPosition = rayOrigin + rayDirection * (r.dist + m.depthBias);
-                f3 vertexNormal = r.normal;
-                f3 specular = ld_v3(m.specularColor) * r.specular;
-                bool storeHit = false;
-                if (m.fogEnabled) {
-                    f4 fog = fog_from_camera(P, m, vertexPosition);
-                    resTransparent = resTransparent + xyz(fog) * (fog.w * alphaContrib);
-                    alphaContrib *= (1.0f - fog.w);
-                }
-                if (m.reflectionFactor > RT_EPSILON) {
-                    float fresnelAmount = fresnel_reflect_amount(vertexNormal, rayDirection, m.reflectionFactor, m.reflectionFresnelFactor);
-                    float reflectAmount = fresnelAmount * alphaContrib;
-                    reflA = reflectAmount;
-                    alphaContrib *= (1.0f - fresnelAmount);
-                    storeHit = true;
-                    resLockMask += reflectAmount;
-                }
-                f3 resColorAdd = xyz(hitColor) * alphaContrib;
-                if (applyLighting) {
-                    storeHit = true;
-                    resColor.x += resColorAdd.x; resColor.y += resColorAdd.y; resColor.z += resColorAdd.z;
-                }
-                else if (TRANSPARENT_LIGHT && usesLighting) {
-                    if (!resTransparentLightComputed) {
-                        resTransparentLight = compute_lights_random(P, env, px, py, rayDirection, instanceId, vertexPosition, vertexNormal, specular, 1, true);
-                        resTransparentLightComputed = true;
-                    }
-                    resTransparent = resTransparent + resColorAdd * ((ambient + ld_v3(m.selfLight)) + resTransparentLight);
-                }
-                else resTransparent = resTransparent + resColorAdd * (ambient + ld_v3(m.selfLight));
-                resColor.w *= (1.0f - hitColor.w);
-                if (m.refractionFactor > RT_EPSILON) { storeHit = true; refrA = resColor.w; resColor.w = 0.0f; }
-                if (storeHit && resInstanceId < 0) {
-                    f2 prevPos, curPos; prevPos.x = prevPos.y = curPos.x = curPos.y = 0.0f;
-                    if (FULL) { prevPos = world_to_screen(P.prevViewProj, vertexPosition - r.flow); curPos = world_to_screen(P.viewProj, vertexPosition); }
-                    f4 projPos = mul4(P.viewProj, mk4(vertexPosition.x, vertexPosition.y, vertexPosition.z, 1.0f));
-                    resPosition = vertexPosition; resNormal = vertexNormal; resSpecular = specular; resInstanceId = (int)instanceId;
-                    resFlowX = (curPos.x - prevPos.x) * (float)P.width; resFlowY = (curPos.y - prevPos.y) * (float)P.height;
-                    resDepth = s_div(projPos.z, projPos.w);
-                }
-            }
-            if (resColor.w <= RT_EPSILON) break;
-        }
-        resReactiveMask += fmaxf(resTransparent.x, fmaxf(resTransparent.y, resTransparent.z));
-        if (resColor.w != 0.0f) {
-            const f4 skyColor = sample_sky_2d(P, screenUV);
-            // lerp(background, sky, 1) is the sky itself up to one rounding of (sky - bg) + bg: skip the gBackground fetch under an opaque sky
-            f3 bgColor = skyColor.w >= 1.0f ? xyz(skyColor) : lerp3(sample_background_2d(P, screenUV), xyz(skyColor), skyColor.w);
-            resColor.x += bgColor.x * resColor.w; resColor.y += bgColor.y * resColor.w; resColor.z += bgColor.z * resColor.w;
-        }
-        resColor.w = 1.0f - resColor.w;
+        PrimaryResolve R;
+        resolve_primary<TRANSPARENT_LIGHT, KLIST, FULL>(P, I, env, px, py, i, rayOrigin, rayDirection, d, best, nhits, R);
 
         if (FULL) {
-            store_rgba16f(I.reflection, i, 0.0f, 0.0f, 0.0f, reflA);
-            store_rgba16f(I.refraction, i, 0.0f, 0.0f, 0.0f, refrA);
+            store_rgba16f(I.reflection, i, 0.0f, 0.0f, 0.0f, R.reflA);
+            store_rgba16f(I.refraction, i, 0.0f, 0.0f, 0.0f, R.refrA);
         }
         // Lean frame: DirectRayGen reads position / normal / specular only where a surface was hit, so miss pixels skip those stores.
-        if (FULL || resInstanceId >= 0) {
-            reinterpret_cast<float4 *>(I.shadingPosition)[i] = make_float4(resPosition.x, resPosition.y, resPosition.z, 0.0f);
-            store_rgba16f(I.shadingNormal, i, resNormal.x, resNormal.y, resNormal.z, 0.0f);
-            store_rgba16f(I.shadingSpecular, i, resSpecular.x, resSpecular.y, resSpecular.z, 0.0f);
+        if (FULL || R.instanceId >= 0) {
+            reinterpret_cast<float4 *>(I.shadingPosition)[i] = make_float4(R.position.x, R.position.y, R.position.z, 0.0f);
+            store_rgba16f(I.shadingNormal, i, R.normal.x, R.normal.y, R.normal.z, 0.0f);
+            store_rgba16f(I.shadingSpecular, i, R.specular.x, R.specular.y, R.specular.z, 0.0f);
         }
-        store_rgba8(I.diffuse, i, resColor.x, resColor.y, resColor.z, resColor.w);
-        I.instanceId[i] = resInstanceId;
+        store_rgba8(I.diffuse, i, R.color.x, R.color.y, R.color.z, R.color.w);
+        I.instanceId[i] = R.instanceId;
         if (FULL) {
-            I.firstInstanceId[i] = resInstanceId;                   // CopyResource(rtFirstInstanceId, rtInstanceId), rt64_view.cpp:1383
-            store_rgba16f(I.transparent, i, resTransparent.x, resTransparent.y, resTransparent.z, 1.0f);
-            reinterpret_cast<uint32_t *>(I.flow)[i] = (uint32_t)f32_to_f16_bits(-resFlowX) | ((uint32_t)f32_to_f16_bits(resFlowY) << 16);
-            I.reactiveMask[i] = to_unorm8(fminf(resReactiveMask, 0.9f));
-            I.lockMask[i] = to_unorm8(P.binaryLockMask ? (resLockMask >= 0.5f ? 1.0f : 0.0f) : fminf(resLockMask, 1.0f));
+            I.firstInstanceId[i] = R.instanceId;                    // CopyResource(rtFirstInstanceId, rtInstanceId), rt64_view.cpp:1383
+            store_rgba16f(I.transparent, i, R.transparent.x, R.transparent.y, R.transparent.z, 1.0f);
+            reinterpret_cast<uint32_t *>(I.flow)[i] = (uint32_t)f32_to_f16_bits(-R.flowX) | ((uint32_t)f32_to_f16_bits(R.flowY) << 16);
+            I.reactiveMask[i] = to_unorm8(fminf(R.reactiveMask, 0.9f));
+            I.lockMask[i] = to_unorm8(P.binaryLockMask ? (R.lockMask >= 0.5f ? 1.0f : 0.0f) : fminf(R.lockMask, 1.0f));
         }
         if (FULL) {                                                 // history guides of the temporal / SVGF passes: no consumer on a lean frame
-            store_rgba16f(I.normal[cur], i, resNormal.x, resNormal.y, resNormal.z, 0.0f);
-            I.depth[cur][i] = resDepth;
+            store_rgba16f(I.normal[cur], i, R.normal.x, R.normal.y, R.normal.z, 0.0f);
+            I.depth[cur][i] = R.depth;
         }
     }
     flush_env(P, env, PASS_PRIMARY_SHADE, CTR_PRIMARY, 0);
@@ -399,6 +440,17 @@ DEV float history_weight(const FrameParams &P, const ViewImages &I, size_t i, ui
 // ComposePS + PostProcessPS of a LEAN frame for one pixel (same arithmetic as compose_post_kernel<true>): everything it reads is
 // the pixel's own diffuse colour and direct light, so DirectRayGen's kernel finishes the pixel instead of a separate launch
 // (one kernel boundary less per frame: ~11 us of kernel + the inter-kernel gap and cache refill).
+DEV f3 compose_lean_value(const FrameParams &P, f4 d, f3 directStored) {
+    f3 result;
+    if (d.w > RT_EPSILON) {
+        f3 diffuse = xyz(d);
+        f3 indirect = mk3(q_f16(P.ambientBaseColor[0] + P.ambientNoGIColor[0]), q_f16(P.ambientBaseColor[1] + P.ambientNoGIColor[1]), q_f16(P.ambientBaseColor[2] + P.ambientNoGIColor[2]));
+        result = diffuse * (directStored + indirect);
+        result = lerp3(diffuse, result, d.w);
+    }
+    else result = xyz(d);
+    return result;
+}
 DEV void compose_lean_pixel(const FrameParams &P, const ViewImages &I, size_t i, f3 directStored) {
     f4 d = load_rgba8(I.diffuse, i);
     f3 result;
@@ -422,6 +474,20 @@ DEV void cached_env(const FrameParams &P, ShadeEnv &env, u32x4_lds *dynLds) {
     float *li = reinterpret_cast<float *>(dynLds + P.cacheWords);
     env.lightIntensity = li + threadIdx.x;
     env.lightIndex = reinterpret_cast<uint8_t *>(li + light_slots(P) * RT_BLOCK) + threadIdx.x;
+}
+
+// DirectRayGen.hlsl:47-58 for one lit pixel: sampled lights + self light + eye light (before the temporal accumulation).
+template <bool CACHED>
+DEV f3 direct_light_pixel(const FrameParams &P, ShadeEnv &env, uint32_t px, uint32_t py, f3 rayDirection, int instanceId, f3 position, f3 normal, f3 specular) {
+    f3 selfLight; float specularExponent;
+    waterfall((uint32_t)instanceId, [&](uint32_t k) { const RT64_MATERIAL mk = load_const(&P.instances[k].material); selfLight = ld_v3(mk.selfLight); specularExponent = mk.specularExponent; });
+    f3 resDirect = compute_lights_random<CACHED>(P, env, px, py, rayDirection, (uint32_t)instanceId, position, normal, specular, P.maxLights, true);
+    resDirect = resDirect + selfLight;
+    float eyeLambert = fmaxf(dot3(normal, -rayDirection), 0.0f);
+    f3 eyeReflected = reflect3(rayDirection, normal);
+    float eyeSpec = s_pow(fmaxf(saturatef(dot3(eyeReflected, -rayDirection)), 0.0f), specularExponent);
+    f3 eyeD = mk3(P.eyeLightDiffuseColor[0], P.eyeLightDiffuseColor[1], P.eyeLightDiffuseColor[2]), eyeS = mk3(P.eyeLightSpecularColor[0], P.eyeLightSpecularColor[1], P.eyeLightSpecularColor[2]);
+    return resDirect + (eyeD * eyeLambert + eyeS * (specular * eyeSpec));
 }
 
 template <bool FULL, bool CACHED = false>
@@ -456,14 +522,7 @@ __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void direct_kernel(FramePar
             f4 prevAccum = j >= 0 ? load_rgba16f(I.directLight[cur ^ 1], (size_t)j) : mk4(0, 0, 0, 0);
             newDirect = xyz(prevAccum); historyLength = prevAccum.w * w;
         }
-        const RT64_MATERIAL &m = P.instances[instanceId].material;
-        f3 resDirect = compute_lights_random<CACHED>(P, env, px, py, rayDirection, (uint32_t)instanceId, position, normal, specular, P.maxLights, true);
-        resDirect = resDirect + ld_v3(m.selfLight);
-        float eyeLambert = fmaxf(dot3(normal, -rayDirection), 0.0f);
-        f3 eyeReflected = reflect3(rayDirection, normal);
-        float eyeSpec = s_pow(fmaxf(saturatef(dot3(eyeReflected, -rayDirection)), 0.0f), m.specularExponent);
-        f3 eyeD = mk3(P.eyeLightDiffuseColor[0], P.eyeLightDiffuseColor[1], P.eyeLightDiffuseColor[2]), eyeS = mk3(P.eyeLightSpecularColor[0], P.eyeLightSpecularColor[1], P.eyeLightSpecularColor[2]);
-        resDirect = resDirect + (eyeD * eyeLambert + eyeS * (specular * eyeSpec));
+        const f3 resDirect = direct_light_pixel<CACHED>(P, env, px, py, rayDirection, instanceId, position, normal, specular);
         historyLength = fminf(historyLength + 1.0f, 64.0f);
         newDirect = lerp3(newDirect, resDirect, s_rcp(historyLength));
         store_rgba16f(I.directLight[cur], i, newDirect.x, newDirect.y, newDirect.z, historyLength);
@@ -471,6 +530,69 @@ __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void direct_kernel(FramePar
         else compose_lean_pixel(P, I, i, mk3(q_f16(newDirect.x), q_f16(newDirect.y), q_f16(newDirect.z)));      // Compose reads the RGBA16F value
     }
     flush_env(P, env, PASS_DIRECT, CTR_PRIMARY, 0);
+}
+
+// ---- lean frame in one kernel ----------------------------------------------------------------------------------------------
+// A lean frame (every instance provably opaque, no fog / reflection / refraction / GI / motion blur) is pixel-local from the primary
+// ray to the back buffer, so one kernel carries each pixel through PrimaryRayGen (visibility + resolve), DirectRayGen and Compose /
+// PostProcess with the intermediate G-buffer values in registers.  Every value that the separate kernels pass through an image is
+// rounded here exactly as that image's format rounds it (RGBA16F normal / specular / direct light, RGBA8 diffuse), so the back buffer
+// is bit-identical to the three-kernel path.  It still stores what View::materialise needs to rebuild the full G-buffer on demand:
+// the hit record (16 + 4 B) and the direct-light accumulation (8 B); rtOutput is written only when PostProcess runs separately.
+template <bool CACHED>
+#ifndef LEAN_WAVES
+#define LEAN_WAVES 2          // 2: no spills (about 200 VGPRs); 3 spills ~46 VGPRs and measured 1.5 % slower -- the kernel is latency bound, not occupancy bound
+#endif
+__global__ __launch_bounds__(RT_BLOCK, LEAN_WAVES) void lean_frame_kernel(FrameParams P, ViewImages I, int32_t *hitInstance, int cur) {
+    __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED : RT_STACK_LDS) * RT_BLOCK];
+    __shared__ float ldsLightIntensity[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
+    __shared__ uint8_t ldsLightIndex[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
+    extern __shared__ u32x4_lds dynLds[];
+    ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
+    env.lightIntensity = ldsLightIntensity + threadIdx.x; env.lightIndex = ldsLightIndex + threadIdx.x;
+    if (CACHED) cached_env(P, env, dynLds);
+    uint32_t rays = 0;
+    TraceCounts primaryCnt; primaryCnt.nodes = primaryCnt.tris = 0;
+    const uint32_t tiles = tile_count(P);
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        Pixel p = tile_pixel(P, tile);
+        if (!p.valid) continue;
+        const uint32_t px = p.x, py = p.y;
+        const size_t i = (size_t)py * (size_t)P.width + px;
+        f3 o, rayDirection; f2 ndc;
+        primary_ray(P, px, py, o, rayDirection, ndc);
+        RayDiff noDiff; noDiff.dOdx = noDiff.dOdy = noDiff.dDdx = noDiff.dDdy = mk3s(0.0f);
+        SurfaceHit h;
+        const TraceCounts before = env.cnt;
+        const uint32_t nhits = trace_surface<false, CACHED>(P, env, I, i, o, rayDirection, noDiff, px, py, h);
+        primaryCnt.nodes += env.cnt.nodes - before.nodes; primaryCnt.tris += env.cnt.tris - before.tris;
+        rays++;
+        uint4 rec;
+        if (h.hit) { rec.x = __float_as_uint(h.t); rec.y = __float_as_uint(h.u); rec.z = __float_as_uint(h.v); rec.w = h.prim; hitInstance[i] = (int32_t)h.instance; }
+        else { rec.x = rec.y = rec.z = rec.w = 0xFFFFFFFFu; hitInstance[i] = -1; }
+        reinterpret_cast<uint4 *>(I.primaryHit)[i] = rec;
+
+        PrimaryResolve R;
+        resolve_primary<false, false, false>(P, I, env, px, py, i, o, rayDirection, ndc, h, nhits, R);
+        const f4 diffuse = mk4(q_unorm8(R.color.x), q_unorm8(R.color.y), q_unorm8(R.color.z), q_unorm8(R.color.w));     // rtDiffuse is RGBA8
+        f3 direct = mk3s(1.0f); float historyLength = 0.0f;                                                            // DirectRayGen.hlsl:19
+        if (R.instanceId >= 0) {
+            const f3 normal = mk3(q_f16(R.normal.x), q_f16(R.normal.y), q_f16(R.normal.z));                            // rtShadingNormal / rtShadingSpecular are RGBA16F
+            const f3 specular = mk3(q_f16(R.specular.x), q_f16(R.specular.y), q_f16(R.specular.z));
+            const f3 resDirect = direct_light_pixel<CACHED>(P, env, px, py, rayDirection, R.instanceId, R.position, normal, specular);
+            historyLength = 1.0f;
+            direct = lerp3(mk3s(0.0f), resDirect, s_rcp(historyLength));
+        }
+        store_rgba16f(I.directLight[cur], i, direct.x, direct.y, direct.z, historyLength);
+        const f3 result = compose_lean_value(P, diffuse, mk3(q_f16(direct.x), q_f16(direct.y), q_f16(direct.z)));
+        if (P.separatePost) reinterpret_cast<float4 *>(I.output)[i] = make_float4(result.x, result.y, result.z, 1.0f);
+        else store_rgba8(I.final, i, result.x, result.y, result.z, 1.0f);
+    }
+    // counters: the primary rays' visits under PASS_PRIMARY_TRACE, the shadow rays' under PASS_DIRECT (same split as the separate kernels)
+    TraceCounts directCnt; directCnt.nodes = env.cnt.nodes - primaryCnt.nodes; directCnt.tris = env.cnt.tris - primaryCnt.tris;
+    flush_counts(P, primaryCnt, PASS_PRIMARY_TRACE);
+    env.cnt = directCnt;
+    flush_env(P, env, PASS_DIRECT, CTR_PRIMARY, rays);
 }
 
 // ---- bounce-ray resolve shared by Indirect / Refraction / Reflection ------------------------------------------------------
@@ -1017,7 +1139,7 @@ __global__ __launch_bounds__(256) void gaussian_kernel(const uint16_t *in, uint1
 // LEAN: direct light straight from the raw accumulation, constant ambient for the indirect term (giSamples == 0), and no
 // reflection / refraction / transparent reads -- all of them are exact zeros on a lean frame.
 template <bool LEAN>
-__global__ __launch_bounds__(256) void compose_post_kernel(FrameParams P, ViewImages I, int cur) {
+__global__ __launch_bounds__(256) void compose_post_kernel(FrameParams P, ViewImages I, int cur, int writeFinal) {
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = P.tileY0 + blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= P.width || y >= P.tileY1 || !row_owned(P, y)) return;
     const size_t i = (size_t)y * (size_t)P.width + x;
@@ -1041,7 +1163,7 @@ __global__ __launch_bounds__(256) void compose_post_kernel(FrameParams P, ViewIm
     }
     else result = xyz(d);
     reinterpret_cast<float4 *>(I.output)[i] = make_float4(result.x, result.y, result.z, 1.0f);
-    if (!P.separatePost) store_rgba8(I.final, i, result.x, result.y, result.z, 1.0f);   // PostProcessPS passthrough (motionBlurStrength == 0, render size == screen size)
+    if (!P.separatePost && writeFinal) store_rgba8(I.final, i, result.x, result.y, result.z, 1.0f);   // PostProcessPS passthrough (motionBlurStrength == 0, render size == screen size)
 }
 
 // PostProcessPS.hlsl:13-36 as its own pass: the screen-size back buffer resampled from the render-size output with the static
@@ -1165,6 +1287,14 @@ hipError_t launch_direct(const FrameParams &P, const ViewImages &I, int cur, boo
     if (lean) LAUNCH_RAY(direct_kernel<false>, P, I, cur);
     LAUNCH_RAY(direct_kernel<true>, P, I, cur);
 }
+// The one-kernel frame holds LEAN_WAVES waves per SIMD, i.e. LEAN_WAVES workgroups per CU: a grid of exactly one resident round
+// (256 CUs) fills the scene cache once per workgroup slot instead of once per four tiles.
+hipError_t launch_lean_frame(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, int cur, hipStream_t s) {
+    const unsigned resident = 256u * LEAN_WAVES, all = rt_grid(P), grid = all < resident ? all : resident;
+    if (P.cacheWords) hipLaunchKernelGGL(lean_frame_kernel<true>, dim3(grid), dim3(RT_BLOCK), cached_lds_bytes(P, true), s, P, I, hitInstance, cur);
+    else hipLaunchKernelGGL(lean_frame_kernel<false>, dim3(grid), dim3(RT_BLOCK), 0, s, P, I, hitInstance, cur);
+    return hipGetLastError();
+}
 hipError_t launch_indirect(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, bool refill, hipStream_t s) {
     if (klist) LAUNCH_RAY(indirect_kernel<true>, P, I, cur, writeFiltered ? 1 : 0);
     if (P.giSamples == 0 || !I.bounceRecords) LAUNCH_RAY(indirect_kernel<false>, P, I, cur, writeFiltered ? 1 : 0);
@@ -1198,10 +1328,10 @@ hipError_t launch_gaussian(const uint16_t *in, uint16_t *out, int width, int hei
     hipLaunchKernelGGL(gaussian_kernel, grid, dim3(256), 0, s, in, out, width, height, y0, y1);
     return hipGetLastError();
 }
-hipError_t launch_compose_post(const FrameParams &P, const ViewImages &I, int cur, bool lean, hipStream_t s) {
+hipError_t launch_compose_post(const FrameParams &P, const ViewImages &I, int cur, bool lean, bool writeFinal, hipStream_t s) {
     dim3 grid((unsigned)(P.width + 31) / 32, (unsigned)(P.tileY1 - P.tileY0 + 7) / 8);
-    if (lean) hipLaunchKernelGGL(compose_post_kernel<true>, grid, dim3(256), 0, s, P, I, cur);
-    else hipLaunchKernelGGL(compose_post_kernel<false>, grid, dim3(256), 0, s, P, I, cur);
+    if (lean) hipLaunchKernelGGL(compose_post_kernel<true>, grid, dim3(256), 0, s, P, I, cur, writeFinal ? 1 : 0);
+    else hipLaunchKernelGGL(compose_post_kernel<false>, grid, dim3(256), 0, s, P, I, cur, writeFinal ? 1 : 0);
     return hipGetLastError();
 }
 hipError_t launch_post_process(const FrameParams &P, const ViewImages &I, hipStream_t s) {

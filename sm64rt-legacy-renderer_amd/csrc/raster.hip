@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void raster_draw_kernel(const GpuRasterInstanc
             f2 ddx, ddy;
             ddx.x = interp(wx, u0[0], u1[0], u2[0]) - u; ddx.y = interp(wx, u0[1], u1[1], u2[1]) - v;
             ddy.x = interp(wy, u0[0], u1[0], u2[0]) - u; ddy.y = interp(wy, u0[1], u1[1], u2[1]) - v;
-            texVal0 = tex_sample_grad(textures[in.texDiffuse], u, v, ddx, ddy, in.filter, in.hAddr, in.vAddr);
+            texVal0 = tex_sample_grad(tex_view(textures + in.texDiffuse), u, v, ddx, ddy, in.filter, in.hAddr, in.vAddr);
         }
         const f4 t1 = mk4(1.0f, 0.0f, 1.0f, 1.0f);                                       // rt64_shader.cpp:377 (TODO in the reference)
         f4 src;

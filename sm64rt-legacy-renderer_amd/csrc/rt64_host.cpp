@@ -135,7 +135,7 @@ static GpuCombiner decode_combiner(uint32_t shaderId) {
 // ---- objects ---------------------------------------------------------------------------------------------------------------
 
 struct Options {
-    bool countTraversal = false, profilePasses = true, syncPresent = true, alwaysRebuild = false, leanFrames = true;
+    bool countTraversal = false, profilePasses = true, syncPresent = true, alwaysRebuild = false, leanFrames = true, fusedLean = true;
     bool ldsCache = true;         // small scenes: BVH nodes + instance records cached in LDS by the ray kernels (0: always walk from HBM/L2)
     bool spinPresent = true;      // RT64_DrawDevice waits for the frame by polling the stream (0: blocking hipStreamSynchronize)
     int bounceRefill = -1;        // bounce-ray traversal with wave-ballot refill: 1 on, 0 off, -1 auto (on when the scene has >= 64 Ki triangles)
@@ -294,6 +294,7 @@ struct View {
     float maxDepthBias = 0.0f;
     bool anyNonOpaque = false, anyReflection = false, anyRefraction = false, anyFog = false;
     bool leanFrame = false;                   // last frame skipped the images no pass consumed (see materialise)
+    bool fusedFrame = false;                  // ... and ran as lean_frame_kernel: rtOutput was not written either (unless PostProcess ran separately)
     FrameParams lastParams; int lastCur = 0;
 
     explicit View(Scene *s);
@@ -534,7 +535,7 @@ View::~View() {
     auto &v = scene->views; v.erase(std::remove(v.begin(), v.end(), this), v.end());
     releaseImages();
 }
-void View::releaseImages() { for (void *p : allocations) hipFree(p); allocations.clear(); img = ViewImages(); bounceSamples = 0; leanFrame = false; }
+void View::releaseImages() { for (void *p : allocations) hipFree(p); allocations.clear(); img = ViewImages(); bounceSamples = 0; leanFrame = false; fusedFrame = false; }
 
 void View::createImages(int w, int h, int screenW, int screenH) {       // View::createOutputBuffers, rt64_view.cpp:105-298 (same formats)
     scene->device->use();
@@ -929,16 +930,25 @@ void View::render() {                          // View::render, rt64_view.cpp:11
             const int halo = dev->opt.denoiserMode == 1 ? SVGF_HALO_ROWS : GAUSSIAN_HALO_ROWS;
             X.tileY0 = std::max(0, P.tileY0 - halo); X.tileY1 = std::min(imgH, P.tileY1 + halo);
         }
-        L(launch_primary_trace(X, img, hitInstance.ptr, klist, s));
-        mark(Device::EV_PRIMARY_TRACE);
         const bool lean = leanNow;
-        leanFrame = lean; lastParams = P; lastCur = cur;
-        L(launch_primary_shade(X, img, hitInstance.ptr, cur, anyNonOpaque, lean, s));
-        mark(Device::EV_PRIMARY);
-        // DirectRayGen also writes the "filtered" copy: DI denoising is compiled out in the reference (rt64_view.cpp:1438-1463),
-        // so rtFilteredDirectLight[1] is always a plain copy of the raw accumulation.
-        L(launch_direct(P, img, cur, lean, s));
-        mark(Device::EV_DIRECT);
+        // A lean frame is pixel-local end to end: one kernel carries every pixel from the primary ray to the back buffer
+        // (device option fused_lean = 0 keeps the three separate kernels; same back buffer bit for bit).
+        const bool fused = lean && dev->opt.fusedLean;
+        leanFrame = lean; fusedFrame = fused; lastParams = P; lastCur = cur;
+        if (fused) {
+            L(launch_lean_frame(P, img, hitInstance.ptr, cur, s));
+            mark(Device::EV_PRIMARY_TRACE); mark(Device::EV_PRIMARY); mark(Device::EV_DIRECT);
+        }
+        else {
+            L(launch_primary_trace(X, img, hitInstance.ptr, klist, s));
+            mark(Device::EV_PRIMARY_TRACE);
+            L(launch_primary_shade(X, img, hitInstance.ptr, cur, anyNonOpaque, lean, s));
+            mark(Device::EV_PRIMARY);
+            // DirectRayGen also writes the "filtered" copy: DI denoising is compiled out in the reference (rt64_view.cpp:1438-1463),
+            // so rtFilteredDirectLight[1] is always a plain copy of the raw accumulation.
+            L(launch_direct(P, img, cur, lean, s));
+            mark(Device::EV_DIRECT);
+        }
         if (lean) {}                                                                  // constant ambient folded into Compose
         else if (giSamples == 0) L(launch_indirect_constant(P, img, cur, s));  // IndirectRayGen.hlsl:135: constant ambient
         else {
@@ -958,7 +968,7 @@ void View::render() {                          // View::render, rt64_view.cpp:11
                 L(launch_gaussian(img.filteredIndirect[k % 2], img.filteredIndirect[(k % 2) ^ 1], imgW, imgH, X.tileY0, X.tileY1, s));
         }
         mark(Device::EV_DENOISE);
-        if (!lean) L(launch_compose_post(P, img, cur, false, s));       // a lean frame is composed by direct_kernel<false> itself
+        if (!lean) L(launch_compose_post(P, img, cur, false, true, s));       // a lean frame is composed by direct_kernel<false> itself
         if (rtRect) {            // the ray-traced picture covers only its rectangle: cleared buffer + background instances show around it (rt64_view.cpp:1292-1296)
             L(launch_clear_final(P, img, s));
             drawRasterList(rasterBgScreen, img.final);
@@ -966,7 +976,7 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         if (P.separatePost) L(launch_post_process(P, img, s));
     }
     else {
-        leanFrame = false;
+        leanFrame = false; fusedFrame = false;
         mark(Device::EV_PRIMARY_TRACE); mark(Device::EV_PRIMARY); mark(Device::EV_DIRECT); mark(Device::EV_INDIRECT); mark(Device::EV_REFL); mark(Device::EV_DENOISE);
         L(launch_clear_final(P, img, s));
         drawRasterList(rasterBgScreen, img.final);           // nothing ray traced covers the background instances (rt64_view.cpp:1292-1296)
@@ -985,8 +995,10 @@ void View::materialise() {
     HIP_CHECK(launch_indirect_constant(lastParams, img, lastCur, dev->stream));
     const size_t rowBytes = (size_t)imgW * 8, off = (size_t)lastParams.tileY0 * rowBytes, bytes = (size_t)(lastParams.tileY1 - lastParams.tileY0) * rowBytes;
     HIP_CHECK(hipMemcpyAsync(reinterpret_cast<uint8_t *>(img.filteredDirect[1]) + off, reinterpret_cast<uint8_t *>(img.directLight[lastCur]) + off, bytes, hipMemcpyDeviceToDevice, dev->stream));
+    // the one-kernel lean frame kept the composed colour in registers: rtOutput from the images just rebuilt (the back buffer already has the foreground drawn over it)
+    if (fusedFrame && !lastParams.separatePost) HIP_CHECK(launch_compose_post(lastParams, img, lastCur, true, false, dev->stream));
     HIP_CHECK(hipStreamSynchronize(dev->stream));
-    leanFrame = false;
+    leanFrame = false; fusedFrame = false;
 }
 
 void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:1027-1083
@@ -1131,7 +1143,7 @@ static size_t readback(Device *dev, int image, void *dst, size_t dstBytes, bool 
         HIP_CHECK(hipStreamSynchronize(dev->stream));
         return need;
     }
-    if (image != RT64_IMAGE_FINAL_RGBA8 && image != RT64_IMAGE_OUTPUT_RGBA32F) v->materialise();
+    if (image != RT64_IMAGE_FINAL_RGBA8 && (image != RT64_IMAGE_OUTPUT_RGBA32F || v->fusedFrame)) v->materialise();
     ImageInfo info; size_t dstPixelBytes;
     if (!image_info(v, image, info, dstPixelBytes)) throw std::runtime_error("RT64_ReadbackDevice: unknown image id.");
     // Sizes: every image has the render size except the back buffer (screen size); they differ only with resolutionScale != 1,
@@ -1256,6 +1268,7 @@ RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, doubl
     else if (k == "spin_present") d->opt.spinPresent = value != 0.0;
     else if (k == "lds_cache") d->opt.ldsCache = value != 0.0;
     else if (k == "reset_accum") { d->finishStats(); d->accum = RT64_FRAME_STATS(); }
+    else if (k == "fused_lean") d->opt.fusedLean = value != 0.0;                  // 0: a lean frame runs as primary_trace + primary_shade + direct instead of lean_frame_kernel
     else if (k == "lean_frames") d->opt.leanFrames = value != 0.0;                // 0: always write every image of the reference's G-buffer
     else if (k == "always_rebuild") d->opt.alwaysRebuild = value != 0.0;          // upload tables + rebuild the TLAS every frame like the reference
     else if (k == "max_reflections") d->opt.maxReflections = std::max(0, (int)value);

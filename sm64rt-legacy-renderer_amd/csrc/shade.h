@@ -28,26 +28,71 @@ template <bool POW2> DEV int tex_address(int i, int n, uint32_t mode) {
     return j;
 }
 
-DEV f4 tex_texel(const GpuTexture &t, uint32_t level, int x, int y, int w) {
-    const uint32_t *base = reinterpret_cast<const uint32_t *>(t.texels) + t.mipOffset[level];
+// ---- wave-uniform table reads ---------------------------------------------------------------------------------------
+// The per-frame tables (GpuInstance, GpuTexture) are uploaded before the kernel starts and never written by it, so they are read
+// through the constant address space: with a wave-uniform index the loads are scalar (s_load into SGPRs, no VGPRs, no exec-masked
+// branches on the values); with a divergent index they are ordinary vector loads.  `waterfall` makes an index uniform: it runs
+// its body once per distinct key among the active lanes, with the key in a scalar register.
+template <class T> DEV T load_const(const T *p) {
+    typedef const T __attribute__((address_space(4))) *CP;
+    T r; __builtin_memcpy(&r, reinterpret_cast<CP>(reinterpret_cast<uintptr_t>(p)), sizeof(T)); return r;
+}
+template <class F> DEV void waterfall(uint32_t key, F &&f) {
+    // The loop condition is a wave vote, not `for (;;) ... break`: in the compiler's single-thread view the first-lane value is loop
+    // invariant, so a loop that can only leave when key == first-lane(key) is "infinite or one trip" and the comparison gets deleted.
+    bool todo = true;
+    while (__ballot(todo) != 0ull) {
+        if (todo) {
+            const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+            if (key == k) {
+                f((uint32_t)__builtin_amdgcn_readfirstlane((int)key));       // read again inside the branch: keeps the vector `key` from being substituted back in
+                todo = false;
+            }
+        }
+    }
+}
+
+// The fields of a GpuTexture the sampler needs; the mip offset is indexed by the (per-lane) level, so it stays in memory.
+struct TexView { const uint8_t *texels; uint32_t width, height, mips, pow2; const uint32_t *mipOffset; };
+struct TexHead { const uint8_t *texels; uint32_t width, height, mips, pow2; };
+static_assert(offsetof(GpuTexture, mipOffset) == sizeof(TexHead), "GpuTexture head");
+DEV TexView tex_view(const GpuTexture *t) {             // table entry (constant address space)
+    const TexHead h = load_const(reinterpret_cast<const TexHead *>(t));
+    TexView v; v.texels = h.texels; v.width = h.width; v.height = h.height; v.mips = h.mips; v.pow2 = h.pow2; v.mipOffset = t->mipOffset;
+    return v;
+}
+DEV TexView tex_view_arg(const GpuTexture &t) {         // a GpuTexture inside the kernel arguments (FrameParams::background)
+    TexView v; v.texels = t.texels; v.width = t.width; v.height = t.height; v.mips = t.mips; v.pow2 = t.pow2; v.mipOffset = t.mipOffset;
+    return v;
+}
+
+// Offset of a mip level in texels (per-lane level: a vector load from the texture's table; a scalar fetch per distinct level of the
+// wave was measured 5x slower for the whole shading kernel -- the vote loop serialises the sample around it).
+DEV uint32_t tex_mip_offset(const TexView &t, uint32_t level) {
+    if (t.mips == 1) return 0;                               // mipOffset[0] == 0 (Texture::set*, rt64_host.cpp)
+    return t.mipOffset[level];
+}
+DEV f4 tex_texel(const TexView &t, uint32_t mipOffset, int x, int y, int w) {
+    const uint32_t *base = reinterpret_cast<const uint32_t *>(t.texels) + mipOffset;
     uint32_t v = base[(size_t)y * (size_t)w + (size_t)x];
     const float k = 1.0f / 255.0f;
     return mk4((float)(v & 0xFF) * k, (float)((v >> 8) & 0xFF) * k, (float)((v >> 16) & 0xFF) * k, (float)(v >> 24) * k);
 }
 
 template <bool POW2>
-DEV f4 tex_sample_level_impl(const GpuTexture &t, float u, float v, uint32_t level, uint32_t filter, uint32_t hAddr, uint32_t vAddr) {
+DEV f4 tex_sample_level_impl(const TexView &t, float u, float v, uint32_t level, uint32_t filter, uint32_t hAddr, uint32_t vAddr) {
     int w = max((int)(t.width >> level), 1), h = max((int)(t.height >> level), 1);
+    const uint32_t mo = tex_mip_offset(t, level);
     if (filter == 0) {
         int x = tex_address<POW2>((int)floorf(u * (float)w), w, hAddr), y = tex_address<POW2>((int)floorf(v * (float)h), h, vAddr);
-        return tex_texel(t, level, x, y, w);
+        return tex_texel(t, mo, x, y, w);
     }
     float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
     float x0f = floorf(x), y0f = floorf(y);
     float fx = x - x0f, fy = y - y0f;
     int x0 = tex_address<POW2>((int)x0f, w, hAddr), x1 = tex_address<POW2>((int)x0f + 1, w, hAddr);
     int y0 = tex_address<POW2>((int)y0f, h, vAddr), y1 = tex_address<POW2>((int)y0f + 1, h, vAddr);
-    f4 c00 = tex_texel(t, level, x0, y0, w), c10 = tex_texel(t, level, x1, y0, w), c01 = tex_texel(t, level, x0, y1, w), c11 = tex_texel(t, level, x1, y1, w);
+    f4 c00 = tex_texel(t, mo, x0, y0, w), c10 = tex_texel(t, mo, x1, y0, w), c01 = tex_texel(t, mo, x0, y1, w), c11 = tex_texel(t, mo, x1, y1, w);
     f4 r;
     { float top = c00.x + fx * (c10.x - c00.x), bot = c01.x + fx * (c11.x - c01.x); r.x = top + fy * (bot - top); }
     { float top = c00.y + fx * (c10.y - c00.y), bot = c01.y + fx * (c11.y - c01.y); r.y = top + fy * (bot - top); }
@@ -55,11 +100,11 @@ DEV f4 tex_sample_level_impl(const GpuTexture &t, float u, float v, uint32_t lev
     { float top = c00.w + fx * (c10.w - c00.w), bot = c01.w + fx * (c11.w - c01.w); r.w = top + fy * (bot - top); }
     return r;
 }
-DEV f4 tex_sample_level(const GpuTexture &t, float u, float v, uint32_t level, uint32_t filter, uint32_t hAddr, uint32_t vAddr) {
+DEV f4 tex_sample_level(const TexView &t, float u, float v, uint32_t level, uint32_t filter, uint32_t hAddr, uint32_t vAddr) {
     return t.pow2 ? tex_sample_level_impl<true>(t, u, v, level, filter, hAddr, vAddr) : tex_sample_level_impl<false>(t, u, v, level, filter, hAddr, vAddr);
 }
 
-DEV f4 tex_sample_grad(const GpuTexture &t, float u, float v, f2 ddx, f2 ddy, uint32_t filter, uint32_t hAddr, uint32_t vAddr) {
+DEV f4 tex_sample_grad(const TexView &t, float u, float v, f2 ddx, f2 ddy, uint32_t filter, uint32_t hAddr, uint32_t vAddr) {
     if (t.mips == 1) return tex_sample_level(t, u, v, 0, filter, hAddr, vAddr);
     float w0 = (float)t.width, h0 = (float)t.height;
     float ax = ddx.x * w0, ay = ddx.y * h0, bx = ddy.x * w0, by = ddy.y * h0;
@@ -133,23 +178,23 @@ DEV f4 sky_finish(const FrameParams &P, f4 tex) {
 DEV f4 sample_sky_2d(const FrameParams &P, f2 screenUV) {                       // SampleSky2D :54-70
     if (P.skyPlaneTexIndex < 0) return mk4(0, 0, 0, 0);
     f2 uv = sky_plane_uv(P, screenUV);
-    return sky_finish(P, tex_sample_level(P.textures[P.skyPlaneTexIndex], uv.x, uv.y, 0, 1, 0, 0));
+    return sky_finish(P, tex_sample_level(tex_view(P.textures + P.skyPlaneTexIndex), uv.x, uv.y, 0, 1, 0, 0));
 }
 DEV f4 sample_sky_plane(const FrameParams &P, f3 rayDirection) {                // SampleSkyPlane :72-87
     if (P.skyPlaneTexIndex < 0) return mk4(0, 0, 0, 0);
     f2 uv = fake_envmap_uv(rayDirection, P.skyYawOffset);
-    return sky_finish(P, tex_sample_level(P.textures[P.skyPlaneTexIndex], uv.x, uv.y, 0, 1, 0, 0));
+    return sky_finish(P, tex_sample_level(tex_view(P.textures + P.skyPlaneTexIndex), uv.x, uv.y, 0, 1, 0, 0));
 }
 // gBackground: the raster background instances drawn into a screen-size RGBA8 target (rt64_view.cpp:1296-1319, raster.hip),
 // sampled with the static LINEAR / WRAP sampler (BgSky.hlsli:89-95).  No background instance => transparent black.
 DEV f3 sample_background_2d(const FrameParams &P, f2 screenUV) {
     if (!P.background.texels) return mk3s(0.0f);
-    return xyz(tex_sample_level(P.background, screenUV.x, screenUV.y, 0, 1, 0, 0));
+    return xyz(tex_sample_level(tex_view_arg(P.background), screenUV.x, screenUV.y, 0, 1, 0, 0));
 }
 DEV f3 sample_background_envmap(const FrameParams &P, f3 rayDirection) {
     if (!P.background.texels) return mk3s(0.0f);
     const f2 uv = fake_envmap_uv(rayDirection, 0.0f);
-    return xyz(tex_sample_level(P.background, uv.x, uv.y, 0, 1, 0, 0));
+    return xyz(tex_sample_level(tex_view_arg(P.background), uv.x, uv.y, 0, 1, 0, 0));
 }
 
 DEV f4 fog_from_camera(const FrameParams &P, const RT64_MATERIAL &m, f3 position) {    // Fog.hlsli:5-18
@@ -195,7 +240,33 @@ struct VertexData {
 
 DEV f3 ld_f3(const uint8_t *p) { const float *f = reinterpret_cast<const float *>(p); return mk3(f[0], f[1], f[2]); }
 
-DEV void get_vertex_data(const GpuInstance &in, uint32_t prim, const float b[3], bool wantTangent, VertexData &vd) {   // rt64_shader.cpp:156-226
+// Copy of the GpuInstance fields the any-hit programs read (scalar registers when the instance index is wave-uniform; only the
+// fields a program touches are actually loaded).
+struct Mat16 { float m[16]; };
+struct InstView {
+    GpuCombiner cc; RT64_MATERIAL material; Mat16 objectToWorld, objectToWorldNormal, objectToWorldPrevious;
+    const uint8_t *vertices; const uint32_t *indices; int32_t texDiffuse, texNormal, texSpecular; uint32_t filter, hAddr, vAddr, flags;
+};
+struct CombinerWords { uint32_t w[sizeof(GpuCombiner) / 4]; };          // the combiner's int8 / int16 fields come out of whole-dword scalar loads
+static_assert(sizeof(GpuCombiner) % 4 == 0 && offsetof(GpuInstance, cc) % 4 == 0, "GpuCombiner is read as dwords");
+struct InstTail { int32_t texDiffuse, texNormal, texSpecular; uint32_t filter, hAddr, vAddr, flags; };
+static_assert(offsetof(GpuInstance, flags) - offsetof(GpuInstance, texDiffuse) == offsetof(InstTail, flags), "GpuInstance tail");
+DEV InstView inst_view(const FrameParams &P, uint32_t instance) {
+    const GpuInstance *g = P.instances + instance;
+    InstView v;
+    const CombinerWords cw = load_const(reinterpret_cast<const CombinerWords *>(&g->cc));
+    __builtin_memcpy(&v.cc, &cw, sizeof(v.cc));
+    v.material = load_const(&g->material);
+    v.objectToWorld = load_const(reinterpret_cast<const Mat16 *>(g->objectToWorld));
+    v.objectToWorldNormal = load_const(reinterpret_cast<const Mat16 *>(g->objectToWorldNormal));
+    v.objectToWorldPrevious = load_const(reinterpret_cast<const Mat16 *>(g->objectToWorldPrevious));
+    v.vertices = load_const(&g->vertices); v.indices = load_const(&g->indices);
+    const InstTail tl = load_const(reinterpret_cast<const InstTail *>(&g->texDiffuse));
+    v.texDiffuse = tl.texDiffuse; v.texNormal = tl.texNormal; v.texSpecular = tl.texSpecular; v.filter = tl.filter; v.hAddr = tl.hAddr; v.vAddr = tl.vAddr; v.flags = tl.flags;
+    return v;
+}
+
+DEV void get_vertex_data(const InstView &in, uint32_t prim, const float b[3], bool wantTangent, VertexData &vd) {   // rt64_shader.cpp:156-226
     const GpuCombiner &cc = in.cc;
     const uint8_t *vp[3];
     f3 norm[3];
@@ -203,14 +274,14 @@ DEV void get_vertex_data(const GpuInstance &in, uint32_t prim, const float b[3],
     for (int k = 0; k < 3; k++) {
         vp[k] = in.vertices + (size_t)in.indices[3 * prim + k] * (size_t)cc.vertexSize;
         vd.pos[k] = ld_f3(vp[k]);
-        vd.posW[k] = mul_point(in.objectToWorld, vd.pos[k]);
+        vd.posW[k] = mul_point(in.objectToWorld.m, vd.pos[k]);
         norm[k] = ld_f3(vp[k] + cc.normalOffset);
     }
     vd.vertexPosition = (vd.pos[0] * b[0] + vd.pos[1] * b[1]) + vd.pos[2] * b[2];
     f3 vn = (norm[0] * b[0] + norm[1] * b[1]) + norm[2] * b[2];
     f3 tn = -cross3(vd.pos[2] - vd.pos[0], vd.pos[1] - vd.pos[0]);
     vd.vertexNormal = (vn.x != 0.0f || vn.y != 0.0f || vn.z != 0.0f) ? normalize3(vn) : tn;
-    vd.triangleNormal = normalize3(mul_vector(in.objectToWorldNormal, tn));
+    vd.triangleNormal = normalize3(mul_vector(in.objectToWorldNormal.m, tn));
     if (cc.vertexUV) {
 #pragma unroll
         for (int k = 0; k < 3; k++) { const float *f = reinterpret_cast<const float *>(vp[k] + cc.uvOffset); vd.uv[k].x = f[0]; vd.uv[k].y = f[1]; }
@@ -318,9 +389,9 @@ struct HitRecord {
 };
 
 // Surface any-hit, rt64_shader.cpp:444-581.  Returns false when the candidate is ignored before it is stored.
-DEV bool surface_anyhit(const FrameParams &P, uint32_t instance, uint32_t prim, float t, float u, float v, f3 rayDirW,
-                        const RayDiff &payloadDiff, uint32_t px, uint32_t py, HitRecord &rec) {
-    const GpuInstance &in = P.instances[instance];
+// `in` = inst_view(P, instance); callers that can make the instance wave-uniform (waterfall) get the scalar version of everything below.
+DEV bool surface_anyhit_view(const FrameParams &P, const InstView &in, uint32_t instance, uint32_t prim, float t, float u, float v, f3 rayDirW,
+                             const RayDiff &payloadDiff, uint32_t px, uint32_t py, HitRecord &rec) {
     const GpuCombiner &cc = in.cc;
     const RT64_MATERIAL &mat = in.material;
     const bool normalMap = (in.flags & GPU_INST_NORMAL_MAP) != 0, specularMap = (in.flags & GPU_INST_SPECULAR_MAP) != 0;
@@ -347,7 +418,7 @@ DEV bool surface_anyhit(const FrameParams &P, uint32_t instance, uint32_t prim, 
         float uv01x = vd.uv[1].x - vd.uv[0].x, uv01y = vd.uv[1].y - vd.uv[0].y, uv02x = vd.uv[2].x - vd.uv[0].x, uv02y = vd.uv[2].y - vd.uv[0].y;
         ddx.x = dBdx_x * uv01x + dBdx_y * uv02x; ddx.y = dBdx_x * uv01y + dBdx_y * uv02y;
         ddy.x = dBdy_x * uv01x + dBdy_y * uv02x; ddy.y = dBdy_x * uv01y + dBdy_y * uv02y;
-        f4 tex = tex_sample_grad(P.textures[in.texDiffuse], vd.vertexUV.x, vd.vertexUV.y, ddx, ddy, in.filter, in.hAddr, in.vAddr);
+        f4 tex = tex_sample_grad(tex_view(P.textures + in.texDiffuse), vd.vertexUV.x, vd.vertexUV.y, ddx, ddy, in.filter, in.hAddr, in.vAddr);
         float k = fmaxf(-mix.w, 0.0f);
         t0 = mk4(lerpf(tex.x, mix.x, k), lerpf(tex.y, mix.y, k), lerpf(tex.z, mix.z, k), tex.w);
     }
@@ -367,27 +438,27 @@ DEV bool surface_anyhit(const FrameParams &P, uint32_t instance, uint32_t prim, 
         uint32_t seed = init_rand(px + py * (uint32_t)P.width, P.frameCount, 16);
         result.w *= rintf(next_rand(seed));
     }
-    f3 vertexNormal = normalize3(mul_vector(in.objectToWorldNormal, vd.vertexNormal));
+    f3 vertexNormal = normalize3(mul_vector(in.objectToWorldNormal.m, vd.vertexNormal));
     float normalSign = (dot3(vd.triangleNormal, rayDirW) <= 0.0f) ? 1.0f : -1.0f;
     vertexNormal = vertexNormal * normalSign;
     if (cc.vertexUV && normalMap) {                                                         // :522-533
-        f3 tangent = normalize3(mul_vector(in.objectToWorldNormal, vd.vertexTangent)) * normalSign;
-        f3 binormal = normalize3(mul_vector(in.objectToWorldNormal, vd.vertexBinormal)) * normalSign;
+        f3 tangent = normalize3(mul_vector(in.objectToWorldNormal.m, vd.vertexTangent)) * normalSign;
+        f3 binormal = normalize3(mul_vector(in.objectToWorldNormal.m, vd.vertexBinormal)) * normalSign;
         if (in.texNormal >= 0) {
             float s = mat.uvDetailScale;
             f2 gx, gy; gx.x = ddx.x * s; gx.y = ddx.y * s; gy.x = ddy.x * s; gy.y = ddy.y * s;
-            f4 tex = tex_sample_grad(P.textures[in.texNormal], vd.vertexUV.x * s, vd.vertexUV.y * s, gx, gy, in.filter, in.hAddr, in.vAddr);
+            f4 tex = tex_sample_grad(tex_view(P.textures + in.texNormal), vd.vertexUV.x * s, vd.vertexUV.y * s, gx, gy, in.filter, in.hAddr, in.vAddr);
             f3 nc = mk3(tex.x * 2.0f - 1.0f, tex.y * 2.0f - 1.0f, tex.z * 2.0f - 1.0f);
             vertexNormal = normalize3((vertexNormal * nc.z + tangent * nc.x) + binormal * nc.y);
         }
     }
-    f3 prevWorldPos = mul_point(in.objectToWorldPrevious, vd.vertexPosition);
-    f3 curWorldPos = mul_point(in.objectToWorld, vd.vertexPosition);
+    f3 prevWorldPos = mul_point(in.objectToWorldPrevious.m, vd.vertexPosition);
+    f3 curWorldPos = mul_point(in.objectToWorld.m, vd.vertexPosition);
     f3 vertexSpecular = mk3s(1.0f);
     if (cc.vertexUV && specularMap && in.texSpecular >= 0) {                               // :539-545
         float s = mat.uvDetailScale;
         f2 gx, gy; gx.x = ddx.x * s; gx.y = ddx.y * s; gy.x = ddy.x * s; gy.y = ddy.y * s;
-        f4 tex = tex_sample_grad(P.textures[in.texSpecular], vd.vertexUV.x * s, vd.vertexUV.y * s, gx, gy, in.filter, in.hAddr, in.vAddr);
+        f4 tex = tex_sample_grad(tex_view(P.textures + in.texSpecular), vd.vertexUV.x * s, vd.vertexUV.y * s, gx, gy, in.filter, in.hAddr, in.vAddr);
         vertexSpecular = xyz(tex);
     }
     rec.dist = t - mat.depthBias;
@@ -398,16 +469,22 @@ DEV bool surface_anyhit(const FrameParams &P, uint32_t instance, uint32_t prim, 
     rec.instanceId = instance;
     return true;
 }
+// Any instance index per lane: one pass per distinct instance of the wave, each with the instance's data in scalar registers.
+DEV bool surface_anyhit(const FrameParams &P, uint32_t instance, uint32_t prim, float t, float u, float v, f3 rayDirW,
+                        const RayDiff &payloadDiff, uint32_t px, uint32_t py, HitRecord &rec) {
+    bool ok = false;
+    waterfall(instance, [&](uint32_t k) { ok = surface_anyhit_view(P, inst_view(P, k), k, prim, t, u, v, rayDirW, payloadDiff, px, py, rec); });
+    return ok;
+}
 
 // Shadow any-hit alpha, rt64_shader.cpp:611-659.  Negative = candidate ignored (texture edge).
-DEV float shadow_anyhit_alpha(const FrameParams &P, uint32_t instance, uint32_t prim, float u, float v, uint32_t px, uint32_t py) {
-    const GpuInstance &in = P.instances[instance];
+DEV float shadow_anyhit_alpha_view(const FrameParams &P, const InstView &in, uint32_t prim, float u, float v, uint32_t px, uint32_t py) {
     const GpuCombiner &cc = in.cc;
     const float b[3] = { 1.0f - u - v, u, v };
     VertexData vd;
     get_vertex_data(in, prim, b, false, vd);
     f4 t0 = mk4(0, 0, 0, 0), t1 = mk4(1.0f, 0.0f, 1.0f, 1.0f);
-    if (cc.useTex0) t0 = tex_sample_level(P.textures[in.texDiffuse], vd.vertexUV.x, vd.vertexUV.y, 0, in.filter, in.hAddr, in.vAddr);
+    if (cc.useTex0) t0 = tex_sample_level(tex_view(P.textures + in.texDiffuse), vd.vertexUV.x, vd.vertexUV.y, 0, in.filter, in.hAddr, in.vAddr);
     float a;
     if (!cc.colorAlphaSame && cc.optAlpha) a = alpha_formula(cc, vd, t0, t1);
     else a = color_formula(cc, cc.optAlpha, cc.optAlpha, vd, t0, t1).w;
@@ -417,6 +494,11 @@ DEV float shadow_anyhit_alpha(const FrameParams &P, uint32_t instance, uint32_t 
         uint32_t seed = init_rand(px + py * (uint32_t)P.width, P.frameCount, 16);
         a *= rintf(next_rand(seed));
     }
+    return a;
+}
+DEV float shadow_anyhit_alpha(const FrameParams &P, uint32_t instance, uint32_t prim, float u, float v, uint32_t px, uint32_t py) {
+    float a = 0.0f;
+    waterfall(instance, [&](uint32_t k) { a = shadow_anyhit_alpha_view(P, inst_view(P, k), prim, u, v, px, py); });
     return a;
 }
 
@@ -461,7 +543,8 @@ DEV float light_intensity_simple(const RT64_LIGHT &L, f3 position, f3 normal, fl
 template <bool CACHED = false>
 DEV f3 compute_light(const FrameParams &P, ShadeEnv &env, uint32_t px, uint32_t py, uint32_t lightIndex, f3 rayDirection,
                      const RT64_MATERIAL &m, f3 position, f3 normal, f3 specular, bool checkShadows) {   // :67-113
-    const RT64_LIGHT &L = P.lights[lightIndex];
+    RT64_LIGHT L;
+    waterfall(lightIndex, [&](uint32_t k) { L = load_const(P.lights + k); });      // one scalar fetch per distinct light chosen in the wave
     f3 lp = ld_v3(L.position);
     f3 lightDirection = normalize3(lp - position);
     float lightPointRadius = (P.diSamples > 0) ? L.pointRadius : 0.0f;
@@ -471,11 +554,16 @@ DEV f3 compute_light(const FrameParams &P, ShadeEnv &env, uint32_t px, uint32_t 
     uint32_t maxSamples = P.diSamples > 1 ? P.diSamples : 1, samples = maxSamples;
     float lLambert = 0.0f, lShadow = 0.0f; f3 lSpec = mk3s(0.0f);
     while (samples > 0) {
-        f3 bn = blue_noise(P, px, py, P.frameCount + samples);
-        float scx = bn.x * 2.0f - 1.0f, scy = bn.y * 2.0f - 1.0f;
-        float len = s_sqrt(scx * scx + scy * scy), sat = saturatef(len), rlen = s_rcp(len);
-        scx = scx * rlen * sat; scy = scy * rlen * sat;
-        f3 samplePosition = (lp + (perpX * scx) * lightPointRadius) + (perpY * scy) * lightPointRadius;
+        // Point light (radius 0): the disc offsets are finite numbers times 0 (a blue-noise byte / 255 is never 0.5, so the disc
+        // vector is never 0 / 0), i.e. the sample position is lp exactly -- no blue-noise fetch needed for the same value.
+        f3 samplePosition = lp;
+        if (lightPointRadius != 0.0f || !(lightDirection.x == lightDirection.x)) {      // (a NaN light direction -- shading point exactly at the light -- keeps the reference's NaN)
+            f3 bn = blue_noise(P, px, py, P.frameCount + samples);
+            float scx = bn.x * 2.0f - 1.0f, scy = bn.y * 2.0f - 1.0f;
+            float len = s_sqrt(scx * scx + scy * scy), sat = saturatef(len), rlen = s_rcp(len);
+            scx = scx * rlen * sat; scy = scy * rlen * sat;
+            samplePosition = (lp + (perpX * scx) * lightPointRadius) + (perpY * scy) * lightPointRadius;
+        }
         float sampleDistance = len3_exact(position - samplePosition);          // ray tmax and ...
         f3 sampleDirection = normalize3_exact(samplePosition - position);      // ... ray direction: exact
         float sampleIntensityFactor = s_pow(fmaxf(1.0f - s_div(sampleDistance, L.attenuationRadius), 0.0f), L.attenuationExponent);
@@ -500,15 +588,21 @@ template <bool CACHED = false>
 DEV f3 compute_lights_random(const FrameParams &P, ShadeEnv &env, uint32_t px, uint32_t py, f3 rayDirection, uint32_t instanceId,
                              f3 position, f3 normal, f3 specular, uint32_t maxLightCount, bool checkShadows) {   // :115-168
     f3 result = mk3s(0.0f);
-    const RT64_MATERIAL &m = P.instances[instanceId].material;
+    // the material fields the light loop reads, fetched once per distinct instance of the wave through scalar loads
+    RT64_MATERIAL m;
+    waterfall(instanceId, [&](uint32_t k) {
+        const RT64_MATERIAL mk = load_const(&P.instances[k].material);
+        m.lightGroupMaskBits = mk.lightGroupMaskBits; m.ignoreNormalFactor = mk.ignoreNormalFactor; m.shadowRayBias = mk.shadowRayBias; m.specularExponent = mk.specularExponent;
+    });
     if (m.lightGroupMaskBits == 0) return result;
     // sLightIntensities / sLightIndices (Lights.hlsli:121-122) live in LDS, one column per lane: dynamically indexed
     // per-lane arrays would otherwise go to scratch memory.
     float *sInt = env.lightIntensity; uint8_t *sIdx = env.lightIndex;
     uint32_t sCount = 0; float total = 0.0f;
     for (uint32_t l = 0; l < P.lightCount && sCount < RT64_MAX_LIGHTS; l++) {
-        if (m.lightGroupMaskBits & P.lights[l].groupBits) {
-            float li = light_intensity_simple(P.lights[l], position, normal, m.ignoreNormalFactor);
+        const RT64_LIGHT Ll = load_const(P.lights + l);           // uniform index: scalar loads
+        if (m.lightGroupMaskBits & Ll.groupBits) {
+            float li = light_intensity_simple(Ll, position, normal, m.ignoreNormalFactor);
             if (li > RT_EPSILON) { sInt[sCount * RT_BLOCK] = li; sIdx[sCount * RT_BLOCK] = (uint8_t)l; total += li; sCount++; }
         }
     }

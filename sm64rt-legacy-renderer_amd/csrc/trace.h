@@ -67,9 +67,14 @@ DEV bool tri_hit(const RaySpace &r, const GpuTri &tri, bool cull, float tmin, fl
 
 typedef uint32_t u32x4_lds __attribute__((ext_vector_type(4)));      // a 16-byte word of the LDS scene cache
 
+// The two halves of the stack carry their address spaces in the pointer types: with plain pointers the compiler merges the two
+// branches of push / pop into ONE flat access through a selected pointer (flat_load / flat_store: both wait counters, the texture
+// addresser's queue) -- on every pop of the node loop.  Typed, the LDS half is a ds_read_b32 / ds_write_b32.
+typedef uint32_t __attribute__((address_space(3))) *LdsU32Ptr;
+typedef uint32_t __attribute__((address_space(1))) *GlobalU32Ptr;
 struct TraceStack {
-    uint32_t *lds;        // &ldsStack[threadIdx.x], stride RT_BLOCK
-    uint32_t *spill;      // per-lane slab of RT_STACK_SPILL entries
+    LdsU32Ptr lds;        // &ldsStack[threadIdx.x], stride RT_BLOCK
+    GlobalU32Ptr spill;   // per-lane slab of RT_STACK_SPILL entries
     const u32x4_lds *cache;   // LDS scene cache (see fill_scene_cache), nullptr when the scene does not fit
     int ldsEntries;       // entries of this lane's stack that live in LDS (RT_STACK_LDS or RT_STACK_LDS_CACHED)
     DEV void push(int &sp, uint32_t v) const {
