@@ -221,6 +221,7 @@ def main():
                   trisPrimary=st.trianglesPrimary, nodesDirect=st.nodesDirect, trisDirect=st.trianglesDirect,
                   nodesIndirect=st.nodesIndirect, trisIndirect=st.trianglesIndirect)
     lean = bool(st.leanFrame)
+    fused = bool(st.fusedFrame)
     hit_pixels = int((scene.readback(rt64.IMAGE_FIRST_INSTANCE_ID) >= 0).sum())
     scene.option("count_traversal", 0)
 
@@ -278,6 +279,13 @@ def main():
             "direct": (kms["direct"], my_pixels * (DIRECT_PIXEL_B + (0 if lean else 8)) + hit_pixels * DIRECT_HIT_B + NODE_B * counts["nodesDirect"] + TRI_B * counts["trisDirect"] + 4 * counts["shadow"]
                        + (my_pixels * COMPOSE_PIXEL_LEAN_B if lean else 0)),          # lean frame: direct_kernel<false> composes the pixel itself
         }
+        if fused:
+            # one kernel carries the pixel from the primary ray to the back buffer: what it has to move is the hit record it keeps for
+            # on-demand G-buffer rebuilds, the direct-light accumulation, the back buffer, the vertex / texel operands of the any-hit
+            # program and the BVH records its rays visit (served from the LDS scene cache on this scene -- see `traffic` for the HBM bytes)
+            kernels = {"lean_frame(trace+shade+direct+compose)": (kms["trace"],
+                       my_pixels * (PRIMARY_TRACE_PIXEL_B + 8 + 4) + hit_pixels * PRIMARY_SHADE_HIT_B + (my_pixels - hit_pixels) * PRIMARY_SHADE_MISS_B
+                       + NODE_B * (counts["nodesPrimary"] + counts["nodesDirect"]) + TRI_B * (counts["trisPrimary"] + counts["trisDirect"]) + 4 * counts["shadow"])}
         if not lean:
             kernels["compose_post"] = (kms["compose"], my_pixels * COMPOSE_PIXEL_B)
         else:
@@ -296,7 +304,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dominant)
+                traffic = json.load(open(tpath)).get(dominant.split("(")[0])
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -304,7 +312,7 @@ def main():
                     "measured_triad_GBps": HBM_TRIAD_GBS, "frac_of_triad": round(achieved / HBM_TRIAD_GBS, 4),
                     "algorithmic_bytes_per_launch": int(d_bytes), "ms_per_launch": round(d_ms, 5),
                     "kernels": {k: {"ms": round(v[0], 5), "alg_bytes": int(v[1]), "GBps": round(v[1] / (v[0] * 1e-3) / 1e9, 2) if v[0] > 0 else 0.0} for k, v in kernels.items()},
-                    "lean_frame": lean, "frame_gpu_ms": round(kms["total"], 5), "build_ms": round(kms["build"], 5),
+                    "lean_frame": lean, "fused_frame": fused, "frame_gpu_ms": round(kms["total"], 5), "build_ms": round(kms["build"], 5),
                     "nodes_per_primary_ray": round(counts["nodesPrimary"] / max(counts["primary"], 1), 3),
                     "tris_per_primary_ray": round(counts["trisPrimary"] / max(counts["primary"], 1), 3),
                     "nodes_per_shadow_ray": round(counts["nodesDirect"] / max(counts["shadow"], 1), 3),

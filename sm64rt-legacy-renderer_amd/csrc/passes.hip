@@ -1287,10 +1287,14 @@ hipError_t launch_direct(const FrameParams &P, const ViewImages &I, int cur, boo
     if (lean) LAUNCH_RAY(direct_kernel<false>, P, I, cur);
     LAUNCH_RAY(direct_kernel<true>, P, I, cur);
 }
-// The one-kernel frame holds LEAN_WAVES waves per SIMD, i.e. LEAN_WAVES workgroups per CU: a grid of exactly one resident round
-// (256 CUs) fills the scene cache once per workgroup slot instead of once per four tiles.
+// The one-kernel frame holds LEAN_WAVES waves per SIMD, i.e. LEAN_WAVES workgroups per CU.  A big share of the frame runs as exactly
+// one resident round (256 CUs x LEAN_WAVES workgroups, each walking its tiles round-robin): the scene cache is filled once per
+// workgroup slot.  A small share (a 1/4 or 1/8 strip set of a multi-GPU partition: <= 2048 tiles) gets one workgroup per tile, so
+// the hardware dispatcher balances sky tiles against geometry tiles (measured on a 1/4 share: 87 us against 105 us).
 hipError_t launch_lean_frame(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, int cur, hipStream_t s) {
-    const unsigned resident = 256u * LEAN_WAVES, all = rt_grid(P), grid = all < resident ? all : resident;
+    const unsigned strips = (unsigned)(P.tileY1 - P.tileY0 + 15) / 16, owned = strips > (unsigned)P.stripRank ? (strips - (unsigned)P.stripRank + (unsigned)P.stripCount - 1) / (unsigned)P.stripCount : 0u;
+    const unsigned tiles = (unsigned)((P.width + 15) / 16) * owned, resident = 256u * LEAN_WAVES;
+    const unsigned grid = tiles < 1u ? 1u : (tiles <= (unsigned)RT_GRID_BLOCKS ? tiles : resident);
     if (P.cacheWords) hipLaunchKernelGGL(lean_frame_kernel<true>, dim3(grid), dim3(RT_BLOCK), cached_lds_bytes(P, true), s, P, I, hitInstance, cur);
     else hipLaunchKernelGGL(lean_frame_kernel<false>, dim3(grid), dim3(RT_BLOCK), 0, s, P, I, hitInstance, cur);
     return hipGetLastError();

@@ -1042,7 +1042,7 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
         if (haveView) continue;
         haveView = true;
         st.instanceCount = (unsigned)v->rtInstances.size();
-        st.leanFrame = v->leanFrame ? 1u : 0u;
+        st.leanFrame = v->leanFrame ? 1u : 0u; st.fusedFrame = v->fusedFrame ? 1u : 0u;
         st.width = (unsigned)v->imgW; st.height = (unsigned)v->imgH;          // render size ("Render buffer: WxH")
         unsigned tri = 0, nodeBytes = 0, triBytes = 0;
         for (auto &ri : v->rtInstances) { tri += ri.instance->mesh->blasCount; nodeBytes += (unsigned)(std::max<uint32_t>(ri.instance->mesh->blasCount - 1, 1) * sizeof(GpuNode)); triBytes += (unsigned)(ri.instance->mesh->blasCount * sizeof(GpuTri)); }

@@ -298,3 +298,31 @@ def test_c4_refit_of_updatable_mesh(rt64_lib, sample_data):
         o.set_mesh(o.meshes[0], v, data.meshes[0].indices)
     got, ref, st = _render_pair(rt64_lib, data, frames=3, per_frame=per_frame)
     _check(got, ref, st)
+
+
+@pytest.mark.gpu
+def test_one_kernel_lean_frame_matches_the_three_kernel_path(rt64_lib, sample_data):
+    """A lean frame runs as lean_frame_kernel (device option fused_lean, default 1) or as primary_trace + primary_shade + direct
+    (fused_lean = 0).  Same arithmetic, same rounding points: every image is bit-identical, including the ones the fused frame only
+    produces on readback (View::materialise), and so are the ray / node / triangle counters."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    images = [rt64.IMAGE_FINAL_RGBA8, rt64.IMAGE_OUTPUT_RGBA32F, rt64.IMAGE_PRIMARY_HIT, rt64.IMAGE_INSTANCE_ID, rt64.IMAGE_DIFFUSE, rt64.IMAGE_DIRECT_LIGHT_RAW,
+              rt64.IMAGE_DIRECT_LIGHT_FILTERED, rt64.IMAGE_INDIRECT_LIGHT_FILTERED, rt64.IMAGE_SHADING_POSITION, rt64.IMAGE_SHADING_NORMAL, rt64.IMAGE_SHADING_SPECULAR,
+              rt64.IMAGE_FLOW, rt64.IMAGE_DEPTH, rt64.IMAGE_VIEW_DIRECTION, rt64.IMAGE_FIRST_INSTANCE_ID]
+    got = {}
+    for fused in (1, 0):
+        s = sample_scene.Rt64Scene(rt64_lib, sample_data, 333, 187, hip_device=0)
+        try:
+            s.option("fused_lean", fused)
+            s.option("count_traversal", 1)
+            s.draw(); s.draw()                               # second frame: the steady state (cached frame tables)
+            st = s.stats()
+            assert st.leanFrame == 1 and st.fusedFrame == fused
+            final_first = s.readback(rt64.IMAGE_FINAL_RGBA8)     # before anything materialises the other images
+            got[fused] = ([final_first] + [s.readback(i) for i in images],
+                          (st.primaryRays, st.shadowRays, st.nodesVisited, st.trianglesTested, st.nodesPrimary, st.trianglesPrimary, st.nodesDirect, st.trianglesDirect))
+        finally:
+            s.close()
+    assert got[1][1] == got[0][1]
+    for a, b in zip(got[1][0], got[0][0]):
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8))

@@ -13,7 +13,7 @@ import json
 import sys
 from collections import defaultdict
 
-SHORT = {"primary_trace_kernel": "primary_trace", "primary_shade_kernel": "primary_shade", "direct_kernel": "direct",
+SHORT = {"lean_frame_kernel": "lean_frame", "raster_draw_kernel": "raster_draw", "primary_trace_kernel": "primary_trace", "primary_shade_kernel": "primary_shade", "direct_kernel": "direct",
          "compose_post_kernel": "compose_post", "indirect_constant_kernel": "indirect_constant", "indirect_kernel": "indirect",
          "lbvh_small_kernel": "lbvh_small", "svgf_atrous_kernel": "svgf_atrous", "svgf_variance_kernel": "svgf_variance"}
 
