@@ -166,9 +166,8 @@ struct Device {
     Device(int w, int h, int dev);
     ~Device();
     void use() const { HIP_CHECK(hipSetDevice(hipDevice)); }
-    // Pinned upload buffers.  An async copy out of a pool must have completed before the pool is written again: pool 0 carries the
-    // frame tables (drained by the end-of-frame wait) and the synchronous mesh / texture uploads, pool 1 the raster lists, which are
-    // staged in the same View::update right after the frame tables were queued.
+    // Pinned upload buffer of the synchronous texture uploads (the caller waits for the copy before the pool is written again).
+    // Everything that is queued without a wait -- mesh arrays, frame tables, raster lists -- is staged in the upload ring below.
     void *staging(size_t bytes, int pool = 0) {
         if (bytes > pinnedBytes[pool]) {
             if (pinned[pool]) { HIP_CHECK(hipStreamSynchronize(stream)); hipHostFree(pinned[pool]); }
@@ -288,7 +287,11 @@ struct View {
     void prepareRasterList(const std::vector<RenderInstance> &list, RasterList &rl, int w, int h, int y0, int y1, bool apply);
     void drawRasterList(RasterList &rl, uint8_t *target);
     std::vector<Texture *> usedTextures;
-    DevArray<GpuInstance> dInstances; DevArray<GpuTexture> dTextures; DevArray<RT64_LIGHT> dLights;
+    // The frame tables live in ONE device allocation in their staging order (instances | textures | lights) so that a changed
+    // frame costs one host-to-device copy (each copy packet is ~10 us of stream time, whatever its size).
+    template <class T> struct TablePtr { T *ptr = nullptr; };
+    DevArray<uint8_t> dTables; TablePtr<GpuInstance> dInstances; TablePtr<GpuTexture> dTextures; TablePtr<RT64_LIGHT> dLights;
+    std::vector<uint8_t> tableScratch;
     DevArray<GpuNode> tlasNodes; DevArray<uint32_t> tlasIndex, tlasMorton, tlasLeafParent; DevArray<BlasHeader> tlasHeader; DevArray<uint8_t> tlasScratch;
     std::vector<uint8_t> uploadedTables;      // bytes of the last uploaded instance/texture/light tables (cache key)
     float maxDepthBias = 0.0f;
@@ -637,10 +640,9 @@ void View::prepareRasterList(const std::vector<RenderInstance> &list, RasterList
                       rl.w == w && rl.h == h && rl.y0 == y0 && rl.y1 == y1 && rl.apply == apply && !dev->opt.alwaysRebuild;
     if (same) return;
     rl.table.reserve(hst.size()); rl.tris.reserve(std::max<size_t>(raster_tri_bytes(triTotal), 16));
-    uint8_t *stage = static_cast<uint8_t *>(dev->staging(bytes, 1));
+    uint8_t *stage = static_cast<uint8_t *>(dev->ringAlloc(bytes));       // pinned upload ring: queued without a wait
     memcpy(stage, hst.data(), bytes);
     HIP_CHECK(hipMemcpyAsync(rl.table.ptr, stage, bytes, hipMemcpyHostToDevice, dev->stream));
-    HIP_CHECK(hipStreamSynchronize(dev->stream));                // the staging buffer is shared with the frame tables
     rl.uploaded.assign(reinterpret_cast<uint8_t *>(hst.data()), reinterpret_cast<uint8_t *>(hst.data()) + bytes);
     rl.triTotal = triTotal; rl.w = w; rl.h = h; rl.y0 = y0; rl.y1 = y1; rl.apply = apply; rl.ready = true; rl.changed = true;
     rl.bounds[0] = std::max(0, (int)std::floor(std::min(bx0, 1e9f)) - 1); rl.bounds[1] = std::max(y0, (int)std::floor(std::min(by0, 1e9f)) - 1);
@@ -696,7 +698,8 @@ void View::update() {                          // View::update, rt64_view.cpp:10
     // Tables: instances (transforms rt64_view.cpp:348-376, materials :388-410), textures, lights -> one staged upload.
     const size_t nInst = rtInstances.size(), nTex = usedTextures.size(), nLights = scene->lights.size();
     const size_t instBytes = nInst * sizeof(GpuInstance), texBytes = nTex * sizeof(GpuTexture), lightBytes = nLights * sizeof(RT64_LIGHT);
-    uint8_t *stage = static_cast<uint8_t *>(dev->staging(instBytes + texBytes + lightBytes + 64));
+    tableScratch.resize(instBytes + texBytes + lightBytes + 64);
+    uint8_t *stage = tableScratch.data();
     GpuInstance *hInst = reinterpret_cast<GpuInstance *>(stage);
     GpuTexture *hTex = reinterpret_cast<GpuTexture *>(stage + instBytes);
     RT64_LIGHT *hLights = reinterpret_cast<RT64_LIGHT *>(stage + instBytes + texBytes);
@@ -760,11 +763,14 @@ void View::update() {                          // View::update, rt64_view.cpp:10
     const size_t tableBytes = instBytes + texBytes + lightBytes;
     const bool unchanged = uploadedTables.size() == tableBytes && tableBytes && memcmp(uploadedTables.data(), stage, tableBytes) == 0 && !dev->opt.alwaysRebuild;
     if (!unchanged) {
-        dInstances.reserve(std::max<size_t>(nInst, 1)); dTextures.reserve(std::max<size_t>(nTex, 1)); dLights.reserve(std::max<size_t>(nLights, 1));
-        if (instBytes) HIP_CHECK(hipMemcpyAsync(dInstances.ptr, hInst, instBytes, hipMemcpyHostToDevice, dev->stream));
-        if (texBytes) HIP_CHECK(hipMemcpyAsync(dTextures.ptr, hTex, texBytes, hipMemcpyHostToDevice, dev->stream));
-        if (lightBytes) HIP_CHECK(hipMemcpyAsync(dLights.ptr, hLights, lightBytes, hipMemcpyHostToDevice, dev->stream));
-        if (!dev->opt.syncPresent) HIP_CHECK(hipStreamSynchronize(dev->stream));      // frames are enqueued without a host wait: the staging buffer must be drained before its next use
+        dTables.reserve(std::max<size_t>(tableBytes, 4096));
+        dInstances.ptr = reinterpret_cast<GpuInstance *>(dTables.ptr); dTextures.ptr = reinterpret_cast<GpuTexture *>(dTables.ptr + instBytes);
+        dLights.ptr = reinterpret_cast<RT64_LIGHT *>(dTables.ptr + instBytes + texBytes);
+        if (tableBytes) {       // staged in the pinned upload ring: no wait before the region is reused (a wrap-around of the ring drains the stream)
+            void *pinnedStage = dev->ringAlloc(tableBytes);
+            memcpy(pinnedStage, stage, tableBytes);
+            HIP_CHECK(hipMemcpyAsync(dTables.ptr, pinnedStage, tableBytes, hipMemcpyHostToDevice, dev->stream));
+        }
         // TLAS: full rebuild (rt64_view.cpp:412-452 rebuilds every frame, updateOnly = false).
         if (nInst) {
             const uint32_t n = (uint32_t)nInst;
