@@ -221,7 +221,8 @@ def main():
                   trisPrimary=st.trianglesPrimary, nodesDirect=st.nodesDirect, trisDirect=st.trianglesDirect,
                   nodesIndirect=st.nodesIndirect, trisIndirect=st.trianglesIndirect)
     lean = bool(st.leanFrame)
-    fused = bool(st.fusedFrame)
+    fused = st.fusedFrame == 1
+    fused_full = st.fusedFrame == 2
     hit_pixels = int((scene.readback(rt64.IMAGE_FIRST_INSTANCE_ID) >= 0).sum())
     scene.option("count_traversal", 0)
 
@@ -279,6 +280,9 @@ def main():
             "direct": (kms["direct"], my_pixels * (DIRECT_PIXEL_B + (0 if lean else 8)) + hit_pixels * DIRECT_HIT_B + NODE_B * counts["nodesDirect"] + TRI_B * counts["trisDirect"] + 4 * counts["shadow"]
                        + (my_pixels * COMPOSE_PIXEL_LEAN_B if lean else 0)),          # lean frame: direct_kernel<false> composes the pixel itself
         }
+        if fused_full:           # full frame, all instances opaque: primary visibility + G-buffer + DirectRayGen are one kernel (same bytes as the three it replaces, minus the hit-record hand-over)
+            tb, sb, db = kernels.pop("primary_trace")[1], kernels.pop("primary_shade")[1], kernels.pop("direct")[1]
+            kernels["full_frame(trace+gbuffer+direct)"] = (kms["trace"], tb + sb + db - my_pixels * 2 * PRIMARY_TRACE_PIXEL_B + my_pixels * PRIMARY_TRACE_PIXEL_B)
         if fused:
             # one kernel carries the pixel from the primary ray to the back buffer: what it has to move is the hit record it keeps for
             # on-demand G-buffer rebuilds, the direct-light accumulation, the back buffer, the vertex / texel operands of the any-hit

@@ -363,7 +363,7 @@ typedef struct {
        frames reads them once instead of calling RT64_GetDeviceStats inside its frame loop. */
     unsigned int accumFrames;
     float accumMsTotal, accumMsBuild, accumMsPrimaryTrace, accumMsPrimaryShade, accumMsDirect, accumMsIndirect, accumMsReflectRefract, accumMsDenoise, accumMsComposePost;
-    unsigned int fusedFrame;                /* 1: the lean frame ran as ONE kernel (primary visibility + resolve + direct light + compose); its time is reported as msPrimaryTrace */
+    unsigned int fusedFrame;                /* 1: the lean frame ran as ONE kernel (primary visibility + resolve + direct light + compose); 2: a full frame's primary visibility + G-buffer + direct light ran as one kernel; the kernel's time is reported as msPrimaryTrace */
 } RT64_FRAME_STATS;
 
 #define RT64_EXT_API_LIST(X) \

@@ -48,7 +48,7 @@ hipError_t launch_reflection(const FrameParams &P, const ViewImages &I, bool kli
 hipError_t launch_gaussian(const uint16_t *in, uint16_t *out, int width, int height, int y0, int y1, hipStream_t s);
 hipError_t launch_compose_post(const FrameParams &P, const ViewImages &I, int cur, bool lean, bool writeFinal, hipStream_t s);
 // A lean frame in one launch: primary visibility + resolve + direct light + compose (passes.hip, lean_frame_kernel).
-hipError_t launch_lean_frame(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, int cur, hipStream_t s);
+hipError_t launch_lean_frame(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, int cur, bool full, int ownedY0, int ownedY1, hipStream_t s);
 hipError_t launch_post_process(const FrameParams &P, const ViewImages &I, hipStream_t s);      // PostProcessPS as its own pass (resolution scale / motion blur)
 hipError_t launch_clear_final(const FrameParams &P, const ViewImages &I, hipStream_t s);
 

@@ -364,6 +364,34 @@ DEV void resolve_primary(const FrameParams &P, const ViewImages &I, ShadeEnv &en
     R.instanceId = resInstanceId;
 }
 
+// The image stores of PrimaryRayGen for one pixel (FULL: the reference's whole G-buffer; lean: what DirectRayGen + Compose read).
+template <bool FULL>
+DEV void store_primary(const FrameParams &P, const ViewImages &I, size_t i, int cur, f3 rayDirection, const PrimaryResolve &R) {
+    if (FULL) {
+        store_rgba16f(I.viewDirection, i, rayDirection.x, rayDirection.y, rayDirection.z, 0.0f);
+        store_rgba16f(I.reflection, i, 0.0f, 0.0f, 0.0f, R.reflA);
+        store_rgba16f(I.refraction, i, 0.0f, 0.0f, 0.0f, R.refrA);
+    }
+    // Lean frame: DirectRayGen reads position / normal / specular only where a surface was hit, so miss pixels skip those stores.
+    if (FULL || R.instanceId >= 0) {
+        reinterpret_cast<float4 *>(I.shadingPosition)[i] = make_float4(R.position.x, R.position.y, R.position.z, 0.0f);
+        store_rgba16f(I.shadingNormal, i, R.normal.x, R.normal.y, R.normal.z, 0.0f);
+        store_rgba16f(I.shadingSpecular, i, R.specular.x, R.specular.y, R.specular.z, 0.0f);
+    }
+    store_rgba8(I.diffuse, i, R.color.x, R.color.y, R.color.z, R.color.w);
+    I.instanceId[i] = R.instanceId;
+    if (FULL) {
+        I.firstInstanceId[i] = R.instanceId;                    // CopyResource(rtFirstInstanceId, rtInstanceId), rt64_view.cpp:1383
+        store_rgba16f(I.transparent, i, R.transparent.x, R.transparent.y, R.transparent.z, 1.0f);
+        reinterpret_cast<uint32_t *>(I.flow)[i] = (uint32_t)f32_to_f16_bits(-R.flowX) | ((uint32_t)f32_to_f16_bits(R.flowY) << 16);
+        I.reactiveMask[i] = to_unorm8(fminf(R.reactiveMask, 0.9f));
+        I.lockMask[i] = to_unorm8(P.binaryLockMask ? (R.lockMask >= 0.5f ? 1.0f : 0.0f) : fminf(R.lockMask, 1.0f));
+        // history guides of the temporal / SVGF passes: no consumer on a lean frame
+        store_rgba16f(I.normal[cur], i, R.normal.x, R.normal.y, R.normal.z, 0.0f);
+        I.depth[cur][i] = R.depth;
+    }
+}
+
 template <bool TRANSPARENT_LIGHT, bool KLIST, bool FULL>
 __global__ __launch_bounds__(RT_BLOCK, SHADE_WAVES) void primary_shade_kernel(FrameParams P, ViewImages I, const int32_t *hitInstance, int cur) {
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
@@ -379,8 +407,6 @@ __global__ __launch_bounds__(RT_BLOCK, SHADE_WAVES) void primary_shade_kernel(Fr
         const size_t i = (size_t)py * (size_t)P.width + px;
         f3 rayOrigin, rayDirection; f2 d;
         primary_ray(P, px, py, rayOrigin, rayDirection, d);
-        if (FULL) store_rgba16f(I.viewDirection, i, rayDirection.x, rayDirection.y, rayDirection.z, 0.0f);
-
         const uint4 hrec = reinterpret_cast<const uint4 *>(I.primaryHit)[i];
         const int hInst = hitInstance[i];
         SurfaceHit best;
@@ -390,29 +416,7 @@ __global__ __launch_bounds__(RT_BLOCK, SHADE_WAVES) void primary_shade_kernel(Fr
         PrimaryResolve R;
         resolve_primary<TRANSPARENT_LIGHT, KLIST, FULL>(P, I, env, px, py, i, rayOrigin, rayDirection, d, best, nhits, R);
 
-        if (FULL) {
-            store_rgba16f(I.reflection, i, 0.0f, 0.0f, 0.0f, R.reflA);
-            store_rgba16f(I.refraction, i, 0.0f, 0.0f, 0.0f, R.refrA);
-        }
-        // Lean frame: DirectRayGen reads position / normal / specular only where a surface was hit, so miss pixels skip those stores.
-        if (FULL || R.instanceId >= 0) {
-            reinterpret_cast<float4 *>(I.shadingPosition)[i] = make_float4(R.position.x, R.position.y, R.position.z, 0.0f);
-            store_rgba16f(I.shadingNormal, i, R.normal.x, R.normal.y, R.normal.z, 0.0f);
-            store_rgba16f(I.shadingSpecular, i, R.specular.x, R.specular.y, R.specular.z, 0.0f);
-        }
-        store_rgba8(I.diffuse, i, R.color.x, R.color.y, R.color.z, R.color.w);
-        I.instanceId[i] = R.instanceId;
-        if (FULL) {
-            I.firstInstanceId[i] = R.instanceId;                    // CopyResource(rtFirstInstanceId, rtInstanceId), rt64_view.cpp:1383
-            store_rgba16f(I.transparent, i, R.transparent.x, R.transparent.y, R.transparent.z, 1.0f);
-            reinterpret_cast<uint32_t *>(I.flow)[i] = (uint32_t)f32_to_f16_bits(-R.flowX) | ((uint32_t)f32_to_f16_bits(R.flowY) << 16);
-            I.reactiveMask[i] = to_unorm8(fminf(R.reactiveMask, 0.9f));
-            I.lockMask[i] = to_unorm8(P.binaryLockMask ? (R.lockMask >= 0.5f ? 1.0f : 0.0f) : fminf(R.lockMask, 1.0f));
-        }
-        if (FULL) {                                                 // history guides of the temporal / SVGF passes: no consumer on a lean frame
-            store_rgba16f(I.normal[cur], i, R.normal.x, R.normal.y, R.normal.z, 0.0f);
-            I.depth[cur][i] = R.depth;
-        }
+        store_primary<FULL>(P, I, i, cur, rayDirection, R);
     }
     flush_env(P, env, PASS_PRIMARY_SHADE, CTR_PRIMARY, 0);
 }
@@ -539,11 +543,15 @@ __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void direct_kernel(FramePar
 // rounded here exactly as that image's format rounds it (RGBA16F normal / specular / direct light, RGBA8 diffuse), so the back buffer
 // is bit-identical to the three-kernel path.  It still stores what View::materialise needs to rebuild the full G-buffer on demand:
 // the hit record (16 + 4 B) and the direct-light accumulation (8 B); rtOutput is written only when PostProcess runs separately.
-template <bool CACHED>
+// FULL = true is the same kernel for a frame that is NOT lean but whose instances are all provably opaque (GI, denoiser, reflection,
+// refraction, fog, motion blur downstream): it writes the reference's whole G-buffer like primary_shade_kernel<.., FULL> and
+// DirectRayGen's two images like direct_kernel<true>, and leaves Compose to its own pass.  ownedY0 / ownedY1: the rows DirectRayGen
+// covers (the frame parameters may include a denoiser halo above and below them, which only the G-buffer part renders).
+template <bool CACHED, bool FULL>
 #ifndef LEAN_WAVES
 #define LEAN_WAVES 2          // 2: no spills (about 200 VGPRs); 3 spills ~46 VGPRs and measured 1.5 % slower -- the kernel is latency bound, not occupancy bound
 #endif
-__global__ __launch_bounds__(RT_BLOCK, LEAN_WAVES) void lean_frame_kernel(FrameParams P, ViewImages I, int32_t *hitInstance, int cur) {
+__global__ __launch_bounds__(RT_BLOCK, LEAN_WAVES) void lean_frame_kernel(FrameParams P, ViewImages I, int32_t *hitInstance, int cur, int ownedY0, int ownedY1) {
     __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED : RT_STACK_LDS) * RT_BLOCK];
     __shared__ float ldsLightIntensity[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -573,7 +581,11 @@ __global__ __launch_bounds__(RT_BLOCK, LEAN_WAVES) void lean_frame_kernel(FrameP
         reinterpret_cast<uint4 *>(I.primaryHit)[i] = rec;
 
         PrimaryResolve R;
-        resolve_primary<false, false, false>(P, I, env, px, py, i, o, rayDirection, ndc, h, nhits, R);
+        resolve_primary<false, false, FULL>(P, I, env, px, py, i, o, rayDirection, ndc, h, nhits, R);
+        if (FULL) {
+            store_primary<true>(P, I, i, cur, rayDirection, R);
+            if ((int)py < ownedY0 || (int)py >= ownedY1) continue;          // halo row: G-buffer only
+        }
         const f4 diffuse = mk4(q_unorm8(R.color.x), q_unorm8(R.color.y), q_unorm8(R.color.z), q_unorm8(R.color.w));     // rtDiffuse is RGBA8
         f3 direct = mk3s(1.0f); float historyLength = 0.0f;                                                            // DirectRayGen.hlsl:19
         if (R.instanceId >= 0) {
@@ -584,6 +596,7 @@ __global__ __launch_bounds__(RT_BLOCK, LEAN_WAVES) void lean_frame_kernel(FrameP
             direct = lerp3(mk3s(0.0f), resDirect, s_rcp(historyLength));
         }
         store_rgba16f(I.directLight[cur], i, direct.x, direct.y, direct.z, historyLength);
+        if (FULL) { store_rgba16f(I.filteredDirect[1], i, direct.x, direct.y, direct.z, historyLength); continue; }
         const f3 result = compose_lean_value(P, diffuse, mk3(q_f16(direct.x), q_f16(direct.y), q_f16(direct.z)));
         if (P.separatePost) reinterpret_cast<float4 *>(I.output)[i] = make_float4(result.x, result.y, result.z, 1.0f);
         else store_rgba8(I.final, i, result.x, result.y, result.z, 1.0f);
@@ -1291,12 +1304,17 @@ hipError_t launch_direct(const FrameParams &P, const ViewImages &I, int cur, boo
 // one resident round (256 CUs x LEAN_WAVES workgroups, each walking its tiles round-robin): the scene cache is filled once per
 // workgroup slot.  A small share (a 1/4 or 1/8 strip set of a multi-GPU partition: <= 2048 tiles) gets one workgroup per tile, so
 // the hardware dispatcher balances sky tiles against geometry tiles (measured on a 1/4 share: 87 us against 105 us).
-hipError_t launch_lean_frame(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, int cur, hipStream_t s) {
+hipError_t launch_lean_frame(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, int cur, bool full, int ownedY0, int ownedY1, hipStream_t s) {
     const unsigned strips = (unsigned)(P.tileY1 - P.tileY0 + 15) / 16, owned = strips > (unsigned)P.stripRank ? (strips - (unsigned)P.stripRank + (unsigned)P.stripCount - 1) / (unsigned)P.stripCount : 0u;
     const unsigned tiles = (unsigned)((P.width + 15) / 16) * owned, resident = 256u * LEAN_WAVES;
     const unsigned grid = tiles < 1u ? 1u : (tiles <= (unsigned)RT_GRID_BLOCKS ? tiles : resident);
-    if (P.cacheWords) hipLaunchKernelGGL(lean_frame_kernel<true>, dim3(grid), dim3(RT_BLOCK), cached_lds_bytes(P, true), s, P, I, hitInstance, cur);
-    else hipLaunchKernelGGL(lean_frame_kernel<false>, dim3(grid), dim3(RT_BLOCK), 0, s, P, I, hitInstance, cur);
+    const size_t lds = P.cacheWords ? cached_lds_bytes(P, true) : 0;
+    if (P.cacheWords) {
+        if (full) hipLaunchKernelGGL((lean_frame_kernel<true, true>), dim3(grid), dim3(RT_BLOCK), lds, s, P, I, hitInstance, cur, ownedY0, ownedY1);
+        else hipLaunchKernelGGL((lean_frame_kernel<true, false>), dim3(grid), dim3(RT_BLOCK), lds, s, P, I, hitInstance, cur, ownedY0, ownedY1);
+    }
+    else if (full) hipLaunchKernelGGL((lean_frame_kernel<false, true>), dim3(grid), dim3(RT_BLOCK), 0, s, P, I, hitInstance, cur, ownedY0, ownedY1);
+    else hipLaunchKernelGGL((lean_frame_kernel<false, false>), dim3(grid), dim3(RT_BLOCK), 0, s, P, I, hitInstance, cur, ownedY0, ownedY1);
     return hipGetLastError();
 }
 hipError_t launch_indirect(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, bool refill, hipStream_t s) {

@@ -297,6 +297,7 @@ struct View {
     float maxDepthBias = 0.0f;
     bool anyNonOpaque = false, anyReflection = false, anyRefraction = false, anyFog = false;
     bool leanFrame = false;                   // last frame skipped the images no pass consumed (see materialise)
+    bool fusedFullFrame = false;              // full frame whose primary + direct passes ran as lean_frame_kernel<.., FULL>
     bool fusedFrame = false;                  // ... and ran as lean_frame_kernel: rtOutput was not written either (unless PostProcess ran separately)
     FrameParams lastParams; int lastCur = 0;
 
@@ -940,9 +941,17 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         // A lean frame is pixel-local end to end: one kernel carries every pixel from the primary ray to the back buffer
         // (device option fused_lean = 0 keeps the three separate kernels; same back buffer bit for bit).
         const bool fused = lean && dev->opt.fusedLean;
-        leanFrame = lean; fusedFrame = fused; lastParams = P; lastCur = cur;
+        // The same one-kernel form serves full frames whose instances are all provably opaque (GI / denoiser / reflection frames):
+        // it then writes the whole G-buffer over the rows with the denoiser halo (X) and DirectRayGen's images over the owned rows.
+        const bool fusedFull = !lean && !klist && dev->opt.fusedLean;
+        leanFrame = lean; fusedFrame = fused; fusedFullFrame = fusedFull; lastParams = P; lastCur = cur;
         if (fused) {
-            L(launch_lean_frame(P, img, hitInstance.ptr, cur, s));
+            L(launch_lean_frame(P, img, hitInstance.ptr, cur, false, 0, imgH, s));
+            mark(Device::EV_PRIMARY_TRACE); mark(Device::EV_PRIMARY); mark(Device::EV_DIRECT);
+        }
+        else if (fusedFull) {
+            if (P.stripCount > 1 && (X.tileY0 != P.tileY0 || X.tileY1 != P.tileY1)) throw std::runtime_error("RT64_DrawDevice: interleaved strips with a denoiser halo.");
+            L(launch_lean_frame(X, img, hitInstance.ptr, cur, true, P.tileY0, P.tileY1, s));
             mark(Device::EV_PRIMARY_TRACE); mark(Device::EV_PRIMARY); mark(Device::EV_DIRECT);
         }
         else {
@@ -982,7 +991,7 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         if (P.separatePost) L(launch_post_process(P, img, s));
     }
     else {
-        leanFrame = false; fusedFrame = false;
+        leanFrame = false; fusedFrame = false; fusedFullFrame = false;
         mark(Device::EV_PRIMARY_TRACE); mark(Device::EV_PRIMARY); mark(Device::EV_DIRECT); mark(Device::EV_INDIRECT); mark(Device::EV_REFL); mark(Device::EV_DENOISE);
         L(launch_clear_final(P, img, s));
         drawRasterList(rasterBgScreen, img.final);           // nothing ray traced covers the background instances (rt64_view.cpp:1292-1296)
@@ -1048,7 +1057,7 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
         if (haveView) continue;
         haveView = true;
         st.instanceCount = (unsigned)v->rtInstances.size();
-        st.leanFrame = v->leanFrame ? 1u : 0u; st.fusedFrame = v->fusedFrame ? 1u : 0u;
+        st.leanFrame = v->leanFrame ? 1u : 0u; st.fusedFrame = v->fusedFrame ? 1u : (v->fusedFullFrame ? 2u : 0u);
         st.width = (unsigned)v->imgW; st.height = (unsigned)v->imgH;          // render size ("Render buffer: WxH")
         unsigned tri = 0, nodeBytes = 0, triBytes = 0;
         for (auto &ri : v->rtInstances) { tri += ri.instance->mesh->blasCount; nodeBytes += (unsigned)(std::max<uint32_t>(ri.instance->mesh->blasCount - 1, 1) * sizeof(GpuNode)); triBytes += (unsigned)(ri.instance->mesh->blasCount * sizeof(GpuTri)); }

@@ -326,3 +326,36 @@ def test_one_kernel_lean_frame_matches_the_three_kernel_path(rt64_lib, sample_da
     assert got[1][1] == got[0][1]
     for a, b in zip(got[1][0], got[0][0]):
         assert a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("band", [None, (48, 128)])
+def test_one_kernel_full_frame_matches_the_separate_kernels(rt64_lib, sample_data, band):
+    """Full (non-lean) frames whose instances are all opaque -- here 1 GI sample + SVGF -- run primary visibility, the G-buffer and
+    DirectRayGen as lean_frame_kernel<.., FULL> (fusedFrame == 2) unless fused_lean = 0.  Both forms give the same bytes in every image
+    over three frames of temporal history, also on a band of the frame with the denoiser halo around it."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    images = [rt64.IMAGE_FINAL_RGBA8, rt64.IMAGE_OUTPUT_RGBA32F, rt64.IMAGE_PRIMARY_HIT, rt64.IMAGE_INSTANCE_ID, rt64.IMAGE_DIFFUSE, rt64.IMAGE_DIRECT_LIGHT_RAW,
+              rt64.IMAGE_DIRECT_LIGHT_FILTERED, rt64.IMAGE_INDIRECT_LIGHT_RAW, rt64.IMAGE_INDIRECT_LIGHT_FILTERED, rt64.IMAGE_SHADING_POSITION, rt64.IMAGE_SHADING_NORMAL,
+              rt64.IMAGE_SHADING_SPECULAR, rt64.IMAGE_FLOW, rt64.IMAGE_DEPTH, rt64.IMAGE_VIEW_DIRECTION, rt64.IMAGE_FIRST_INSTANCE_ID, rt64.IMAGE_REACTIVE_MASK, rt64.IMAGE_LOCK_MASK]
+    got = {}
+    for fused in (1, 0):
+        s = sample_scene.Rt64Scene(rt64_lib, sample_data, 240, 176, hip_device=0)
+        try:
+            s.option("fused_lean", fused)
+            s.option("count_traversal", 1)
+            s.set_view_description(gi_samples=1, denoiser=True)
+            if band:
+                s.set_tile(*band)
+            for _ in range(3):
+                s.draw()
+            st = s.stats()
+            assert st.leanFrame == 0 and st.fusedFrame == (2 if fused else 0)
+            y0, y1 = band if band else (0, 176)
+            got[fused] = ([s.readback(i)[y0:y1] for i in images],
+                          (st.primaryRays, st.shadowRays, st.indirectRays, st.nodesVisited, st.trianglesTested))
+        finally:
+            s.close()
+    assert got[1][1] == got[0][1]
+    for a, b in zip(got[1][0], got[0][0]):
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8))
