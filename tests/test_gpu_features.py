@@ -359,3 +359,44 @@ def test_one_kernel_full_frame_matches_the_separate_kernels(rt64_lib, sample_dat
     assert got[1][1] == got[0][1]
     for a, b in zip(got[1][0], got[0][0]):
         assert a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks,fused", [(2, 1), (3, 1), (8, 1), (8, 0)])
+def test_interleaved_strip_partition_reassembles_the_whole_frame(rt64_lib, sample_data, ranks, fused):
+    """bench.py's N > 1 partition of a pixel-local frame: rank r renders the 16-row strips r, r + N, ... (RT64_SetDeviceInterleave) and
+    RT64_CopyDeviceImage packs them back to back for the gather.  Every rank's strips, rendered here one rank after the other on one
+    device, reassemble (tiles.assemble, the function rank 0 runs on the gathered buckets) into exactly the frame a single device renders;
+    a height that is not a multiple of the strip height leaves a ragged last strip."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene, tiles
+    hip = C.CDLL("libamdhip64.so")              # the runtime librt64.so is linked against: a device buffer for RT64_CopyDeviceImage
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]; hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]; hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    W, H = 208, 150
+    s = sample_scene.Rt64Scene(rt64_lib, sample_data, W, H, hip_device=0)
+    try:
+        s.option("fused_lean", fused)
+        s.draw()
+        whole = s.readback(rt64.IMAGE_FINAL_RGBA8).copy()
+        mx = tiles.max_owned_rows(H, ranks) * W * 4
+        dev_buf = C.c_void_p()
+        assert hip.hipMalloc(C.byref(dev_buf), ranks * mx) == 0 and hip.hipMemset(dev_buf, 0, ranks * mx) == 0
+        rows_seen = np.zeros(H, dtype=np.int32)
+        for r in range(ranks):
+            s.set_interleave(r, ranks)
+            s.draw()
+            st = s.stats()
+            assert st.stripRank == r and st.stripCount == ranks and st.rowsRendered == tiles.owned_rows(H, r, ranks)
+            n = rt64_lib.CopyDeviceImage(s.device, rt64.IMAGE_FINAL_RGBA8, dev_buf.value + r * mx, mx)
+            assert n == tiles.owned_rows(H, r, ranks) * W * 4
+            mine = s.readback(rt64.IMAGE_FINAL_RGBA8)                # the host readback packs the owned rows the same way
+            assert np.array_equal(mine, np.concatenate([whole[a:b] for a, b in tiles.strip_ranges(H, r, ranks)]))
+            for a, b in tiles.strip_ranges(H, r, ranks):
+                rows_seen[a:b] += 1
+        packed = np.zeros((ranks, mx), dtype=np.uint8)
+        assert hip.hipMemcpy(packed.ctypes.data_as(C.c_void_p), dev_buf, ranks * mx, 2) == 0          # hipMemcpyDeviceToHost (synchronises)
+        hip.hipFree(dev_buf)
+        assert (rows_seen == 1).all()
+        assert np.array_equal(tiles.assemble(packed, H, W, ranks), whole)
+    finally:
+        s.close()
