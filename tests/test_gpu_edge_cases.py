@@ -243,3 +243,77 @@ def test_five_thousand_instances_use_the_large_tlas_builder(rt64_lib, sample_dat
         assert np.array_equal(nodes.view(np.uint8), tl["nodes"].view(np.uint8).reshape(-1))
     finally:
         s.close(); o.close()
+
+
+def test_soak_random_frame_sequence_ends_like_a_fresh_render(rt64_lib, sample_data):
+    """120 frames of seeded random host activity on ONE device -- instance transforms and materials changing, the view description
+    hopping between pixel-local frames, GI + SVGF, GI without a filter and soft shadows, mesh re-uploads, image
+    readbacks in between (G-buffer rebuilds on demand), enqueued and synchronous frames -- then the scene is put into a known state
+    and one pixel-local frame is rendered.  That frame must equal, byte for byte, what a fresh device renders from the same state:
+    none of the caches in between (frame tables, raster lists, LDS scene cache layout, lean / fused frame bookkeeping, upload ring,
+    temporal history) may leak into it."""
+    import copy
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    Wd, Hd = 224, 128
+    rng = np.random.default_rng(20261004)
+    data = copy.copy(sample_data)
+    data.instances = [copy.copy(i) for i in sample_data.instances]
+    for i in data.instances:
+        i.material = sample_scene.copy_material(i.material)
+    data.meshes = [copy.copy(m) for m in sample_data.meshes]
+    k_sphere = next(i for i, inst in enumerate(data.instances) if inst.name == "sphere")
+    base_vertices = data.meshes[data.instances[k_sphere].mesh].vertices.copy()
+    images = [rt64.IMAGE_FINAL_RGBA8, rt64.IMAGE_OUTPUT_RGBA32F, rt64.IMAGE_INSTANCE_ID, rt64.IMAGE_DIFFUSE, rt64.IMAGE_DIRECT_LIGHT_RAW, rt64.IMAGE_SHADING_NORMAL,
+              rt64.IMAGE_DEPTH, rt64.IMAGE_FLOW, rt64.IMAGE_PRIMARY_HIT]
+    views = [dict(), dict(gi_samples=1, denoiser=True), dict(gi_samples=2, denoiser=False), dict(di_samples=2), dict(gi_samples=1, denoiser=True, di_samples=1)]
+
+    def translate(dx, dy, dz):
+        m = np.eye(4, dtype=np.float32); m[3, :3] = (dx, dy, dz); return m
+
+    s = sample_scene.Rt64Scene(rt64_lib, data, Wd, Hd, hip_device=0)
+    try:
+        for frame in range(120):
+            op = rng.integers(0, 10)
+            if op <= 2:                                  # the sphere moves (tables change: upload + TLAS rebuild)
+                inst = copy.copy(data.instances[k_sphere])
+                inst.previous_transform = inst.transform
+                inst.transform = translate(*(rng.uniform(-1.5, 1.5, 3) * (1, 0.3, 1)))
+                data.instances[k_sphere] = inst
+                s.set_instance(k_sphere, inst)
+            elif op == 3:                                # material change on a random ray-traced instance
+                k = int(rng.integers(0, len(data.instances)))
+                inst = copy.copy(data.instances[k]); inst.material = sample_scene.copy_material(inst.material)
+                inst.material.specularExponent = float(rng.uniform(1, 40)); inst.material.selfLight.x = float(rng.uniform(0, 0.2))
+                data.instances[k] = inst
+                s.set_instance(k, inst)
+            elif op == 4:                                # another kind of frame
+                s.set_view_description(**views[int(rng.integers(0, len(views)))])
+            elif op == 5:                                # re-upload of the sphere mesh (same counts)
+                v = base_vertices.copy(); v["position"][:, :3] *= np.float32(rng.uniform(0.9, 1.1))
+                s.set_mesh(s.meshes[data.instances[k_sphere].mesh], v, data.meshes[data.instances[k_sphere].mesh].indices)
+            elif op == 6:
+                s.option("sync_present", int(rng.integers(0, 2)))
+            elif op == 7:
+                s.readback(images[int(rng.integers(0, len(images)))])
+            elif op == 8:
+                s.option("fused_lean", int(rng.integers(0, 2)))
+            s.draw(can_reproject=bool(rng.integers(0, 4)))
+        # known state
+        s.option("sync_present", 1); s.option("fused_lean", 1)
+        s.set_view_description()
+        s.set_mesh(s.meshes[data.instances[k_sphere].mesh], base_vertices, data.meshes[data.instances[k_sphere].mesh].indices)
+        final_inst = copy.copy(data.instances[k_sphere]); final_inst.transform = translate(0.25, 0.0, -0.5); final_inst.previous_transform = final_inst.transform
+        data.instances[k_sphere] = final_inst
+        s.set_instance(k_sphere, final_inst)
+        s.draw()
+        after_soak = [s.readback(i) for i in images]
+    finally:
+        s.close()
+    f = sample_scene.Rt64Scene(rt64_lib, data, Wd, Hd, hip_device=0)
+    try:
+        f.draw()
+        fresh = [f.readback(i) for i in images]
+    finally:
+        f.close()
+    for name, a, b in zip(images, after_soak, fresh):
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8)), "image %d differs after the soak" % name
