@@ -244,6 +244,9 @@ def main():
     for _ in range(args.steps):
         last_slot = step()
     enqueue_ms = (time.perf_counter() - t0) * 1e3 / args.steps      # host time per step before the closing barrier (= frame time when frames are synchronous)
+    if G:
+        for sl in (0, 1):
+            gatherer.wait(sl)            # the last two gathers (and rank 0's assembly of them) complete inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
     stat_frames = args.steps
@@ -345,6 +348,8 @@ def main():
             result["frame_checksum"] = gathered_checksum
         print(json.dumps(result), flush=True)
 
+    if G:
+        gatherer.close()                 # torch's current stream goes back to the default one before the renderer's stream is destroyed
     scene.close()
     if G:
         dist.barrier()

@@ -100,14 +100,17 @@ def strips_per_rank(height, count):
 
 class FrameGatherer:
     """Pipelined gather of the composited framebuffer: rank r fills `local(slot)` with its packed strips, `submit(slot)` starts ONE
-    asynchronous collective (dist.gather to rank 0 == RCCL send/recv over xGMI) and, on rank 0, one strided copy that de-interleaves
-    the strips into the frame; `wait(slot)` orders the caller's stream behind both before the slot is reused.  With two slots the
-    gather of frame k overlaps the rendering of frame k+1.
+    asynchronous collective (dist.gather to rank 0 == RCCL send/recv over xGMI); `wait(slot)` -- called before the slot is refilled, two
+    frames later, or before rank 0 reads `frame(slot)` -- orders the caller's stream behind the collective and, on rank 0, runs the one
+    strided copy that de-interleaves the strips into the frame.  With two slots the gather of frame k overlaps the rendering of frame
+    k+1 (RCCL works on its own stream; by the time the slot comes round again the collective has long finished, so the wait is free).
 
     Layout: every rank's buffer is [K][16 rows][W][4] with K = strips_per_rank (unused strips stay empty), so the bucket on rank 0 is
     [N][K][S] and the frame, padded to N*K strips, is bucket.transpose(0, 1): strip k of rank r is frame strip k*N + r.
     `stream` (a torch.cuda.Stream, e.g. the renderer's stream wrapped in torch.cuda.ExternalStream) is the stream the local buffer
-    is produced on; None = the current stream / CPU tensors (gloo rehearsal)."""
+    is produced on: it becomes this process's current torch stream, once, so that no per-frame call has to switch streams (a
+    `with torch.cuda.stream(...)` block costs ~25 us of host time per frame -- a third of what a 1/8 share of the frame takes to render).
+    None = the current stream / CPU tensors (gloo rehearsal)."""
 
     def __init__(self, height, width, rank, count, device, group=None, slots=2, stream=None, bands=False):
         import torch
@@ -118,13 +121,24 @@ class FrameGatherer:
         n = self.k * self.strip_elems
         if bands:
             n = band_rows(height, count) * width * 4
+        self._previous_stream = None
+        if stream is not None:
+            self._previous_stream = torch.cuda.current_stream()
+            torch.cuda.set_stream(stream)
         self.locals = [torch.zeros(n, dtype=torch.uint8, device=device) for _ in range(slots)]
         self.work = [None] * slots
         self.frames = [None] * slots
+        self.outputs = [None] * slots
         if rank == 0:
             self.buckets = [torch.empty((count, n), dtype=torch.uint8, device=device) for _ in range(slots)]
+            self.outputs = [list(b.unbind(0)) for b in self.buckets]            # built once: the per-frame call only passes them on
             self.padded = [None if bands else torch.empty((self.k * count, self.strip_elems), dtype=torch.uint8, device=device) for _ in range(slots)]
-        self.side = torch.cuda.Stream(device=device) if (stream is not None) else None      # assembly runs beside the renderer's stream
+            for sl in range(slots):                 # the views every frame is read through
+                flat = self.buckets[sl] if bands else self.padded[sl]
+                self.frames[sl] = flat.view(-1)[:height * width * 4].view(height, width, 4)
+            if not bands:
+                self._dst = [p.view(self.k, count, self.strip_elems) for p in self.padded]
+                self._src = [b.view(count, self.k, self.strip_elems).transpose(0, 1) for b in self.buckets]
 
     def local(self, slot):
         return self.locals[slot]
@@ -136,39 +150,50 @@ class FrameGatherer:
         return owned_rows(self.height, self.rank, self.count) * self.width * 4
 
     def submit(self, slot):
-        import torch
+        """Start the collective of `slot`: ordered behind whatever produced locals[slot] on the current stream; returns at once."""
+        if self._pg is None:
+            self._bind()
+        if self._pg is not False:       # the process group's own entry point: same collective as dist.gather without ~20 us of per-call argument checking
+            self.work[slot] = self._pg.gather(self._out_arg[slot], self._in_arg[slot], self._opts)
+        else:
+            import torch.distributed as dist
+            self.work[slot] = dist.gather(self.locals[slot], self.outputs[slot], dst=0, group=self.group, async_op=True)
+
+    _pg = None
+
+    def _bind(self):
         import torch.distributed as dist
-        ctx = torch.cuda.stream(self.stream) if self.stream is not None else _Null()
-        with ctx:                                   # the collective is ordered behind whatever produced locals[slot] on this stream
-            if self.rank == 0:
-                self.work[slot] = dist.gather(self.locals[slot], list(self.buckets[slot].unbind(0)), dst=0, group=self.group, async_op=True)
-            else:
-                self.work[slot] = dist.gather(self.locals[slot], None, dst=0, group=self.group, async_op=True)
-        if self.rank == 0:
-            ctx = torch.cuda.stream(self.side) if self.side is not None else _Null()
-            with ctx:
-                self.work[slot].wait()              # stream-level wait on CUDA tensors, blocking on CPU tensors
-                if self.bands:                      # rank r's band is rows [r*B, (r+1)*B): the bucket, flattened, IS the frame
-                    self.frames[slot] = self.buckets[slot].view(-1)[:self.height * self.width * 4].view(self.height, self.width, 4)
-                else:
-                    self.padded[slot].view(self.k, self.count, self.strip_elems).copy_(self.buckets[slot].view(self.count, self.k, self.strip_elems).transpose(0, 1))
-                    self.frames[slot] = self.padded[slot].view(-1)[:self.height * self.width * 4].view(self.height, self.width, 4)
+        try:
+            pg = self.group if self.group is not None else dist.distributed_c10d._get_default_group()
+            opts = dist.GatherOptions(); opts.rootRank = 0
+            self._out_arg = [[o] if self.rank == 0 else [] for o in (self.outputs if self.rank == 0 else [None] * len(self.locals))]
+            self._in_arg = [[t] for t in self.locals]
+            pg.gather; self._pg, self._opts = pg, opts
+        except Exception:                # another torch version: the public wrapper does the same thing
+            self._pg = False
 
     def wait(self, slot):
-        """Before refilling locals[slot]: the collective that reads it (and rank 0's assembly of it) must have run."""
-        import torch
+        """Before refilling locals[slot] / reading frame(slot): the collective that used the slot must have run; rank 0 assembles."""
         w = self.work[slot]
         if w is None:
             return
-        ctx = torch.cuda.stream(self.stream) if self.stream is not None else _Null()
-        with ctx:
-            w.wait()
-            if self.side is not None:
-                torch.cuda.current_stream().wait_stream(self.side)
+        w.wait()                                    # stream-level wait on CUDA tensors, blocking on CPU tensors
+        if self.rank == 0 and not self.bands:       # rank r's band is rows [r*B, (r+1)*B): with bands the bucket, flattened, IS the frame
+            self._dst[slot].copy_(self._src[slot])
         self.work[slot] = None
 
+    def close(self):
+        """Finish the outstanding collectives and hand torch's current stream back (the renderer's stream dies with its device)."""
+        for slot in range(len(self.work)):
+            self.wait(slot)
+        if self._previous_stream is not None:
+            import torch
+            torch.cuda.current_stream().synchronize()
+            torch.cuda.set_stream(self._previous_stream)
+            self._previous_stream = None
+
     def frame(self, slot):
-        """Rank 0: the assembled frame of the last submit(slot) (valid after wait(slot) / a device synchronise)."""
+        """Rank 0: the assembled frame of the last submit(slot), valid after wait(slot) (on the current stream for CUDA tensors)."""
         return self.frames[slot]
 
 
