@@ -52,7 +52,9 @@ DEV bool tri_hit(const RaySpace &r, const GpuTri &tri, bool cull, float tmin, fl
     for (int k = 0; k < 3; k++) { e1[k] = tri.v1[k] - tri.v0[k]; e2[k] = tri.v2[k] - tri.v0[k]; }
     g_cross3(r.d, e2, p);
     float det = g_dot3(e1, p);
-    if (cull ? !(det > 0.0f) : (det == 0.0f || det != det)) return false;
+    // one exit instead of two: the determinant test joins the final condition (a rejected determinant only feeds inf / NaN into
+    // comparisons that are then ignored), so a wave does not pay an exec-mask round trip before the division
+    const bool detRejected = cull ? !(det > 0.0f) : (det == 0.0f || det != det);
     float inv = 1.0f / det;
 #pragma unroll
     for (int k = 0; k < 3; k++) tv[k] = r.o[k] - tri.v0[k];
@@ -60,7 +62,7 @@ DEV bool tri_hit(const RaySpace &r, const GpuTri &tri, bool cull, float tmin, fl
     g_cross3(tv, e1, q);
     float vv = g_dot3(r.d, q) * inv;
     float tt = g_dot3(e2, q) * inv;
-    if (!(uu >= 0.0f) || !(vv >= 0.0f) || !(uu + vv <= 1.0f) || !(tt > tmin) || !(tt < tmax)) return false;
+    if (detRejected || !(uu >= 0.0f) || !(vv >= 0.0f) || !(uu + vv <= 1.0f) || !(tt > tmin) || !(tt < tmax)) return false;
     t = tt; u = uu; v = vv;
     return true;
 }
@@ -162,12 +164,12 @@ DEV void trace_ray(const FrameParams &P, const float o[3], const float d[3], flo
             float tl, tr;
             const bool hl = box_hit(R, nd.lmin, nd.lmax, tmin, tmax, tl);
             const bool hr = box_hit(R, nd.rmin, nd.rmax, tmin, tmax, tr);
-            if (hl && hr) {
-                if (tr < tl) { stk.push(sp, nd.left); cur = nd.right; }
-                else { stk.push(sp, nd.right); cur = nd.left; }
-            }
-            else if (hl) cur = nd.left;
-            else if (hr) cur = nd.right;
+            // same decisions as "both: push the farther, go to the nearer; one: go there; none: pop", as value selects with two
+            // predicated regions (push, pop) instead of a five-way branch nest: fewer exec-mask round trips per visited node
+            const bool both = hl && hr, rightFirst = tr < tl;
+            const uint32_t nearChild = both ? (rightFirst ? nd.right : nd.left) : (hl ? nd.left : nd.right);
+            if (both) stk.push(sp, rightFirst ? nd.left : nd.right);
+            if (hl || hr) cur = nearChild;
             else alive = popNext();
         }
         if (!alive) break;
@@ -263,12 +265,10 @@ struct RayWalk {
                 float tl, tr;
                 const bool hl = box_hit(R, nd.lmin, nd.lmax, tmin, tmax, tl);
                 const bool hr = box_hit(R, nd.rmin, nd.rmax, tmin, tmax, tr);
-                if (hl && hr) {
-                    if (tr < tl) { stk.push(sp, nd.left); cur = nd.right; }
-                    else { stk.push(sp, nd.right); cur = nd.left; }
-                }
-                else if (hl) cur = nd.left;
-                else if (hr) cur = nd.right;
+                const bool both = hl && hr, rightFirst = tr < tl;          // (value selects, as in trace_ray)
+                const uint32_t nearChild = both ? (rightFirst ? nd.right : nd.left) : (hl ? nd.left : nd.right);
+                if (both) stk.push(sp, rightFirst ? nd.left : nd.right);
+                if (hl || hr) cur = nearChild;
                 else alive = pop_next(P, stk);
             }
             if (!alive) break;
