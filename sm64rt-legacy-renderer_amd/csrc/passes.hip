@@ -29,14 +29,14 @@ struct Pixel { uint32_t x, y; bool valid; };
 enum TileShape { TILE_SQUARE = 0, TILE_ROWS = 1 };
 template <int SHAPE> struct TileDim { static constexpr int W = SHAPE == TILE_SQUARE ? 16 : 32, H = SHAPE == TILE_SQUARE ? 16 : 8; };
 
-DEV uint32_t owned_strips(const FrameParams &P) {
+DEV uint32_t owned_strips(PRef P) {
     const uint32_t all = (uint32_t)(P.tileY1 - P.tileY0 + 15) / 16;
     return all > (uint32_t)P.stripRank ? (all - (uint32_t)P.stripRank + (uint32_t)P.stripCount - 1) / (uint32_t)P.stripCount : 0u;
 }
-template <int SHAPE = TILE_SQUARE> DEV uint32_t tile_count(const FrameParams &P) {
+template <int SHAPE = TILE_SQUARE> DEV uint32_t tile_count(PRef P) {
     return (uint32_t)((P.width + TileDim<SHAPE>::W - 1) / TileDim<SHAPE>::W) * owned_strips(P) * (16u / TileDim<SHAPE>::H);
 }
-template <int SHAPE = TILE_SQUARE> DEV Pixel tile_pixel_at(const FrameParams &P, uint32_t tile, uint32_t wave, uint32_t lane) {
+template <int SHAPE = TILE_SQUARE> DEV Pixel tile_pixel_at(PRef P, uint32_t tile, uint32_t wave, uint32_t lane) {
     constexpr uint32_t TW = TileDim<SHAPE>::W, TH = TileDim<SHAPE>::H, perStrip = 16u / TH;
     const uint32_t tilesX = ((uint32_t)P.width + TW - 1) / TW;
     const uint32_t tx = tile % tilesX, lt = tile / tilesX;
@@ -48,13 +48,13 @@ template <int SHAPE = TILE_SQUARE> DEV Pixel tile_pixel_at(const FrameParams &P,
     p.valid = p.x < (uint32_t)P.width && p.y < (uint32_t)P.tileY1;
     return p;
 }
-template <int SHAPE = TILE_SQUARE> DEV Pixel tile_pixel(const FrameParams &P, uint32_t tile) {
+template <int SHAPE = TILE_SQUARE> DEV Pixel tile_pixel(PRef P, uint32_t tile) {
     return tile_pixel_at<SHAPE>(P, tile, threadIdx.x >> 6, threadIdx.x & 63);
 }
 
-DEV bool row_owned(const FrameParams &P, int y) { return (((y - P.tileY0) / 16) % P.stripCount) == P.stripRank; }
+DEV bool row_owned(PRef P, int y) { return (((y - P.tileY0) / 16) % P.stripCount) == P.stripRank; }
 
-DEV TraceStack make_stack(const FrameParams &P, uint32_t *ldsStack) {
+DEV TraceStack make_stack(PRef P, uint32_t *ldsStack) {
     TraceStack s;
     s.lds = (LdsU32Ptr)(ldsStack + threadIdx.x);
     s.spill = (GlobalU32Ptr)(P.traversalStack + ((size_t)blockIdx.x * RT_BLOCK + threadIdx.x) * RT_STACK_SPILL);
@@ -68,7 +68,7 @@ DEV TraceStack make_stack(const FrameParams &P, uint32_t *ldsStack) {
 //   [4m, 4m + 4 nT)    TLAS nodes, nT = max(m - 1, 1)
 //   [cacheNodeOffset)  the BLAS nodes of every instance (offsets assigned by View::update)
 // The host enables it (FrameParams::cacheWords != 0) when all of that is at most RT_CACHE_MAX_WORDS: small scenes, like the sample.
-DEV void fill_scene_cache(const FrameParams &P, u32x4_lds *cache) {
+DEV void fill_scene_cache(PRef P, u32x4_lds *cache) {
     const uint32_t m = P.cacheInstances, T = blockDim.x, tid = threadIdx.x;
     typedef const u32x4 __attribute__((address_space(1))) *G4;
     for (uint32_t k = tid; k < m; k += T) {
@@ -98,7 +98,7 @@ DEV void fill_scene_cache(const FrameParams &P, u32x4_lds *cache) {
     __syncthreads();
 }
 
-DEV void flush_env(const FrameParams &P, const ShadeEnv &env, int pass, int rayCounter, uint32_t rays) {
+DEV void flush_env(PRef P, const ShadeEnv &env, int pass, int rayCounter, uint32_t rays) {
     flush_counts(P, env.cnt, pass);
     if (!P.countTraversal) return;
     unsigned long long a = rays, b = env.shadowRays;
@@ -117,7 +117,7 @@ DEV void flush_env(const FrameParams &P, const ShadeEnv &env, int pass, int rayC
 struct SurfaceHit { float key, t, u, v; uint32_t instance, prim; bool hit; };
 
 template <bool KLIST, bool CACHED = false>
-DEV uint32_t trace_surface(const FrameParams &P, ShadeEnv &env, const ViewImages &I, size_t pixel, f3 o, f3 d, const RayDiff &rayDiff,
+DEV uint32_t trace_surface(PRef P, ShadeEnv &env, const ViewImages &I, size_t pixel, f3 o, f3 d, const RayDiff &rayDiff,
                            uint32_t px, uint32_t py, SurfaceHit &best) {
     float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
     best.hit = false; best.key = INFINITY;
@@ -162,7 +162,7 @@ DEV uint32_t trace_surface(const FrameParams &P, ShadeEnv &env, const ViewImages
 // Reads beyond the 17 allocated slots return an empty record like an out-of-bounds typed UAV load.
 // Entry `hit` of the pixel's sorted list as (instance, primitive, t, u, v), without running the any-hit program.
 template <bool KLIST>
-DEV bool surface_entry(const FrameParams &P, const ViewImages &I, size_t pixel, uint32_t hit, const SurfaceHit &best, SurfaceHit &e) {
+DEV bool surface_entry(PRef P, const ViewImages &I, size_t pixel, uint32_t hit, const SurfaceHit &best, SurfaceHit &e) {
     if (!KLIST) { e = best; return true; }
     if (hit > RT64_MAX_HIT_QUERIES) return false;
     const size_t stride = (size_t)P.width * (size_t)P.height;
@@ -172,7 +172,7 @@ DEV bool surface_entry(const FrameParams &P, const ViewImages &I, size_t pixel, 
     return true;
 }
 template <bool KLIST>
-DEV bool surface_record(const FrameParams &P, const ViewImages &I, size_t pixel, uint32_t hit, const SurfaceHit &best, f3 dir,
+DEV bool surface_record(PRef P, const ViewImages &I, size_t pixel, uint32_t hit, const SurfaceHit &best, f3 dir,
                         const RayDiff &rayDiff, uint32_t px, uint32_t py, HitRecord &r) {
     if (!KLIST) return surface_anyhit(P, best.instance, best.prim, best.t, best.u, best.v, dir, rayDiff, px, py, r);
     if (hit > RT64_MAX_HIT_QUERIES) return false;
@@ -188,7 +188,8 @@ DEV bool surface_record(const FrameParams &P, const ViewImages &I, size_t pixel,
 // ---- primary visibility --------------------------------------------------------------------------------------------------
 
 template <bool KLIST, bool CACHED = false>
-__global__ __launch_bounds__(RT_BLOCK, KLIST ? 2 : TRACE_WAVES) void primary_trace_kernel(FrameParams P, ViewImages I, int32_t *hitInstance) {
+__global__ __launch_bounds__(RT_BLOCK, KLIST ? 2 : TRACE_WAVES) void primary_trace_kernel(FrameParams Pv, ViewImages I, int32_t *hitInstance) {
+    PRef P = *kernel_params(); (void)Pv;
     __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED : RT_STACK_LDS) * RT_BLOCK];
     extern __shared__ u32x4_lds dynLds[];
     if (CACHED) fill_scene_cache(P, dynLds);
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(RT_BLOCK, KLIST ? 2 : TRACE_WAVES) void primary_tra
     uint32_t rays = 0;
     const uint32_t tiles = tile_count(P);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        PRef P = *kernel_params_here();          // this trip's view of the frame constants (read where used, never carried across trips)
         Pixel p = tile_pixel(P, tile);
         if (!p.valid) continue;
         f3 o, d; f2 ndc;
@@ -261,7 +263,7 @@ struct PrimaryResolve {
 // PrimaryRayGen.hlsl:47-196 for one pixel whose visibility is already known (`best` / the k-buffer): the resolve loop over the
 // sorted hits + the background term.  Shared by primary_shade_kernel (hit records from HBM) and lean_frame_kernel (hit in registers).
 template <bool TRANSPARENT_LIGHT, bool KLIST, bool FULL>
-DEV void resolve_primary(const FrameParams &P, const ViewImages &I, ShadeEnv &env, uint32_t px, uint32_t py, size_t i, f3 rayOrigin, f3 rayDirection, f2 d,
+DEV void resolve_primary(PRef P, const ViewImages &I, ShadeEnv &env, uint32_t px, uint32_t py, size_t i, f3 rayOrigin, f3 rayDirection, f2 d,
                          const SurfaceHit &best, uint32_t nhits, PrimaryResolve &R) {
     f3 cU = mk3(P.cameraU[0], P.cameraU[1], P.cameraU[2]), cV = mk3(P.cameraV[0], P.cameraV[1], P.cameraV[2]), cW = mk3(P.cameraW[0], P.cameraW[1], P.cameraW[2]);
     f3 nonNormRayDir = (cU * d.x + cV * d.y) + cW;
@@ -273,7 +275,7 @@ DEV void resolve_primary(const FrameParams &P, const ViewImages &I, ShadeEnv &en
     f2 prevBgPos, curBgPos; prevBgPos.x = prevBgPos.y = curBgPos.x = curBgPos.y = 0.0f;
     if (FULL) {
         f3 bgPosition = rayOrigin + rayDirection * RT_RAY_MAX_DISTANCE;
-        prevBgPos = world_to_screen(P.prevViewProj, bgPosition); curBgPos = world_to_screen(P.viewProj, bgPosition);
+        prevBgPos = world_to_screen(cmat(P.prevViewProj).m, bgPosition); curBgPos = world_to_screen(cmat(P.viewProj).m, bgPosition);
     }
 
     RayDiff rayDiff;
@@ -338,11 +340,11 @@ DEV void resolve_primary(const FrameParams &P, const ViewImages &I, ShadeEnv &en
             if (m.refractionFactor > RT_EPSILON) { storeHit = true; refrA = resColor.w; resColor.w = 0.0f; }
             if (storeHit && resInstanceId < 0) {
                 f2 prevPos, curPos; prevPos.x = prevPos.y = curPos.x = curPos.y = 0.0f;
-                if (FULL) { prevPos = world_to_screen(P.prevViewProj, vertexPosition - r.flow); curPos = world_to_screen(P.viewProj, vertexPosition); }
+                if (FULL) { prevPos = world_to_screen(cmat(P.prevViewProj).m, vertexPosition - r.flow); curPos = world_to_screen(cmat(P.viewProj).m, vertexPosition); }
                 resPosition = vertexPosition; resNormal = vertexNormal; resSpecular = specular; resInstanceId = (int)instanceId;
                 resFlowX = (curPos.x - prevPos.x) * (float)P.width; resFlowY = (curPos.y - prevPos.y) * (float)P.height;
                 if (FULL) {
-                    f4 projPos = mul4(P.viewProj, mk4(vertexPosition.x, vertexPosition.y, vertexPosition.z, 1.0f));
+                    f4 projPos = mul4(cmat(P.viewProj).m, mk4(vertexPosition.x, vertexPosition.y, vertexPosition.z, 1.0f));
                     resDepth = s_div(projPos.z, projPos.w);
                 }
             }
@@ -366,7 +368,7 @@ DEV void resolve_primary(const FrameParams &P, const ViewImages &I, ShadeEnv &en
 
 // The image stores of PrimaryRayGen for one pixel (FULL: the reference's whole G-buffer; lean: what DirectRayGen + Compose read).
 template <bool FULL>
-DEV void store_primary(const FrameParams &P, const ViewImages &I, size_t i, int cur, f3 rayDirection, const PrimaryResolve &R) {
+DEV void store_primary(PRef P, const ViewImages &I, size_t i, int cur, f3 rayDirection, const PrimaryResolve &R) {
     if (FULL) {
         store_rgba16f(I.viewDirection, i, rayDirection.x, rayDirection.y, rayDirection.z, 0.0f);
         store_rgba16f(I.reflection, i, 0.0f, 0.0f, 0.0f, R.reflA);
@@ -393,7 +395,8 @@ DEV void store_primary(const FrameParams &P, const ViewImages &I, size_t i, int 
 }
 
 template <bool TRANSPARENT_LIGHT, bool KLIST, bool FULL>
-__global__ __launch_bounds__(RT_BLOCK, SHADE_WAVES) void primary_shade_kernel(FrameParams P, ViewImages I, const int32_t *hitInstance, int cur) {
+__global__ __launch_bounds__(RT_BLOCK, SHADE_WAVES) void primary_shade_kernel(FrameParams Pv, ViewImages I, const int32_t *hitInstance, int cur) {
+    PRef P = *kernel_params(); (void)Pv;
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -401,6 +404,7 @@ __global__ __launch_bounds__(RT_BLOCK, SHADE_WAVES) void primary_shade_kernel(Fr
     env.lightIntensity = ldsLightIntensity + threadIdx.x; env.lightIndex = ldsLightIndex + threadIdx.x;
     const uint32_t tiles = tile_count<SHADE_TILE>(P);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        PRef P = *kernel_params_here();          // this trip's view of the frame constants (read where used, never carried across trips)
         Pixel p = tile_pixel<SHADE_TILE>(P, tile);
         if (!p.valid) continue;
         const uint32_t px = p.x, py = p.y;
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(RT_BLOCK, SHADE_WAVES) void primary_shade_kernel(Fr
 
 // ---- DirectRayGen ----------------------------------------------------------------------------------------------------------
 
-DEV float history_weight(const FrameParams &P, const ViewImages &I, size_t i, uint32_t px, uint32_t py, f3 normal, int cur, long &prevIndex) {
+DEV float history_weight(PRef P, const ViewImages &I, size_t i, uint32_t px, uint32_t py, f3 normal, int cur, long &prevIndex) {
     // DirectRayGen.hlsl:31-45 / IndirectRayGen.hlsl:43-56
     uint32_t fl = reinterpret_cast<const uint32_t *>(I.flow)[i];
     float fx = f16_bits_to_f32((uint16_t)(fl & 0xFFFFu)), fy = f16_bits_to_f32((uint16_t)(fl >> 16));
@@ -444,7 +448,7 @@ DEV float history_weight(const FrameParams &P, const ViewImages &I, size_t i, ui
 // ComposePS + PostProcessPS of a LEAN frame for one pixel (same arithmetic as compose_post_kernel<true>): everything it reads is
 // the pixel's own diffuse colour and direct light, so DirectRayGen's kernel finishes the pixel instead of a separate launch
 // (one kernel boundary less per frame: ~11 us of kernel + the inter-kernel gap and cache refill).
-DEV f3 compose_lean_value(const FrameParams &P, f4 d, f3 directStored) {
+DEV f3 compose_lean_value(PRef P, f4 d, f3 directStored) {
     f3 result;
     if (d.w > RT_EPSILON) {
         f3 diffuse = xyz(d);
@@ -455,7 +459,7 @@ DEV f3 compose_lean_value(const FrameParams &P, f4 d, f3 directStored) {
     else result = xyz(d);
     return result;
 }
-DEV void compose_lean_pixel(const FrameParams &P, const ViewImages &I, size_t i, f3 directStored) {
+DEV void compose_lean_pixel(PRef P, const ViewImages &I, size_t i, f3 directStored) {
     f4 d = load_rgba8(I.diffuse, i);
     f3 result;
     if (d.w > RT_EPSILON) {
@@ -471,8 +475,8 @@ DEV void compose_lean_pixel(const FrameParams &P, const ViewImages &I, size_t i,
 
 // CACHED variants of the ray kernels keep the scene cache and the light-selection columns in dynamic LDS:
 //   [scene cache: P.cacheWords x 16 B][light intensities: slots x RT_BLOCK floats][light indices: slots x RT_BLOCK bytes], slots = min(lights, 16) + 1
-DEV uint32_t light_slots(const FrameParams &P) { return (P.lightCount < RT64_MAX_LIGHTS ? P.lightCount : (uint32_t)RT64_MAX_LIGHTS) + 1u; }
-DEV void cached_env(const FrameParams &P, ShadeEnv &env, u32x4_lds *dynLds) {
+DEV uint32_t light_slots(PRef P) { return (P.lightCount < RT64_MAX_LIGHTS ? P.lightCount : (uint32_t)RT64_MAX_LIGHTS) + 1u; }
+DEV void cached_env(PRef P, ShadeEnv &env, u32x4_lds *dynLds) {
     fill_scene_cache(P, dynLds);
     env.stk.cache = dynLds; env.stk.ldsEntries = RT_STACK_LDS_CACHED;
     float *li = reinterpret_cast<float *>(dynLds + P.cacheWords);
@@ -482,7 +486,7 @@ DEV void cached_env(const FrameParams &P, ShadeEnv &env, u32x4_lds *dynLds) {
 
 // DirectRayGen.hlsl:47-58 for one lit pixel: sampled lights + self light + eye light (before the temporal accumulation).
 template <bool CACHED>
-DEV f3 direct_light_pixel(const FrameParams &P, ShadeEnv &env, uint32_t px, uint32_t py, f3 rayDirection, int instanceId, f3 position, f3 normal, f3 specular) {
+DEV f3 direct_light_pixel(PRef P, ShadeEnv &env, uint32_t px, uint32_t py, f3 rayDirection, int instanceId, f3 position, f3 normal, f3 specular) {
     f3 selfLight; float specularExponent;
     waterfall((uint32_t)instanceId, [&](uint32_t k) { const RT64_MATERIAL mk = load_const(&P.instances[k].material); selfLight = ld_v3(mk.selfLight); specularExponent = mk.specularExponent; });
     f3 resDirect = compute_lights_random<CACHED>(P, env, px, py, rayDirection, (uint32_t)instanceId, position, normal, specular, P.maxLights, true);
@@ -495,7 +499,8 @@ DEV f3 direct_light_pixel(const FrameParams &P, ShadeEnv &env, uint32_t px, uint
 }
 
 template <bool FULL, bool CACHED = false>
-__global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void direct_kernel(FrameParams P, ViewImages I, int cur) {
+__global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void direct_kernel(FrameParams Pv, ViewImages I, int cur) {
+    PRef P = *kernel_params(); (void)Pv;
     __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED : RT_STACK_LDS) * RT_BLOCK];
     __shared__ float ldsLightIntensity[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -505,6 +510,7 @@ __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void direct_kernel(FramePar
     if (CACHED) cached_env(P, env, dynLds);
     const uint32_t tiles = tile_count<DIRECT_TILE>(P);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        PRef P = *kernel_params_here();          // this trip's view of the frame constants (read where used, never carried across trips)
         Pixel p = tile_pixel<DIRECT_TILE>(P, tile);
         if (!p.valid) continue;
         const uint32_t px = p.x, py = p.y;
@@ -551,7 +557,8 @@ template <bool CACHED, bool FULL>
 #ifndef LEAN_WAVES
 #define LEAN_WAVES 2          // 2: no spills (about 200 VGPRs); 3 spills ~46 VGPRs and measured 1.5 % slower -- the kernel is latency bound, not occupancy bound
 #endif
-__global__ __launch_bounds__(RT_BLOCK, LEAN_WAVES) void lean_frame_kernel(FrameParams P, ViewImages I, int32_t *hitInstance, int cur, int ownedY0, int ownedY1) {
+__global__ __launch_bounds__(RT_BLOCK, LEAN_WAVES) void lean_frame_kernel(FrameParams Pv, ViewImages I, int32_t *hitInstance, int cur, int ownedY0, int ownedY1) {
+    PRef P = *kernel_params(); (void)Pv;
     __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED : RT_STACK_LDS) * RT_BLOCK];
     __shared__ float ldsLightIntensity[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -563,6 +570,7 @@ __global__ __launch_bounds__(RT_BLOCK, LEAN_WAVES) void lean_frame_kernel(FrameP
     TraceCounts primaryCnt; primaryCnt.nodes = primaryCnt.tris = 0;
     const uint32_t tiles = tile_count(P);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        PRef P = *kernel_params_here();          // this tile's view of the frame constants: read where used, never carried across tiles
         Pixel p = tile_pixel(P, tile);
         if (!p.valid) continue;
         const uint32_t px = p.x, py = p.y;
@@ -611,7 +619,8 @@ __global__ __launch_bounds__(RT_BLOCK, LEAN_WAVES) void lean_frame_kernel(FrameP
 // ---- bounce-ray resolve shared by Indirect / Refraction / Reflection ------------------------------------------------------
 
 template <bool KLIST>
-__global__ __launch_bounds__(RT_BLOCK, 3) void indirect_kernel(FrameParams P, ViewImages I, int cur, int writeFiltered) {
+__global__ __launch_bounds__(RT_BLOCK, 3) void indirect_kernel(FrameParams Pv, ViewImages I, int cur, int writeFiltered) {
+    PRef P = *kernel_params(); (void)Pv;
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -622,6 +631,7 @@ __global__ __launch_bounds__(RT_BLOCK, 3) void indirect_kernel(FrameParams P, Vi
     const f3 ambient = ambientBase + mk3(P.ambientNoGIColor[0], P.ambientNoGIColor[1], P.ambientNoGIColor[2]);
     const uint32_t tiles = tile_count(P);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        PRef P = *kernel_params_here();          // this trip's view of the frame constants (read where used, never carried across trips)
         Pixel p = tile_pixel(P, tile);
         if (!p.valid) continue;
         const uint32_t px = p.x, py = p.y;
@@ -706,7 +716,7 @@ __global__ __launch_bounds__(RT_BLOCK, 3) void indirect_kernel(FrameParams P, Vi
 // grid, workgroup b on the segments of workgroup b: lanes that shade a surface and trace a shadow ray are no longer interleaved with
 // lanes that only look up the sky (the one-kernel form ran at 30 % VALU lane utilisation).
 struct BounceSegments { uint32_t perBlock; };        // list entries reserved per workgroup and list
-DEV uint32_t bounce_segment_size(const FrameParams &P) {
+DEV uint32_t bounce_segment_size(PRef P) {
     const uint32_t tiles = tile_count(P);
     return ((tiles + gridDim.x - 1) / gridDim.x) * RT_BLOCK * P.giSamples;
 }
@@ -726,10 +736,11 @@ DEV void bounce_append(const ViewImages &I, uint32_t *ldsCount, uint32_t segment
     if (hit) I.bounceLists[seg + hbase + (uint32_t)__popcll(hm & below)] = id;
     else I.bounceLists[missBase + seg + mbase + (uint32_t)__popcll(mm & below)] = id;
 }
-DEV size_t bounce_miss_base(const FrameParams &P, uint32_t segment) { return (size_t)gridDim.x * segment; }
+DEV size_t bounce_miss_base(PRef P, uint32_t segment) { return (size_t)gridDim.x * segment; }
 
 template <bool CACHED>
-__global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kernel(FrameParams P, ViewImages I) {
+__global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kernel(FrameParams Pv, ViewImages I) {
+    PRef P = *kernel_params(); (void)Pv;
     __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED : RT_STACK_LDS) * RT_BLOCK];
     __shared__ uint32_t ldsCount[2];
     extern __shared__ u32x4_lds dynLds[];
@@ -744,6 +755,7 @@ __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kern
     const size_t stride = (size_t)P.width * (size_t)P.height;
     const uint32_t tiles = tile_count(P);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        PRef P = *kernel_params_here();          // this trip's view of the frame constants (read where used, never carried across trips)
         Pixel p = tile_pixel(P, tile);
         if (!p.valid) continue;
         const uint32_t px = p.x, py = p.y;
@@ -777,7 +789,8 @@ __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kern
 // ray has finished are REFILLED: when fewer than BOUNCE_MIN_LIVE lanes are still walking, the walk pauses (RayWalk::run), the
 // finished lanes claim the next stream positions by rank in the idle ballot, generate their rays and join the walk.
 #define BOUNCE_MIN_LIVE 40
-__global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_refill_kernel(FrameParams P, ViewImages I) {
+__global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_refill_kernel(FrameParams Pv, ViewImages I) {
+    PRef P = *kernel_params(); (void)Pv;
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     __shared__ uint32_t ldsCount[2];
     if (threadIdx.x < 2) ldsCount[threadIdx.x] = 0;
@@ -851,14 +864,15 @@ __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_refill_ker
 // bounce_miss_kernel  : one list entry per lane: sky / background environment lookup                          -> sample radiance
 // bounce_resolve_kernel: per pixel, samples in the reference's order: temporal accumulation, luminance moments, stores.
 // Per-sample arithmetic and its order are those of indirect_kernel<false>.
-DEV f3 bounce_sky_term(const FrameParams &P, f3 rayDirection) {
+DEV f3 bounce_sky_term(PRef P, f3 rayDirection) {
     f3 bgColor = sample_background_envmap(P, rayDirection);
     f4 sky = sample_sky_plane(P, rayDirection);
     return lerp3(bgColor, xyz(sky), sky.w);
 }
 
 template <bool CACHED>
-__global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void bounce_hit_kernel(FrameParams P, ViewImages I) {
+__global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void bounce_hit_kernel(FrameParams Pv, ViewImages I) {
+    PRef P = *kernel_params(); (void)Pv;
     __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED : RT_STACK_LDS) * RT_BLOCK];
     __shared__ float ldsLightIntensity[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -871,6 +885,7 @@ __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void bounce_hit_kernel(Fram
     const uint32_t stride = (uint32_t)P.width * (uint32_t)P.height;
     const uint32_t segment = bounce_segment_size(P), n = I.bounceCounts[2 * blockIdx.x];      // the segment bounce_trace's workgroup blockIdx.x filled
     for (uint32_t e = threadIdx.x; e < n; e += RT_BLOCK) {
+        PRef P = *kernel_params_here();          // this trip's view of the frame constants (read where used, never carried across trips)
         const uint32_t id = I.bounceLists[(size_t)blockIdx.x * segment + e], i = id % stride;
         const uint32_t px = i % (uint32_t)P.width, py = i / (uint32_t)P.width;
         const uint4 a = I.bounceRecords[(size_t)id * 2], b = I.bounceRecords[(size_t)id * 2 + 1];
@@ -905,11 +920,13 @@ __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void bounce_hit_kernel(Fram
     flush_env(P, env, PASS_INDIRECT, CTR_INDIRECT, 0);
 }
 
-__global__ __launch_bounds__(RT_BLOCK) void bounce_miss_kernel(FrameParams P, ViewImages I) {
+__global__ __launch_bounds__(RT_BLOCK) void bounce_miss_kernel(FrameParams Pv, ViewImages I) {
+    PRef P = *kernel_params(); (void)Pv;
     const f3 ambientBase = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]);
     const uint32_t segment = bounce_segment_size(P), n = I.bounceCounts[2 * blockIdx.x + 1];
     const size_t base = bounce_miss_base(P, segment) + (size_t)blockIdx.x * segment;
     for (uint32_t e = threadIdx.x; e < n; e += RT_BLOCK) {
+        PRef P = *kernel_params_here();          // this trip's view of the frame constants (read where used, never carried across trips)
         const uint32_t id = I.bounceLists[base + e];
         const uint4 b = I.bounceRecords[(size_t)id * 2 + 1];
         const f3 rayDirection = mk3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
@@ -918,7 +935,8 @@ __global__ __launch_bounds__(RT_BLOCK) void bounce_miss_kernel(FrameParams P, Vi
     }
 }
 
-__global__ __launch_bounds__(256) void bounce_resolve_kernel(FrameParams P, ViewImages I, int cur, int writeFiltered) {
+__global__ __launch_bounds__(256) void bounce_resolve_kernel(FrameParams Pv, ViewImages I, int cur, int writeFiltered) {
+    PRef P = *kernel_params(); (void)Pv;
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = P.tileY0 + blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= P.width || y >= P.tileY1 || !row_owned(P, y)) return;
     const uint32_t px = (uint32_t)x, py = (uint32_t)y;
@@ -962,7 +980,8 @@ DEV f3 hlsl_refract(f3 i, f3 n, float eta) {
 }
 
 template <bool KLIST>
-__global__ __launch_bounds__(RT_BLOCK) void refraction_kernel(FrameParams P, ViewImages I) {
+__global__ __launch_bounds__(RT_BLOCK) void refraction_kernel(FrameParams Pv, ViewImages I) {
+    PRef P = *kernel_params(); (void)Pv;
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -972,6 +991,7 @@ __global__ __launch_bounds__(RT_BLOCK) void refraction_kernel(FrameParams P, Vie
     const f3 ambient = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]) + mk3(P.ambientNoGIColor[0], P.ambientNoGIColor[1], P.ambientNoGIColor[2]);
     const uint32_t tiles = tile_count(P);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        PRef P = *kernel_params_here();          // this trip's view of the frame constants (read where used, never carried across trips)
         Pixel p = tile_pixel(P, tile);
         if (!p.valid) continue;
         const uint32_t px = p.x, py = p.y;
@@ -1027,7 +1047,8 @@ __global__ __launch_bounds__(RT_BLOCK) void refraction_kernel(FrameParams P, Vie
 }
 
 template <bool KLIST>
-__global__ __launch_bounds__(RT_BLOCK) void reflection_kernel(FrameParams P, ViewImages I) {
+__global__ __launch_bounds__(RT_BLOCK) void reflection_kernel(FrameParams Pv, ViewImages I) {
+    PRef P = *kernel_params(); (void)Pv;
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -1037,6 +1058,7 @@ __global__ __launch_bounds__(RT_BLOCK) void reflection_kernel(FrameParams P, Vie
     const f3 ambient = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]) + mk3(P.ambientNoGIColor[0], P.ambientNoGIColor[1], P.ambientNoGIColor[2]);
     const uint32_t tiles = tile_count(P);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        PRef P = *kernel_params_here();          // this trip's view of the frame constants (read where used, never carried across trips)
         Pixel p = tile_pixel(P, tile);
         if (!p.valid) continue;
         const uint32_t px = p.x, py = p.y;
@@ -1152,7 +1174,8 @@ __global__ __launch_bounds__(256) void gaussian_kernel(const uint16_t *in, uint1
 // LEAN: direct light straight from the raw accumulation, constant ambient for the indirect term (giSamples == 0), and no
 // reflection / refraction / transparent reads -- all of them are exact zeros on a lean frame.
 template <bool LEAN>
-__global__ __launch_bounds__(256) void compose_post_kernel(FrameParams P, ViewImages I, int cur, int writeFinal) {
+__global__ __launch_bounds__(256) void compose_post_kernel(FrameParams Pv, ViewImages I, int cur, int writeFinal) {
+    PRef P = *kernel_params(); (void)Pv;
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = P.tileY0 + blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= P.width || y >= P.tileY1 || !row_owned(P, y)) return;
     const size_t i = (size_t)y * (size_t)P.width + x;
@@ -1207,7 +1230,8 @@ DEV f2 sample_flow_linear_wrap(const uint16_t *img, int w, int h, float u, float
     { const float top = c00.y + fx * (c10.y - c00.y), bot = c01.y + fx * (c11.y - c01.y); r.y = top + fy * (bot - top); }
     return r;
 }
-__global__ __launch_bounds__(256) void post_process_kernel(FrameParams P, ViewImages I) {
+__global__ __launch_bounds__(256) void post_process_kernel(FrameParams Pv, ViewImages I) {
+    PRef P = *kernel_params(); (void)Pv;
     const int sw = (int)P.resolution[2], sh = (int)P.resolution[3];
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= sw || y >= sh) return;
@@ -1240,7 +1264,8 @@ __global__ __launch_bounds__(256) void post_process_kernel(FrameParams P, ViewIm
 }
 
 // IndirectRayGen with giSamples == 0 (IndirectRayGen.hlsl:135): every pixel gets ambientBase + ambientNoGI, history 0.
-__global__ __launch_bounds__(256) void indirect_constant_kernel(FrameParams P, ViewImages I, int cur) {
+__global__ __launch_bounds__(256) void indirect_constant_kernel(FrameParams Pv, ViewImages I, int cur) {
+    PRef P = *kernel_params(); (void)Pv;
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = P.tileY0 + blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= P.width || y >= P.tileY1 || !row_owned(P, y)) return;
     const size_t i = (size_t)y * (size_t)P.width + x;
@@ -1249,7 +1274,8 @@ __global__ __launch_bounds__(256) void indirect_constant_kernel(FrameParams P, V
     store_rgba16f(I.filteredIndirect[1], i, r, g, b, 0.0f);
 }
 
-__global__ __launch_bounds__(256) void clear_final_kernel(FrameParams P, ViewImages I) {
+__global__ __launch_bounds__(256) void clear_final_kernel(FrameParams Pv, ViewImages I) {
+    PRef P = *kernel_params(); (void)Pv;
     if (P.separatePost) {         // the back buffer has the screen size, the frame is not partitioned
         const int sw = (int)P.resolution[2], sh = (int)P.resolution[3];
         const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);

@@ -61,8 +61,8 @@ DEV TexView tex_view(const GpuTexture *t) {             // table entry (constant
     TexView v; v.texels = h.texels; v.width = h.width; v.height = h.height; v.mips = h.mips; v.pow2 = h.pow2; v.mipOffset = t->mipOffset;
     return v;
 }
-DEV TexView tex_view_arg(const GpuTexture &t) {         // a GpuTexture inside the kernel arguments (FrameParams::background)
-    TexView v; v.texels = t.texels; v.width = t.width; v.height = t.height; v.mips = t.mips; v.pow2 = t.pow2; v.mipOffset = t.mipOffset;
+DEV TexView tex_view_arg(const GpuTexture __attribute__((address_space(4))) &t) {         // a GpuTexture inside the kernel arguments (FrameParams::background)
+    TexView v; v.texels = t.texels; v.width = t.width; v.height = t.height; v.mips = t.mips; v.pow2 = t.pow2; v.mipOffset = nullptr;          // a one-level texture: tex_mip_offset never reads the table
     return v;
 }
 
@@ -160,14 +160,14 @@ DEV f2 fake_envmap_uv(f3 d, float yawOffset) {                                  
 
 // ComputeSkyPlaneUV, BgSky.hlsli:20-52.  Everything that depends only on the view (yaw, pitch, aspect) is evaluated once
 // per frame on the host (sky_plane_base in rt64_host.cpp: P.skyBase = {baseU, baseV, 0.25 * ratioDivision, 0.25}).
-DEV f2 sky_plane_uv(const FrameParams &P, f2 uv) {
+DEV f2 sky_plane_uv(PRef P, f2 uv) {
     f2 r;
     r.x = P.skyBase[0] + uv.x * P.skyBase[2];
     r.y = P.skyBase[1] + uv.y * P.skyBase[3];
     return r;
 }
 
-DEV f4 sky_finish(const FrameParams &P, f4 tex) {
+DEV f4 sky_finish(PRef P, f4 tex) {
     f4 sky = mk4(tex.x * P.skyDiffuseMultiplier[0], tex.y * P.skyDiffuseMultiplier[1], tex.z * P.skyDiffuseMultiplier[2], tex.w);
     if (P.skyHSLModifier[0] != 0.0f || P.skyHSLModifier[1] != 0.0f || P.skyHSLModifier[2] != 0.0f) {
         f3 r = mod_rgb_with_hsl(xyz(sky), mk3(P.skyHSLModifier[0], P.skyHSLModifier[1], P.skyHSLModifier[2]));
@@ -175,30 +175,30 @@ DEV f4 sky_finish(const FrameParams &P, f4 tex) {
     }
     return sky;
 }
-DEV f4 sample_sky_2d(const FrameParams &P, f2 screenUV) {                       // SampleSky2D :54-70
+DEV f4 sample_sky_2d(PRef P, f2 screenUV) {                       // SampleSky2D :54-70
     if (P.skyPlaneTexIndex < 0) return mk4(0, 0, 0, 0);
     f2 uv = sky_plane_uv(P, screenUV);
     return sky_finish(P, tex_sample_level(tex_view(P.textures + P.skyPlaneTexIndex), uv.x, uv.y, 0, 1, 0, 0));
 }
-DEV f4 sample_sky_plane(const FrameParams &P, f3 rayDirection) {                // SampleSkyPlane :72-87
+DEV f4 sample_sky_plane(PRef P, f3 rayDirection) {                // SampleSkyPlane :72-87
     if (P.skyPlaneTexIndex < 0) return mk4(0, 0, 0, 0);
     f2 uv = fake_envmap_uv(rayDirection, P.skyYawOffset);
     return sky_finish(P, tex_sample_level(tex_view(P.textures + P.skyPlaneTexIndex), uv.x, uv.y, 0, 1, 0, 0));
 }
 // gBackground: the raster background instances drawn into a screen-size RGBA8 target (rt64_view.cpp:1296-1319, raster.hip),
 // sampled with the static LINEAR / WRAP sampler (BgSky.hlsli:89-95).  No background instance => transparent black.
-DEV f3 sample_background_2d(const FrameParams &P, f2 screenUV) {
+DEV f3 sample_background_2d(PRef P, f2 screenUV) {
     if (!P.background.texels) return mk3s(0.0f);
     return xyz(tex_sample_level(tex_view_arg(P.background), screenUV.x, screenUV.y, 0, 1, 0, 0));
 }
-DEV f3 sample_background_envmap(const FrameParams &P, f3 rayDirection) {
+DEV f3 sample_background_envmap(PRef P, f3 rayDirection) {
     if (!P.background.texels) return mk3s(0.0f);
     const f2 uv = fake_envmap_uv(rayDirection, 0.0f);
     return xyz(tex_sample_level(tex_view_arg(P.background), uv.x, uv.y, 0, 1, 0, 0));
 }
 
-DEV f4 fog_from_camera(const FrameParams &P, const RT64_MATERIAL &m, f3 position) {    // Fog.hlsli:5-18
-    f4 clip = mul4(P.viewProj, mk4(position.x, position.y, position.z, 1.0f));
+DEV f4 fog_from_camera(PRef P, const RT64_MATERIAL &m, f3 position) {    // Fog.hlsli:5-18
+    f4 clip = mul4(cmat(P.viewProj).m, mk4(position.x, position.y, position.z, 1.0f));
     clip.z = clip.z * 2.0f - clip.w;
     float winv = 1.0f / fmaxf(clip.w, 0.001f);
     return mk4(m.fogColor.x, m.fogColor.y, m.fogColor.z, clampf((clip.z * winv * m.fogMul + m.fogOffset) / 255.0f, 0.0f, 1.0f));
@@ -208,7 +208,7 @@ DEV f4 fog_from_origin(const RT64_MATERIAL &m, f3 position, f3 origin) {        
     return mk4(m.fogColor.x, m.fogColor.y, m.fogColor.z, clampf(((distance + m.fogOffset) / m.fogMul) * 0.5f, 0.0f, 1.0f));
 }
 
-DEV f3 blue_noise(const FrameParams &P, uint32_t px, uint32_t py, uint32_t frame) {     // BlueNoise.hlsli:7-13
+DEV f3 blue_noise(PRef P, uint32_t px, uint32_t py, uint32_t frame) {     // BlueNoise.hlsli:7-13
     uint32_t f = frame % 64u;
     uint32_t bx = (f % 8u) * 64u + px % 64u, by = (f / 8u) * 64u + py % 64u;
     uint32_t v = reinterpret_cast<const uint32_t *>(P.blueNoise)[(size_t)by * 512u + bx];
@@ -251,7 +251,7 @@ struct CombinerWords { uint32_t w[sizeof(GpuCombiner) / 4]; };          // the c
 static_assert(sizeof(GpuCombiner) % 4 == 0 && offsetof(GpuInstance, cc) % 4 == 0, "GpuCombiner is read as dwords");
 struct InstTail { int32_t texDiffuse, texNormal, texSpecular; uint32_t filter, hAddr, vAddr, flags; };
 static_assert(offsetof(GpuInstance, flags) - offsetof(GpuInstance, texDiffuse) == offsetof(InstTail, flags), "GpuInstance tail");
-DEV InstView inst_view(const FrameParams &P, uint32_t instance) {
+DEV InstView inst_view(PRef P, uint32_t instance) {
     const GpuInstance *g = P.instances + instance;
     InstView v;
     const CombinerWords cw = load_const(reinterpret_cast<const CombinerWords *>(&g->cc));
@@ -390,7 +390,7 @@ struct HitRecord {
 
 // Surface any-hit, rt64_shader.cpp:444-581.  Returns false when the candidate is ignored before it is stored.
 // `in` = inst_view(P, instance); callers that can make the instance wave-uniform (waterfall) get the scalar version of everything below.
-DEV bool surface_anyhit_view(const FrameParams &P, const InstView &in, uint32_t instance, uint32_t prim, float t, float u, float v, f3 rayDirW,
+DEV bool surface_anyhit_view(PRef P, const InstView &in, uint32_t instance, uint32_t prim, float t, float u, float v, f3 rayDirW,
                              const RayDiff &payloadDiff, uint32_t px, uint32_t py, HitRecord &rec) {
     const GpuCombiner &cc = in.cc;
     const RT64_MATERIAL &mat = in.material;
@@ -470,7 +470,7 @@ DEV bool surface_anyhit_view(const FrameParams &P, const InstView &in, uint32_t 
     return true;
 }
 // Any instance index per lane: one pass per distinct instance of the wave, each with the instance's data in scalar registers.
-DEV bool surface_anyhit(const FrameParams &P, uint32_t instance, uint32_t prim, float t, float u, float v, f3 rayDirW,
+DEV bool surface_anyhit(PRef P, uint32_t instance, uint32_t prim, float t, float u, float v, f3 rayDirW,
                         const RayDiff &payloadDiff, uint32_t px, uint32_t py, HitRecord &rec) {
     bool ok = false;
     waterfall(instance, [&](uint32_t k) { ok = surface_anyhit_view(P, inst_view(P, k), k, prim, t, u, v, rayDirW, payloadDiff, px, py, rec); });
@@ -478,7 +478,7 @@ DEV bool surface_anyhit(const FrameParams &P, uint32_t instance, uint32_t prim, 
 }
 
 // Shadow any-hit alpha, rt64_shader.cpp:611-659.  Negative = candidate ignored (texture edge).
-DEV float shadow_anyhit_alpha_view(const FrameParams &P, const InstView &in, uint32_t prim, float u, float v, uint32_t px, uint32_t py) {
+DEV float shadow_anyhit_alpha_view(PRef P, const InstView &in, uint32_t prim, float u, float v, uint32_t px, uint32_t py) {
     const GpuCombiner &cc = in.cc;
     const float b[3] = { 1.0f - u - v, u, v };
     VertexData vd;
@@ -496,7 +496,7 @@ DEV float shadow_anyhit_alpha_view(const FrameParams &P, const InstView &in, uin
     }
     return a;
 }
-DEV float shadow_anyhit_alpha(const FrameParams &P, uint32_t instance, uint32_t prim, float u, float v, uint32_t px, uint32_t py) {
+DEV float shadow_anyhit_alpha(PRef P, uint32_t instance, uint32_t prim, float u, float v, uint32_t px, uint32_t py) {
     float a = 0.0f;
     waterfall(instance, [&](uint32_t k) { a = shadow_anyhit_alpha_view(P, inst_view(P, k), prim, u, v, px, py); });
     return a;
@@ -513,7 +513,7 @@ struct ShadeEnv {                // per-lane traversal resources handed down to 
 };
 
 template <bool CACHED = false>
-DEV float trace_shadow(const FrameParams &P, ShadeEnv &env, f3 origin, f3 dir, float tmin, float tmax, uint32_t px, uint32_t py) {   // :27-52
+DEV float trace_shadow(PRef P, ShadeEnv &env, f3 origin, f3 dir, float tmin, float tmax, uint32_t px, uint32_t py) {   // :27-52
     float o[3] = { origin.x, origin.y, origin.z }, d[3] = { dir.x, dir.y, dir.z };
     float shadowHit = 1.0f;
     env.shadowRays++;
@@ -541,7 +541,7 @@ DEV float light_intensity_simple(const RT64_LIGHT &L, f3 position, f3 normal, fl
 }
 
 template <bool CACHED = false>
-DEV f3 compute_light(const FrameParams &P, ShadeEnv &env, uint32_t px, uint32_t py, uint32_t lightIndex, f3 rayDirection,
+DEV f3 compute_light(PRef P, ShadeEnv &env, uint32_t px, uint32_t py, uint32_t lightIndex, f3 rayDirection,
                      const RT64_MATERIAL &m, f3 position, f3 normal, f3 specular, bool checkShadows) {   // :67-113
     RT64_LIGHT L;
     waterfall(lightIndex, [&](uint32_t k) { L = load_const(P.lights + k); });      // one scalar fetch per distinct light chosen in the wave
@@ -585,7 +585,7 @@ DEV f3 compute_light(const FrameParams &P, ShadeEnv &env, uint32_t px, uint32_t 
 }
 
 template <bool CACHED = false>
-DEV f3 compute_lights_random(const FrameParams &P, ShadeEnv &env, uint32_t px, uint32_t py, f3 rayDirection, uint32_t instanceId,
+DEV f3 compute_lights_random(PRef P, ShadeEnv &env, uint32_t px, uint32_t py, f3 rayDirection, uint32_t instanceId,
                              f3 position, f3 normal, f3 specular, uint32_t maxLightCount, bool checkShadows) {   // :115-168
     f3 result = mk3s(0.0f);
     // the material fields the light loop reads, fetched once per distinct instance of the wave through scalar loads
@@ -630,7 +630,7 @@ DEV f3 perpendicular_vector(f3 u) {                                             
     uint32_t zm = 1u ^ (xm | ym);
     return cross3(u, mk3((float)xm, (float)ym, (float)zm));
 }
-DEV f3 cos_hemisphere_blue_noise(const FrameParams &P, uint32_t px, uint32_t py, uint32_t frame, f3 hitNorm) {   // IndirectRayGen.hlsl:18-29
+DEV f3 cos_hemisphere_blue_noise(PRef P, uint32_t px, uint32_t py, uint32_t frame, f3 hitNorm) {   // IndirectRayGen.hlsl:18-29
     f3 bn = blue_noise(P, px, py, frame);
     f3 bitangent = perpendicular_vector(hitNorm);
     f3 tangent = cross3(bitangent, hitNorm);
@@ -648,10 +648,11 @@ DEV float fresnel_reflect_amount(f3 normal, f3 incident, float reflectivity, flo
     float ret = s_pow(clampf(1.0f + dot3(normal, incident), RT_EPSILON, 1.0f), 5.0f);
     return reflectivity + ((1.0f - reflectivity) * ret * fresnelMultiplier);
 }
-DEV void primary_ray(const FrameParams &P, uint32_t px, uint32_t py, f3 &origin, f3 &dir, f2 &d) {          // :33-39
+DEV void primary_ray(PRef P, uint32_t px, uint32_t py, f3 &origin, f3 &dir, f2 &d) {          // :33-39
     d.x = (((float)px + 0.5f + P.pixelJitter[0]) / (float)P.width) * 2.0f - 1.0f;
     d.y = (((float)py + 0.5f + P.pixelJitter[1]) / (float)P.height) * 2.0f - 1.0f;
-    f4 target = mul4(P.projectionI, mk4(d.x, -d.y, 1.0f, 1.0f));
-    origin = mul_point(P.viewI, mk3s(0.0f));
-    dir = mul_vector(P.viewI, xyz(target));
+    f4 target = mul4(cmat(P.projectionI).m, mk4(d.x, -d.y, 1.0f, 1.0f));
+    const Mat16c viewI = cmat(P.viewI);
+    origin = mul_point(viewI.m, mk3s(0.0f));
+    dir = mul_vector(viewI.m, xyz(target));
 }

@@ -19,6 +19,16 @@
 #include "rt64_gpu.h"
 #include "device_math.h"
 
+// Frame constants as the device functions see them: a reference into the constant address space (the kernel-argument segment),
+// so that a field is read where it is used (scalar load, scalar cache) instead of being held -- or spilled -- from kernel entry.
+typedef const FrameParams __attribute__((address_space(4))) &PRef;
+typedef const FrameParams __attribute__((address_space(4))) *PPtr;
+struct Mat16c { float m[16]; };
+DEV Mat16c cmat(const float __attribute__((address_space(4))) *p) { Mat16c r; __builtin_memcpy(&r, p, sizeof(r)); return r; }
+// The kernel's FrameParams argument is its first parameter: offset 0 of the kernel-argument segment.
+DEV PPtr kernel_params() { return (PPtr)__builtin_amdgcn_kernarg_segment_ptr(); }
+// Same, through an offset the compiler cannot see through (always 0): loads that depend on it stay inside the loop iteration that made it.
+DEV PPtr kernel_params_here() { uint32_t z; asm volatile("s_mov_b32 %0, 0" : "=s"(z)); return (PPtr)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + z); }
 #define RT_BLOCK 256                 // threads per workgroup of every ray kernel
 #define RT_STACK_LDS 24
 #define RT_STACK_SPILL 84               // entries per lane in the HBM slab behind the LDS entries
@@ -132,7 +142,7 @@ DEV GpuNode load_node_lds(const u32x4_lds *q) {
 }
 
 template <bool CACHED = false, class OnHit>
-DEV void trace_ray(const FrameParams &P, const float o[3], const float d[3], float tmin, float tmax, bool cullBackFaces,
+DEV void trace_ray(PRef P, const float o[3], const float d[3], float tmin, float tmax, bool cullBackFaces,
                    const TraceStack &stk, OnHit &&onHit, TraceCounts &cnt) {
     if (P.instanceCount == 0) return;
     RaySpace W, R;
@@ -237,7 +247,7 @@ struct RayWalk {
     uint32_t inst, cur;
     bool cull, alive;
 
-    DEV void begin(const FrameParams &P, const float o[3], const float d[3], float tmin_, float tmax_) {
+    DEV void begin(PRef P, const float o[3], const float d[3], float tmin_, float tmax_) {
         make_ray_space(o, d, W);
         R = W;
         nodes = P.tlasNodes; tris = nullptr;
@@ -246,7 +256,7 @@ struct RayWalk {
         alive = P.instanceCount != 0;
     }
 
-    DEV bool pop_next(const FrameParams &P, const TraceStack &stk) {
+    DEV bool pop_next(PRef P, const TraceStack &stk) {
         if (blasBase >= 0 && sp == blasBase) {          // BLAS exhausted: resume the TLAS walk in world space
             blasBase = -1; R = W; nodes = P.tlasNodes;
         }
@@ -256,7 +266,7 @@ struct RayWalk {
     }
 
     template <int MIN_LIVE = 0, class OnHit>
-    DEV void run(const FrameParams &P, bool cullBackFaces, const TraceStack &stk, OnHit &&onHit, TraceCounts &cnt, bool mayPause = false) {
+    DEV void run(PRef P, bool cullBackFaces, const TraceStack &stk, OnHit &&onHit, TraceCounts &cnt, bool mayPause = false) {
         while (alive) {
             // ---- inner nodes ----
             while (alive && !(cur & RT64_LEAF_BIT)) {
@@ -307,7 +317,7 @@ struct RayWalk {
 };
 
 // Wave-level add of the per-lane traversal counters into the frame counters (only when instrumentation is on).
-DEV void flush_counts(const FrameParams &P, const TraceCounts &c, int pass) {
+DEV void flush_counts(PRef P, const TraceCounts &c, int pass) {
     if (!P.countTraversal) return;
     unsigned long long n = c.nodes, t = c.tris;
 #pragma unroll
