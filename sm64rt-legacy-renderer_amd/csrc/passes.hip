@@ -117,7 +117,7 @@ DEV void flush_env(PRef P, const ShadeEnv &env, int pass, int rayCounter, uint32
 struct SurfaceHit { float key, t, u, v; uint32_t instance, prim; bool hit; };
 
 template <bool KLIST, bool CACHED = false>
-DEV uint32_t trace_surface(PRef P, ShadeEnv &env, const ViewImages &I, size_t pixel, f3 o, f3 d, const RayDiff &rayDiff,
+DEV uint32_t trace_surface(PRef P, ShadeEnv &env, IRef I, size_t pixel, f3 o, f3 d, const RayDiff &rayDiff,
                            uint32_t px, uint32_t py, SurfaceHit &best) {
     float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
     best.hit = false; best.key = INFINITY;
@@ -162,7 +162,7 @@ DEV uint32_t trace_surface(PRef P, ShadeEnv &env, const ViewImages &I, size_t pi
 // Reads beyond the 17 allocated slots return an empty record like an out-of-bounds typed UAV load.
 // Entry `hit` of the pixel's sorted list as (instance, primitive, t, u, v), without running the any-hit program.
 template <bool KLIST>
-DEV bool surface_entry(PRef P, const ViewImages &I, size_t pixel, uint32_t hit, const SurfaceHit &best, SurfaceHit &e) {
+DEV bool surface_entry(PRef P, IRef I, size_t pixel, uint32_t hit, const SurfaceHit &best, SurfaceHit &e) {
     if (!KLIST) { e = best; return true; }
     if (hit > RT64_MAX_HIT_QUERIES) return false;
     const size_t stride = (size_t)P.width * (size_t)P.height;
@@ -172,7 +172,7 @@ DEV bool surface_entry(PRef P, const ViewImages &I, size_t pixel, uint32_t hit, 
     return true;
 }
 template <bool KLIST>
-DEV bool surface_record(PRef P, const ViewImages &I, size_t pixel, uint32_t hit, const SurfaceHit &best, f3 dir,
+DEV bool surface_record(PRef P, IRef I, size_t pixel, uint32_t hit, const SurfaceHit &best, f3 dir,
                         const RayDiff &rayDiff, uint32_t px, uint32_t py, HitRecord &r) {
     if (!KLIST) return surface_anyhit(P, best.instance, best.prim, best.t, best.u, best.v, dir, rayDiff, px, py, r);
     if (hit > RT64_MAX_HIT_QUERIES) return false;
@@ -188,8 +188,8 @@ DEV bool surface_record(PRef P, const ViewImages &I, size_t pixel, uint32_t hit,
 // ---- primary visibility --------------------------------------------------------------------------------------------------
 
 template <bool KLIST, bool CACHED = false>
-__global__ __launch_bounds__(RT_BLOCK, KLIST ? 2 : TRACE_WAVES) void primary_trace_kernel(FrameParams Pv, ViewImages I, int32_t *hitInstance) {
-    PRef P = *kernel_params(); (void)Pv;
+__global__ __launch_bounds__(RT_BLOCK, KLIST ? 2 : TRACE_WAVES) void primary_trace_kernel(FrameParams Pv, ViewImages Iv, int32_t *hitInstance) {
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
     __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED : RT_STACK_LDS) * RT_BLOCK];
     extern __shared__ u32x4_lds dynLds[];
     if (CACHED) fill_scene_cache(P, dynLds);
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(RT_BLOCK, KLIST ? 2 : TRACE_WAVES) void primary_tra
     uint32_t rays = 0;
     const uint32_t tiles = tile_count(P);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        PRef P = *kernel_params_here();          // this trip's view of the frame constants (read where used, never carried across trips)
+        PRef P = *kernel_params_here(); IRef I = *kernel_images_here();      // this trip's view of the frame constants and the image table (read where used, never carried across trips)
         Pixel p = tile_pixel(P, tile);
         if (!p.valid) continue;
         f3 o, d; f2 ndc;
@@ -263,7 +263,7 @@ struct PrimaryResolve {
 // PrimaryRayGen.hlsl:47-196 for one pixel whose visibility is already known (`best` / the k-buffer): the resolve loop over the
 // sorted hits + the background term.  Shared by primary_shade_kernel (hit records from HBM) and lean_frame_kernel (hit in registers).
 template <bool TRANSPARENT_LIGHT, bool KLIST, bool FULL>
-DEV void resolve_primary(PRef P, const ViewImages &I, ShadeEnv &env, uint32_t px, uint32_t py, size_t i, f3 rayOrigin, f3 rayDirection, f2 d,
+DEV void resolve_primary(PRef P, IRef I, ShadeEnv &env, uint32_t px, uint32_t py, size_t i, f3 rayOrigin, f3 rayDirection, f2 d,
                          const SurfaceHit &best, uint32_t nhits, PrimaryResolve &R) {
     f3 cU = mk3(P.cameraU[0], P.cameraU[1], P.cameraU[2]), cV = mk3(P.cameraV[0], P.cameraV[1], P.cameraV[2]), cW = mk3(P.cameraW[0], P.cameraW[1], P.cameraW[2]);
     f3 nonNormRayDir = (cU * d.x + cV * d.y) + cW;
@@ -368,7 +368,7 @@ DEV void resolve_primary(PRef P, const ViewImages &I, ShadeEnv &env, uint32_t px
 
 // The image stores of PrimaryRayGen for one pixel (FULL: the reference's whole G-buffer; lean: what DirectRayGen + Compose read).
 template <bool FULL>
-DEV void store_primary(PRef P, const ViewImages &I, size_t i, int cur, f3 rayDirection, const PrimaryResolve &R) {
+DEV void store_primary(PRef P, IRef I, size_t i, int cur, f3 rayDirection, const PrimaryResolve &R) {
     if (FULL) {
         store_rgba16f(I.viewDirection, i, rayDirection.x, rayDirection.y, rayDirection.z, 0.0f);
         store_rgba16f(I.reflection, i, 0.0f, 0.0f, 0.0f, R.reflA);
@@ -395,8 +395,8 @@ DEV void store_primary(PRef P, const ViewImages &I, size_t i, int cur, f3 rayDir
 }
 
 template <bool TRANSPARENT_LIGHT, bool KLIST, bool FULL>
-__global__ __launch_bounds__(RT_BLOCK, SHADE_WAVES) void primary_shade_kernel(FrameParams Pv, ViewImages I, const int32_t *hitInstance, int cur) {
-    PRef P = *kernel_params(); (void)Pv;
+__global__ __launch_bounds__(RT_BLOCK, SHADE_WAVES) void primary_shade_kernel(FrameParams Pv, ViewImages Iv, const int32_t *hitInstance, int cur) {
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(RT_BLOCK, SHADE_WAVES) void primary_shade_kernel(Fr
     env.lightIntensity = ldsLightIntensity + threadIdx.x; env.lightIndex = ldsLightIndex + threadIdx.x;
     const uint32_t tiles = tile_count<SHADE_TILE>(P);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        PRef P = *kernel_params_here();          // this trip's view of the frame constants (read where used, never carried across trips)
+        PRef P = *kernel_params_here(); IRef I = *kernel_images_here();      // this trip's view of the frame constants and the image table (read where used, never carried across trips)
         Pixel p = tile_pixel<SHADE_TILE>(P, tile);
         if (!p.valid) continue;
         const uint32_t px = p.x, py = p.y;
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(RT_BLOCK, SHADE_WAVES) void primary_shade_kernel(Fr
 
 // ---- DirectRayGen ----------------------------------------------------------------------------------------------------------
 
-DEV float history_weight(PRef P, const ViewImages &I, size_t i, uint32_t px, uint32_t py, f3 normal, int cur, long &prevIndex) {
+DEV float history_weight(PRef P, IRef I, size_t i, uint32_t px, uint32_t py, f3 normal, int cur, long &prevIndex) {
     // DirectRayGen.hlsl:31-45 / IndirectRayGen.hlsl:43-56
     uint32_t fl = reinterpret_cast<const uint32_t *>(I.flow)[i];
     float fx = f16_bits_to_f32((uint16_t)(fl & 0xFFFFu)), fy = f16_bits_to_f32((uint16_t)(fl >> 16));
@@ -459,7 +459,7 @@ DEV f3 compose_lean_value(PRef P, f4 d, f3 directStored) {
     else result = xyz(d);
     return result;
 }
-DEV void compose_lean_pixel(PRef P, const ViewImages &I, size_t i, f3 directStored) {
+DEV void compose_lean_pixel(PRef P, IRef I, size_t i, f3 directStored) {
     f4 d = load_rgba8(I.diffuse, i);
     f3 result;
     if (d.w > RT_EPSILON) {
@@ -499,8 +499,8 @@ DEV f3 direct_light_pixel(PRef P, ShadeEnv &env, uint32_t px, uint32_t py, f3 ra
 }
 
 template <bool FULL, bool CACHED = false>
-__global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void direct_kernel(FrameParams Pv, ViewImages I, int cur) {
-    PRef P = *kernel_params(); (void)Pv;
+__global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void direct_kernel(FrameParams Pv, ViewImages Iv, int cur) {
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
     __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED : RT_STACK_LDS) * RT_BLOCK];
     __shared__ float ldsLightIntensity[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void direct_kernel(FramePar
     if (CACHED) cached_env(P, env, dynLds);
     const uint32_t tiles = tile_count<DIRECT_TILE>(P);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        PRef P = *kernel_params_here();          // this trip's view of the frame constants (read where used, never carried across trips)
+        PRef P = *kernel_params_here(); IRef I = *kernel_images_here();      // this trip's view of the frame constants and the image table (read where used, never carried across trips)
         Pixel p = tile_pixel<DIRECT_TILE>(P, tile);
         if (!p.valid) continue;
         const uint32_t px = p.x, py = p.y;
@@ -557,8 +557,8 @@ template <bool CACHED, bool FULL>
 #ifndef LEAN_WAVES
 #define LEAN_WAVES 2          // 2: no spills (about 200 VGPRs); 3 spills ~46 VGPRs and measured 1.5 % slower -- the kernel is latency bound, not occupancy bound
 #endif
-__global__ __launch_bounds__(RT_BLOCK, LEAN_WAVES) void lean_frame_kernel(FrameParams Pv, ViewImages I, int32_t *hitInstance, int cur, int ownedY0, int ownedY1) {
-    PRef P = *kernel_params(); (void)Pv;
+__global__ __launch_bounds__(RT_BLOCK, LEAN_WAVES) void lean_frame_kernel(FrameParams Pv, ViewImages Iv, int32_t *hitInstance, int cur, int ownedY0, int ownedY1) {
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
     __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED : RT_STACK_LDS) * RT_BLOCK];
     __shared__ float ldsLightIntensity[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(RT_BLOCK, LEAN_WAVES) void lean_frame_kernel(FrameP
     TraceCounts primaryCnt; primaryCnt.nodes = primaryCnt.tris = 0;
     const uint32_t tiles = tile_count(P);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        PRef P = *kernel_params_here();          // this tile's view of the frame constants: read where used, never carried across tiles
+        PRef P = *kernel_params_here(); IRef I = *kernel_images_here();      // this tile's view of the frame constants and the image table: read where used, never carried across tiles
         Pixel p = tile_pixel(P, tile);
         if (!p.valid) continue;
         const uint32_t px = p.x, py = p.y;
@@ -619,8 +619,8 @@ __global__ __launch_bounds__(RT_BLOCK, LEAN_WAVES) void lean_frame_kernel(FrameP
 // ---- bounce-ray resolve shared by Indirect / Refraction / Reflection ------------------------------------------------------
 
 template <bool KLIST>
-__global__ __launch_bounds__(RT_BLOCK, 3) void indirect_kernel(FrameParams Pv, ViewImages I, int cur, int writeFiltered) {
-    PRef P = *kernel_params(); (void)Pv;
+__global__ __launch_bounds__(RT_BLOCK, 3) void indirect_kernel(FrameParams Pv, ViewImages Iv, int cur, int writeFiltered) {
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(RT_BLOCK, 3) void indirect_kernel(FrameParams Pv, V
     const f3 ambient = ambientBase + mk3(P.ambientNoGIColor[0], P.ambientNoGIColor[1], P.ambientNoGIColor[2]);
     const uint32_t tiles = tile_count(P);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        PRef P = *kernel_params_here();          // this trip's view of the frame constants (read where used, never carried across trips)
+        PRef P = *kernel_params_here(); IRef I = *kernel_images_here();      // this trip's view of the frame constants and the image table (read where used, never carried across trips)
         Pixel p = tile_pixel(P, tile);
         if (!p.valid) continue;
         const uint32_t px = p.x, py = p.y;
@@ -721,7 +721,7 @@ DEV uint32_t bounce_segment_size(PRef P) {
     return ((tiles + gridDim.x - 1) / gridDim.x) * RT_BLOCK * P.giSamples;
 }
 // called by the lanes that hold a finished ray (any subset of the wave); ldsCount = the workgroup's two running counts
-DEV void bounce_append(const ViewImages &I, uint32_t *ldsCount, uint32_t segment, size_t missBase, bool hit, uint32_t id) {
+DEV void bounce_append(IRef I, uint32_t *ldsCount, uint32_t segment, size_t missBase, bool hit, uint32_t id) {
     const unsigned long long hm = __ballot(hit), mm = __ballot(!hit);
     const uint32_t lane = threadIdx.x & 63;
     const int leader = __ffsll((long long)(hm | mm)) - 1;
@@ -739,8 +739,8 @@ DEV void bounce_append(const ViewImages &I, uint32_t *ldsCount, uint32_t segment
 DEV size_t bounce_miss_base(PRef P, uint32_t segment) { return (size_t)gridDim.x * segment; }
 
 template <bool CACHED>
-__global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kernel(FrameParams Pv, ViewImages I) {
-    PRef P = *kernel_params(); (void)Pv;
+__global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kernel(FrameParams Pv, ViewImages Iv) {
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
     __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED : RT_STACK_LDS) * RT_BLOCK];
     __shared__ uint32_t ldsCount[2];
     extern __shared__ u32x4_lds dynLds[];
@@ -755,7 +755,7 @@ __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kern
     const size_t stride = (size_t)P.width * (size_t)P.height;
     const uint32_t tiles = tile_count(P);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        PRef P = *kernel_params_here();          // this trip's view of the frame constants (read where used, never carried across trips)
+        PRef P = *kernel_params_here(); IRef I = *kernel_images_here();      // this trip's view of the frame constants and the image table (read where used, never carried across trips)
         Pixel p = tile_pixel(P, tile);
         if (!p.valid) continue;
         const uint32_t px = p.x, py = p.y;
@@ -789,8 +789,8 @@ __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kern
 // ray has finished are REFILLED: when fewer than BOUNCE_MIN_LIVE lanes are still walking, the walk pauses (RayWalk::run), the
 // finished lanes claim the next stream positions by rank in the idle ballot, generate their rays and join the walk.
 #define BOUNCE_MIN_LIVE 40
-__global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_refill_kernel(FrameParams Pv, ViewImages I) {
-    PRef P = *kernel_params(); (void)Pv;
+__global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_refill_kernel(FrameParams Pv, ViewImages Iv) {
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     __shared__ uint32_t ldsCount[2];
     if (threadIdx.x < 2) ldsCount[threadIdx.x] = 0;
@@ -871,8 +871,8 @@ DEV f3 bounce_sky_term(PRef P, f3 rayDirection) {
 }
 
 template <bool CACHED>
-__global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void bounce_hit_kernel(FrameParams Pv, ViewImages I) {
-    PRef P = *kernel_params(); (void)Pv;
+__global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void bounce_hit_kernel(FrameParams Pv, ViewImages Iv) {
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
     __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED : RT_STACK_LDS) * RT_BLOCK];
     __shared__ float ldsLightIntensity[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -885,7 +885,7 @@ __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void bounce_hit_kernel(Fram
     const uint32_t stride = (uint32_t)P.width * (uint32_t)P.height;
     const uint32_t segment = bounce_segment_size(P), n = I.bounceCounts[2 * blockIdx.x];      // the segment bounce_trace's workgroup blockIdx.x filled
     for (uint32_t e = threadIdx.x; e < n; e += RT_BLOCK) {
-        PRef P = *kernel_params_here();          // this trip's view of the frame constants (read where used, never carried across trips)
+        PRef P = *kernel_params_here(); IRef I = *kernel_images_here();      // this trip's view of the frame constants and the image table (read where used, never carried across trips)
         const uint32_t id = I.bounceLists[(size_t)blockIdx.x * segment + e], i = id % stride;
         const uint32_t px = i % (uint32_t)P.width, py = i / (uint32_t)P.width;
         const uint4 a = I.bounceRecords[(size_t)id * 2], b = I.bounceRecords[(size_t)id * 2 + 1];
@@ -920,13 +920,13 @@ __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void bounce_hit_kernel(Fram
     flush_env(P, env, PASS_INDIRECT, CTR_INDIRECT, 0);
 }
 
-__global__ __launch_bounds__(RT_BLOCK) void bounce_miss_kernel(FrameParams Pv, ViewImages I) {
-    PRef P = *kernel_params(); (void)Pv;
+__global__ __launch_bounds__(RT_BLOCK) void bounce_miss_kernel(FrameParams Pv, ViewImages Iv) {
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
     const f3 ambientBase = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]);
     const uint32_t segment = bounce_segment_size(P), n = I.bounceCounts[2 * blockIdx.x + 1];
     const size_t base = bounce_miss_base(P, segment) + (size_t)blockIdx.x * segment;
     for (uint32_t e = threadIdx.x; e < n; e += RT_BLOCK) {
-        PRef P = *kernel_params_here();          // this trip's view of the frame constants (read where used, never carried across trips)
+        PRef P = *kernel_params_here(); IRef I = *kernel_images_here();      // this trip's view of the frame constants and the image table (read where used, never carried across trips)
         const uint32_t id = I.bounceLists[base + e];
         const uint4 b = I.bounceRecords[(size_t)id * 2 + 1];
         const f3 rayDirection = mk3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
@@ -935,8 +935,8 @@ __global__ __launch_bounds__(RT_BLOCK) void bounce_miss_kernel(FrameParams Pv, V
     }
 }
 
-__global__ __launch_bounds__(256) void bounce_resolve_kernel(FrameParams Pv, ViewImages I, int cur, int writeFiltered) {
-    PRef P = *kernel_params(); (void)Pv;
+__global__ __launch_bounds__(256) void bounce_resolve_kernel(FrameParams Pv, ViewImages Iv, int cur, int writeFiltered) {
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = P.tileY0 + blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= P.width || y >= P.tileY1 || !row_owned(P, y)) return;
     const uint32_t px = (uint32_t)x, py = (uint32_t)y;
@@ -980,8 +980,8 @@ DEV f3 hlsl_refract(f3 i, f3 n, float eta) {
 }
 
 template <bool KLIST>
-__global__ __launch_bounds__(RT_BLOCK) void refraction_kernel(FrameParams Pv, ViewImages I) {
-    PRef P = *kernel_params(); (void)Pv;
+__global__ __launch_bounds__(RT_BLOCK) void refraction_kernel(FrameParams Pv, ViewImages Iv) {
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -991,7 +991,7 @@ __global__ __launch_bounds__(RT_BLOCK) void refraction_kernel(FrameParams Pv, Vi
     const f3 ambient = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]) + mk3(P.ambientNoGIColor[0], P.ambientNoGIColor[1], P.ambientNoGIColor[2]);
     const uint32_t tiles = tile_count(P);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        PRef P = *kernel_params_here();          // this trip's view of the frame constants (read where used, never carried across trips)
+        PRef P = *kernel_params_here(); IRef I = *kernel_images_here();      // this trip's view of the frame constants and the image table (read where used, never carried across trips)
         Pixel p = tile_pixel(P, tile);
         if (!p.valid) continue;
         const uint32_t px = p.x, py = p.y;
@@ -1047,8 +1047,8 @@ __global__ __launch_bounds__(RT_BLOCK) void refraction_kernel(FrameParams Pv, Vi
 }
 
 template <bool KLIST>
-__global__ __launch_bounds__(RT_BLOCK) void reflection_kernel(FrameParams Pv, ViewImages I) {
-    PRef P = *kernel_params(); (void)Pv;
+__global__ __launch_bounds__(RT_BLOCK) void reflection_kernel(FrameParams Pv, ViewImages Iv) {
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -1058,7 +1058,7 @@ __global__ __launch_bounds__(RT_BLOCK) void reflection_kernel(FrameParams Pv, Vi
     const f3 ambient = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]) + mk3(P.ambientNoGIColor[0], P.ambientNoGIColor[1], P.ambientNoGIColor[2]);
     const uint32_t tiles = tile_count(P);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        PRef P = *kernel_params_here();          // this trip's view of the frame constants (read where used, never carried across trips)
+        PRef P = *kernel_params_here(); IRef I = *kernel_images_here();      // this trip's view of the frame constants and the image table (read where used, never carried across trips)
         Pixel p = tile_pixel(P, tile);
         if (!p.valid) continue;
         const uint32_t px = p.x, py = p.y;
@@ -1174,8 +1174,8 @@ __global__ __launch_bounds__(256) void gaussian_kernel(const uint16_t *in, uint1
 // LEAN: direct light straight from the raw accumulation, constant ambient for the indirect term (giSamples == 0), and no
 // reflection / refraction / transparent reads -- all of them are exact zeros on a lean frame.
 template <bool LEAN>
-__global__ __launch_bounds__(256) void compose_post_kernel(FrameParams Pv, ViewImages I, int cur, int writeFinal) {
-    PRef P = *kernel_params(); (void)Pv;
+__global__ __launch_bounds__(256) void compose_post_kernel(FrameParams Pv, ViewImages Iv, int cur, int writeFinal) {
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = P.tileY0 + blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= P.width || y >= P.tileY1 || !row_owned(P, y)) return;
     const size_t i = (size_t)y * (size_t)P.width + x;
@@ -1230,8 +1230,8 @@ DEV f2 sample_flow_linear_wrap(const uint16_t *img, int w, int h, float u, float
     { const float top = c00.y + fx * (c10.y - c00.y), bot = c01.y + fx * (c11.y - c01.y); r.y = top + fy * (bot - top); }
     return r;
 }
-__global__ __launch_bounds__(256) void post_process_kernel(FrameParams Pv, ViewImages I) {
-    PRef P = *kernel_params(); (void)Pv;
+__global__ __launch_bounds__(256) void post_process_kernel(FrameParams Pv, ViewImages Iv) {
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
     const int sw = (int)P.resolution[2], sh = (int)P.resolution[3];
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= sw || y >= sh) return;
@@ -1264,8 +1264,8 @@ __global__ __launch_bounds__(256) void post_process_kernel(FrameParams Pv, ViewI
 }
 
 // IndirectRayGen with giSamples == 0 (IndirectRayGen.hlsl:135): every pixel gets ambientBase + ambientNoGI, history 0.
-__global__ __launch_bounds__(256) void indirect_constant_kernel(FrameParams Pv, ViewImages I, int cur) {
-    PRef P = *kernel_params(); (void)Pv;
+__global__ __launch_bounds__(256) void indirect_constant_kernel(FrameParams Pv, ViewImages Iv, int cur) {
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = P.tileY0 + blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= P.width || y >= P.tileY1 || !row_owned(P, y)) return;
     const size_t i = (size_t)y * (size_t)P.width + x;
@@ -1274,8 +1274,8 @@ __global__ __launch_bounds__(256) void indirect_constant_kernel(FrameParams Pv, 
     store_rgba16f(I.filteredIndirect[1], i, r, g, b, 0.0f);
 }
 
-__global__ __launch_bounds__(256) void clear_final_kernel(FrameParams Pv, ViewImages I) {
-    PRef P = *kernel_params(); (void)Pv;
+__global__ __launch_bounds__(256) void clear_final_kernel(FrameParams Pv, ViewImages Iv) {
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
     if (P.separatePost) {         // the back buffer has the screen size, the frame is not partitioned
         const int sw = (int)P.resolution[2], sh = (int)P.resolution[3];
         const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);

@@ -25,6 +25,12 @@ typedef const FrameParams __attribute__((address_space(4))) &PRef;
 typedef const FrameParams __attribute__((address_space(4))) *PPtr;
 struct Mat16c { float m[16]; };
 DEV Mat16c cmat(const float __attribute__((address_space(4))) *p) { Mat16c r; __builtin_memcpy(&r, p, sizeof(r)); return r; }
+typedef const ViewImages __attribute__((address_space(4))) &IRef;
+typedef const ViewImages __attribute__((address_space(4))) *IPtr;
+// The image table is the second parameter of every ray kernel: it follows the frame constants in the kernel-argument segment.
+#define RT_KERNARG_IMAGES_OFFSET ((sizeof(FrameParams) + alignof(ViewImages) - 1) / alignof(ViewImages) * alignof(ViewImages))
+DEV IPtr kernel_images() { return (IPtr)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + RT_KERNARG_IMAGES_OFFSET); }
+DEV IPtr kernel_images_here() { uint32_t z; asm volatile("s_mov_b32 %0, 0" : "=s"(z)); return (IPtr)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + RT_KERNARG_IMAGES_OFFSET + z); }
 // The kernel's FrameParams argument is its first parameter: offset 0 of the kernel-argument segment.
 DEV PPtr kernel_params() { return (PPtr)__builtin_amdgcn_kernarg_segment_ptr(); }
 // Same, through an offset the compiler cannot see through (always 0): loads that depend on it stay inside the loop iteration that made it.
