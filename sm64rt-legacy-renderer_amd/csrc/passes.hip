@@ -555,7 +555,7 @@ __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void direct_kernel(FramePar
 // covers (the frame parameters may include a denoiser halo above and below them, which only the G-buffer part renders).
 template <bool CACHED, bool FULL>
 #ifndef LEAN_WAVES
-#define LEAN_WAVES 2          // 2: no spills (about 200 VGPRs); 3 spills ~46 VGPRs and measured 1.5 % slower -- the kernel is latency bound, not occupancy bound
+#define LEAN_WAVES 3          // waves per SIMD of the one-kernel frame: 3 (168 VGPRs, ~30 spilled) measured 12 % faster than 2 (193 VGPRs, no spills) once the frame constants stopped occupying registers
 #endif
 __global__ __launch_bounds__(RT_BLOCK, LEAN_WAVES) void lean_frame_kernel(FrameParams Pv, ViewImages Iv, int32_t *hitInstance, int cur, int ownedY0, int ownedY1) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
