@@ -319,6 +319,7 @@ def main():
                     "measured_triad_GBps": HBM_TRIAD_GBS, "frac_of_triad": round(achieved / HBM_TRIAD_GBS, 4),
                     "algorithmic_bytes_per_launch": int(d_bytes), "ms_per_launch": round(d_ms, 5),
                     "kernels": {k: {"ms": round(v[0], 5), "alg_bytes": int(v[1]), "GBps": round(v[1] / (v[0] * 1e-3) / 1e9, 2) if v[0] > 0 else 0.0} for k, v in kernels.items()},
+                    "note": ("algorithmic bytes count every BVH record a ray visits; on this scene the node records (%d %% of them) are served from the LDS scene cache and most of the rest from L2, so `achieved` can exceed the HBM peak -- `traffic` is the HBM traffic measured with the PMC counters" % round(100.0 * NODE_B * (counts["nodesPrimary"] + counts["nodesDirect"]) / max(d_bytes, 1))) if fused else None,
                     "lean_frame": lean, "fused_frame": fused, "frame_gpu_ms": round(kms["total"], 5), "build_ms": round(kms["build"], 5),
                     "nodes_per_primary_ray": round(counts["nodesPrimary"] / max(counts["primary"], 1), 3),
                     "tris_per_primary_ray": round(counts["trisPrimary"] / max(counts["primary"], 1), 3),
