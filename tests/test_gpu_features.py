@@ -301,7 +301,8 @@ def test_c4_refit_of_updatable_mesh(rt64_lib, sample_data):
 
 
 @pytest.mark.gpu
-def test_one_kernel_lean_frame_matches_the_three_kernel_path(rt64_lib, sample_data):
+@pytest.mark.parametrize("lds_cache", [1, 0])
+def test_one_kernel_lean_frame_matches_the_three_kernel_path(rt64_lib, sample_data, lds_cache):
     """A lean frame runs as lean_frame_kernel (device option fused_lean, default 1) or as primary_trace + primary_shade + direct
     (fused_lean = 0).  Same arithmetic, same rounding points: every image is bit-identical, including the ones the fused frame only
     produces on readback (View::materialise), and so are the ray / node / triangle counters."""
@@ -314,6 +315,7 @@ def test_one_kernel_lean_frame_matches_the_three_kernel_path(rt64_lib, sample_da
         s = sample_scene.Rt64Scene(rt64_lib, sample_data, 333, 187, hip_device=0)
         try:
             s.option("fused_lean", fused)
+            s.option("lds_cache", lds_cache)                 # 0: BVH nodes and instance records from HBM / L2 (the path of scenes too big for the LDS scene cache)
             s.option("count_traversal", 1)
             s.draw(); s.draw()                               # second frame: the steady state (cached frame tables)
             st = s.stats()
