@@ -17,6 +17,7 @@
 // neighbouring tiles spread over all eight L2s while each tile's BVH nodes stay hot in its own.
 #include "kernels.h"
 #include "shade.h"
+#include "raster_pixel.h"
 
 namespace {
 
@@ -189,7 +190,7 @@ DEV bool surface_record(PRef P, IRef I, size_t pixel, uint32_t hit, const Surfac
 
 template <bool KLIST, bool CACHED = false>
 __global__ __launch_bounds__(RT_BLOCK, KLIST ? 2 : TRACE_WAVES) void primary_trace_kernel(FrameParams Pv, ViewImages Iv, int32_t *hitInstance) {
-    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
     __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED : RT_STACK_LDS) * RT_BLOCK];
     extern __shared__ u32x4_lds dynLds[];
     if (CACHED) fill_scene_cache(P, dynLds);
@@ -396,7 +397,7 @@ DEV void store_primary(PRef P, IRef I, size_t i, int cur, f3 rayDirection, const
 
 template <bool TRANSPARENT_LIGHT, bool KLIST, bool FULL>
 __global__ __launch_bounds__(RT_BLOCK, SHADE_WAVES) void primary_shade_kernel(FrameParams Pv, ViewImages Iv, const int32_t *hitInstance, int cur) {
-    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -500,7 +501,7 @@ DEV f3 direct_light_pixel(PRef P, ShadeEnv &env, uint32_t px, uint32_t py, f3 ra
 
 template <bool FULL, bool CACHED = false>
 __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void direct_kernel(FrameParams Pv, ViewImages Iv, int cur) {
-    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
     __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED : RT_STACK_LDS) * RT_BLOCK];
     __shared__ float ldsLightIntensity[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -558,7 +559,7 @@ template <bool CACHED, bool FULL>
 #define LEAN_WAVES 3          // waves per SIMD of the one-kernel frame: 3 (168 VGPRs, ~30 spilled) measured 12 % faster than 2 (193 VGPRs, no spills) once the frame constants stopped occupying registers
 #endif
 __global__ __launch_bounds__(RT_BLOCK, LEAN_WAVES) void lean_frame_kernel(FrameParams Pv, ViewImages Iv, int32_t *hitInstance, int cur, int ownedY0, int ownedY1) {
-    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
     __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED : RT_STACK_LDS) * RT_BLOCK];
     __shared__ float ldsLightIntensity[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -607,7 +608,17 @@ __global__ __launch_bounds__(RT_BLOCK, LEAN_WAVES) void lean_frame_kernel(FrameP
         if (FULL) { store_rgba16f(I.filteredDirect[1], i, direct.x, direct.y, direct.z, historyLength); continue; }
         const f3 result = compose_lean_value(P, diffuse, mk3(q_f16(direct.x), q_f16(direct.y), q_f16(direct.z)));
         if (P.separatePost) reinterpret_cast<float4 *>(I.output)[i] = make_float4(result.x, result.y, result.z, 1.0f);
-        else store_rgba8(I.final, i, result.x, result.y, result.z, 1.0f);
+        else {
+            // the back-buffer pixel, and over it the foreground (HUD) draw list when the host folded it into this kernel: blended here
+            // in RGBA8 exactly as raster_draw_kernel would blend it over the stored pixel (rt64_view.cpp:1657-1661), without the launch
+            uint32_t bits = (uint32_t)to_unorm8(result.x) | ((uint32_t)to_unorm8(result.y) << 8) | ((uint32_t)to_unorm8(result.z) << 16) | ((uint32_t)to_unorm8(1.0f) << 24);
+            if (P.rasterFgCount) {
+                const int wx0 = __builtin_amdgcn_readfirstlane((int)(px & ~7u)), wy0 = __builtin_amdgcn_readfirstlane((int)(py & ~7u));      // the wave's 8 x 8 pixel block
+                bool loaded = true, dirty = false;
+                raster_blend_pixel(P.rasterFg, static_cast<const RasterTri *>(P.rasterFgTris), P.rasterFgCount, P.textures, (int)px, (int)py, true, wx0, wx0 + 7, wy0, wy0 + 7, nullptr, bits, loaded, dirty);
+            }
+            reinterpret_cast<uint32_t *>(I.final)[i] = bits;
+        }
     }
     // counters: the primary rays' visits under PASS_PRIMARY_TRACE, the shadow rays' under PASS_DIRECT (same split as the separate kernels)
     TraceCounts directCnt; directCnt.nodes = env.cnt.nodes - primaryCnt.nodes; directCnt.tris = env.cnt.tris - primaryCnt.tris;
@@ -620,7 +631,7 @@ __global__ __launch_bounds__(RT_BLOCK, LEAN_WAVES) void lean_frame_kernel(FrameP
 
 template <bool KLIST>
 __global__ __launch_bounds__(RT_BLOCK, 3) void indirect_kernel(FrameParams Pv, ViewImages Iv, int cur, int writeFiltered) {
-    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -740,7 +751,7 @@ DEV size_t bounce_miss_base(PRef P, uint32_t segment) { return (size_t)gridDim.x
 
 template <bool CACHED>
 __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kernel(FrameParams Pv, ViewImages Iv) {
-    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
     __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED : RT_STACK_LDS) * RT_BLOCK];
     __shared__ uint32_t ldsCount[2];
     extern __shared__ u32x4_lds dynLds[];
@@ -790,7 +801,7 @@ __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kern
 // finished lanes claim the next stream positions by rank in the idle ballot, generate their rays and join the walk.
 #define BOUNCE_MIN_LIVE 40
 __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_refill_kernel(FrameParams Pv, ViewImages Iv) {
-    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     __shared__ uint32_t ldsCount[2];
     if (threadIdx.x < 2) ldsCount[threadIdx.x] = 0;
@@ -872,7 +883,7 @@ DEV f3 bounce_sky_term(PRef P, f3 rayDirection) {
 
 template <bool CACHED>
 __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void bounce_hit_kernel(FrameParams Pv, ViewImages Iv) {
-    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
     __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED : RT_STACK_LDS) * RT_BLOCK];
     __shared__ float ldsLightIntensity[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -921,7 +932,7 @@ __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void bounce_hit_kernel(Fram
 }
 
 __global__ __launch_bounds__(RT_BLOCK) void bounce_miss_kernel(FrameParams Pv, ViewImages Iv) {
-    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
     const f3 ambientBase = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]);
     const uint32_t segment = bounce_segment_size(P), n = I.bounceCounts[2 * blockIdx.x + 1];
     const size_t base = bounce_miss_base(P, segment) + (size_t)blockIdx.x * segment;
@@ -936,7 +947,7 @@ __global__ __launch_bounds__(RT_BLOCK) void bounce_miss_kernel(FrameParams Pv, V
 }
 
 __global__ __launch_bounds__(256) void bounce_resolve_kernel(FrameParams Pv, ViewImages Iv, int cur, int writeFiltered) {
-    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = P.tileY0 + blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= P.width || y >= P.tileY1 || !row_owned(P, y)) return;
     const uint32_t px = (uint32_t)x, py = (uint32_t)y;
@@ -981,7 +992,7 @@ DEV f3 hlsl_refract(f3 i, f3 n, float eta) {
 
 template <bool KLIST>
 __global__ __launch_bounds__(RT_BLOCK) void refraction_kernel(FrameParams Pv, ViewImages Iv) {
-    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -1048,7 +1059,7 @@ __global__ __launch_bounds__(RT_BLOCK) void refraction_kernel(FrameParams Pv, Vi
 
 template <bool KLIST>
 __global__ __launch_bounds__(RT_BLOCK) void reflection_kernel(FrameParams Pv, ViewImages Iv) {
-    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
     __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -1175,7 +1186,7 @@ __global__ __launch_bounds__(256) void gaussian_kernel(const uint16_t *in, uint1
 // reflection / refraction / transparent reads -- all of them are exact zeros on a lean frame.
 template <bool LEAN>
 __global__ __launch_bounds__(256) void compose_post_kernel(FrameParams Pv, ViewImages Iv, int cur, int writeFinal) {
-    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = P.tileY0 + blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= P.width || y >= P.tileY1 || !row_owned(P, y)) return;
     const size_t i = (size_t)y * (size_t)P.width + x;
@@ -1231,7 +1242,7 @@ DEV f2 sample_flow_linear_wrap(const uint16_t *img, int w, int h, float u, float
     return r;
 }
 __global__ __launch_bounds__(256) void post_process_kernel(FrameParams Pv, ViewImages Iv) {
-    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
     const int sw = (int)P.resolution[2], sh = (int)P.resolution[3];
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= sw || y >= sh) return;
@@ -1265,7 +1276,7 @@ __global__ __launch_bounds__(256) void post_process_kernel(FrameParams Pv, ViewI
 
 // IndirectRayGen with giSamples == 0 (IndirectRayGen.hlsl:135): every pixel gets ambientBase + ambientNoGI, history 0.
 __global__ __launch_bounds__(256) void indirect_constant_kernel(FrameParams Pv, ViewImages Iv, int cur) {
-    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = P.tileY0 + blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= P.width || y >= P.tileY1 || !row_owned(P, y)) return;
     const size_t i = (size_t)y * (size_t)P.width + x;
@@ -1275,7 +1286,7 @@ __global__ __launch_bounds__(256) void indirect_constant_kernel(FrameParams Pv, 
 }
 
 __global__ __launch_bounds__(256) void clear_final_kernel(FrameParams Pv, ViewImages Iv) {
-    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv;
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
     if (P.separatePost) {         // the back buffer has the screen size, the frame is not partitioned
         const int sw = (int)P.resolution[2], sh = (int)P.resolution[3];
         const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);

@@ -117,6 +117,8 @@ struct FrameParams {
     // traversal stacks, the ray kernels copy them in once per workgroup and walk from there.  cacheWords = size in 16-byte words, 0 = off.
     uint32_t cacheWords, cacheInstances;
     uint32_t separatePost;               // 1: render size != screen size or motion blur on -> PostProcessPS runs as post_process_kernel
+    // Foreground (HUD) raster list folded into the one-kernel lean frame: table + triangle records of raster.hip, 0 triangles = not folded.
+    const GpuRasterInstance *rasterFg; const void *rasterFgTris; uint32_t rasterFgCount, rasterFgPad;
     float skyBase[4];                    // ComputeSkyPlaneUV: base u, base v, 0.25 * ratioDivision, 0.25
     uint32_t lightCount, instanceCount, countTraversal;
     const GpuInstance *instances;

@@ -135,7 +135,7 @@ static GpuCombiner decode_combiner(uint32_t shaderId) {
 // ---- objects ---------------------------------------------------------------------------------------------------------------
 
 struct Options {
-    bool countTraversal = false, profilePasses = true, syncPresent = true, alwaysRebuild = false, leanFrames = true, fusedLean = true;
+    bool countTraversal = false, profilePasses = true, syncPresent = true, alwaysRebuild = false, leanFrames = true, fusedLean = true, foldForeground = true;
     bool ldsCache = true;         // small scenes: BVH nodes + instance records cached in LDS by the ray kernels (0: always walk from HBM/L2)
     bool spinPresent = true;      // RT64_DrawDevice waits for the frame by polling the stream (0: blocking hipStreamSynchronize)
     int bounceRefill = -1;        // bounce-ray traversal with wave-ballot refill: 1 on, 0 off, -1 auto (on when the scene has >= 64 Ki triangles)
@@ -848,6 +848,7 @@ void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64
     P.width = imgW; P.height = imgH; P.tileY0 = dev->tileY0; P.tileY1 = dev->tileY1; P.stripRank = dev->stripRank; P.stripCount = dev->stripCount;
     P.cacheWords = cacheWords; P.cacheInstances = cacheWords ? (uint32_t)rtInstances.size() : 0u;
     P.separatePost = separatePost() ? 1u : 0u;
+    P.rasterFg = nullptr; P.rasterFgTris = nullptr; P.rasterFgCount = 0; P.rasterFgPad = 0;
     memset(&P.background, 0, sizeof(P.background));
     if (rasterBgEnv.ready) { P.background.texels = background.ptr; P.background.width = (uint32_t)backgroundW; P.background.height = (uint32_t)backgroundH; P.background.mips = 1; P.background.pow2 = ((backgroundW & (backgroundW - 1)) == 0 && (backgroundH & (backgroundH - 1)) == 0) ? 1u : 0u; }
     if (P.separatePost) { P.tileY0 = 0; P.tileY1 = imgH; P.stripRank = 0; P.stripCount = 1; }       // device rows are screen rows; the render target has its own height
@@ -904,6 +905,7 @@ void View::render() {                          // View::render, rt64_view.cpp:11
     const int cur = rtSwap ? 1 : 0;
     const size_t n = (size_t)imgW * imgH;
     mark(Device::EV_BUILD);
+    bool fgFolded = false;
     if (!rtInstances.empty()) {
         if (anyNonOpaque && !img.klistA) {          // sorted per-pixel hit lists, only while some instance is not provably opaque
             const size_t slots = (size_t)(RT64_MAX_HIT_QUERIES + 1) * n;
@@ -945,6 +947,11 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         // it then writes the whole G-buffer over the rows with the denoiser halo (X) and DirectRayGen's images over the owned rows.
         const bool fusedFull = !lean && !klist && dev->opt.fusedLean;
         leanFrame = lean; fusedFrame = fused; fusedFullFrame = fusedFull; lastParams = P; lastCur = cur;
+        // The foreground (HUD) list is pixel-local too: the one-kernel frame blends it over each pixel before the store, no launch of its own.
+        if (fused && !P.separatePost && !rtRect && rasterFgScreen.ready && rasterFgScreen.triTotal > 0 && dev->opt.foldForeground) {
+            P.rasterFg = rasterFgScreen.table.ptr; P.rasterFgTris = rasterFgScreen.tris.ptr; P.rasterFgCount = rasterFgScreen.triTotal;
+            fgFolded = true;
+        }
         if (fused) {
             L(launch_lean_frame(P, img, hitInstance.ptr, cur, false, 0, imgH, s));
             mark(Device::EV_PRIMARY_TRACE); mark(Device::EV_PRIMARY); mark(Device::EV_DIRECT);
@@ -996,7 +1003,7 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         L(launch_clear_final(P, img, s));
         drawRasterList(rasterBgScreen, img.final);           // nothing ray traced covers the background instances (rt64_view.cpp:1292-1296)
     }
-    drawRasterList(rasterFgScreen, img.final);               // foreground instances over the finished frame (rt64_view.cpp:1657-1661)
+    if (!fgFolded) drawRasterList(rasterFgScreen, img.final);   // foreground instances over the finished frame (rt64_view.cpp:1657-1661)
     // End of frame (rt64_view.cpp:1663-1667)
     rtSwap = !rtSwap; skipReprojection = false; frameCount++;
 }
@@ -1283,6 +1290,7 @@ RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, doubl
     else if (k == "spin_present") d->opt.spinPresent = value != 0.0;
     else if (k == "lds_cache") d->opt.ldsCache = value != 0.0;
     else if (k == "reset_accum") { d->finishStats(); d->accum = RT64_FRAME_STATS(); }
+    else if (k == "fold_foreground") d->opt.foldForeground = value != 0.0;        // 0: the foreground (HUD) list keeps its own raster_draw launch after a one-kernel frame
     else if (k == "fused_lean") d->opt.fusedLean = value != 0.0;                  // 0: a lean frame runs as primary_trace + primary_shade + direct instead of lean_frame_kernel
     else if (k == "lean_frames") d->opt.leanFrames = value != 0.0;                // 0: always write every image of the reference's G-buffer
     else if (k == "always_rebuild") d->opt.alwaysRebuild = value != 0.0;          // upload tables + rebuild the TLAS every frame like the reference
