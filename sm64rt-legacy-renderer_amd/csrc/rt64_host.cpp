@@ -1041,7 +1041,10 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
     for (Scene *sc : scenes) for (View *v : sc->views) v->render();
     auto tu2 = std::chrono::steady_clock::now();
     hostUpdateUs += std::chrono::duration<double, std::micro>(tu1 - tu0).count(); hostRenderUs += std::chrono::duration<double, std::micro>(tu2 - tu1).count(); hostFrames++;
-    if (opt.profilePasses) { HIP_CHECK(hipEventRecord(events[EV_END], stream)); eventAlias[EV_END] = EV_END; }
+    if (opt.profilePasses) {             // the end mark shares the last mark's event when nothing was launched after it (one barrier packet less per frame)
+        if (workSinceMark) { HIP_CHECK(hipEventRecord(events[EV_END], stream)); eventAlias[EV_END] = EV_END; }
+        else eventAlias[EV_END] = eventAlias[lastMark];
+    }
     // postRender: Present + waitForGPU (:1006-1025).  Option sync_present = 0 turns RT64_DrawDevice into "enqueue the frame": the
     // host returns at once and orders its own work behind the frame on RT64_GetDeviceStream (pipelined multi-GPU gather in bench.py).
     if (opt.syncPresent) {
