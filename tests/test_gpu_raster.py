@@ -126,3 +126,42 @@ def test_ray_traced_picture_in_the_first_instances_viewport_and_scissor(rt64_lib
     inside = np.zeros((H, W), dtype=bool); inside[H - 30 - 100:H - 30, 50:250] = True
     assert (f[~inside][:, :3].max(axis=1) == 0).mean() > 0.9                             # outside the scissor: cleared buffer (+ the HUD triangles)
     assert (f[inside][:, :3].max(axis=1) > 0).mean() > 0.99                              # inside: the squeezed picture
+
+
+def test_hud_blended_inside_the_frame_kernel_equals_its_own_launch(rt64_lib, sample_data):
+    """fold_foreground (default 1): on a one-kernel lean frame the foreground list is blended over each pixel before the kernel stores
+    it.  Translucent overlapping layers in two instances, drawn that way and as a separate raster_draw launch (fold_foreground = 0),
+    give the same back buffer byte for byte; so does a 3-way interleaved strip partition of the folded frame."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene, tiles
+
+    def mod(d):
+        d.meshes.append(_hud_mesh(sample_scene, rt64, [[(-0.9, -0.8), (0.6, -0.6), (-0.2, 0.9)], [(-0.5, -0.9), (0.9, 0.1), (-0.7, 0.5)],
+                                                        [(0.1, -0.7), (0.8, 0.8), (-0.6, 0.2)]], alpha=0.6))
+        d.meshes.append(_hud_mesh(sample_scene, rt64, [[(-0.3, -0.3), (0.3, -0.3), (0.0, 0.4)]], alpha=0.35))
+        base = d.instances[0]
+        for m in (len(d.meshes) - 2, len(d.meshes) - 1):
+            i = copy.copy(base); i.mesh = m; i.material = sample_scene.copy_material(base.material); i.name = "hud%d" % m
+            d.instances.append(i)
+    data = _variant(sample_data, mod)
+    finals = {}
+    for fold in (1, 0):
+        s = sample_scene.Rt64Scene(rt64_lib, data, 272, 150, hip_device=0)
+        try:
+            s.option("fold_foreground", fold)
+            s.draw(); s.draw()
+            assert s.stats().fusedFrame == 1
+            finals[fold] = s.readback(rt64.IMAGE_FINAL_RGBA8).copy()
+            if fold:
+                parts = []
+                for r in range(3):
+                    s.set_interleave(r, 3); s.draw()
+                    parts.append(s.readback(rt64.IMAGE_FINAL_RGBA8).copy())
+                mx = tiles.max_owned_rows(150, 3) * 272 * 4
+                packed = np.zeros((3, mx), dtype=np.uint8)
+                for r in range(3):
+                    packed[r, :parts[r].size] = parts[r].reshape(-1)
+                assert np.array_equal(tiles.assemble(packed, 150, 272, 3), finals[1])
+        finally:
+            s.close()
+    assert np.array_equal(finals[1], finals[0])
+    assert (finals[1] != 0).any()
