@@ -179,6 +179,7 @@ def main():
 
     frame_no = [0]
     step_no = [0]
+    packed = [None]              # None: not probed yet; True: frames write the gather slot themselves (RT64_SetDeviceGatherTarget); False: RT64_CopyDeviceImage after each frame
 
     def step():
         if anim is not None:
@@ -190,8 +191,16 @@ def main():
         slot = step_no[0] % 2
         step_no[0] += 1
         gatherer.wait(slot)          # the gather that last read this slot (two frames ago) is ordered before the refill
+        if pipelined and packed[0] is not False:
+            lib.SetDeviceGatherTarget(scene.device, gatherer.local(slot).data_ptr(), gatherer.local(slot).numel())     # the frame's last kernel fills the send buffer itself
         scene.draw()
-        if pipelined:
+        if pipelined and packed[0] is None:      # first frame: does this kind of frame honour the gather target?  (reading the stats waits for the frame)
+            packed[0] = bool(scene.stats().packedFinal)
+            if not packed[0]:
+                lib.SetDeviceGatherTarget(scene.device, None, 0)
+        if pipelined and packed[0]:
+            pass
+        elif pipelined:
             fetch(gatherer.local(slot))
         else:                        # gloo rehearsal: CPU-staged
             fetch(staging)
@@ -338,6 +347,7 @@ def main():
         }
         if G:
             result["pipeline"] = {"frames": "enqueued (sync_present=0), 2 gather slots" if pipelined else "synchronous, CPU-staged gather (rehearsal)",
+                              "send_buffer": "written by the frame kernel (RT64_SetDeviceGatherTarget)" if packed[0] else "RT64_CopyDeviceImage after each frame",
                                   "host_ms_per_step": round(enqueue_ms, 5)}
         if N == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(data, W, H, args.cpu_baseline_height)

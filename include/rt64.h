@@ -364,6 +364,7 @@ typedef struct {
     unsigned int accumFrames;
     float accumMsTotal, accumMsBuild, accumMsPrimaryTrace, accumMsPrimaryShade, accumMsDirect, accumMsIndirect, accumMsReflectRefract, accumMsDenoise, accumMsComposePost;
     unsigned int fusedFrame;                /* 1: the lean frame ran as ONE kernel (primary visibility + resolve + direct light + compose); 2: a full frame's primary visibility + G-buffer + direct light ran as one kernel; the kernel's time is reported as msPrimaryTrace */
+    unsigned int packedFinal;               /* 1: the frame wrote its owned back-buffer rows to the RT64_SetDeviceGatherTarget memory */
 } RT64_FRAME_STATS;
 
 #define RT64_EXT_API_LIST(X) \
@@ -383,6 +384,11 @@ typedef struct {
     /* Same, device-to-device into a caller-owned device pointer (e.g. a torch tensor feeding an RCCL gather), \
        ordered on the device's stream; the call returns after the copy has completed. */ \
     X(CopyDeviceImage, RT64_CopyDeviceImage, size_t, (RT64_DEVICE *device, int image, void *devicePtr, size_t dstBytes)) \
+    /* Device memory (e.g. the send buffer of an RCCL gather) that the frames from now on ALSO write the back-buffer pixels of the rows \
+       this device owns to, tightly packed in the order RT64_CopyDeviceImage(RT64_IMAGE_FINAL_RGBA8) returns them -- by the frame's own \
+       last kernel, so no copy is queued after it.  Honoured by frames whose last pass is the one-kernel frame (RT64_FRAME_STATS.packedFinal \
+       = 1 tells; any other frame leaves the memory alone and the caller copies as before).  devicePtr = NULL turns it off. */ \
+    X(SetDeviceGatherTarget, RT64_SetDeviceGatherTarget, void, (RT64_DEVICE *device, void *devicePtr, size_t bytes)) \
     X(GetDeviceStats, RT64_GetDeviceStats, int, (RT64_DEVICE *device, RT64_FRAME_STATS *stats)) \
     /* Named numeric knobs ("count_traversal", "profile_passes", "sync_present", ...). Returns 0 when the key is unknown. */ \
     X(SetDeviceOption, RT64_SetDeviceOption, int, (RT64_DEVICE *device, const char *key, double value)) \

@@ -618,6 +618,10 @@ __global__ __launch_bounds__(RT_BLOCK, LEAN_WAVES) void lean_frame_kernel(FrameP
                 raster_blend_pixel(P.rasterFg, static_cast<const RasterTri *>(P.rasterFgTris), P.rasterFgCount, P.textures, (int)px, (int)py, true, wx0, wx0 + 7, wy0, wy0 + 7, nullptr, bits, loaded, dirty);
             }
             reinterpret_cast<uint32_t *>(I.final)[i] = bits;
+            if (P.finalPacked) {        // the gather's send buffer: row r of the owned rows, strips back to back (same order as RT64_CopyDeviceImage)
+                const uint32_t rel = py - (uint32_t)P.tileY0, prow = ((rel >> 4) / (uint32_t)P.stripCount) * 16u + (rel & 15u);
+                P.finalPacked[(size_t)prow * (size_t)P.width + px] = bits;
+            }
         }
     }
     // counters: the primary rays' visits under PASS_PRIMARY_TRACE, the shadow rays' under PASS_DIRECT (same split as the separate kernels)

@@ -119,6 +119,7 @@ struct FrameParams {
     uint32_t separatePost;               // 1: render size != screen size or motion blur on -> PostProcessPS runs as post_process_kernel
     // Foreground (HUD) raster list folded into the one-kernel lean frame: table + triangle records of raster.hip, 0 triangles = not folded.
     const GpuRasterInstance *rasterFg; const void *rasterFgTris; uint32_t rasterFgCount, rasterFgPad;
+    uint32_t *finalPacked;               // RT64_SetDeviceGatherTarget: the owned rows of the back buffer, packed strip after strip (nullptr = off)
     float skyBase[4];                    // ComputeSkyPlaneUV: base u, base v, 0.25 * ratioDivision, 0.25
     uint32_t lightCount, instanceCount, countTraversal;
     const GpuInstance *instances;

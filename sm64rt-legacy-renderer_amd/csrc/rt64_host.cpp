@@ -155,6 +155,7 @@ struct Device {
     double hostUpdateUs = 0.0, hostRenderUs = 0.0, hostStageUs[16] = {}, hostEventUs = 0.0; unsigned long long hostFrames = 0;      // host-side cost of View::update / View::render (RT64_HOST_TIMING=1 prints them)
     void finishStats();
     DevArray<uint32_t> spillStack;
+    void *gatherTarget = nullptr; size_t gatherTargetBytes = 0;          // RT64_SetDeviceGatherTarget
     DevArray<unsigned long long> counters;
     DevArray<uint8_t> blueNoise;
     uint8_t *pinned[2] = { nullptr, nullptr }; size_t pinnedBytes[2] = { 0, 0 };
@@ -298,6 +299,7 @@ struct View {
     bool anyNonOpaque = false, anyReflection = false, anyRefraction = false, anyFog = false;
     bool leanFrame = false;                   // last frame skipped the images no pass consumed (see materialise)
     bool fusedFullFrame = false;              // full frame whose primary + direct passes ran as lean_frame_kernel<.., FULL>
+    bool packedFinal = false;                 // the frame also wrote its owned back-buffer rows to the device's gather target
     bool fusedFrame = false;                  // ... and ran as lean_frame_kernel: rtOutput was not written either (unless PostProcess ran separately)
     FrameParams lastParams; int lastCur = 0;
 
@@ -848,7 +850,7 @@ void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64
     P.width = imgW; P.height = imgH; P.tileY0 = dev->tileY0; P.tileY1 = dev->tileY1; P.stripRank = dev->stripRank; P.stripCount = dev->stripCount;
     P.cacheWords = cacheWords; P.cacheInstances = cacheWords ? (uint32_t)rtInstances.size() : 0u;
     P.separatePost = separatePost() ? 1u : 0u;
-    P.rasterFg = nullptr; P.rasterFgTris = nullptr; P.rasterFgCount = 0; P.rasterFgPad = 0;
+    P.rasterFg = nullptr; P.rasterFgTris = nullptr; P.rasterFgCount = 0; P.rasterFgPad = 0; P.finalPacked = nullptr;
     memset(&P.background, 0, sizeof(P.background));
     if (rasterBgEnv.ready) { P.background.texels = background.ptr; P.background.width = (uint32_t)backgroundW; P.background.height = (uint32_t)backgroundH; P.background.mips = 1; P.background.pow2 = ((backgroundW & (backgroundW - 1)) == 0 && (backgroundH & (backgroundH - 1)) == 0) ? 1u : 0u; }
     if (P.separatePost) { P.tileY0 = 0; P.tileY1 = imgH; P.stripRank = 0; P.stripCount = 1; }       // device rows are screen rows; the render target has its own height
@@ -952,6 +954,14 @@ void View::render() {                          // View::render, rt64_view.cpp:11
             P.rasterFg = rasterFgScreen.table.ptr; P.rasterFgTris = rasterFgScreen.tris.ptr; P.rasterFgCount = rasterFgScreen.triTotal;
             fgFolded = true;
         }
+        // ... and so is the copy into a gather's send buffer: when the frame's last writer of the back buffer is this kernel, it stores
+        // the packed copy itself (RT64_SetDeviceGatherTarget).
+        packedFinal = false;
+        if (fused && !P.separatePost && !rtRect && (fgFolded || !(rasterFgScreen.ready && rasterFgScreen.triTotal > 0)) && dev->gatherTarget &&
+            dev->gatherTargetBytes >= (size_t)dev->ownedRows() * (size_t)imgW * 4) {
+            P.finalPacked = static_cast<uint32_t *>(dev->gatherTarget);
+            packedFinal = true;
+        }
         if (fused) {
             L(launch_lean_frame(P, img, hitInstance.ptr, cur, false, 0, imgH, s));
             mark(Device::EV_PRIMARY_TRACE); mark(Device::EV_PRIMARY); mark(Device::EV_DIRECT);
@@ -998,7 +1008,7 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         if (P.separatePost) L(launch_post_process(P, img, s));
     }
     else {
-        leanFrame = false; fusedFrame = false; fusedFullFrame = false;
+        leanFrame = false; fusedFrame = false; fusedFullFrame = false; packedFinal = false;
         mark(Device::EV_PRIMARY_TRACE); mark(Device::EV_PRIMARY); mark(Device::EV_DIRECT); mark(Device::EV_INDIRECT); mark(Device::EV_REFL); mark(Device::EV_DENOISE);
         L(launch_clear_final(P, img, s));
         drawRasterList(rasterBgScreen, img.final);           // nothing ray traced covers the background instances (rt64_view.cpp:1292-1296)
@@ -1067,7 +1077,7 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
         if (haveView) continue;
         haveView = true;
         st.instanceCount = (unsigned)v->rtInstances.size();
-        st.leanFrame = v->leanFrame ? 1u : 0u; st.fusedFrame = v->fusedFrame ? 1u : (v->fusedFullFrame ? 2u : 0u);
+        st.packedFinal = v->packedFinal ? 1u : 0u; st.leanFrame = v->leanFrame ? 1u : 0u; st.fusedFrame = v->fusedFrame ? 1u : (v->fusedFullFrame ? 2u : 0u);
         st.width = (unsigned)v->imgW; st.height = (unsigned)v->imgH;          // render size ("Render buffer: WxH")
         unsigned tri = 0, nodeBytes = 0, triBytes = 0;
         for (auto &ri : v->rtInstances) { tri += ri.instance->mesh->blasCount; nodeBytes += (unsigned)(std::max<uint32_t>(ri.instance->mesh->blasCount - 1, 1) * sizeof(GpuNode)); triBytes += (unsigned)(ri.instance->mesh->blasCount * sizeof(GpuTri)); }
@@ -1270,6 +1280,11 @@ RT64_EXPORT size_t RT64_ReadbackDevice(RT64_DEVICE *device, int image, void *dst
 }
 RT64_EXPORT size_t RT64_CopyDeviceImage(RT64_DEVICE *device, int image, void *devicePtr, size_t dstBytes) {
     RT64_TRY if (!device || !devicePtr) throw std::runtime_error("RT64_CopyDeviceImage: NULL argument."); return readback(reinterpret_cast<Device *>(device), image, devicePtr, dstBytes, true); RT64_CATCH(0)
+}
+RT64_EXPORT void RT64_SetDeviceGatherTarget(RT64_DEVICE *device, void *devicePtr, size_t bytes) {
+    Device *d = reinterpret_cast<Device *>(device);
+    if (!d) return;
+    d->gatherTarget = devicePtr; d->gatherTargetBytes = devicePtr ? bytes : 0;
 }
 RT64_EXPORT int RT64_GetDeviceStats(RT64_DEVICE *device, RT64_FRAME_STATS *stats) {
     Device *d = reinterpret_cast<Device *>(device);

@@ -134,7 +134,7 @@ class FRAME_STATS(C.Structure):
                 ("screenWidth", C.c_uint), ("screenHeight", C.c_uint), ("accumFrames", C.c_uint),
                 ("accumMsTotal", C.c_float), ("accumMsBuild", C.c_float), ("accumMsPrimaryTrace", C.c_float), ("accumMsPrimaryShade", C.c_float),
                 ("accumMsDirect", C.c_float), ("accumMsIndirect", C.c_float), ("accumMsReflectRefract", C.c_float), ("accumMsDenoise", C.c_float),
-                ("accumMsComposePost", C.c_float), ("fusedFrame", C.c_uint)]
+                ("accumMsComposePost", C.c_float), ("fusedFrame", C.c_uint), ("packedFinal", C.c_uint)]
 
 
 assert C.sizeof(MATERIAL) == 132 and C.sizeof(LIGHT) == 60 and C.sizeof(SCENE_DESC) == 84
@@ -188,6 +188,7 @@ EXT_API = [
     ("GetDeviceStats", "RT64_GetDeviceStats", C.c_int, [_P, C.POINTER(FRAME_STATS)]),
     ("SetDeviceOption", "RT64_SetDeviceOption", C.c_int, [_P, C.c_char_p, C.c_double]),
     ("GetDeviceStream", "RT64_GetDeviceStream", _P, [_P]),
+    ("SetDeviceGatherTarget", "RT64_SetDeviceGatherTarget", None, [_P, _P, C.c_size_t]),
     ("ReadbackMeshAccel", "RT64_ReadbackMeshAccel", C.c_size_t, [_P, C.c_int, _P, C.c_size_t]),
     ("ReadbackViewAccel", "RT64_ReadbackViewAccel", C.c_size_t, [_P, C.c_int, _P, C.c_size_t]),
 ]

@@ -391,6 +391,19 @@ def test_interleaved_strip_partition_reassembles_the_whole_frame(rt64_lib, sampl
             assert st.stripRank == r and st.stripCount == ranks and st.rowsRendered == tiles.owned_rows(H, r, ranks)
             n = rt64_lib.CopyDeviceImage(s.device, rt64.IMAGE_FINAL_RGBA8, dev_buf.value + r * mx, mx)
             assert n == tiles.owned_rows(H, r, ranks) * W * 4
+            if fused:            # RT64_SetDeviceGatherTarget: the frame kernel itself leaves the same packed rows in a send buffer
+                target = C.c_void_p()
+                assert hip.hipMalloc(C.byref(target), mx) == 0 and hip.hipMemset(target, 0xAB, mx) == 0
+                rt64_lib.SetDeviceGatherTarget(s.device, target, mx)
+                s.draw()
+                assert s.stats().packedFinal == 1
+                a = np.zeros(n, dtype=np.uint8); b = np.zeros(n, dtype=np.uint8)
+                assert hip.hipMemcpy(a.ctypes.data_as(C.c_void_p), target, n, 2) == 0 and hip.hipMemcpy(b.ctypes.data_as(C.c_void_p), C.c_void_p(dev_buf.value + r * mx), n, 2) == 0
+                assert np.array_equal(a, b)
+                rt64_lib.SetDeviceGatherTarget(s.device, None, 0)
+                s.draw()
+                assert s.stats().packedFinal == 0
+                hip.hipFree(target)
             mine = s.readback(rt64.IMAGE_FINAL_RGBA8)                # the host readback packs the owned rows the same way
             assert np.array_equal(mine, np.concatenate([whole[a:b] for a, b in tiles.strip_ranges(H, r, ranks)]))
             for a, b in tiles.strip_ranges(H, r, ranks):
