@@ -572,7 +572,9 @@ __global__ __launch_bounds__(RT_BLOCK, LEAN_WAVES) void lean_frame_kernel(FrameP
     const uint32_t tiles = tile_count(P);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         PRef P = *kernel_params_here(); IRef I = *kernel_images_here();      // this tile's view of the frame constants and the image table: read where used, never carried across tiles
-        Pixel p = tile_pixel(P, tile);
+        // tiles are walked from the bottom of the frame up: the expensive ones (geometry) start first and the cheap ones (sky, at the
+        // top of a typical frame) fill the tail of the launch
+        Pixel p = tile_pixel(P, tiles - 1u - tile);
         if (!p.valid) continue;
         const uint32_t px = p.x, py = p.y;
         const size_t i = (size_t)py * (size_t)P.width + px;
