@@ -36,7 +36,7 @@ hipError_t bc7_decode_launch(const uint8_t *blocks, uint8_t *rgba, uint32_t widt
 // ---- passes.hip ---------------------------------------------------------------------------------------------------
 #define RT_CACHE_MAX_WORDS 1536       // LDS scene cache: at most 24 KB next to the 24 KB of traversal stacks (3 workgroups per CU)
 #define RT_GRID_BLOCKS 2048           // persistent grid of every ray kernel (8 workgroups of 256 per CU)
-size_t rt_stack_spill_bytes();        // bytes of FrameParams::traversalStack
+size_t rt_stack_spill_bytes(int width, int rows);        // bytes FrameParams::traversalStack needs for a frame of that size
 
 hipError_t launch_primary_trace(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, bool klist, hipStream_t s);
 hipError_t launch_primary_shade(const FrameParams &P, const ViewImages &I, const int32_t *hitInstance, int cur, bool transparentLighting, bool lean, hipStream_t s);

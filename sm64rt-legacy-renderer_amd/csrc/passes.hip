@@ -1306,7 +1306,12 @@ __global__ __launch_bounds__(256) void clear_final_kernel(FrameParams Pv, ViewIm
 
 }  // namespace
 
-size_t rt_stack_spill_bytes() { return (size_t)RT_GRID_BLOCKS * RT_BLOCK * RT_STACK_SPILL * sizeof(uint32_t); }
+// One spill slab per lane of every workgroup of the largest grid a frame of `width` x `rows` can launch: the persistent kernels use
+// at most RT_GRID_BLOCKS workgroups, the one-kernel frame one per 16 x 16 tile.
+size_t rt_stack_spill_bytes(int width, int rows) {
+    const size_t tiles = (size_t)((width + 15) / 16) * (size_t)((rows + 15) / 16), blocks = tiles > (size_t)RT_GRID_BLOCKS ? tiles : (size_t)RT_GRID_BLOCKS;
+    return blocks * RT_BLOCK * RT_STACK_SPILL * sizeof(uint32_t);
+}
 
 // Grid of a ray kernel: one persistent workgroup per CU slot (RT_GRID_BLOCKS), or one per tile when the device's share of the
 // frame has fewer tiles than that (small frames, a 1/8 strip share): workgroups without a tile only cost launch time.
@@ -1343,14 +1348,16 @@ hipError_t launch_direct(const FrameParams &P, const ViewImages &I, int cur, boo
     if (lean) LAUNCH_RAY(direct_kernel<false>, P, I, cur);
     LAUNCH_RAY(direct_kernel<true>, P, I, cur);
 }
-// The one-kernel frame holds LEAN_WAVES waves per SIMD, i.e. LEAN_WAVES workgroups per CU.  A big share of the frame runs as exactly
-// one resident round (256 CUs x LEAN_WAVES workgroups, each walking its tiles round-robin): the scene cache is filled once per
-// workgroup slot.  A small share (a 1/4 or 1/8 strip set of a multi-GPU partition: <= 2048 tiles) gets one workgroup per tile, so
-// the hardware dispatcher balances sky tiles against geometry tiles (measured on a 1/4 share: 87 us against 105 us).
+// One workgroup per tile: the hardware dispatcher hands the next tile to whichever CU has a free slot (LEAN_WAVES workgroups per
+// CU), which together with the bottom-up tile order (geometry first) is a longest-job-first schedule; a resident round of
+// persistent workgroups with a static round-robin walk measured 8 % slower on the full frame (181 against 165 us) and keeps every
+// register file full until the launch ends, so nothing on another stream (the RCCL gather) can run beside it.
 hipError_t launch_lean_frame(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, int cur, bool full, int ownedY0, int ownedY1, hipStream_t s) {
     const unsigned strips = (unsigned)(P.tileY1 - P.tileY0 + 15) / 16, owned = strips > (unsigned)P.stripRank ? (strips - (unsigned)P.stripRank + (unsigned)P.stripCount - 1) / (unsigned)P.stripCount : 0u;
-    const unsigned tiles = (unsigned)((P.width + 15) / 16) * owned, resident = 256u * LEAN_WAVES;
-    const unsigned grid = tiles < 1u ? 1u : (tiles <= (unsigned)RT_GRID_BLOCKS ? tiles : resident);
+    const unsigned tiles = (unsigned)((P.width + 15) / 16) * owned;
+    // ... up to 8192 workgroups; bigger frames give every workgroup ceil(tiles / 8192) tiles (round-robin, same bottom-up order), which
+    // amortises the scene-cache fill again (1440p: 2 tiles per workgroup, 4K: 4)
+    const unsigned perGroup = (tiles + 8191u) / 8192u, grid = tiles < 1u ? 1u : (tiles + perGroup - 1u) / perGroup;
     const size_t lds = P.cacheWords ? cached_lds_bytes(P, true) : 0;
     if (P.cacheWords) {
         if (full) hipLaunchKernelGGL((lean_frame_kernel<true, true>), dim3(grid), dim3(RT_BLOCK), lds, s, P, I, hitInstance, cur, ownedY0, ownedY1);

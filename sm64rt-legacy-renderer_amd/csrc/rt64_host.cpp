@@ -341,7 +341,7 @@ Device::Device(int w, int h, int dev) {
     width = pendingWidth = w; height = pendingHeight = h; tileY0 = 0; tileY1 = h;
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     for (auto &ev : events) HIP_CHECK(hipEventCreate(&ev));
-    spillStack.reserve(rt_stack_spill_bytes() / sizeof(uint32_t));
+    spillStack.reserve(rt_stack_spill_bytes(w, h) / sizeof(uint32_t));
     counters.reserve(CTR_COUNT);
     HIP_CHECK(hipMemsetAsync(counters.ptr, 0, counters.bytes(), stream));
     // Blue-noise table (Device::loadBlueNoise, rt64_device.cpp:794-797): 512x512 RGBA8.
@@ -877,6 +877,7 @@ void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64
     P.lightCount = (uint32_t)scene->lights.size(); P.instanceCount = (uint32_t)rtInstances.size();
     P.countTraversal = dev->opt.countTraversal ? 1u : 0u;
     P.instances = dInstances.ptr; P.tlasNodes = tlasNodes.ptr; P.tlasIndex = tlasIndex.ptr; P.textures = dTextures.ptr; P.lights = dLights.ptr;
+    dev->spillStack.reserve(rt_stack_spill_bytes(imgW, imgH) / sizeof(uint32_t));      // grows with the render size (no-op otherwise)
     P.blueNoise = dev->blueNoise.ptr; P.traversalStack = dev->spillStack.ptr; P.counters = dev->counters.ptr;
 }
 
