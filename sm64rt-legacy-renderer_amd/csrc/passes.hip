@@ -105,7 +105,7 @@ DEV void flush_env(PRef P, const ShadeEnv &env, int pass, int rayCounter, uint32
     unsigned long long a = rays, b = env.shadowRays;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { a += __shfl_down(a, d, 64); b += __shfl_down(b, d, 64); }
-    if ((threadIdx.x & 63) == 0) { if (a) atomicAdd(&P.counters[rayCounter], a); if (b) atomicAdd(&P.counters[CTR_SHADOW], b); }
+    if ((threadIdx.x & 63) == 0) { unsigned long long *ctr = P.counters + (size_t)(blockIdx.x % RT_COUNTER_STRIPES) * CTR_COUNT; if (a) atomicAdd(&ctr[rayCounter], a); if (b) atomicAdd(&ctr[CTR_SHADOW], b); }
 }
 
 // ---- surface rays ---------------------------------------------------------------------------------------------------------

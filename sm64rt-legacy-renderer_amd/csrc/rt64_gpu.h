@@ -160,6 +160,7 @@ struct ViewImages {
     uint32_t *klistCount;                // payload.nhits of the primary ray (per pixel)
 };
 
+#define RT_COUNTER_STRIPES 64          // copies of the counter block, chosen by workgroup number: the per-wave atomics of a counting frame spread over 64 lines
 enum { CTR_NODES = 0, CTR_TRIS, CTR_PRIMARY, CTR_SHADOW, CTR_INDIRECT, CTR_REFLECTION, CTR_REFRACTION,
        CTR_PASS_BASE,                    // then {nodes, triangles} per pass:
        CTR_COUNT = CTR_PASS_BASE + 2 * 6 };

@@ -342,7 +342,7 @@ Device::Device(int w, int h, int dev) {
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     for (auto &ev : events) HIP_CHECK(hipEventCreate(&ev));
     spillStack.reserve(rt_stack_spill_bytes(w, h) / sizeof(uint32_t));
-    counters.reserve(CTR_COUNT);
+    counters.reserve((size_t)CTR_COUNT * RT_COUNTER_STRIPES);
     HIP_CHECK(hipMemsetAsync(counters.ptr, 0, counters.bytes(), stream));
     // Blue-noise table (Device::loadBlueNoise, rt64_device.cpp:794-797): 512x512 RGBA8.
     blueNoise.reserve(512 * 512 * 4);
@@ -1110,8 +1110,9 @@ void Device::finishStats() {
     st.accumMsPrimaryShade = accum.accumMsPrimaryShade; st.accumMsDirect = accum.accumMsDirect; st.accumMsIndirect = accum.accumMsIndirect;
     st.accumMsReflectRefract = accum.accumMsReflectRefract; st.accumMsDenoise = accum.accumMsDenoise; st.accumMsComposePost = accum.accumMsComposePost;
     if (opt.countTraversal) {
-        unsigned long long c[CTR_COUNT];
-        HIP_CHECK(hipMemcpy(c, counters.ptr, sizeof(c), hipMemcpyDeviceToHost));
+        unsigned long long all[CTR_COUNT * RT_COUNTER_STRIPES], c[CTR_COUNT] = {};
+        HIP_CHECK(hipMemcpy(all, counters.ptr, sizeof(all), hipMemcpyDeviceToHost));
+        for (int sidx = 0; sidx < RT_COUNTER_STRIPES; sidx++) for (int k = 0; k < CTR_COUNT; k++) c[k] += all[sidx * CTR_COUNT + k];
         st.nodesVisited = c[CTR_NODES]; st.trianglesTested = c[CTR_TRIS]; st.primaryRays = c[CTR_PRIMARY]; st.shadowRays = c[CTR_SHADOW];
         st.indirectRays = c[CTR_INDIRECT]; st.reflectionRays = c[CTR_REFLECTION]; st.refractionRays = c[CTR_REFRACTION];
         st.nodesPrimary = c[CTR_PASS_BASE + 2 * PASS_PRIMARY_TRACE]; st.trianglesPrimary = c[CTR_PASS_BASE + 2 * PASS_PRIMARY_TRACE + 1];

@@ -329,7 +329,8 @@ DEV void flush_counts(PRef P, const TraceCounts &c, int pass) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { n += __shfl_down(n, d, 64); t += __shfl_down(t, d, 64); }
     if ((threadIdx.x & 63) == 0 && (n | t)) {
-        atomicAdd(&P.counters[CTR_NODES], n); atomicAdd(&P.counters[CTR_TRIS], t);
-        atomicAdd(&P.counters[CTR_PASS_BASE + 2 * pass], n); atomicAdd(&P.counters[CTR_PASS_BASE + 2 * pass + 1], t);
+        unsigned long long *ctr = P.counters + (size_t)(blockIdx.x % RT_COUNTER_STRIPES) * CTR_COUNT;
+        atomicAdd(&ctr[CTR_NODES], n); atomicAdd(&ctr[CTR_TRIS], t);
+        atomicAdd(&ctr[CTR_PASS_BASE + 2 * pass], n); atomicAdd(&ctr[CTR_PASS_BASE + 2 * pass + 1], t);
     }
 }
