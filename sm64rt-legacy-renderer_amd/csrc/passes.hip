@@ -1386,13 +1386,23 @@ hipError_t launch_indirect_constant(const FrameParams &P, const ViewImages &I, i
     hipLaunchKernelGGL(indirect_constant_kernel, grid, dim3(256), 0, s, P, I, cur);
     return hipGetLastError();
 }
+// Refraction / reflection only have work where the primary hit has the factor: most tiles return at once, so these two take one
+// workgroup per tile (up to 8192) and let the dispatcher balance them (C5 reflection: 0.315 -> 0.26 ms against the persistent grid).
+static unsigned sparse_grid(const FrameParams &P) {
+    const unsigned all = (unsigned)(P.tileY1 - P.tileY0 + 15) / 16;
+    const unsigned strips = all > (unsigned)P.stripRank ? (all - (unsigned)P.stripRank + (unsigned)P.stripCount - 1) / (unsigned)P.stripCount : 0u;
+    const unsigned tiles = (unsigned)((P.width + 15) / 16) * strips;
+    return tiles < 1u ? 1u : (tiles < 8192u ? tiles : 8192u);
+}
 hipError_t launch_refraction(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s) {
-    if (klist) LAUNCH_RAY(refraction_kernel<true>, P, I);
-    LAUNCH_RAY(refraction_kernel<false>, P, I);
+    if (klist) hipLaunchKernelGGL(refraction_kernel<true>, dim3(sparse_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
+    else hipLaunchKernelGGL(refraction_kernel<false>, dim3(sparse_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
+    return hipGetLastError();
 }
 hipError_t launch_reflection(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s) {
-    if (klist) LAUNCH_RAY(reflection_kernel<true>, P, I);
-    LAUNCH_RAY(reflection_kernel<false>, P, I);
+    if (klist) hipLaunchKernelGGL(reflection_kernel<true>, dim3(sparse_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
+    else hipLaunchKernelGGL(reflection_kernel<false>, dim3(sparse_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
+    return hipGetLastError();
 }
 
 hipError_t launch_gaussian(const uint16_t *in, uint16_t *out, int width, int height, int y0, int y1, hipStream_t s) {
