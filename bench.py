@@ -67,8 +67,32 @@ def parse_args():
     return ap.parse_args()
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here, BEFORE this process imports torch or loads librt64.so
+    (no GPU call has happened yet, and none happens in this parent), one child per GPU with the launcher's environment contract,
+    and exit with their status.  A child that fails fails the run: a request for N GPUs never ends as a 1-GPU line with rc 0."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    raise SystemExit(rc)
+
+
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)
     import numpy as np
     import torch
     import __graft_entry__ as graft
@@ -78,8 +102,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launcher's world size and --gpus must agree" % (args.gpus, world))
     N = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback.")
@@ -101,13 +125,11 @@ def main():
             dist.init_process_group(backend="gloo")
     comm_device = "cuda" if args.backend == "nccl" else "cpu" 
 
-    if args.config == "C3":
-        args.gi_samples, args.denoiser = 1, True
-    elif args.config == "C4":
-        args.width, args.height, args.gi_samples, args.denoiser = 2560, 1440, 2, True
-    elif args.config == "C5":
-        args.width, args.height, args.gi_samples, args.denoiser = 3840, 2160, 4, True
+    if args.config != "C2":
+        c = sample_scene.BENCH_CONFIGS[args.config]
+        args.width, args.height, args.gi_samples, args.denoiser = c["width"], c["height"], c["gi_samples"], c["denoiser"]
     W, H = args.width, args.height
+    COUNTER_WORKLOAD[0] = ("stress_%d_%d" % (args.subdiv, args.floor_grid)) if (args.subdiv or args.floor_grid > 1) else args.config
     lib = rt64.Library()
     data = sample_scene.make_sample_scene(subdiv=args.subdiv, floor_grid=args.floor_grid)
     dbg = os.environ.get("RT64_BENCH_DEBUG", "")          # diagnosis only (never set by the driver): "nosky", "tinytex"
@@ -117,20 +139,7 @@ def main():
         for t in data.textures:
             if t.format == rt64.TEXTURE_FORMAT_RGBA8:
                 t.data = np.ascontiguousarray(t.data[:4, :4]); t.width = t.height = 4
-    anim = None
-    if args.config == "C4":         # sphere UPDATABLE, p += 0.1 n sin(frame 0.1 + p.y); 16 precomputed frames, SetMesh (host copy + refit) per step
-        m = data.meshes[0]
-        m.flags |= rt64.MESH_RAYTRACE_UPDATABLE
-        base = m.vertices.copy()
-        anim = []
-        for f in range(16):
-            v = base.copy()
-            v["position"][:, :3] += (0.1 * np.sin(f * 0.1 + base["position"][:, 1]))[:, None].astype(np.float32) * base["normal"]
-            anim.append(v)
-    elif args.config == "C5":       # reflective floor
-        for inst in data.instances:
-            if inst.name == "floor":
-                inst.material.reflectionFactor = 0.3
+    anim = sample_scene.apply_bench_config(data, args.config)     # C4: per-frame SetMesh (host copy + refit) of the UPDATABLE sphere; C5: reflective floor
     scene = sample_scene.Rt64Scene(lib, data, W, H, hip_device=local_rank)
     # Partition: interleaved 16-row strips balance sky against geometry; a frame with GI + denoiser filters across rows, so it is
     # cut into contiguous bands and the library renders each band with the filter's halo (no mid-frame exchange).
@@ -267,6 +276,25 @@ def main():
         assert s.accumFrames == args.steps, (s.accumFrames, args.steps)
         acc.update(trace=s.accumMsPrimaryTrace, shade=s.accumMsPrimaryShade, direct=s.accumMsDirect, indirect=s.accumMsIndirect, compose=s.accumMsComposePost,
                    build=s.accumMsBuild, total=s.accumMsTotal, denoise=s.accumMsDenoise, reflect=s.accumMsReflectRefract)
+    # The reference uploads its tables and rebuilds the TLAS every frame (rt64_view.cpp:451 updateOnly = false, :1150-1152); the timed
+    # loop above ran with the frame-table cache (identical descriptors are not re-uploaded).  Same K steps again with the cache off,
+    # outside the timed region of `value`, so that the line carries both figures.
+    rebuild = None
+    if not G and PR <= 1 and not args.always_rebuild:
+        scene.option("always_rebuild", 1)
+        for _ in range(min(args.warmup, 5)):
+            step()
+        barrier()
+        scene.option("reset_accum", 1)
+        tr = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        r_ms = (time.perf_counter() - tr) * 1e3 / args.steps
+        sr = scene.stats()
+        rebuild = {"ms_per_step": round(r_ms, 5), "value": round(rays_total / (r_ms * 1e-3) / 1e6, 2), "build_ms": round(sr.accumMsBuild / max(sr.accumFrames, 1), 5),
+                   "what": "always_rebuild=1: frame tables uploaded + TLAS rebuilt + raster lists re-staged every frame, as the reference does (rt64_view.cpp:451,1150-1152)"}
+        scene.option("always_rebuild", 0)
     if G or PR > 1:                  # per-kernel timings of this rank's strips from a few untimed frames (reading them synchronises)
         stat_frames = 10
         for _ in range(stat_frames):
@@ -315,25 +343,12 @@ def main():
             kernels["reflection_refraction"] = (kms["reflect"], 0)
         dominant = max((k for k in kernels if kernels[k][1] > 0), key=lambda k: kernels[k][0])
         d_ms, d_bytes = kernels[dominant]
-        achieved = d_bytes / (d_ms * 1e-3) / 1e9 if d_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(dominant.split("(")[0])
-            except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "measured_triad_GBps": HBM_TRIAD_GBS, "frac_of_triad": round(achieved / HBM_TRIAD_GBS, 4),
-                    "algorithmic_bytes_per_launch": int(d_bytes), "ms_per_launch": round(d_ms, 5),
-                    "kernels": {k: {"ms": round(v[0], 5), "alg_bytes": int(v[1]), "GBps": round(v[1] / (v[0] * 1e-3) / 1e9, 2) if v[0] > 0 else 0.0} for k, v in kernels.items()},
-                    "note": ("algorithmic bytes count every BVH record a ray visits; on this scene the node records (%d %% of them) are served from the LDS scene cache and most of the rest from L2, so `achieved` can exceed the HBM peak -- `traffic` is the HBM traffic measured with the PMC counters" % round(100.0 * NODE_B * (counts["nodesPrimary"] + counts["nodesDirect"]) / max(d_bytes, 1))) if fused else None,
-                    "lean_frame": lean, "fused_frame": fused, "frame_gpu_ms": round(kms["total"], 5), "build_ms": round(kms["build"], 5),
-                    "nodes_per_primary_ray": round(counts["nodesPrimary"] / max(counts["primary"], 1), 3),
-                    "tris_per_primary_ray": round(counts["trisPrimary"] / max(counts["primary"], 1), 3),
-                    "nodes_per_shadow_ray": round(counts["nodesDirect"] / max(counts["shadow"], 1), 3),
-                    "tris_per_shadow_ray": round(counts["trisDirect"] / max(counts["shadow"], 1), 3)}
+        roofline = roofline_object(dominant, d_ms, d_bytes, kernels)
+        roofline.update({"lean_frame": lean, "fused_frame": fused, "frame_gpu_ms": round(kms["total"], 5), "build_ms": round(kms["build"], 5),
+                         "nodes_per_primary_ray": round(counts["nodesPrimary"] / max(counts["primary"], 1), 3),
+                         "tris_per_primary_ray": round(counts["trisPrimary"] / max(counts["primary"], 1), 3),
+                         "nodes_per_shadow_ray": round(counts["nodesDirect"] / max(counts["shadow"], 1), 3),
+                         "tris_per_shadow_ray": round(counts["trisDirect"] / max(counts["shadow"], 1), 3)})
         result = {
             "metric": "Mrays/s (primary+shadow), sample scene 1080p 1spp", "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
@@ -349,6 +364,9 @@ def main():
             result["pipeline"] = {"frames": "enqueued (sync_present=0), 2 gather slots" if pipelined else "synchronous, CPU-staged gather (rehearsal)",
                               "send_buffer": "written by the frame kernel (RT64_SetDeviceGatherTarget)" if packed[0] else "RT64_CopyDeviceImage after each frame",
                                   "host_ms_per_step": round(enqueue_ms, 5)}
+        if rebuild is not None:
+            result["always_rebuild"] = rebuild
+        result["frame_tables"] = "rebuilt every frame (always_rebuild)" if args.always_rebuild else "cached while the host re-sends identical descriptors (steady state of the sample host, main.cpp:97-134); `always_rebuild` holds the figure with the cache off"
         if N == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(data, W, H, args.cpu_baseline_height)
         if not G:
@@ -367,10 +385,125 @@ def main():
         dist.destroy_process_group()
 
 
+VALU_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: fp32 vector peak = 1024 SIMD-32s x 32 lanes x 2 flop x 2.4 GHz, i.e. ONE wave64 instruction per SIMD every 2 cycles
+SIMDS, CLOCK_HZ = 1024, 2.4e9
+
+
+def source_hash():
+    """Identity of the kernel sources a counter profile belongs to (the GPU box has no .git): sha256 over csrc/."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "sm64rt-legacy-renderer_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp", ".inc")) or name == "Makefile":
+            h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_counters(workload):
+    """profiles/kernel_counters.json (tools/collect_counters.py: rocprofv3 PMC passes of this workload) -- only if it was collected from
+    exactly these kernel sources; a stale file is refused (returns None and the reason)."""
+    path = os.path.join(ROOT, "profiles", "kernel_counters.json")
+    if not os.path.exists(path):
+        return None, "no profiles/kernel_counters.json"
+    try:
+        doc = json.load(open(path))
+    except Exception as e:
+        return None, "unreadable profiles/kernel_counters.json (%r)" % (e,)
+    if doc.get("source_hash") != source_hash():
+        return None, "profiles/kernel_counters.json was collected from other kernel sources (%s, these are %s): refused" % (doc.get("source_hash"), source_hash())
+    w = doc.get("workloads", {}).get(workload)
+    if not w:
+        return None, "profiles/kernel_counters.json has no counters for workload %s" % workload
+    return w, None
+
+
+COUNTER_WORKLOAD = [None]
+# bench.py's kernel groups -> (profile kernel, launches per frame)
+GROUPS = {"indirect": [("bounce_trace", 1), ("bounce_hit", 1), ("bounce_miss", 1), ("bounce_resolve", 1)],
+          "svgf_denoise": [("svgf_guide", 1), ("svgf_variance", 1), ("svgf_atrous", 5)], "reflection_refraction": [("reflection", 2)]}
+
+
+def group_counters(kernels, key):
+    """Counters of one bench.py kernel group per frame: a single profiled kernel, or the sum over the launches the group stands for."""
+    if key in kernels:
+        return kernels[key]
+    if key not in GROUPS or any(k not in kernels for k, _ in GROUPS[key]):
+        return None
+    out = {}
+    for k, n in GROUPS[key]:
+        for c, v in kernels[k].items():
+            if c.startswith("SQ_") or c in ("hbm_bytes", "fetch_bytes_x2", "write_bytes", "avg_ns"):
+                out[c] = out.get(c, 0.0) + n * v
+    return out
+
+
+def roofline_object(dominant, d_ms, d_bytes, kernels):
+    """What binds the dominant kernel, from counters: `frac` is the utilisation of the binding resource (<= 1 by construction) --
+    VALU issue slots (SQ_INSTS_VALU wave-instructions x 2 cycles each at full rate, over 1024 SIMDs x the launch duration measured live
+    in this run) or HBM (PMC bytes / the same duration / 8 TB/s), whichever is larger.  The algorithmic bytes of SURVEY 8(d) (every BVH
+    record a ray visits, wherever it is served from) stay in the line under their own name and are never called a roofline fraction."""
+    key = dominant.split("(")[0]
+    secs = d_ms * 1e-3
+    alg = {"bytes_per_launch": int(d_bytes), "GBps": round(d_bytes / secs / 1e9, 2) if secs > 0 else 0.0,
+           "note": "SURVEY 8(d) accounting: 64 B per node visit + 48 B per triangle test + per-pixel records, counted whether HBM, L2 or the LDS scene cache serves them -- not HBM traffic, not a roofline fraction"}
+    w, why = load_counters(COUNTER_WORKLOAD[0])
+    c = group_counters((w or {}).get("kernels", {}), key)
+    out = {"kernel": dominant, "ms_per_launch": round(d_ms, 5), "algorithmic": alg,
+           "kernels": {k: {"ms": round(v[0], 5), "alg_bytes": int(v[1])} for k, v in kernels.items()}}
+    if not c or secs <= 0:
+        out.update({"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                    "note": "no counter profile for this build (%s): the binding resource is not claimed" % (why or "kernel %s not in the profile" % key)})
+        return out
+    hbm_bytes = c["hbm_bytes"]
+    hbm_gbps = hbm_bytes / secs / 1e9
+    hbm_frac = hbm_gbps / HBM_PEAK_GBS
+    valu_tflops = c["SQ_INSTS_VALU"] * 128.0 / secs / 1e12          # one wave64 instruction = 64 lanes x 2 flop of issue capacity (FMA-equivalent)
+    valu_frac = valu_tflops / VALU_PEAK_TFLOPS
+    detail = {"hbm": {"bytes_per_launch": int(hbm_bytes), "fetch_bytes_x2": int(c["fetch_bytes_x2"]), "write_bytes": int(c["write_bytes"]), "GBps": round(hbm_gbps, 1), "frac": round(hbm_frac, 4),
+                      "frac_of_measured_copy_roof_6290GBps": round(hbm_gbps / 6290.0, 4)},
+              "valu": {"wave_insts_per_launch": int(c["SQ_INSTS_VALU"]), "issue_frac": round(valu_frac, 4),
+                       "active_quad_cycles_per_launch": int(c.get("SQ_ACTIVE_INST_VALU", 0)),
+                       "active_frac": round(c.get("SQ_ACTIVE_INST_VALU", 0) * 4.0 / (SIMDS * secs * CLOCK_HZ), 4),
+                       "note": "issue_frac prices every VALU wave-instruction at 2 cycles (the SIMD-32 full rate, reachable with >= 2 waves per SIMD); active_frac = SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x duration x 2.4 GHz) is the counter's own busy figure (a wave holds the VALU 4 cycles per instruction) and can overlap between waves"},
+              "wave": {k: int(c[k]) for k in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_BUSY_CYCLES") if k in c},
+              "registers": {k: c[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size", "LDS_Block_Size") if k in c},
+              "profile": {"source_hash": source_hash(), "rocprofv3_avg_ns": c.get("avg_ns"), "live_avg_ns": round(d_ms * 1e6, 1)}}
+    if valu_frac >= hbm_frac:
+        out.update({"bound": "valu", "achieved": round(valu_tflops, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(valu_frac, 4),
+                    "note": "VALU issue capacity in fp32 FMA-equivalent TFLOP/s (wave-instructions x 128 / s); the kernel traces rays (integer / compare / select work included), it does not do that many flops"})
+    else:
+        out.update({"bound": "hbm", "achieved": round(hbm_gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4)})
+    out["traffic"] = int(hbm_bytes)
+    out["counters"] = detail
+    if "SQ_WAVE_CYCLES" in c and c.get("SQ_WAVE_CYCLES"):
+        wc = float(c["SQ_WAVE_CYCLES"])
+        out["counters"]["wave"]["share_of_wave_cycles"] = {k: round(c[k] / wc, 3) for k in ("SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if k in c}
+    return out
+
+
+def host_threads():
+    """Threads the CPU baseline may really use: the affinity mask, cut by the cgroup's CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            t = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if t[0] != "max":
+                    n = min(n, max(1, int(float(t[0]) / float(t[1]) + 0.5)))
+            else:
+                q = int(t[0]); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(data, W, H, rows):
     """The scalar C oracle (kind "port": same LBVH, same traversal, same shading math) on the host cores."""
     from oracle import oracle_py
-    threads = min(os.cpu_count() or 1, 16)
+    threads = host_threads()            # every host core this process may use (SURVEY 8d: omp_get_max_threads())
     ora = oracle_py.OracleScene(data)
     try:
         tile = (0, rows) if rows and rows < H else None

@@ -36,6 +36,7 @@ hipError_t bc7_decode_launch(const uint8_t *blocks, uint8_t *rgba, uint32_t widt
 // ---- passes.hip ---------------------------------------------------------------------------------------------------
 #define RT_CACHE_MAX_WORDS 1536       // LDS scene cache: at most 24 KB next to the 24 KB of traversal stacks (3 workgroups per CU)
 #define RT_GRID_BLOCKS 2048           // persistent grid of every ray kernel (8 workgroups of 256 per CU)
+#define RT_MAX_FRAME_GROUPS 8192u     // largest grid of the one-workgroup-per-tile kernels (bigger frames give every workgroup a few tiles)
 size_t rt_stack_spill_bytes(int width, int rows);        // bytes FrameParams::traversalStack needs for a frame of that size
 
 hipError_t launch_primary_trace(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, bool klist, hipStream_t s);
@@ -48,7 +49,8 @@ hipError_t launch_reflection(const FrameParams &P, const ViewImages &I, bool kli
 hipError_t launch_gaussian(const uint16_t *in, uint16_t *out, int width, int height, int y0, int y1, hipStream_t s);
 hipError_t launch_compose_post(const FrameParams &P, const ViewImages &I, int cur, bool lean, bool writeFinal, hipStream_t s);
 // A lean frame in one launch: primary visibility + resolve + direct light + compose (passes.hip, lean_frame_kernel).
-hipError_t launch_lean_frame(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, int cur, bool full, int ownedY0, int ownedY1, hipStream_t s);
+// maxGroups: cap of the grid (RT_MAX_FRAME_GROUPS; device option max_frame_groups lowers it so that small frames exercise the several-tiles-per-workgroup walk)
+hipError_t launch_lean_frame(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, int cur, bool full, int ownedY0, int ownedY1, unsigned maxGroups, hipStream_t s);
 hipError_t launch_post_process(const FrameParams &P, const ViewImages &I, hipStream_t s);      // PostProcessPS as its own pass (resolution scale / motion blur)
 hipError_t launch_clear_final(const FrameParams &P, const ViewImages &I, hipStream_t s);
 

@@ -288,16 +288,25 @@ __global__ __launch_bounds__(LBVH_THREADS) void lbvh_small_batch_kernel(const Lb
 
 size_t lbvh_small_lds_bytes(uint32_t n) { return ((size_t)7 * n + 64) * sizeof(uint32_t); }
 
+// More than 64 KB of dynamic LDS has to be allowed per kernel AND per device: remembered per (kernel, current device), so a second
+// Device on another GPU of the same process gets the attribute too.
+static hipError_t allow_big_lds(const void *kernel, int which) {
+    static unsigned long long done[2] = { 0ull, 0ull };
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && (done[which] >> dev) & 1ull) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lbvh_small_lds_bytes(LBVH_SMALL_MAX));
+    if (e == hipSuccess && dev >= 0 && dev < 64) done[which] |= 1ull << dev;
+    return e;
+}
+
 hipError_t lbvh_launch(const LbvhArgs &args, hipStream_t stream) {
     if (args.n == 0) return hipErrorInvalidValue;
     if (args.n <= LBVH_SMALL_MAX) {
         size_t lds = lbvh_small_lds_bytes(args.n);
-        static bool attrSet = false;
-        if (!attrSet) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lbvh_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lbvh_small_lds_bytes(LBVH_SMALL_MAX));
-            if (e != hipSuccess) return e;
-            attrSet = true;
-        }
+        hipError_t e = allow_big_lds(reinterpret_cast<const void *>(lbvh_small_kernel), 0);
+        if (e != hipSuccess) return e;
         const uint32_t threads = args.n >= LBVH_THREADS ? LBVH_THREADS : ((args.n + 63u) / 64u) * 64u;
         hipLaunchKernelGGL(lbvh_small_kernel, dim3(1), dim3(threads), lds, stream, args);
         return hipGetLastError();
@@ -309,12 +318,8 @@ hipError_t lbvh_launch(const LbvhArgs &args, hipStream_t stream) {
 hipError_t lbvh_launch_batch(const LbvhArgs *deviceArgs, uint32_t count, uint32_t maxN, hipStream_t stream) {
     if (count == 0) return hipSuccess;
     if (maxN == 0 || maxN > LBVH_SMALL_MAX) return hipErrorInvalidValue;
-    static bool attrSet = false;
-    if (!attrSet) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lbvh_small_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lbvh_small_lds_bytes(LBVH_SMALL_MAX));
-        if (e != hipSuccess) return e;
-        attrSet = true;
-    }
+    hipError_t e = allow_big_lds(reinterpret_cast<const void *>(lbvh_small_batch_kernel), 1);
+    if (e != hipSuccess) return e;
     const uint32_t threads = maxN >= LBVH_THREADS ? LBVH_THREADS : ((maxN + 63u) / 64u) * 64u;
     hipLaunchKernelGGL(lbvh_small_batch_kernel, dim3(count), dim3(threads), lbvh_small_lds_bytes(maxN), stream, deviceArgs);
     return hipGetLastError();

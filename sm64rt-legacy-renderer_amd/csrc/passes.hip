@@ -1309,7 +1309,9 @@ __global__ __launch_bounds__(256) void clear_final_kernel(FrameParams Pv, ViewIm
 // One spill slab per lane of every workgroup of the largest grid a frame of `width` x `rows` can launch: the persistent kernels use
 // at most RT_GRID_BLOCKS workgroups, the one-kernel frame one per 16 x 16 tile.
 size_t rt_stack_spill_bytes(int width, int rows) {
-    const size_t tiles = (size_t)((width + 15) / 16) * (size_t)((rows + 15) / 16), blocks = tiles > (size_t)RT_GRID_BLOCKS ? tiles : (size_t)RT_GRID_BLOCKS;
+    const size_t tiles = (size_t)((width + 15) / 16) * (size_t)((rows + 15) / 16);
+    size_t blocks = tiles > (size_t)RT_GRID_BLOCKS ? tiles : (size_t)RT_GRID_BLOCKS;
+    if (blocks > RT_MAX_FRAME_GROUPS) blocks = RT_MAX_FRAME_GROUPS;       // no launch has more workgroups than that (launch_lean_frame, sparse_grid)
     return blocks * RT_BLOCK * RT_STACK_SPILL * sizeof(uint32_t);
 }
 
@@ -1352,12 +1354,13 @@ hipError_t launch_direct(const FrameParams &P, const ViewImages &I, int cur, boo
 // CU), which together with the bottom-up tile order (geometry first) is a longest-job-first schedule; a resident round of
 // persistent workgroups with a static round-robin walk measured 8 % slower on the full frame (181 against 165 us) and keeps every
 // register file full until the launch ends, so nothing on another stream (the RCCL gather) can run beside it.
-hipError_t launch_lean_frame(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, int cur, bool full, int ownedY0, int ownedY1, hipStream_t s) {
+hipError_t launch_lean_frame(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, int cur, bool full, int ownedY0, int ownedY1, unsigned maxGroups, hipStream_t s) {
     const unsigned strips = (unsigned)(P.tileY1 - P.tileY0 + 15) / 16, owned = strips > (unsigned)P.stripRank ? (strips - (unsigned)P.stripRank + (unsigned)P.stripCount - 1) / (unsigned)P.stripCount : 0u;
     const unsigned tiles = (unsigned)((P.width + 15) / 16) * owned;
     // ... up to 8192 workgroups; bigger frames give every workgroup ceil(tiles / 8192) tiles (round-robin, same bottom-up order), which
     // amortises the scene-cache fill again (1440p: 2 tiles per workgroup, 4K: 4)
-    const unsigned perGroup = (tiles + 8191u) / 8192u, grid = tiles < 1u ? 1u : (tiles + perGroup - 1u) / perGroup;
+    if (maxGroups < 1u || maxGroups > RT_MAX_FRAME_GROUPS) maxGroups = RT_MAX_FRAME_GROUPS;
+    const unsigned perGroup = (tiles + maxGroups - 1u) / maxGroups, grid = tiles < 1u ? 1u : (tiles + perGroup - 1u) / perGroup;
     const size_t lds = P.cacheWords ? cached_lds_bytes(P, true) : 0;
     if (P.cacheWords) {
         if (full) hipLaunchKernelGGL((lean_frame_kernel<true, true>), dim3(grid), dim3(RT_BLOCK), lds, s, P, I, hitInstance, cur, ownedY0, ownedY1);
@@ -1392,7 +1395,7 @@ static unsigned sparse_grid(const FrameParams &P) {
     const unsigned all = (unsigned)(P.tileY1 - P.tileY0 + 15) / 16;
     const unsigned strips = all > (unsigned)P.stripRank ? (all - (unsigned)P.stripRank + (unsigned)P.stripCount - 1) / (unsigned)P.stripCount : 0u;
     const unsigned tiles = (unsigned)((P.width + 15) / 16) * strips;
-    return tiles < 1u ? 1u : (tiles < 8192u ? tiles : 8192u);
+    return tiles < 1u ? 1u : (tiles < RT_MAX_FRAME_GROUPS ? tiles : RT_MAX_FRAME_GROUPS);
 }
 hipError_t launch_refraction(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s) {
     if (klist) hipLaunchKernelGGL(refraction_kernel<true>, dim3(sparse_grid(P)), dim3(RT_BLOCK), 0, s, P, I);

@@ -92,6 +92,7 @@ struct alignas(16) GpuRasterInstance {
     uint32_t filter, hAddr, vAddr;
     int32_t scissorRect[4], viewportRect[4];     // RT64_RECT x, y, w, h (origin bottom-left); w or h <= 0 = unset
     uint32_t meshVersion;
+    uint32_t texSerial;                  // identity of the diffuse texture object (texDiffuse is only its slot in this frame's table)
 };
 
 // Constant block of one frame (reference: GlobalParams.hlsli:8-43 / rt64_view.cpp:961-1028), passed by value.

@@ -141,6 +141,7 @@ struct Options {
     int bounceRefill = -1;        // bounce-ray traversal with wave-ballot refill: 1 on, 0 off, -1 auto (on when the scene has >= 64 Ki triangles)
     int denoiserMode = 1;          // 0 = reference 5x Gaussian, 1 = SVGF
     int maxReflections = 2;        // rt64_view.cpp:60 (inspector-only knob in the reference)
+    unsigned maxFrameGroups = RT_MAX_FRAME_GROUPS;   // grid cap of the one-kernel frame (tests lower it: several tiles per workgroup on a small frame)
 };
 
 struct Device {
@@ -210,7 +211,8 @@ struct Texture {
     DevArray<uint8_t> texels; uint32_t mipOffset[RT64_MAX_MIPS] = {};
     uint8_t minAlpha = 255, maxAlpha = 255;
     int currentIndex = -1;
-    explicit Texture(Device *d) : device(d) {}
+    uint32_t serial;                                   // unique per texture object: part of the raster-list cache key (a slot index alone does not identify a texture)
+    explicit Texture(Device *d) : device(d) { static uint32_t globalTextureSerial = 0; serial = ++globalTextureSerial; }
     void setRGBA8(const void *bytes, int byteCount, int w, int h, int rowPitch);
     void setDDS(const void *bytes, int byteCount);
 };
@@ -441,6 +443,8 @@ void Texture::setDDS(const void *data, int byteCount) {
 
 void Mesh::set(const void *vertexArray, int vcount, int vstride, const unsigned int *indexArray, int icount) {
     if (!vertexArray || !indexArray || vcount <= 0 || icount <= 0 || vstride < 12) throw std::runtime_error("RT64_SetMesh: invalid arguments.");
+    // An index past the vertex array would make the BLAS builder and the any-hit vertex fetches read outside the buffer (a GPU memory fault).
+    for (int i = 0; i < icount; i++) if (indexArray[i] >= (unsigned int)vcount) throw std::runtime_error("RT64_SetMesh: index " + std::to_string(i) + " (" + std::to_string(indexArray[i]) + ") is out of range for " + std::to_string(vcount) + " vertices.");
     device->use();
     // rt64_mesh.cpp:30-39,76-82: a change of counts/stride discards the BLAS even if updatable.
     const bool sameShape = vertices.ptr && vertexCount == vcount && vertexStride == vstride && indexCount == icount;
@@ -622,6 +626,7 @@ void View::prepareRasterList(const std::vector<RenderInstance> &list, RasterList
         g.vertexStride = (uint32_t)inst->mesh->vertexStride; g.triCount = (uint32_t)inst->mesh->indexCount / 3; g.firstTri = triTotal;
         g.cc = inst->shader->cc;
         g.texDiffuse = inst->diffuse->currentIndex; g.filter = inst->shader->filter; g.hAddr = inst->shader->hAddr; g.vAddr = inst->shader->vAddr;
+        g.texSerial = inst->diffuse->serial;
         g.scissorRect[0] = inst->scissorRect.x; g.scissorRect[1] = inst->scissorRect.y; g.scissorRect[2] = inst->scissorRect.w; g.scissorRect[3] = inst->scissorRect.h;
         g.viewportRect[0] = inst->viewportRect.x; g.viewportRect[1] = inst->viewportRect.y; g.viewportRect[2] = inst->viewportRect.w; g.viewportRect[3] = inst->viewportRect.h;
         g.meshVersion = inst->mesh->version;
@@ -964,12 +969,12 @@ void View::render() {                          // View::render, rt64_view.cpp:11
             packedFinal = true;
         }
         if (fused) {
-            L(launch_lean_frame(P, img, hitInstance.ptr, cur, false, 0, imgH, s));
+            L(launch_lean_frame(P, img, hitInstance.ptr, cur, false, 0, imgH, dev->opt.maxFrameGroups, s));
             mark(Device::EV_PRIMARY_TRACE); mark(Device::EV_PRIMARY); mark(Device::EV_DIRECT);
         }
         else if (fusedFull) {
             if (P.stripCount > 1 && (X.tileY0 != P.tileY0 || X.tileY1 != P.tileY1)) throw std::runtime_error("RT64_DrawDevice: interleaved strips with a denoiser halo.");
-            L(launch_lean_frame(X, img, hitInstance.ptr, cur, true, P.tileY0, P.tileY1, s));
+            L(launch_lean_frame(X, img, hitInstance.ptr, cur, true, P.tileY0, P.tileY1, dev->opt.maxFrameGroups, s));
             mark(Device::EV_PRIMARY_TRACE); mark(Device::EV_PRIMARY); mark(Device::EV_DIRECT);
         }
         else {
@@ -1095,9 +1100,11 @@ void Device::finishStats() {
     statsPending = false;
     RT64_FRAME_STATS st = stats;
     const bool haveView = statsHaveView;
-    if (!opt.syncPresent) HIP_CHECK(hipStreamSynchronize(stream));
+    // The timings and counters below belong to the LAST frame handed to RT64_DrawDevice (one event set, re-recorded by every frame):
+    // wait for it whatever sync_present says now -- the option may have been switched since the frame was enqueued.
+    HIP_CHECK(hipStreamSynchronize(stream));
     if (opt.profilePasses && haveView) {
-        auto ms = [&](int a, int b) { float v = 0.0f; if (eventAlias[a] != eventAlias[b]) hipEventElapsedTime(&v, events[eventAlias[a]], events[eventAlias[b]]); return v; };
+        auto ms = [&](int a, int b) { float v = 0.0f; if (eventAlias[a] != eventAlias[b] && hipEventElapsedTime(&v, events[eventAlias[a]], events[eventAlias[b]]) != hipSuccess) { (void)hipGetLastError(); v = 0.0f; } return v; };
         st.msTotal = ms(EV_BEGIN, EV_END); st.msBuild = ms(EV_BEGIN, EV_BUILD); st.msPrimary = ms(EV_BUILD, EV_PRIMARY);
         st.msPrimaryTrace = ms(EV_BUILD, EV_PRIMARY_TRACE); st.msPrimaryShade = ms(EV_PRIMARY_TRACE, EV_PRIMARY);
         st.msDirect = ms(EV_PRIMARY, EV_DIRECT); st.msIndirect = ms(EV_DIRECT, EV_INDIRECT); st.msReflectRefract = ms(EV_INDIRECT, EV_REFL);
@@ -1315,6 +1322,7 @@ RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, doubl
     else if (k == "lean_frames") d->opt.leanFrames = value != 0.0;                // 0: always write every image of the reference's G-buffer
     else if (k == "always_rebuild") d->opt.alwaysRebuild = value != 0.0;          // upload tables + rebuild the TLAS every frame like the reference
     else if (k == "max_reflections") d->opt.maxReflections = std::max(0, (int)value);
+    else if (k == "max_frame_groups") d->opt.maxFrameGroups = value >= 1.0 && value <= (double)RT_MAX_FRAME_GROUPS ? (unsigned)value : RT_MAX_FRAME_GROUPS;
     else return 0;
     return 1;
 }
@@ -1344,7 +1352,9 @@ RT64_EXPORT RT64_INSTANCE *RT64_GetViewRaytracedInstanceAt(RT64_VIEW *viewPtr, i
     if (x < 0 || x >= v->imgW || y < 0 || y >= v->imgH) return nullptr;
     int32_t id = -1;
     v->materialise();
-    HIP_CHECK(hipMemcpy(&id, v->img.firstInstanceId + (size_t)y * v->imgW + x, 4, hipMemcpyDeviceToHost));
+    // ordered behind the frame on the renderer's (non-blocking) stream: a null-stream copy would not wait for an enqueued frame
+    HIP_CHECK(hipMemcpyAsync(&id, v->img.firstInstanceId + (size_t)y * v->imgW + x, 4, hipMemcpyDeviceToHost, dev->stream));
+    HIP_CHECK(hipStreamSynchronize(dev->stream));
     if (id >= 0 && (size_t)id < v->rtInstances.size()) return reinterpret_cast<RT64_INSTANCE *>(v->rtInstances[id].instance);
     return nullptr;
     RT64_CATCH(nullptr)

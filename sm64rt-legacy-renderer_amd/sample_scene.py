@@ -258,6 +258,41 @@ def make_sample_scene(subdiv=0, floor_grid=1, assets=ASSETS) -> SceneData:
                      (45.0 * math.pi) / 180.0, 0.1, 1000.0, bn)
 
 
+# ---- BASELINE.json configurations as bench.py runs them; tests/test_gpu_configs.py renders the same definitions -------
+
+BENCH_CONFIGS = {
+    "C2": dict(width=1920, height=1080, gi_samples=0, denoiser=False),
+    "C3": dict(width=1920, height=1080, gi_samples=1, denoiser=True),
+    "C4": dict(width=2560, height=1440, gi_samples=2, denoiser=True),      # + per-frame SetMesh refit of the UPDATABLE sphere
+    "C5": dict(width=3840, height=2160, gi_samples=4, denoiser=True),      # + reflective floor
+}
+
+
+def c4_animation(data: "SceneData", frames=16):
+    """C4: the sphere mesh becomes UPDATABLE and is displaced every frame, p += 0.1 n sin(frame 0.1 + p.y) (build-defined, seedless).
+    Returns the vertex arrays of `frames` consecutive frames; the caller hands one to RT64_SetMesh per step (host copy + refit)."""
+    m = data.meshes[0]
+    m.flags |= rt64.MESH_RAYTRACE_UPDATABLE
+    base = m.vertices.copy()
+    out = []
+    for f in range(frames):
+        v = base.copy()
+        v["position"][:, :3] += (0.1 * np.sin(f * 0.1 + base["position"][:, 1]))[:, None].astype(np.float32) * base["normal"]
+        out.append(v)
+    return out
+
+
+def apply_bench_config(data: "SceneData", config: str):
+    """Scene-side part of a config: C4 -> list of animated vertex arrays (else None); C5 -> floor reflectionFactor 0.3."""
+    if config == "C4":
+        return c4_animation(data)
+    if config == "C5":
+        for inst in data.instances:
+            if inst.name == "floor":
+                inst.material.reflectionFactor = 0.3
+    return None
+
+
 class Rt64Scene:
     """Drives librt64.so with a SceneData exactly like the sample drives rt64lib.dll."""
 

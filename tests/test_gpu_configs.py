@@ -1,0 +1,205 @@
+"""GPU parity of BASELINE.json's configurations C4 and C5 exactly as bench.py defines them (sample_scene.BENCH_CONFIGS /
+apply_bench_config -- the same code bench.py calls), at a reduced frame size, against the CPU oracle; the several-tiles-per-workgroup
+walk of the one-kernel frame (every frame above 1080p runs on it); the sky modifiers of RT64_SCENE_DESC (Color.hlsli:9-43,
+BgSky.hlsli:20-93); and the raster background cache key (a texture swap in the same slot).
+Tolerances: hit records / ids exact, composed image RMSE <= 1e-3 (BASELINE.json gate), filtered GI RMSE <= 2e-3."""
+import copy
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+W, H = 320, 180
+
+
+def _variant(sample_data, fn=None):
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    d = copy.copy(sample_data)
+    d.instances = [copy.copy(i) for i in sample_data.instances]
+    for i in d.instances:
+        i.material = sample_scene.copy_material(i.material)
+    d.meshes = [copy.copy(m) for m in sample_data.meshes]
+    desc = rt64.SCENE_DESC(); C.memmove(C.byref(desc), C.byref(sample_data.desc), C.sizeof(rt64.SCENE_DESC)); d.desc = desc
+    if fn:
+        fn(d)
+    return d
+
+
+def _rmse(a, b):
+    return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
+
+
+def _bench_pair(rt64_lib, sample_data, config, frames, width=W, height=H, bands=None, options=None):
+    """Render `frames` steps of bench.py's `--config` on the HIP library (whole frame, or one device per band) and on the oracle."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    from oracle import oracle_py
+    data = _variant(sample_data)
+    cfg = sample_scene.BENCH_CONFIGS[config]
+    anim = sample_scene.apply_bench_config(data, config)
+    parts = [sample_scene.Rt64Scene(rt64_lib, data, width, height, hip_device=0) for _ in (bands or [None])]
+    o = oracle_py.OracleScene(data)
+    try:
+        for s, band in zip(parts, bands or [None]):
+            s.set_view_description(gi_samples=cfg["gi_samples"], denoiser=cfg["denoiser"])
+            for k, v in (options or {}).items():
+                assert s.option(k, v)
+            if band:
+                s.set_tile(*band)
+            s.option("count_traversal", 1)
+        kw = dict(giSamples=cfg["gi_samples"], denoiserEnabled=int(cfg["denoiser"]), denoiserMode=1)
+        for f in range(frames):
+            if anim is not None:          # bench.py step(): frame_no += 1; SetMesh(anim[frame_no % len])
+                v = anim[(f + 1) % len(anim)]
+                for s in parts:
+                    s.set_mesh(s.meshes[0], v, data.meshes[0].indices)
+                o.set_mesh(o.meshes[0], v, data.meshes[0].indices)
+            for s in parts:
+                s.draw()
+            ref = o.render(width, height, **kw)
+        names = ("OUTPUT_RGBA32F", "FINAL_RGBA8", "PRIMARY_HIT", "INDIRECT_LIGHT_RAW", "INDIRECT_LIGHT_FILTERED", "REFLECTION", "DIFFUSE")
+        got = {k: np.concatenate([s.readback(getattr(rt64, "IMAGE_" + k)) for s in parts], axis=0) for k in names}
+        return got, ref, [s.stats() for s in parts]
+    finally:
+        for s in parts:
+            s.close()
+        o.close()
+
+
+def _check_gi_frame(got, ref):
+    assert np.array_equal(got["PRIMARY_HIT"], ref["primaryHit"])
+    assert _rmse(got["OUTPUT_RGBA32F"][..., :3], ref["output"][..., :3]) <= 1e-3
+    assert _rmse(got["FINAL_RGBA8"][..., :3] / 255.0, ref["final"][..., :3] / 255.0) <= 1e-3
+    assert _rmse(got["INDIRECT_LIGHT_FILTERED"][..., :3], ref["filteredIndirect"][..., :3]) <= 2e-3
+    assert np.abs(got["DIFFUSE"] - ref["diffuse"]).max() <= 1.0 / 255.0 + 1e-6
+
+
+def test_c4_refit_every_frame_with_two_gi_samples_and_svgf(rt64_lib, sample_data):
+    """C4 as `bench.py --config C4` sets it: the sphere is UPDATABLE and re-sent (refit) every frame, 2 GI samples, SVGF -- 5 frames of
+    temporal history over moving geometry."""
+    got, ref, st = _bench_pair(rt64_lib, sample_data, "C4", frames=5)
+    _check_gi_frame(got, ref)
+    c = ref["counters"]
+    assert st[0].primaryRays == c["primaryRays"] == W * H and st[0].indirectRays == c["indirectRays"] > 0
+    assert st[0].leanFrame == 0 and st[0].fusedFrame == 2
+    hist = ref["indirectLight"][..., 3]
+    assert hist.max() >= 6.0                      # 2 samples per frame: history grows by 2 per frame on pixels that stay valid
+    hit = ref["instanceId"] >= 0
+    assert np.abs(got["INDIRECT_LIGHT_RAW"][..., 3][hit] - hist[hit]).max() < 1.01
+
+
+@pytest.mark.parametrize("bands", [None, [(0, 64), (64, 121), (121, H)]])
+def test_c5_four_gi_samples_reflective_floor_svgf(rt64_lib, sample_data, bands):
+    """C5 as `bench.py --config C5` sets it: 4 GI samples, floor reflectionFactor 0.3 (two reflection bounces), SVGF -- once whole, once
+    as the contiguous bands + denoiser halo of the multi-GPU partition (ragged on purpose)."""
+    got, ref, st = _bench_pair(rt64_lib, sample_data, "C5", frames=4, bands=bands)
+    _check_gi_frame(got, ref)
+    assert np.abs(got["REFLECTION"] - ref["reflection"]).max() < 8e-3
+    assert (ref["reflection"][..., :3] > 0.01).mean() > 0.1
+    c = ref["counters"]
+    if not bands:
+        assert st[0].reflectionRays == c["reflectionRays"] > 0 and st[0].indirectRays == c["indirectRays"] > 0
+    else:                                          # pixel-local passes stay on the owned rows: their rays add up to the whole frame's
+        assert sum(s.reflectionRays for s in st) == c["reflectionRays"] > 0
+
+
+@pytest.mark.parametrize("config", ["C2", "C3"])
+def test_several_tiles_per_workgroup_walk_of_the_one_kernel_frame(rt64_lib, sample_data, config):
+    """launch_lean_frame gives every workgroup ceil(tiles / max groups) tiles once a frame has more than RT_MAX_FRAME_GROUPS tiles (every
+    frame above 1080p: C4 and C5).  max_frame_groups = 50 puts a 320 x 180 frame (240 tiles) on that walk (5 tiles per workgroup) for
+    the lean kernel (C2, FULL = false) and the full one (C3, FULL = true): same bytes as one workgroup per tile, and parity with the oracle."""
+    got, ref, st = _bench_pair(rt64_lib, sample_data, config, frames=3, options={"max_frame_groups": 50})
+    base, _, st0 = _bench_pair(rt64_lib, sample_data, config, frames=3)
+    assert st[0].fusedFrame == st0[0].fusedFrame == (1 if config == "C2" else 2)
+    for k in got:
+        assert np.array_equal(got[k].view(np.uint8), base[k].view(np.uint8)), k
+    assert (st[0].primaryRays, st[0].shadowRays, st[0].nodesVisited, st[0].trianglesTested) == (st0[0].primaryRays, st0[0].shadowRays, st0[0].nodesVisited, st0[0].trianglesTested)
+    assert np.array_equal(got["PRIMARY_HIT"], ref["primaryHit"])
+    assert _rmse(got["OUTPUT_RGBA32F"][..., :3], ref["output"][..., :3]) <= 1e-3
+    c = ref["counters"]          # (bounce directions go through device sin / cos: only the primary rays' visit counts are bit-exact on a GI frame)
+    assert st[0].nodesPrimary == c["nodesVisitedPrimary"] and st[0].trianglesPrimary == c["trianglesTestedPrimary"]
+
+
+def test_sky_modifiers_hsl_yaw_and_diffuse_multiplier(rt64_lib, sample_data):
+    """RT64_SCENE_DESC.skyHSLModifier / skyYawOffset / skyDiffuseMultiplier away from their defaults: ModRGBWithHSL (Color.hlsli:9-43)
+    on the sky plane of the primary rays (SampleSky2D) and of the GI / reflection rays (SampleSkyPlane, BgSky.hlsli:54-87)."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    from oracle import oracle_py
+
+    def mod(d):
+        d.desc.skyHSLModifier = rt64.VECTOR3(0.13, -0.21, 0.06)
+        d.desc.skyYawOffset = 0.83
+        d.desc.skyDiffuseMultiplier = rt64.VECTOR3(0.9, 1.1, 0.7)
+        d.instances[3].material.reflectionFactor = 0.4
+    data = _variant(sample_data, mod)
+    plain = _variant(sample_data, lambda d: setattr(d.instances[3].material, "reflectionFactor", 0.4))
+    out = {}
+    for name, dd in (("mod", data), ("plain", plain)):
+        s = sample_scene.Rt64Scene(rt64_lib, dd, W, H, hip_device=0)
+        o = oracle_py.OracleScene(dd)
+        try:
+            s.set_view_description(gi_samples=1, denoiser=False)
+            for _ in range(2):
+                s.draw()
+                ref = o.render(W, H, giSamples=1)
+            out[name] = ({k: s.readback(getattr(rt64, "IMAGE_" + k)) for k in ("OUTPUT_RGBA32F", "FINAL_RGBA8", "PRIMARY_HIT", "DIFFUSE", "INDIRECT_LIGHT_RAW", "REFLECTION")}, ref)
+        finally:
+            s.close(); o.close()
+    got, ref = out["mod"]
+    assert np.array_equal(got["PRIMARY_HIT"], ref["primaryHit"])
+    assert _rmse(got["OUTPUT_RGBA32F"][..., :3], ref["output"][..., :3]) <= 1e-3
+    assert np.abs(got["FINAL_RGBA8"].astype(np.int32) - ref["final"].astype(np.int32)).max() <= 1
+    sky = ref["primaryHit"][..., 3] == 0xFFFFFFFF
+    assert np.abs(got["DIFFUSE"][sky] - ref["diffuse"][sky]).max() <= 1.0 / 255.0 + 1e-6          # the modified sky colour itself, RGBA8
+    assert _rmse(got["INDIRECT_LIGHT_RAW"][..., :3], ref["indirectLight"][..., :3]) <= 2e-3
+    assert np.abs(got["REFLECTION"] - ref["reflection"]).max() < 8e-3
+    # ... and the modifiers did something: sky pixels, GI and the mirrored sky all moved away from the unmodified scene's
+    p = out["plain"][1]
+    assert np.abs(ref["diffuse"][sky][..., :3] - p["diffuse"][sky][..., :3]).mean() > 0.03
+    assert np.abs(ref["indirectLight"][..., :3] - p["indirectLight"][..., :3]).mean() > 1e-3
+    assert np.abs(ref["reflection"][..., :3] - p["reflection"][..., :3]).mean() > 1e-3
+
+
+def test_background_texture_swapped_in_the_same_slot_redraws_gbackground(rt64_lib, sample_data):
+    """The raster lists are cached on their table bytes; a texture is only a slot number there, so the key also carries the texture
+    object's identity: swapping the background instance's diffuse texture for another one that lands in the same slot must redraw
+    gBackground (the environment map of missed / GI / reflection rays)."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    from oracle import oracle_py
+    T_CLOUDS, T_CHECKER = 3, 7
+    yy, xx = np.mgrid[0:64, 0:64]
+    checker = np.zeros((64, 64, 4), dtype=np.uint8)
+    checker[..., 0] = np.where((xx // 8 + yy // 8) % 2, 230, 30); checker[..., 1] = 90; checker[..., 2] = np.where((xx // 8 + yy // 8) % 2, 20, 200); checker[..., 3] = 255
+
+    def make(tex):
+        def mod(d):
+            d.sky = None                                   # no sky plane: the background shows in every missed pixel (and clouds.png is otherwise unused)
+            d.textures = list(d.textures) + [sample_scene.TextureData("checker", rt64.TEXTURE_FORMAT_RGBA8, checker, 64, 64)]
+            for i in d.instances:
+                if i.name == "hudA":                       # the RASTER_BACKGROUND instance: it is the only user of `tex`, which gets slot 4 of the frame either way
+                    i.diffuse = tex
+            m = copy.copy(d.meshes[1]); v = m.vertices.copy()
+            v["position"][:, :2] = [(-1.0, -1.0), (3.0, -1.0), (-1.0, 3.0)]; v["uv"] = [(0.0, 1.0), (2.0, 1.0), (0.0, -1.0)]      # cover the screen
+            m.vertices = v; d.meshes[1] = m
+        return _variant(sample_data, mod)
+    a, b = make(T_CLOUDS), make(T_CHECKER)
+    s = sample_scene.Rt64Scene(rt64_lib, a, W, H, hip_device=0)
+    oa, ob = oracle_py.OracleScene(a), oracle_py.OracleScene(b)
+    try:
+        s.draw(); s.draw()
+        bg_a = s.readback(rt64.IMAGE_BACKGROUND)
+        ra = oa.render(W, H)
+        assert np.abs(bg_a.astype(np.int32) - ra["background"].astype(np.int32)).max() <= 1
+        k = next(i for i, inst in enumerate(b.instances) if inst.name == "hudA")
+        s.data = b
+        s.set_instance(k, b.instances[k])                  # same mesh, same shader, other texture: the slot order of the frame does not change
+        s.draw()
+        bg_b = s.readback(rt64.IMAGE_BACKGROUND)
+        rb = ob.render(W, H)
+        assert np.abs(bg_b.astype(np.int32) - rb["background"].astype(np.int32)).max() <= 1
+        assert np.abs(rb["background"].astype(np.int32) - ra["background"].astype(np.int32)).mean() > 2.0
+        final = s.readback(rt64.IMAGE_FINAL_RGBA8)
+        assert np.abs(final.astype(np.int32) - rb["final"].astype(np.int32)).max() <= 1
+    finally:
+        s.close(); oa.close(); ob.close()
