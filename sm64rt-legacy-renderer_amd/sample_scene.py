@@ -117,7 +117,9 @@ def load_obj_unrolled(path):
             n = nrm[ni - 1]
             verts["position"][k] = (pos[vi - 1][0], pos[vi - 1][1], pos[vi - 1][2], 1.0)
             verts["normal"][k] = n
-            verts["uv"][k] = (np.arccos(np.float32(n[0])), np.arccos(np.float32(n[1])))
+            # main.cpp:278 acos(n.x), acos(n.y): evaluated in double and rounded once (a correctly rounded float acos; numpy's
+            # float32 arccos and the C library's acosf differ by an ulp on a third of the inputs, tools/sample_host.c does the same)
+            verts["uv"][k] = (np.float32(math.acos(float(n[0]))), np.float32(math.acos(float(n[1]))))
             verts["input1"][k] = (1.0, 1.0, 1.0, 1.0)
             k += 1
     return verts, np.arange(len(verts), dtype=np.uint32)
@@ -141,8 +143,8 @@ def _subdivide_sphere(verts, levels, centre, radius):
     out["position"][:, :3] = flat.astype(np.float32)
     out["position"][:, 3] = 1.0
     out["normal"] = n.astype(np.float32)
-    out["uv"][:, 0] = np.arccos(out["normal"][:, 0])
-    out["uv"][:, 1] = np.arccos(out["normal"][:, 1])
+    out["uv"][:, 0] = np.arccos(out["normal"][:, 0].astype(np.float64)).astype(np.float32)
+    out["uv"][:, 1] = np.arccos(out["normal"][:, 1].astype(np.float64)).astype(np.float32)
     out["input1"] = 1.0
     return out, np.arange(len(out), dtype=np.uint32)
 
