@@ -7,7 +7,15 @@
  * (ref:private/rt64_view.cpp:1225-1254 drawInstances, :1292-1319 background pass + gBackground copy, :1657-1661 foreground pass).
  * The rasteriser itself is fixed-function hardware in the reference; this file follows the published Direct3D 11 rasterisation
  * rules.  Raster spec (every step is part of the contract with csrc/raster.hip; coverage is integer arithmetic => bit-exact):
- *   S0  a triangle with any w <= 0 is skipped (no homogeneous clipping: HUD geometry is emitted with w = 1)
+ *   S0  homogeneous clipping (the fixed-function clipper in front of the rasteriser; D3D11 functional spec: 0 < w, 0 <= z <= w, x and y
+ *       against a guard band).  A triangle whose three vertices satisfy all seven plane distances d >= 0 is drawn as it is (B = identity).
+ *       Otherwise Sutherland-Hodgman over the planes in this order, d evaluated in fp32, unfused:
+ *           W: w - 2^-20   NEAR: z   FAR: w - z   X-: x + 4w   X+: 4w - x   Y-: y + 4w   Y+: 4w - y
+ *       For every polygon edge A -> B: A is kept iff dA >= 0; when exactly one end is inside, with P the inside and Q the outside end,
+ *       t = dP / (dP - dQ) and the new vertex is P + t (Q - P) for x, y, z, w and for the three barycentric weights of the ORIGINAL
+ *       triangle (each component: P.c + t * (Q.c - P.c)).  The polygon (<= 10 vertices) is fanned from its first vertex into
+ *       sub-triangles (V0, Vj, Vj+1); each goes through S1-S8 with its own w.  An attribute at a sub-triangle corner k is
+ *       (B[k][0] a0 + B[k][1] a1) + B[k][2] a2 of the original vertices' values (attributes are linear in clip space).
  *   S1  rw = 1/w ; xs = ((x*rw)*0.5 + 0.5)*vpW + vpX ; ys = (0.5 - (y*rw)*0.5)*vpH + vpY          (fp32, unfused)
  *   S2  X = lrintf(xs*256), Y = lrintf(ys*256) (24.8 fixed point, round-to-nearest-even); |X|,|Y| > 2^22 => triangle skipped
  *   S3  area2 = (X1-X0)(Y2-Y0) - (Y1-Y0)(X2-X0) (int64); 0 => skipped; < 0 => vertices 1 and 2 swapped (CullMode NONE)
@@ -25,24 +33,77 @@
 #include "oracle_internal.h"
 #include "oracle_shade.h"
 
-typedef struct { int64_t X[3], Y[3]; float rw[3]; const uint8_t *vp[3]; int64_t area2; } RasterTri;
+typedef struct { int64_t X[3], Y[3]; float rw[3]; const uint8_t *vp[3]; int64_t area2; int clipped; float B[3][3]; } RasterTri;
 
-static int setup_triangle(const OMesh *mesh, uint32_t tri, float vpX, float vpY, float vpW, float vpH, RasterTri *t) {
+#define RASTER_W_EPS 9.5367431640625e-07f       /* 2^-20 */
+#define RASTER_GUARD 4.0f
+#define RASTER_MAX_POLY 10
+typedef struct { float c[7]; } ClipVertex;       /* x, y, z, w, b0, b1, b2 */
+
+static float clip_distance(int plane, const ClipVertex *v) {
+    const float x = v->c[0], y = v->c[1], z = v->c[2], w = v->c[3];
+    switch (plane) {
+    case 0: return w - RASTER_W_EPS;
+    case 1: return z;
+    case 2: return w - z;
+    case 3: return x + RASTER_GUARD * w;
+    case 4: return RASTER_GUARD * w - x;
+    case 5: return y + RASTER_GUARD * w;
+    default: return RASTER_GUARD * w - y;
+    }
+}
+
+/* S0: clip the triangle; returns the polygon's vertex count (0 = nothing left), *clipped = 0 when the triangle was inside every plane */
+static int clip_triangle(const float p[3][4], ClipVertex poly[RASTER_MAX_POLY], int *clipped) {
+    int n = 3, all = 1;
     for (int k = 0; k < 3; k++) {
-        const uint8_t *vp = mesh->vertices + (size_t)mesh->indices[3 * tri + k] * (size_t)mesh->vertexStride;
-        float p[4]; memcpy(p, vp, 16);
-        if (!(p[3] > 0.0f)) return 0;                                                        /* S0 */
+        for (int c = 0; c < 4; c++) poly[k].c[c] = p[k][c];
+        for (int c = 0; c < 3; c++) poly[k].c[4 + c] = c == k ? 1.0f : 0.0f;
+        for (int pl = 0; pl < 7; pl++) if (!(clip_distance(pl, &poly[k]) >= 0.0f)) all = 0;
+    }
+    *clipped = !all;
+    if (all) return 3;
+    for (int pl = 0; pl < 7 && n >= 3; pl++) {
+        ClipVertex out[RASTER_MAX_POLY + 1]; int m = 0;
+        for (int i = 0; i < n; i++) {
+            const ClipVertex *A = &poly[i], *Bv = &poly[(i + 1) % n];
+            const float dA = clip_distance(pl, A), dB = clip_distance(pl, Bv);
+            const int inA = dA >= 0.0f, inB = dB >= 0.0f;
+            if (inA && m < RASTER_MAX_POLY) out[m++] = *A;
+            if (inA != inB && m < RASTER_MAX_POLY) {
+                const ClipVertex *P = inA ? A : Bv, *Q = inA ? Bv : A;
+                const float dP = inA ? dA : dB, dQ = inA ? dB : dA;
+                const float t = dP / (dP - dQ);
+                for (int c = 0; c < 7; c++) out[m].c[c] = P->c[c] + t * (Q->c[c] - P->c[c]);
+                m++;
+            }
+        }
+        n = m;
+        for (int i = 0; i < n; i++) poly[i] = out[i];
+    }
+    return n >= 3 ? n : 0;
+}
+
+/* S1-S3 for one (sub-)triangle with clip-space corners v[3] (x, y, z, w, barycentrics) */
+static int setup_triangle(const ClipVertex v[3], const uint8_t *const vp[3], int clipped, float vpX, float vpY, float vpW, float vpH, RasterTri *t) {
+    t->clipped = clipped;
+    for (int k = 0; k < 3; k++) {
+        const float *p = v[k].c;
+        if (!(p[3] > 0.0f)) return 0;
+        for (int c = 0; c < 3; c++) t->B[k][c] = p[4 + c];
         float rw = 1.0f / p[3];
         float xs = ((p[0] * rw) * 0.5f + 0.5f) * vpW + vpX, ys = (0.5f - (p[1] * rw) * 0.5f) * vpH + vpY;   /* S1 */
         float xf = xs * 256.0f, yf = ys * 256.0f;
         if (!(fabsf(xf) <= 4194304.0f) || !(fabsf(yf) <= 4194304.0f)) return 0;              /* S2 */
-        t->X[k] = (int64_t)lrintf(xf); t->Y[k] = (int64_t)lrintf(yf); t->rw[k] = rw; t->vp[k] = vp;
+        t->X[k] = (int64_t)lrintf(xf); t->Y[k] = (int64_t)lrintf(yf); t->rw[k] = rw; t->vp[k] = vp[k];
     }
     int64_t a = (t->X[1] - t->X[0]) * (t->Y[2] - t->Y[0]) - (t->Y[1] - t->Y[0]) * (t->X[2] - t->X[0]);      /* S3 */
     if (a == 0) return 0;
     if (a < 0) {
         int64_t tx = t->X[1]; t->X[1] = t->X[2]; t->X[2] = tx; int64_t ty = t->Y[1]; t->Y[1] = t->Y[2]; t->Y[2] = ty;
-        float tr = t->rw[1]; t->rw[1] = t->rw[2]; t->rw[2] = tr; const uint8_t *tp = t->vp[1]; t->vp[1] = t->vp[2]; t->vp[2] = tp;
+        float tr = t->rw[1]; t->rw[1] = t->rw[2]; t->rw[2] = tr;
+        if (!clipped) { const uint8_t *tp = t->vp[1]; t->vp[1] = t->vp[2]; t->vp[2] = tp; }        /* clipped: the original vertices stay, the barycentric rows move */
+        else for (int c = 0; c < 3; c++) { float tb = t->B[1][c]; t->B[1][c] = t->B[2][c]; t->B[2][c] = tb; }
         a = -a;
     }
     t->area2 = a;
@@ -67,6 +128,16 @@ static void weights(const RasterTri *t, int64_t px, int64_t py, float q[3], floa
     *qs = (q[0] + q[1]) + q[2];
 }
 static float interp(const float q[3], float qs, float a0, float a1, float a2) { return ((q[0] * a0 + q[1] * a1) + q[2] * a2) / qs; }
+/* attribute values at the corners of a (sub-)triangle from the original vertices' values a[3] (S0) */
+static void corner_values(const RasterTri *t, const float a[3], float out[3]) {
+    if (!t->clipped) { out[0] = a[0]; out[1] = a[1]; out[2] = a[2]; return; }
+    for (int k = 0; k < 3; k++) out[k] = (t->B[k][0] * a[0] + t->B[k][1] * a[1]) + t->B[k][2] * a[2];
+}
+static float interp_attr(const RasterTri *t, const float q[3], float qs, float a0, float a1, float a2) {
+    const float a[3] = { a0, a1, a2 }; float c[3];
+    corner_values(t, a, c);
+    return interp(q, qs, c[0], c[1], c[2]);
+}
 
 /* Draw `count` instances (scene indices in `list`, draw order) into an RGBA8 target of w x h, rows [y0, y1). */
 void oraster_draw(const OScene *s, const int *list, int count, uint8_t *target, int w, int h, int y0, int y1, int applyScissorsAndViewports) {
@@ -90,8 +161,14 @@ void oraster_draw(const OScene *s, const int *list, int count, uint8_t *target, 
         if (scB > y1) scB = y1;
         const int triCount = mesh->indexCount / 3;
         for (int tri = 0; tri < triCount; tri++) {
+            float p[3][4]; const uint8_t *vp[3];
+            for (int k = 0; k < 3; k++) { vp[k] = mesh->vertices + (size_t)mesh->indices[3 * tri + k] * (size_t)mesh->vertexStride; memcpy(p[k], vp[k], 16); }
+            ClipVertex poly[RASTER_MAX_POLY]; int clipped = 0;
+            const int nv = clip_triangle(p, poly, &clipped);                                  /* S0 */
+            for (int sub = 1; sub + 1 < nv; sub++) {
             RasterTri t;
-            if (!setup_triangle(mesh, (uint32_t)tri, vpX, vpY, vpW, vpH, &t)) continue;
+            const ClipVertex corners[3] = { poly[0], poly[sub], poly[sub + 1] };
+            if (!setup_triangle(corners, vp, clipped, vpX, vpY, vpW, vpH, &t)) continue;
             int64_t minX = t.X[0], maxX = t.X[0], minY = t.Y[0], maxY = t.Y[0];
             for (int k = 1; k < 3; k++) { if (t.X[k] < minX) minX = t.X[k]; if (t.X[k] > maxX) maxX = t.X[k]; if (t.Y[k] < minY) minY = t.Y[k]; if (t.Y[k] > maxY) maxY = t.Y[k]; }
             int px0 = (int)(minX >> 8), px1 = (int)(maxX >> 8), py0 = (int)(minY >> 8), py1 = (int)(maxY >> 8);
@@ -110,13 +187,14 @@ void oraster_draw(const OScene *s, const int *list, int count, uint8_t *target, 
                     for (int i = 0; i < cc.inputCount; i++) {
                         float a[3][4];
                         for (int k = 0; k < 3; k++) { a[k][3] = 1.0f; memcpy(a[k], t.vp[k] + cc.inputOffset[i], cc.opt_alpha ? 16 : 12); }   /* VS: float4(iInput, 1) */
-                        inputs[i].x = interp(q, qs, a[0][0], a[1][0], a[2][0]); inputs[i].y = interp(q, qs, a[0][1], a[1][1], a[2][1]);
-                        inputs[i].z = interp(q, qs, a[0][2], a[1][2], a[2][2]); inputs[i].w = interp(q, qs, a[0][3], a[1][3], a[2][3]);
+                        inputs[i].x = interp_attr(&t, q, qs, a[0][0], a[1][0], a[2][0]); inputs[i].y = interp_attr(&t, q, qs, a[0][1], a[1][1], a[2][1]);
+                        inputs[i].z = interp_attr(&t, q, qs, a[0][2], a[1][2], a[2][2]); inputs[i].w = interp_attr(&t, q, qs, a[0][3], a[1][3], a[2][3]);
                     }
                     of4 texVal0 = { 0.0f, 0.0f, 0.0f, 0.0f };
                     if (cc.useTextures[0] && d->diffuse) {
-                        float uv[3][2];
-                        for (int k = 0; k < 3; k++) memcpy(uv[k], t.vp[k] + cc.uvOffset, 8);
+                        float uv[3][2], uraw[3][2];
+                        for (int k = 0; k < 3; k++) memcpy(uraw[k], t.vp[k] + cc.uvOffset, 8);
+                        for (int c = 0; c < 2; c++) { const float a[3] = { uraw[0][c], uraw[1][c], uraw[2][c] }; float o[3]; corner_values(&t, a, o); uv[0][c] = o[0]; uv[1][c] = o[1]; uv[2][c] = o[2]; }
                         float u = interp(q, qs, uv[0][0], uv[1][0], uv[2][0]), v = interp(q, qs, uv[0][1], uv[1][1], uv[2][1]);
                         float qx[3], qxs, qy[3], qys;                                       /* S7 */
                         weights(&t, cx + 256, cy, qx, &qxs); weights(&t, cx, cy + 256, qy, &qys);
@@ -135,6 +213,7 @@ void oraster_draw(const OScene *s, const int *list, int count, uint8_t *target, 
                     dst[0] = to_unorm8(src[0] * src[3] + dr * ia); dst[1] = to_unorm8(src[1] * src[3] + dg * ia);
                     dst[2] = to_unorm8(src[2] * src[3] + db * ia); dst[3] = to_unorm8(src[3] + da * ia);
                 }
+            }
         }
     }
 }

@@ -20,43 +20,53 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void raster_setup_kernel(const GpuRasterInstance *instances, uint32_t instanceCount, uint32_t triTotal,
-                                                           RasterTri *tris, int w, int h, int y0, int y1, int apply) {
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= triTotal) return;
-    uint32_t lo = 0, hi = instanceCount - 1;                                  // last instance with firstTri <= t
-    while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (instances[mid].firstTri <= t) lo = mid; else hi = mid - 1; }
-    const GpuRasterInstance &in = instances[lo];
-    const uint32_t tri = t - in.firstTri;
-    RasterTri r; memset(&r, 0, sizeof(r));
-    r.inst = lo; r.px0 = 1; r.px1 = 0; r.py0 = 1; r.py1 = 0;
-    float vpX = 0.0f, vpY = 0.0f, vpW = (float)w, vpH = (float)h;
-    int scL = 0, scT = 0, scR = w, scB = h;
-    if (apply) {                                                               // rt64_view.cpp:1114-1136
-        if (in.scissorRect[2] > 0 && in.scissorRect[3] > 0) { scL = in.scissorRect[0]; scT = h - in.scissorRect[1] - in.scissorRect[3]; scR = in.scissorRect[0] + in.scissorRect[2]; scB = h - in.scissorRect[1]; }
-        if (in.viewportRect[2] > 0 && in.viewportRect[3] > 0) { vpX = (float)in.viewportRect[0]; vpY = (float)(h - in.viewportRect[1] - in.viewportRect[3]); vpW = (float)in.viewportRect[2]; vpH = (float)in.viewportRect[3]; }
+// S0 (oracle/oracle_raster.c): plane distances of the homogeneous clipper, fp32, unfused.
+#define RASTER_W_EPS 9.5367431640625e-07f       // 2^-20
+#define RASTER_GUARD 4.0f
+struct ClipVertex { float c[7]; };               // x, y, z, w, b0, b1, b2
+DEV float clip_distance(int plane, const ClipVertex &v) {
+    const float x = v.c[0], y = v.c[1], z = v.c[2], w = v.c[3];
+    switch (plane) {
+    case 0: return w - RASTER_W_EPS;
+    case 1: return z;
+    case 2: return w - z;
+    case 3: return x + RASTER_GUARD * w;
+    case 4: return RASTER_GUARD * w - x;
+    case 5: return y + RASTER_GUARD * w;
+    default: return RASTER_GUARD * w - y;
     }
-    scL = max(scL, 0); scT = max(scT, y0); scR = min(scR, w); scB = min(scB, y1);
+}
+
+// S1-S3 of one (sub-)triangle into a record; false = nothing to draw (the record keeps an empty pixel box).
+DEV bool raster_setup_record(RasterTri &r, const ClipVertex v[3], const uint32_t vtx[3], bool clipped, uint32_t inst,
+                             float vpX, float vpY, float vpW, float vpH, int scL, int scT, int scR, int scB) {
+    memset(&r, 0, sizeof(r));
+    r.inst = inst; r.px0 = 1; r.px1 = 0; r.py0 = 1; r.py1 = 0; r.clipped = clipped ? 1u : 0u;
     bool ok = true;
     int64_t X[3], Y[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        const uint32_t v = in.indices[3 * tri + k];
-        const float *p = reinterpret_cast<const float *>(in.vertices + (size_t)v * in.vertexStride);
-        const float px = p[0], py = p[1], pw = p[3];
-        if (!(pw > 0.0f)) ok = false;                                                                      // S0
+        const float px = v[k].c[0], py = v[k].c[1], pw = v[k].c[3];
+        if (!(pw > 0.0f)) ok = false;
         const float rw = 1.0f / pw;
         const float xs = ((px * rw) * 0.5f + 0.5f) * vpW + vpX, ys = (0.5f - (py * rw) * 0.5f) * vpH + vpY;     // S1
         const float xf = xs * 256.0f, yf = ys * 256.0f;
         if (!(fabsf(xf) <= 4194304.0f) || !(fabsf(yf) <= 4194304.0f)) ok = false;                          // S2
         X[k] = ok ? (int64_t)__float2int_rn(xf) : 0; Y[k] = ok ? (int64_t)__float2int_rn(yf) : 0;
-        r.rw[k] = rw; r.vtx[k] = v;
+        r.rw[k] = rw; r.vtx[k] = vtx[k];
+#pragma unroll
+        for (int c = 0; c < 3; c++) r.B[k][c] = v[k].c[4 + c];
     }
     int64_t area2 = (X[1] - X[0]) * (Y[2] - Y[0]) - (Y[1] - Y[0]) * (X[2] - X[0]);                          // S3
     if (area2 == 0) ok = false;
     if (area2 < 0) {
         int64_t tx = X[1]; X[1] = X[2]; X[2] = tx; int64_t ty = Y[1]; Y[1] = Y[2]; Y[2] = ty;
-        float tr = r.rw[1]; r.rw[1] = r.rw[2]; r.rw[2] = tr; uint32_t tv = r.vtx[1]; r.vtx[1] = r.vtx[2]; r.vtx[2] = tv;
+        float tr = r.rw[1]; r.rw[1] = r.rw[2]; r.rw[2] = tr;
+        if (!clipped) { uint32_t tv = r.vtx[1]; r.vtx[1] = r.vtx[2]; r.vtx[2] = tv; }                       // clipped: the original vertices stay, the barycentric rows move
+        else {
+#pragma unroll
+            for (int c = 0; c < 3; c++) { float tb = r.B[1][c]; r.B[1][c] = r.B[2][c]; r.B[2][c] = tb; }
+        }
     }
     if (ok) {
 #pragma unroll
@@ -65,7 +75,78 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(const GpuRasterInstan
         r.px0 = max((int)(minX >> 8), scL); r.px1 = min((int)(maxX >> 8), scR - 1);
         r.py0 = max((int)(minY >> 8), scT); r.py1 = min((int)(maxY >> 8), scB - 1);
     }
-    tris[t] = r;
+    return ok;
+}
+
+__global__ __launch_bounds__(256) void raster_setup_kernel(const GpuRasterInstance *instances, uint32_t instanceCount, uint32_t triTotal,
+                                                           RasterTri *tris, int w, int h, int y0, int y1, int apply) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= triTotal) return;
+    uint32_t lo = 0, hi = instanceCount - 1;                                  // last instance with firstTri <= t
+    while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (instances[mid].firstTri <= t) lo = mid; else hi = mid - 1; }
+    const GpuRasterInstance &in = instances[lo];
+    const uint32_t tri = t - in.firstTri;
+    float vpX = 0.0f, vpY = 0.0f, vpW = (float)w, vpH = (float)h;
+    int scL = 0, scT = 0, scR = w, scB = h;
+    if (apply) {                                                               // rt64_view.cpp:1114-1136
+        if (in.scissorRect[2] > 0 && in.scissorRect[3] > 0) { scL = in.scissorRect[0]; scT = h - in.scissorRect[1] - in.scissorRect[3]; scR = in.scissorRect[0] + in.scissorRect[2]; scB = h - in.scissorRect[1]; }
+        if (in.viewportRect[2] > 0 && in.viewportRect[3] > 0) { vpX = (float)in.viewportRect[0]; vpY = (float)(h - in.viewportRect[1] - in.viewportRect[3]); vpW = (float)in.viewportRect[2]; vpH = (float)in.viewportRect[3]; }
+    }
+    scL = max(scL, 0); scT = max(scT, y0); scR = min(scR, w); scB = min(scB, y1);
+    // S0: homogeneous clipping
+    ClipVertex poly[RASTER_MAX_POLY + 1];
+    uint32_t vtx[3];
+    bool all = true;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        vtx[k] = in.indices[3 * tri + k];
+        const float *p = reinterpret_cast<const float *>(in.vertices + (size_t)vtx[k] * in.vertexStride);
+        poly[k].c[0] = p[0]; poly[k].c[1] = p[1]; poly[k].c[2] = p[2]; poly[k].c[3] = p[3];
+        poly[k].c[4] = k == 0 ? 1.0f : 0.0f; poly[k].c[5] = k == 1 ? 1.0f : 0.0f; poly[k].c[6] = k == 2 ? 1.0f : 0.0f;
+        for (int pl = 0; pl < 7; pl++) if (!(clip_distance(pl, poly[k]) >= 0.0f)) all = false;
+    }
+    const uint32_t extraBase = triTotal + RASTER_EXTRA_PER_TRI * t;
+    if (all) {
+        const ClipVertex c3[3] = { poly[0], poly[1], poly[2] };
+        RasterTri r;
+        raster_setup_record(r, c3, vtx, false, lo, vpX, vpY, vpW, vpH, scL, scT, scR, scB);
+        r.extraFirst = extraBase; r.extraCount = 0;
+        tris[t] = r;
+        return;
+    }
+    int n = 3;
+    for (int pl = 0; pl < 7 && n >= 3; pl++) {
+        ClipVertex out[RASTER_MAX_POLY + 1]; int m = 0;
+        for (int i = 0; i < n; i++) {
+            const ClipVertex &A = poly[i], &Bv = poly[(i + 1) % n];
+            const float dA = clip_distance(pl, A), dB = clip_distance(pl, Bv);
+            const bool inA = dA >= 0.0f, inB = dB >= 0.0f;
+            if (inA && m < RASTER_MAX_POLY) out[m++] = A;
+            if (inA != inB && m < RASTER_MAX_POLY) {
+                const ClipVertex &P = inA ? A : Bv, &Q = inA ? Bv : A;
+                const float dP = inA ? dA : dB, dQ = inA ? dB : dA;
+                const float tt = dP / (dP - dQ);
+                for (int c = 0; c < 7; c++) out[m].c[c] = P.c[c] + tt * (Q.c[c] - P.c[c]);
+                m++;
+            }
+        }
+        n = m;
+        for (int i = 0; i < n; i++) poly[i] = out[i];
+    }
+    if (n < 3) n = 0;
+    uint32_t pieces = 0;
+    RasterTri first; bool haveFirst = false;
+    for (int sub = 1; sub + 1 < n; sub++) {
+        const ClipVertex c3[3] = { poly[0], poly[sub], poly[sub + 1] };
+        RasterTri r;
+        raster_setup_record(r, c3, vtx, true, lo, vpX, vpY, vpW, vpH, scL, scT, scR, scB);       // a degenerate piece keeps an empty pixel box
+        r.extraFirst = extraBase; r.extraCount = 0;
+        if (!haveFirst) { first = r; haveFirst = true; }
+        else tris[extraBase + pieces++] = r;
+    }
+    if (!haveFirst) { const ClipVertex z3[3] = { poly[0], poly[0], poly[0] }; raster_setup_record(first, z3, vtx, true, lo, vpX, vpY, vpW, vpH, scL, scT, scR, scB); first.px0 = 1; first.px1 = 0; first.py0 = 1; first.py1 = 0; first.extraFirst = extraBase; }
+    first.extraCount = pieces;
+    tris[t] = first;
 }
 
 __global__ __launch_bounds__(256) void raster_draw_kernel(const GpuRasterInstance *__restrict__ instances, const RasterTri *__restrict__ tris, uint32_t triTotal,
@@ -83,7 +164,7 @@ __global__ __launch_bounds__(256) void raster_draw_kernel(const GpuRasterInstanc
 
 }  // namespace
 
-size_t raster_tri_bytes(uint32_t triTotal) { return (size_t)triTotal * sizeof(RasterTri); }
+size_t raster_tri_bytes(uint32_t triTotal) { return (size_t)triTotal * (1 + RASTER_EXTRA_PER_TRI) * sizeof(RasterTri); }       // first pieces + the clipper's further pieces
 
 hipError_t launch_raster_setup(const GpuRasterInstance *instances, uint32_t instanceCount, uint32_t triTotal, void *tris, int w, int h, int y0, int y1, bool apply, hipStream_t s) {
     if (instanceCount == 0 || triTotal == 0) return hipSuccess;

@@ -638,7 +638,8 @@ void View::prepareRasterList(const std::vector<RenderInstance> &list, RasterList
         if (apply && inst->viewportRect.w > 0 && inst->viewportRect.h > 0) { vpX = (float)inst->viewportRect.x; vpY = (float)(h - inst->viewportRect.y - inst->viewportRect.h); vpW = (float)inst->viewportRect.w; vpH = (float)inst->viewportRect.h; }
         for (int v = 0; v < inst->mesh->vertexCount; v++) {
             float p[4]; memcpy(p, inst->mesh->hostVertices.data() + (size_t)v * inst->mesh->vertexStride, 16);
-            if (!(p[3] > 0.0f)) continue;
+            // a vertex outside the clipper's planes (w, near / far, guard band): the clipped pieces can land anywhere on the target
+            if (!(p[3] > 1e-3f) || !(fabsf(p[0]) <= 4.0f * p[3]) || !(fabsf(p[1]) <= 4.0f * p[3])) { bx0 = by0 = -1e9f; bx1 = by1 = 1e9f; continue; }
             const float rw = 1.0f / p[3], xs = ((p[0] * rw) * 0.5f + 0.5f) * vpW + vpX, ys = (0.5f - (p[1] * rw) * 0.5f) * vpH + vpY;
             bx0 = std::min(bx0, xs); bx1 = std::max(bx1, xs); by0 = std::min(by0, ys); by1 = std::max(by1, ys);
         }
