@@ -328,7 +328,8 @@ enum {
     RT64_IMAGE_VIEW_DIRECTION = 19,    /* [f32 x4] */
     RT64_IMAGE_FIRST_INSTANCE_ID = 20, /* [i32]    copy used by GetViewRaytracedInstanceAt           */
     RT64_IMAGE_BACKGROUND = 21,        /* [u8 x 4] gBackground: raster background instances, screen size (zeros when there are none) */
-    RT64_IMAGE_COUNT_ = 22
+    RT64_IMAGE_UPSCALED = 22,          /* [f32 x4] rtOutputUpscaled, screen size: colour + accumulated frames (only behind an upscaler) */
+    RT64_IMAGE_COUNT_ = 23
 };
 
 /* Arrays returned by RT64_ReadbackMeshAccel / RT64_ReadbackViewAccel. */

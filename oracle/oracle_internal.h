@@ -100,6 +100,7 @@ struct OScene {
     float *flow, *reactiveMask, *lockMask, *depth[2];
     uint32_t *primaryHit;
     float *moments[2];                     /* SVGF: luminance moments + history */
+    float *upscaled[2]; int upW, upH, upValid, upSwap;      /* rtOutputUpscaled ping-pong (display size), oracle_upscale.c */
     int rtSwap;
 };
 
@@ -126,6 +127,10 @@ void otex_sample_grad(const OTexture *t, float u, float v, of2 ddx, of2 ddy, int
 
 /* oracle_raster.c */
 void oraster_draw(const OScene *s, const int *list, int count, uint8_t *target, int w, int h, int y0, int y1, int applyScissorsAndViewports);
+
+/* oracle_upscale.c */
+void oupscale_frame(const float *color, const float *flow, const float *reactive, const float *lock, const float *depth, int rw, int rh,
+                    float jx, float jy, const float *prev, float *out, int dw, int dh, int haveHistory);
 
 /* oracle_render.c / oracle_shade.c */
 int omatrix_inverse_d(const om4 *m, om4 *out);

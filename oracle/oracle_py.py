@@ -57,7 +57,8 @@ class OFrameParams(C.Structure):
                 ("diSamples", C.c_uint), ("giSamples", C.c_uint), ("maxLights", C.c_uint),
                 ("denoiserEnabled", C.c_int), ("denoiserMode", C.c_int),
                 ("motionBlurStrength", C.c_float), ("motionBlurSamples", C.c_uint), ("maxReflections", C.c_int),
-                ("bruteForce", C.c_int), ("cullBehindOpaque", C.c_int), ("threads", C.c_int), ("resolutionScale", C.c_float)]
+                ("bruteForce", C.c_int), ("cullBehindOpaque", C.c_int), ("threads", C.c_int), ("resolutionScale", C.c_float),
+                ("upscaler", C.c_int), ("upscalerMode", C.c_int)]
 
 
 _FP = C.POINTER(C.c_float)
@@ -78,7 +79,7 @@ class OFrameResult(C.Structure):
                 ("nodesVisitedPrimary", C.c_uint64), ("trianglesTestedPrimary", C.c_uint64),
                 ("nodesVisitedShadow", C.c_uint64), ("trianglesTestedShadow", C.c_uint64),
                 ("secondsBuild", C.c_double), ("secondsRender", C.c_double), ("screenWidth", C.c_int), ("screenHeight", C.c_int),
-                ("backgroundRGBA8", C.POINTER(C.c_uint8))]
+                ("backgroundRGBA8", C.POINTER(C.c_uint8)), ("upscaledRGBA32F", _FP), ("pixelJitter", C.c_float * 2)]
 
 
 class ONode(C.Structure):
@@ -123,6 +124,7 @@ def lib():
         "oracle_init_rand": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32]),
         "oracle_next_rand": (C.c_float, [C.POINTER(C.c_uint32)]),
         "oracle_halton": (C.c_float, [C.c_int, C.c_int]),
+        "oracle_upscaler_info": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "oracle_rgb_to_hsl": (None, [_FP, _FP]), "oracle_hsl_to_rgb": (None, [_FP, _FP]),
         "oracle_fake_envmap_uv": (None, [_FP, C.c_float, _FP]),
         "oracle_perspective_fov_rh": (None, [C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(M4)]),
@@ -185,7 +187,7 @@ class OracleScene:
             d = self._desc(inst)
             L.oracle_scene_add_instance(self.scene, C.byref(d))
         self.params = dict(diSamples=0, giSamples=0, maxLights=12, denoiserEnabled=0, denoiserMode=0,
-                           motionBlurStrength=0.0, motionBlurSamples=32, maxReflections=2)
+                           motionBlurStrength=0.0, motionBlurSamples=32, maxReflections=2, upscaler=0, upscalerMode=0)
 
     def set_mesh(self, handle, vertices, indices):
         v = np.ascontiguousarray(vertices); i = np.ascontiguousarray(indices, dtype=np.uint32)
@@ -250,6 +252,9 @@ class OracleScene:
         }
         out["background"] = (np.ctypeslib.as_array(r.backgroundRGBA8, shape=(screen_h * screen_w * 4,)).copy().reshape(screen_h, screen_w, 4)
                              if r.backgroundRGBA8 else None)
+        out["upscaled"] = (np.ctypeslib.as_array(r.upscaledRGBA32F, shape=(screen_h * screen_w * 4,)).copy().reshape(screen_h, screen_w, 4)
+                           if r.upscaledRGBA32F else None)
+        out["pixelJitter"] = (float(r.pixelJitter[0]), float(r.pixelJitter[1]))
         out["counters"] = {k: getattr(r, k) for k in ("primaryRays", "shadowRays", "indirectRays", "reflectionRays", "refractionRays",
                                                       "nodesVisited", "trianglesTested", "nodesVisitedPrimary", "trianglesTestedPrimary",
                                                       "nodesVisitedShadow", "trianglesTestedShadow", "secondsBuild", "secondsRender")}

@@ -88,7 +88,7 @@ static void free_images(OScene *s) {
 
 void oracle_scene_destroy(OScene *s) {
     if (!s) return;
-    free_images(s); free(s->finalRGBA8); free(s->backgroundRGBA8); free(s->blueNoise); free(s->instances); free(s->rt); obvh_free(&s->tlas); free(s);
+    free_images(s); free(s->upscaled[0]); free(s->upscaled[1]); free(s->finalRGBA8); free(s->backgroundRGBA8); free(s->blueNoise); free(s->instances); free(s->rt); obvh_free(&s->tlas); free(s);
 }
 
 void oracle_scene_set_desc(OScene *s, const OSceneDesc *d) { s->desc = *d; }
@@ -818,7 +818,7 @@ static void sample_linear_wrap(const float *img, int ch, int w, int h, float u, 
 }
 /* `vp` = viewport (x, y, w, h) and `sc` = scissor (left, top, right, bottom) the full-screen triangle is drawn with: the screen unless
  * the first ray-traced instance carries its own rectangles (ref:rt64_view.cpp:1258-1271,1624-1626). */
-static void pass_post(OScene *s, const OFrameParams *p, int rtW, int rtH, int screenW, int screenH, const float vp[4], const int sc[4]) {
+static void pass_post(OScene *s, const OFrameParams *p, const float *src, int srcW, int srcH, int rtW, int rtH, int screenW, int screenH, const float vp[4], const int sc[4]) {
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < screenH; y++)
         for (int x = 0; x < screenW; x++) {
@@ -841,14 +841,14 @@ static void pass_post(OScene *s, const OFrameParams *p, int rtW, int rtH, int sc
                         float uu = su + flx * (float)k * sampleStep, vv = sv + fly * (float)k * sampleStep;
                         uu = fminf(fmaxf(uu, 0.0f), 1.0f); vv = fminf(fmaxf(vv, 0.0f), 1.0f);
                         float c4[4];
-                        sample_linear_wrap(s->outputRGBA32F, 4, rtW, rtH, uu, vv, c4);
+                        sample_linear_wrap(src, 4, srcW, srcH, uu, vv, c4);
                         sum[0] += c4[0] * 1.0f; sum[1] += c4[1] * 1.0f; sum[2] += c4[2] * 1.0f; sumWeight += 1.0f;
                     }
                     color[0] = sum[0] / sumWeight; color[1] = sum[1] / sumWeight; color[2] = sum[2] / sumWeight;
                     blurred = 1;
                 }
             }
-            if (!blurred) sample_linear_wrap(s->outputRGBA32F, 4, rtW, rtH, u, v, color);
+            if (!blurred) sample_linear_wrap(src, 4, srcW, srcH, u, v, color);
             uint8_t *f = s->finalRGBA8 + 4 * ((size_t)y * (size_t)screenW + (size_t)x);
             f[0] = to_unorm8(color[0]); f[1] = to_unorm8(color[1]); f[2] = to_unorm8(color[2]); f[3] = 255;
         }
@@ -861,9 +861,13 @@ int oracle_render(OScene *s, const OFrameParams *pIn, OFrameResult *out) {
     const float scale = pIn->resolutionScale > 0.0f ? pIn->resolutionScale : 1.0f;
     OFrameParams local = *pIn;
     local.width = (int)lroundf((float)screenW * scale); local.height = (int)lroundf((float)screenH * scale);
+    /* An upscaler decides the render size itself (View::createOutputBuffers, ref:rt64_view.cpp:114-136; upscalerResolutionOverride is off) */
+    int upW = 0, upH = 0, phases = 1;
+    const int upscale = oracle_upscaler_info(pIn->upscaler, pIn->upscalerMode, screenW, screenH, &upW, &upH, &phases);
+    if (upscale) { local.width = upW; local.height = upH; }
     if (local.width < 1) local.width = 1;
     if (local.height < 1) local.height = 1;
-    int separatePost = local.width != screenW || local.height != screenH || (pIn->motionBlurStrength > 0.0f && pIn->motionBlurSamples > 0);
+    int separatePost = upscale || local.width != screenW || local.height != screenH || (pIn->motionBlurStrength > 0.0f && pIn->motionBlurSamples > 0);
     /* Viewport / scissor of the ray-traced content: the rectangles of the first ray-traced instance, when it has any (ref:rt64_view.cpp:1258-1271). */
     float rtVp[4] = { 0.0f, 0.0f, (float)screenW, (float)screenH };
     int rtSc[4] = { 0, 0, screenW, screenH }, rtRect = 0;
@@ -889,6 +893,17 @@ int oracle_render(OScene *s, const OFrameParams *pIn, OFrameResult *out) {
     update_view(s, p);
     OShadeCtx ctx;
     update_global_params(s, p, screenW, screenH, &ctx);
+    if (upscale) {                  /* jitter only with an upscaler (ref:rt64_view.cpp:1273-1281); FSR takes a continuous lock mask (:1018) */
+        const int fi = (int)(s->frameCount % (uint32_t)phases) + 1;
+        ctx.pixelJitter.x = oracle_halton(fi, 2) - 0.5f; ctx.pixelJitter.y = oracle_halton(fi, 3) - 0.5f;
+        ctx.binaryLockMask = 0;
+        if (s->upW != screenW || s->upH != screenH) {
+            for (int k = 0; k < 2; k++) { free(s->upscaled[k]); s->upscaled[k] = (float *)calloc((size_t)screenW * (size_t)screenH * 4, sizeof(float)); }
+            s->upW = screenW; s->upH = screenH; s->upValid = 0;
+        }
+        if (!s->haveHistory) s->upValid = 0;           /* buffers were (re)created: the accumulation starts over */
+    }
+    else s->upValid = 0;
     ctx.separatePost = separatePost;
     ctx.viewportW = rtVp[2]; ctx.viewportH = rtVp[3];                 /* gParams.viewport.zw, ref:rt64_view.cpp:1283-1286 */
     /* Raster instances: everything that is not ray traced, background-flagged ones first (View::update, ref:rt64_view.cpp:1138-1147). */
@@ -934,7 +949,15 @@ int oracle_render(OScene *s, const OFrameParams *pIn, OFrameResult *out) {
             for (size_t i = 0; i < ns; i++) s->finalRGBA8[4 * i + 3] = 255;
             oraster_draw(s, bgList, bgCount, s->finalRGBA8, screenW, screenH, 0, screenH, 1);
         }
-        if (separatePost) pass_post(s, p, p->width, p->height, screenW, screenH, rtVp, rtSc);
+        const float *postSrc = s->outputRGBA32F; int postW = p->width, postH = p->height;
+        if (upscale) {              /* Upscaler::upscale, ref:rt64_view.cpp:1584-1618: jitterX/Y = -pixelJitter is the sample offset convention of the SDKs */
+            const int uc = s->upSwap;
+            oupscale_frame(s->outputRGBA32F, s->flow, s->reactiveMask, s->lockMask, s->depth[cur], p->width, p->height, ctx.pixelJitter.x, ctx.pixelJitter.y,
+                           s->upscaled[uc ^ 1], s->upscaled[uc], screenW, screenH, s->upValid);
+            postSrc = s->upscaled[uc]; postW = screenW; postH = screenH;
+            s->upValid = 1; s->upSwap ^= 1;
+        }
+        if (separatePost) pass_post(s, p, postSrc, postW, postH, p->width, p->height, screenW, screenH, rtVp, rtSc);
     }
     else {
         const size_t ns = (size_t)screenW * (size_t)screenH;
@@ -951,6 +974,8 @@ int oracle_render(OScene *s, const OFrameParams *pIn, OFrameResult *out) {
         memset(out, 0, sizeof(*out));
         out->width = p->width; out->height = p->height; out->screenWidth = screenW; out->screenHeight = screenH;
         out->backgroundRGBA8 = bgCount > 0 ? s->backgroundRGBA8 : NULL;
+        out->upscaledRGBA32F = (upscale && s->rtCount > 0) ? s->upscaled[s->upSwap ^ 1] : NULL;
+        out->pixelJitter[0] = ctx.pixelJitter.x; out->pixelJitter[1] = ctx.pixelJitter.y;
         out->finalRGBA8 = s->finalRGBA8; out->outputRGBA32F = s->outputRGBA32F; out->shadingPosition = s->shadingPosition;
         out->shadingNormal = s->shadingNormal; out->shadingSpecular = s->shadingSpecular; out->diffuse = s->diffuse;
         out->instanceId = s->instanceId; out->directLight = s->directLight[cur]; out->indirectLight = s->indirectLight[cur];

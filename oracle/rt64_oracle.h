@@ -127,6 +127,9 @@ typedef struct {
     /* RT64_VIEW_DESC.resolutionScale (ref:rt64_view.cpp:138-139): width/height above are the SCREEN size, every image except
      * finalRGBA8 is lround(screen * scale); 0 or 1 = off.  With a scale != 1 (or motion blur) the whole frame is rendered. */
     float resolutionScale;
+    /* RT64_VIEW_DESC.upscaler / upscalerMode (RT64_UPSCALER_*, RT64_UPSCALER_MODE_*): AUTO / FSR select the built-in temporal upscaler
+     * (oracle_upscale.c): the render size comes from the quality mode, primary rays are jittered, PostProcessPS reads the upscaled image. */
+    int upscaler, upscalerMode;
 } OFrameParams;
 
 /* Output images of one frame, full-frame row-major arrays owned by the scene (valid until next render). */
@@ -148,6 +151,8 @@ typedef struct {
     double secondsBuild, secondsRender;
     int screenWidth, screenHeight;                /* size of finalRGBA8 */
     const uint8_t *backgroundRGBA8;               /* [screenHeight][screenWidth][4]: gBackground (raster background instances), NULL when there are none */
+    const float *upscaledRGBA32F;                 /* [screenHeight][screenWidth][4]: rtOutputUpscaled (rgb, accumulated frames), NULL without an upscaler */
+    float pixelJitter[2];
 } OFrameResult;
 
 /* ---- API --------------------------------------------------------------------------------------------- */
@@ -188,6 +193,8 @@ uint32_t oracle_scene_frame_count(const OScene *s);
 uint32_t oracle_init_rand(uint32_t v0, uint32_t v1, uint32_t backoff);      /* ref:shaders/Random.hlsli:14-26 */
 float oracle_next_rand(uint32_t *s);                                        /* ref:shaders/Random.hlsli:28-37 */
 float oracle_halton(int i, int b);                                          /* ref:private/rt64_common.h:347-357 */
+/* render size + jitter phase count of the built-in upscaler for a display size; 0 = this (upscaler, mode) selects no upscaler */
+int oracle_upscaler_info(int upscaler, int mode, int displayW, int displayH, int *renderW, int *renderH, int *phases);
 void oracle_rgb_to_hsl(const float rgb[3], float hsl[3]);                   /* ref:shaders/Color.hlsli:36-42 */
 void oracle_hsl_to_rgb(const float hsl[3], float rgb[3]);                   /* ref:shaders/Color.hlsli:29-34 */
 void oracle_fake_envmap_uv(const float dir[3], float yaw, float uv[2]);     /* ref:shaders/BgSky.hlsli:14-18 */

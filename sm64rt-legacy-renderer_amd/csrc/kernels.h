@@ -67,3 +67,8 @@ hipError_t launch_raster_draw(const GpuRasterInstance *instances, const void *tr
 #define SVGF_HALO_ROWS 66            // rows of neighbourhood the SVGF result of a row depends on (62 a-trous + 3 variance + 1 gradient)
 #define GAUSSIAN_HALO_ROWS 5         // five 3x3 passes
 hipError_t launch_svgf(const ViewImages &I, int cur, int width, int height, int y0, int y1, hipStream_t s);
+
+// ---- upscale.hip ---------------------------------------------------------------------------------------------------
+// Temporal upscaler stage (Upscaler::upscale, rt64_view.cpp:1584-1618): rtOutput + flow + masks + depth (render size rw x rh, jitter jx / jy)
+// and the previous upscaled image -> `out` (display size dw x dh, RGBA32F: colour + accumulated frame count).
+hipError_t launch_taa_upsample(const ViewImages &I, int cur, int rw, int rh, float jx, float jy, const float *prev, float *out, int dw, int dh, bool haveHistory, hipStream_t s);

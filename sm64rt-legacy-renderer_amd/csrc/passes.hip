@@ -1269,14 +1269,14 @@ __global__ __launch_bounds__(256) void post_process_kernel(FrameParams Pv, ViewI
             for (uint32_t k = 0; k < P.motionBlurSamples; k++) {
                 float uu = su + flx * (float)k * sampleStep, vv = sv + fly * (float)k * sampleStep;
                 uu = fminf(fmaxf(uu, 0.0f), 1.0f); vv = fminf(fmaxf(vv, 0.0f), 1.0f);
-                const f4 c = sample_output_linear_wrap(I.output, P.width, P.height, uu, vv);
+                const f4 c = sample_output_linear_wrap(P.postSource, P.postSourceW, P.postSourceH, uu, vv);
                 sr += c.x * 1.0f; sg += c.y * 1.0f; sb += c.z * 1.0f; sumWeight += 1.0f;
             }
             color = mk4(sr / sumWeight, sg / sumWeight, sb / sumWeight, 1.0f);
             blurred = true;
         }
     }
-    if (!blurred) color = sample_output_linear_wrap(I.output, P.width, P.height, u, v);
+    if (!blurred) color = sample_output_linear_wrap(P.postSource, P.postSourceW, P.postSourceH, u, v);
     store_rgba8(I.final, (size_t)y * (size_t)sw + x, color.x, color.y, color.z, 1.0f);
 }
 

@@ -118,6 +118,7 @@ struct FrameParams {
     // traversal stacks, the ray kernels copy them in once per workgroup and walk from there.  cacheWords = size in 16-byte words, 0 = off.
     uint32_t cacheWords, cacheInstances;
     uint32_t separatePost;               // 1: render size != screen size or motion blur on -> PostProcessPS runs as post_process_kernel
+    const float *postSource; int32_t postSourceW, postSourceH;      // image PostProcessPS samples: rtOutput (render size), or rtOutputUpscaled (screen size) behind an upscaler (rt64_view.cpp:800-801)
     // Foreground (HUD) raster list folded into the one-kernel lean frame: table + triangle records of raster.hip, 0 triangles = not folded.
     const GpuRasterInstance *rasterFg; const void *rasterFgTris; uint32_t rasterFgCount, rasterFgPad;
     uint32_t *finalPacked;               // RT64_SetDeviceGatherTarget: the owned rows of the back buffer, packed strip after strip (nullptr = off)

@@ -262,6 +262,10 @@ struct View {
     // RT64_VIEW_DESC state + inspector-only knobs, defaults of rt64_view.cpp:47-66
     float resolutionScale = 1.0f, motionBlurStrength = 0.0f; uint32_t diSamples = 0, giSamples = 0, maxLights = 12, motionBlurSamples = 32;
     bool denoiserEnabled = false;
+    // RT64_VIEW_DESC.upscaler / upscalerMode: AUTO and FSR select the built-in temporal upscaler (upscale.hip); the vendor SDKs do not exist here
+    int upscaler = RT64_UPSCALER_OFF, upscalerMode = RT64_UPSCALER_MODE_AUTO; float upscalerSharpness = 0.0f;
+    bool upscaleActive = false; int jitterPhases = 1; float pixelJitter[2] = { 0.0f, 0.0f };
+    float *upscaled[2] = { nullptr, nullptr }; int upW = 0, upH = 0, upSwap = 0; bool upValid = false;
     Texture *skyPlane = nullptr;
     Mat4 view = mat_identity(), projection = mat_identity(), viewI = mat_identity(), projectionI = mat_identity(), viewProj = mat_identity(), prevViewI = mat_identity(), prevViewProj = mat_identity();
     float fov = 0.0f, nearDist = 0.0f, farDist = 0.0f; bool canReproject = true, matricesValid = false, perspectiveSet = false;
@@ -271,7 +275,7 @@ struct View {
     // rectangle of the ray-traced picture: the first ray-traced instance's scissor / viewport when it has any (rt64_view.cpp:1258-1271)
     float rtViewport[4] = { 0, 0, 0, 0 }; int rtScissor[4] = { 0, 0, 0, 0 }; bool rtRect = false;
     uint32_t cacheWords = 0;                   // LDS scene cache size in 16-byte words (0: the scene does not fit / option lds_cache = 0)
-    bool separatePost() const { return rtRect || imgW != finalW || imgH != finalH || (motionBlurStrength > 0.0f && motionBlurSamples > 0); }
+    bool separatePost() const { return upscaleActive || rtRect || imgW != finalW || imgH != finalH || (motionBlurStrength > 0.0f && motionBlurSamples > 0); }
     // device images
     ViewImages img = {};
     std::vector<void *> allocations; uint32_t bounceSamples = 0;
@@ -537,6 +541,34 @@ Instance::~Instance() { auto &v = scene->instances; v.erase(std::remove(v.begin(
 
 // ---- View ---------------------------------------------------------------------------------------------------------------------
 
+// Render size and jitter phase count of the built-in temporal upscaler for a display size; false = (upscaler, mode) selects none.
+// Quality table: rt64_fsr.cpp:98-126 (Native 100 %, UltraQuality 77 %, FSR2's published 1.5 / 1.7 / 2.0 / 3.0 ratios), Auto by display
+// size rt64_upscaler.cpp:11-36; phases = int(8 (display / render)^2) is what ffxFsr2GetJitterPhaseCount (rt64_fsr.cpp:128-130) returns.
+static bool upscaler_info(int upscaler, int mode, int displayW, int displayH, int &renderW, int &renderH, int &phases) {
+    if (!(upscaler == RT64_UPSCALER_AUTO || upscaler == RT64_UPSCALER_FSR)) return false;
+    if (mode == RT64_UPSCALER_MODE_AUTO) {
+        const uint64_t px = (uint64_t)displayW * (uint64_t)displayH;
+        mode = px <= 1280ull * 720 ? RT64_UPSCALER_MODE_ULTRA_QUALITY : (px <= 1920ull * 1080 ? RT64_UPSCALER_MODE_QUALITY : (px <= 2560ull * 1440 ? RT64_UPSCALER_MODE_BALANCED :
+               (px <= 3840ull * 2160 ? RT64_UPSCALER_MODE_PERFORMANCE : RT64_UPSCALER_MODE_ULTRA_PERFORMANCE)));
+    }
+    int w, h;
+    if (mode == RT64_UPSCALER_MODE_NATIVE) { w = displayW; h = displayH; }
+    else if (mode == RT64_UPSCALER_MODE_ULTRA_QUALITY) { w = (displayW * 77) / 100; h = (displayH * 77) / 100; }
+    else {
+        const float ratio = mode == RT64_UPSCALER_MODE_QUALITY ? 1.5f : (mode == RT64_UPSCALER_MODE_BALANCED ? 1.7f : (mode == RT64_UPSCALER_MODE_PERFORMANCE ? 2.0f : 3.0f));
+        w = (int)((float)displayW / ratio); h = (int)((float)displayH / ratio);
+    }
+    renderW = std::max(w, 1); renderH = std::max(h, 1);
+    const float q = (float)displayW / (float)renderW;
+    phases = std::max((int)(8.0f * (q * q)), 1);
+    return true;
+}
+static float halton_sequence(int i, int b) {          // rt64_common.h:347-357
+    float f = 1.0f, r = 0.0f;
+    while (i > 0) { f = f / (float)b; r = r + f * (float)(i % b); i = i / b; }
+    return r;
+}
+
 View::View(Scene *s) : scene(s) {
     s->views.push_back(this);
     createImages(s->device->width, s->device->height, s->device->width, s->device->height);
@@ -545,7 +577,12 @@ View::~View() {
     auto &v = scene->views; v.erase(std::remove(v.begin(), v.end(), this), v.end());
     releaseImages();
 }
-void View::releaseImages() { for (void *p : allocations) hipFree(p); allocations.clear(); img = ViewImages(); bounceSamples = 0; leanFrame = false; fusedFrame = false; }
+void View::releaseImages() {
+    for (void *p : allocations) hipFree(p);
+    allocations.clear(); img = ViewImages(); bounceSamples = 0; leanFrame = false; fusedFrame = false;
+    for (auto &u : upscaled) { if (u) hipFree(u); u = nullptr; }
+    upW = upH = 0; upValid = false;
+}
 
 void View::createImages(int w, int h, int screenW, int screenH) {       // View::createOutputBuffers, rt64_view.cpp:105-298 (same formats)
     scene->device->use();
@@ -670,8 +707,17 @@ void View::update() {                          // View::update, rt64_view.cpp:10
     Device *dev = scene->device;
     {   // View::createOutputBuffers: render size = lround(screen * resolutionScale) (rt64_view.cpp:138-139)
         const float scale = resolutionScale > 0.0f ? resolutionScale : 1.0f;
-        const int rw = std::max(1, (int)lroundf((float)dev->width * scale)), rh = std::max(1, (int)lroundf((float)dev->height * scale));
+        int rw = std::max(1, (int)lroundf((float)dev->width * scale)), rh = std::max(1, (int)lroundf((float)dev->height * scale));
+        // an upscaler decides the render size itself (rt64_view.cpp:114-136; upscalerResolutionOverride is off and not reachable through the C API)
+        int uw = 0, uh = 0, phases = 1;
+        upscaleActive = upscaler_info(upscaler, upscalerMode, dev->width, dev->height, uw, uh, phases);
+        if (upscaleActive) { rw = uw; rh = uh; jitterPhases = phases; }
         if (imgW != rw || imgH != rh || finalW != dev->width || finalH != dev->height) createImages(rw, rh, dev->width, dev->height);
+        if (upscaleActive && (upW != dev->width || upH != dev->height)) {
+            for (auto &u : upscaled) { if (u) hipFree(u); u = nullptr; HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&u), (size_t)dev->width * dev->height * 16)); }
+            upW = dev->width; upH = dev->height; upValid = false;
+        }
+        if (!upscaleActive) upValid = false;
     }
     usedTextures.clear();
     auto textureIndex = [&](Texture *t) -> int {
@@ -844,18 +890,22 @@ void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64
     P.cameraU[0] = U.x; P.cameraU[1] = U.y; P.cameraU[2] = U.z; P.cameraV[0] = V.x; P.cameraV[1] = V.y; P.cameraV[2] = V.z; P.cameraW[0] = W.x; P.cameraW[1] = W.y; P.cameraW[2] = W.z;
     for (int k = 0; k < 4; k++) { P.viewport[k] = rtViewport[k]; P.rtViewport[k] = rtViewport[k]; P.rtScissor[k] = rtScissor[k]; }      // gParams.viewport = rtViewport (rt64_view.cpp:1283-1286)
     P.resolution[0] = (float)imgW; P.resolution[1] = (float)imgH; P.resolution[2] = (float)dev->width; P.resolution[3] = (float)dev->height;
-    P.pixelJitter[0] = P.pixelJitter[1] = 0.0f;              // jitter only with an upscaler (:1273-1281)
+    // jitter only with an upscaler (:1273-1281): HaltonJitter(frameCount, phases), rt64_common.h:359-361
+    pixelJitter[0] = pixelJitter[1] = 0.0f;
+    if (upscaleActive) { const int fi = (int)(frameCount % (uint32_t)jitterPhases) + 1; pixelJitter[0] = halton_sequence(fi, 2) - 0.5f; pixelJitter[1] = halton_sequence(fi, 3) - 0.5f; }
+    P.pixelJitter[0] = pixelJitter[0]; P.pixelJitter[1] = pixelJitter[1];
     P.motionBlurStrength = motionBlurStrength; P.motionBlurSamples = motionBlurSamples;
     P.skyPlaneTexIndex = skyPlane ? 0 : -1;
     P.randomSeed = frameCount; P.frameCount = frameCount;
     P.diSamples = diSamples; P.giSamples = giSamples; P.maxLights = maxLights;
     P.diReproject = 0;                                        // DI_REPROJECTION_SUPPORT undefined (:1012-1016)
     P.giReproject = (!skipReprojection && denoiserEnabled && giSamples > 0) ? 1u : 0u;
-    P.binaryLockMask = 1;                                     // rtUpscaleMode != FSR
+    P.binaryLockMask = upscaleActive ? 0u : 1u;               // rtUpscaleMode != FSR (:1018): the built-in stage stands where FSR does and takes the continuous mask
     P.visualizationMode = 0;
     P.width = imgW; P.height = imgH; P.tileY0 = dev->tileY0; P.tileY1 = dev->tileY1; P.stripRank = dev->stripRank; P.stripCount = dev->stripCount;
     P.cacheWords = cacheWords; P.cacheInstances = cacheWords ? (uint32_t)rtInstances.size() : 0u;
     P.separatePost = separatePost() ? 1u : 0u;
+    P.postSource = img.output; P.postSourceW = imgW; P.postSourceH = imgH;
     P.rasterFg = nullptr; P.rasterFgTris = nullptr; P.rasterFgCount = 0; P.rasterFgPad = 0; P.finalPacked = nullptr;
     memset(&P.background, 0, sizeof(P.background));
     if (rasterBgEnv.ready) { P.background.texels = background.ptr; P.background.width = (uint32_t)backgroundW; P.background.height = (uint32_t)backgroundH; P.background.mips = 1; P.background.pow2 = ((backgroundW & (backgroundW - 1)) == 0 && (backgroundH & (backgroundH - 1)) == 0) ? 1u : 0u; }
@@ -907,7 +957,7 @@ void View::render() {                          // View::render, rt64_view.cpp:11
     // Lean frame: nothing downstream reads the view direction, the reflection / refraction / transparent accumulators, motion
     // vectors, upscaler masks, history guides or a GI buffer.  A full frame after lean ones reads the previous frame's guides and
     // history (temporal reprojection), so what that lean frame skipped is produced first, while its hit records still exist.
-    const bool leanNow = !rtInstances.empty() && dev->opt.leanFrames && !anyNonOpaque && !anyReflection && !anyRefraction && !anyFog && giSamples == 0 && motionBlurStrength <= 0.0f;
+    const bool leanNow = !rtInstances.empty() && dev->opt.leanFrames && !upscaleActive && !anyNonOpaque && !anyReflection && !anyRefraction && !anyFog && giSamples == 0 && motionBlurStrength <= 0.0f;
     if (leanFrame && !leanNow) materialise();
     FrameParams P;
     fillParams(P);
@@ -1011,6 +1061,12 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         if (rtRect) {            // the ray-traced picture covers only its rectangle: cleared buffer + background instances show around it (rt64_view.cpp:1292-1296)
             L(launch_clear_final(P, img, s));
             drawRasterList(rasterBgScreen, img.final);
+        }
+        if (upscaleActive) {        // Upscaler::upscale (rt64_view.cpp:1584-1618): rtOutput -> rtOutputUpscaled; PostProcessPS reads the latter (:800-801)
+            if (skipReprojection) upValid = false;          // buffers were (re)created: the accumulation starts over
+            L(launch_taa_upsample(img, cur, imgW, imgH, pixelJitter[0], pixelJitter[1], upscaled[upSwap ^ 1], upscaled[upSwap], finalW, finalH, upValid, s));
+            P.postSource = upscaled[upSwap]; P.postSourceW = finalW; P.postSourceH = finalH;
+            upValid = true; upSwap ^= 1;
         }
         if (P.separatePost) L(launch_post_process(P, img, s));
     }
@@ -1188,6 +1244,14 @@ static size_t readback(Device *dev, int image, void *dst, size_t dstBytes, bool 
         HIP_CHECK(hipStreamSynchronize(dev->stream));
         return need;
     }
+    if (image == RT64_IMAGE_UPSCALED) {          // rtOutputUpscaled of the last frame: screen size, whole frame
+        const size_t need = (size_t)v->finalW * v->finalH * 16;
+        if (!v->upscaleActive || !v->upValid) throw std::runtime_error("RT64_ReadbackDevice: no upscaled image (no upscaler is active).");
+        if (dstBytes < need) throw std::runtime_error("RT64_ReadbackDevice: destination buffer is too small.");
+        HIP_CHECK(hipMemcpyAsync(dst, v->upscaled[v->upSwap ^ 1], need, toDevice ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, dev->stream));
+        HIP_CHECK(hipStreamSynchronize(dev->stream));
+        return need;
+    }
     if (image != RT64_IMAGE_FINAL_RGBA8 && (image != RT64_IMAGE_OUTPUT_RGBA32F || v->fusedFrame)) v->materialise();
     ImageInfo info; size_t dstPixelBytes;
     if (!image_info(v, image, info, dstPixelBytes)) throw std::runtime_error("RT64_ReadbackDevice: unknown image id.");
@@ -1341,7 +1405,10 @@ RT64_EXPORT void RT64_SetViewDescription(RT64_VIEW *viewPtr, RT64_VIEW_DESC view
     View *v = reinterpret_cast<View *>(viewPtr); if (!v) return;
     v->resolutionScale = viewDesc.resolutionScale; v->motionBlurStrength = viewDesc.motionBlurStrength; v->maxLights = viewDesc.maxLights;
     v->diSamples = viewDesc.diSamples; v->giSamples = viewDesc.giSamples; v->denoiserEnabled = viewDesc.denoiserEnabled;
-    // upscaler / upscalerMode / upscalerSharpness select vendor upscalers (DLSS / FSR2 / XeSS) in the reference; none exists here (see RT64_GetViewUpscalerSupport).
+    // upscaler / upscalerMode (rt64_view.cpp:2109-2163): AUTO prefers DLSS, then XeSS on Intel, then FSR; the vendor SDKs do not exist here, so AUTO and
+    // FSR select the built-in temporal upscaler (upscale.hip) and DLSS / XeSS fall back to the bilinear resample like an uninitialised SDK does (:116,139-141).
+    // upscalerSharpness is accepted and has no effect (no sharpening pass).
+    v->upscaler = viewDesc.upscaler; v->upscalerMode = viewDesc.upscalerMode; v->upscalerSharpness = viewDesc.upscalerSharpness;
 }
 RT64_EXPORT void RT64_SetViewSkyPlane(RT64_VIEW *viewPtr, RT64_TEXTURE *texturePtr) { View *v = reinterpret_cast<View *>(viewPtr); if (v) v->skyPlane = reinterpret_cast<Texture *>(texturePtr); }
 RT64_EXPORT RT64_INSTANCE *RT64_GetViewRaytracedInstanceAt(RT64_VIEW *viewPtr, int x, int y) {         // rt64_view.cpp:1932-1998
@@ -1360,7 +1427,9 @@ RT64_EXPORT RT64_INSTANCE *RT64_GetViewRaytracedInstanceAt(RT64_VIEW *viewPtr, i
     return nullptr;
     RT64_CATCH(nullptr)
 }
-RT64_EXPORT bool RT64_GetViewUpscalerSupport(RT64_VIEW *, int) { return false; }                      // rt64_view.cpp:2183 (declared (view, int) there)
+RT64_EXPORT bool RT64_GetViewUpscalerSupport(RT64_VIEW *viewPtr, int upscaler) {                       // rt64_view.cpp:2183 (declared (view, int) there)
+    return viewPtr != nullptr && upscaler == RT64_UPSCALER_FSR;       // the built-in temporal upscaler answers for FSR; DLSS / XeSS: not initialised
+}
 RT64_EXPORT void RT64_DestroyView(RT64_VIEW *viewPtr) { RT64_TRY delete reinterpret_cast<View *>(viewPtr); RT64_CATCH_VOID }
 
 // ---- scene (rt64_scene.cpp:170-187) ----

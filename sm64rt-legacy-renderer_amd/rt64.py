@@ -19,14 +19,16 @@ SHADER_RASTER_ENABLED, SHADER_RAYTRACE_ENABLED, SHADER_NORMAL_MAP_ENABLED, SHADE
 INSTANCE_RASTER_BACKGROUND, INSTANCE_DISABLE_BACKFACE_CULLING = 0x1, 0x2
 LIGHT_GROUP_MASK_ALL, LIGHT_GROUP_DEFAULT = 0xFFFFFFFF, 0x1
 TEXTURE_FORMAT_RGBA8, TEXTURE_FORMAT_DDS = 0x1, 0x2
-UPSCALER_OFF = 0
+UPSCALER_OFF, UPSCALER_AUTO, UPSCALER_DLSS, UPSCALER_FSR, UPSCALER_XESS = range(5)
+(UPSCALER_MODE_AUTO, UPSCALER_MODE_ULTRA_PERFORMANCE, UPSCALER_MODE_PERFORMANCE, UPSCALER_MODE_BALANCED, UPSCALER_MODE_QUALITY,
+ UPSCALER_MODE_ULTRA_QUALITY, UPSCALER_MODE_NATIVE) = range(7)
 ACCEL_NODES, ACCEL_TRIANGLES, ACCEL_SORTED_INDEX, ACCEL_MORTON, ACCEL_HEADER = range(5)
 
 (IMAGE_FINAL_RGBA8, IMAGE_SHADING_POSITION, IMAGE_SHADING_NORMAL, IMAGE_SHADING_SPECULAR, IMAGE_DIFFUSE,
  IMAGE_INSTANCE_ID, IMAGE_DIRECT_LIGHT_RAW, IMAGE_DIRECT_LIGHT_FILTERED, IMAGE_INDIRECT_LIGHT_RAW,
  IMAGE_INDIRECT_LIGHT_FILTERED, IMAGE_REFLECTION, IMAGE_REFRACTION, IMAGE_TRANSPARENT, IMAGE_FLOW,
  IMAGE_REACTIVE_MASK, IMAGE_LOCK_MASK, IMAGE_DEPTH, IMAGE_OUTPUT_RGBA32F, IMAGE_PRIMARY_HIT,
- IMAGE_VIEW_DIRECTION, IMAGE_FIRST_INSTANCE_ID, IMAGE_BACKGROUND) = range(22)
+ IMAGE_VIEW_DIRECTION, IMAGE_FIRST_INSTANCE_ID, IMAGE_BACKGROUND, IMAGE_UPSCALED) = range(23)
 
 # image id -> (numpy dtype string, channels)
 IMAGE_FORMATS = {
@@ -36,7 +38,7 @@ IMAGE_FORMATS = {
     IMAGE_INDIRECT_LIGHT_FILTERED: ("f4", 4), IMAGE_REFLECTION: ("f4", 4), IMAGE_REFRACTION: ("f4", 4),
     IMAGE_TRANSPARENT: ("f4", 4), IMAGE_FLOW: ("f4", 2), IMAGE_REACTIVE_MASK: ("f4", 1), IMAGE_LOCK_MASK: ("f4", 1),
     IMAGE_DEPTH: ("f4", 1), IMAGE_OUTPUT_RGBA32F: ("f4", 4), IMAGE_PRIMARY_HIT: ("u4", 4),
-    IMAGE_VIEW_DIRECTION: ("f4", 4), IMAGE_FIRST_INSTANCE_ID: ("i4", 1), IMAGE_BACKGROUND: ("u1", 4),
+    IMAGE_VIEW_DIRECTION: ("f4", 4), IMAGE_FIRST_INSTANCE_ID: ("i4", 1), IMAGE_BACKGROUND: ("u1", 4), IMAGE_UPSCALED: ("f4", 4),
 }
 
 

@@ -362,11 +362,11 @@ class Rt64Scene:
         self._desc_cache.pop(k, None)
         self.lib.SetInstanceDescription(self.instances[k], self._instance_desc(inst))
 
-    def set_view_description(self, di_samples=0, gi_samples=0, max_lights=12, denoiser=False, resolution_scale=1.0, motion_blur=0.0):
+    def set_view_description(self, di_samples=0, gi_samples=0, max_lights=12, denoiser=False, resolution_scale=1.0, motion_blur=0.0, upscaler=0, upscaler_mode=0):
         v = rt64.VIEW_DESC()
         v.resolutionScale = resolution_scale; v.motionBlurStrength = motion_blur
         v.diSamples = di_samples; v.giSamples = gi_samples; v.maxLights = max_lights
-        v.upscaler = rt64.UPSCALER_OFF; v.upscalerMode = 0; v.upscalerSharpness = 0.0; v.denoiserEnabled = denoiser
+        v.upscaler = upscaler; v.upscalerMode = upscaler_mode; v.upscalerSharpness = 0.0; v.denoiserEnabled = denoiser
         self.view_desc = v
         self.lib.SetViewDescription(self.view, v)
 
@@ -395,7 +395,7 @@ class Rt64Scene:
         rows, width = (st.rowsRendered if st.rowsRendered else st.tileY1 - st.tileY0), st.width
         if (st.screenWidth, st.screenHeight) != (st.width, st.height):       # resolutionScale: render size != back-buffer size, whole frame
             rows, width = (st.screenHeight, st.screenWidth) if image in (rt64.IMAGE_FINAL_RGBA8, rt64.IMAGE_BACKGROUND) else (st.height, st.width)
-        if image == rt64.IMAGE_BACKGROUND:
+        if image in (rt64.IMAGE_BACKGROUND, rt64.IMAGE_UPSCALED):
             rows, width = st.screenHeight, st.screenWidth                      # always the whole screen, on every device
         out = np.empty((rows, width, ch), dtype=dt)
         n = self.lib.ReadbackDevice(self.device, image, out.ctypes.data, out.nbytes)
