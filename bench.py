@@ -162,22 +162,38 @@ def main():
         scene.set_tile(*tiles.band_range(H, rank, N))
     else:
         scene.set_interleave(rank, N)
+    # The gather itself lives behind the C ABI (RT64_CreateGather / RT64_SubmitGather: grouped ncclSend / ncclRecv on a stream of the
+    # library's own, two slots, reassembly kernel on rank 0).  torch.distributed is the control plane only: rendezvous of the unique id,
+    # barriers, the MAX over ranks.  The gloo backend (CPU rehearsal) keeps the torch-side gatherer of tiles.py.
+    native = G and args.backend == "nccl" and os.environ.get("RT64_BENCH_NATIVE_GATHER", "1") != "0"
+    gather = None
+    if native:
+        uid = torch.zeros(rt64.GATHER_ID_BYTES, dtype=torch.uint8)
+        if rank == 0 and not lib.GetGatherUniqueId(uid.data_ptr(), uid.numel()):
+            raise SystemExit("RT64_GetGatherUniqueId: " + lib.last_error())
+        if N > 1:
+            uid_dev = uid.cuda()
+            dist.broadcast(uid_dev, 0)
+            uid = uid_dev.cpu()
+        gather = lib.CreateGather(scene.device, uid.data_ptr(), uid.numel(), rank, N, int(use_bands))       # also sets this device's share of the frame
+        if not gather:
+            raise SystemExit("RT64_CreateGather: " + lib.last_error())
 
     # N > 1: frames are ENQUEUED (sync_present = 0) on the renderer's stream, the strips are copied into a gather slot on the same
     # stream, and the RCCL gather of frame k runs beside the rendering of frame k+1 (two slots).  Everything is complete at the
     # closing barrier + synchronize, which is inside the timed region.
     pipelined = G and args.backend == "nccl" and os.environ.get("RT64_BENCH_PIPELINE", "1") != "0"
     ext_stream = None
-    if pipelined:
+    if pipelined and not native:
         try:
             ext_stream = torch.cuda.ExternalStream(lib.GetDeviceStream(scene.device))
         except Exception as e:       # keep measuring: synchronous frames + blocking gather (same result, no overlap)
             print("bench.py: renderer stream not usable from torch (%r): synchronous gather" % (e,), file=sys.stderr)
             pipelined = False
-    gatherer = tiles.FrameGatherer(H, W, rank, N, comm_device, stream=ext_stream, bands=use_bands) if G else None
+    gatherer = tiles.FrameGatherer(H, W, rank, N, comm_device, stream=ext_stream, bands=use_bands) if (G and not native) else None
     staging = torch.zeros(max(tiles.strips_per_rank(H, N) * 16, tiles.band_rows(H, N)) * W * 4, dtype=torch.uint8, device="cuda") if (G and not pipelined) else None
     local = torch.zeros(max(tiles.max_owned_rows(H, N), 1) * W * 4, dtype=torch.uint8, device="cuda")
-    my_bytes = gatherer.owned_bytes() if G else H * W * 4
+    my_bytes = (gatherer.owned_bytes() if gatherer else lib.GatherOwnedRows(H, N, int(use_bands), rank) * W * 4) if G else H * W * 4
     if PR > 1:
         my_bytes = ((tiles.band_range(H, 0, PR)[1] - tiles.band_range(H, 0, PR)[0]) if (args.gi_samples > 0 and args.denoiser) else tiles.owned_rows(H, 0, PR)) * W * 4
 
@@ -197,6 +213,12 @@ def main():
         if not G:
             scene.draw()             # returns after the frame is complete in the device's back buffer (HBM): nothing to gather
             return None
+        if native:                   # the frame's last kernel writes the rank's packed rows into the slot's send buffer; the exchange runs beside the next frame
+            scene.draw()
+            slot = lib.SubmitGather(gather)
+            if slot < 0:
+                raise RuntimeError("RT64_SubmitGather: " + lib.last_error())
+            return slot
         slot = step_no[0] % 2
         step_no[0] += 1
         gatherer.wait(slot)          # the gather that last read this slot (two frames ago) is ordered before the refill
@@ -262,14 +284,21 @@ def main():
     for _ in range(args.steps):
         last_slot = step()
     enqueue_ms = (time.perf_counter() - t0) * 1e3 / args.steps      # host time per step before the closing barrier (= frame time when frames are synchronous)
-    if G:
+    if G and not native:
         for sl in (0, 1):
             gatherer.wait(sl)            # the last two gathers (and rank 0's assembly of them) complete inside the timed region
-    barrier()
+    barrier()                            # (torch.cuda.synchronize waits for every stream of the device, the library's two included)
     elapsed = time.perf_counter() - t0
     stat_frames = args.steps
     gathered_checksum = None
-    if G and rank == 0:              # the frame assembled on rank 0 by the gather of the last timed step
+    if native:                       # every rank waits for its part of the last exchange; rank 0 reads the assembled frame
+        host_frame = np.zeros(H * W * 4, dtype=np.uint8)
+        got = lib.ReadbackGather(gather, last_slot, host_frame.ctypes.data, host_frame.nbytes, 0)
+        if rank == 0:
+            if got != host_frame.nbytes:
+                raise RuntimeError("RT64_ReadbackGather: " + lib.last_error())
+            gathered_checksum = int(host_frame.astype(np.int64).sum())
+    elif G and rank == 0:            # the frame assembled on rank 0 by the gather of the last timed step
         gathered_checksum = int(gatherer.frame(last_slot).to(torch.int64).sum().item())
     if not G and PR <= 1:            # N = 1: every timed frame was measured live with HIP events inside the library
         s = scene.stats()
@@ -362,7 +391,8 @@ def main():
         }
         if G:
             result["pipeline"] = {"frames": "enqueued (sync_present=0), 2 gather slots" if pipelined else "synchronous, CPU-staged gather (rehearsal)",
-                              "send_buffer": "written by the frame kernel (RT64_SetDeviceGatherTarget)" if packed[0] else "RT64_CopyDeviceImage after each frame",
+                                  "gather": "in-library (RT64_SubmitGather: grouped ncclSend / ncclRecv + reassembly kernel on the library's comm stream)" if native else "torch.distributed gather (tiles.FrameGatherer)",
+                              "send_buffer": ("written by the frame kernel (RT64_SetDeviceGatherTarget)" if (packed[0] or (native and scene.stats().packedFinal)) else "packed after each frame (RT64_CopyDeviceImage layout)"),
                                   "host_ms_per_step": round(enqueue_ms, 5)}
         if rebuild is not None:
             result["always_rebuild"] = rebuild
@@ -377,8 +407,10 @@ def main():
             result["frame_checksum"] = gathered_checksum
         print(json.dumps(result), flush=True)
 
-    if G:
+    if gatherer:
         gatherer.close()                 # torch's current stream goes back to the default one before the renderer's stream is destroyed
+    if gather:
+        lib.DestroyGather(gather)
     scene.close()
     if G:
         dist.barrier()

@@ -398,7 +398,29 @@ typedef struct {
     /* Debug readback of acceleration structures (RT64_ACCEL_*): the mesh's BLAS / the view's TLAS of the last frame. \
        Returns bytes written (0 on error); pass dst = NULL to query the size. */ \
     X(ReadbackMeshAccel, RT64_ReadbackMeshAccel, size_t, (RT64_MESH *mesh, int what, void *dst, size_t dstBytes)) \
-    X(ReadbackViewAccel, RT64_ReadbackViewAccel, size_t, (RT64_VIEW *view, int what, void *dst, size_t dstBytes))
+    X(ReadbackViewAccel, RT64_ReadbackViewAccel, size_t, (RT64_VIEW *view, int what, void *dst, size_t dstBytes)) \
+    /* ---- multi-GPU: one process per GPU, the frame's rows partitioned over `count` devices, ONE gather of the composited RGBA8 back buffer \
+       to rank 0 per frame over RCCL / xGMI (the reference is single-GPU: NodeMask 0, rt64_device.cpp:753).  Rank 0 fills an id with \
+       RT64_GetGatherUniqueId and passes it to the other ranks (file, pipe, MPI, ...); every rank then calls RT64_CreateGather on its own \
+       device (all devices the same size): bands = 0 partitions into interleaved 16-row strips (pixel-local frames), bands = 1 into contiguous \
+       bands (frames with GI + denoiser: the library renders the filter's halo around the band).  Per frame: RT64_DrawDevice, then \
+       RT64_SubmitGather (returns the slot, 0 / 1, the frame travels in; the exchange runs beside the next frame's rendering). \
+       RT64_ReadbackGather waits for a slot's exchange (slot < 0: the last submitted) and, on rank 0, copies the assembled frame out \
+       (returns its size; 0 on other ranks); RT64_GetGatherFrame is its device pointer on rank 0.  RCCL is loaded on first use. */ \
+    X(GetGatherUniqueId, RT64_GetGatherUniqueId, int, (void *id, size_t idBytes)) \
+    X(CreateGather, RT64_CreateGather, RT64_GATHER *, (RT64_DEVICE *device, const void *id, size_t idBytes, int rank, int count, int bands)) \
+    X(SubmitGather, RT64_SubmitGather, int, (RT64_GATHER *gather)) \
+    X(ReadbackGather, RT64_ReadbackGather, size_t, (RT64_GATHER *gather, int slot, void *dst, size_t dstBytes, int toDevice)) \
+    X(GetGatherFrame, RT64_GetGatherFrame, void *, (RT64_GATHER *gather, int slot)) \
+    X(DestroyGather, RT64_DestroyGather, void, (RT64_GATHER *gather)) \
+    /* the partition's layout as pure functions (usable without a device): owner rank of frame row y and the row's place in that rank's \
+       packed buffer; rows a rank owns; rows every rank's slot is sized for */ \
+    X(GatherRowOwner, RT64_GatherRowOwner, int, (int height, int count, int bands, int y, int *packedRow)) \
+    X(GatherOwnedRows, RT64_GatherOwnedRows, int, (int height, int count, int bands, int rank)) \
+    X(GatherSlotRows, RT64_GatherSlotRows, int, (int height, int count, int bands))
+
+typedef struct RT64_GATHER RT64_GATHER;
+#define RT64_GATHER_ID_BYTES 128       /* size of the rendezvous id (an ncclUniqueId) */
 
 #define RT64_X(member, symbol, ret, args) typedef ret (*member##Ptr) args;
 RT64_EXT_API_LIST(RT64_X)

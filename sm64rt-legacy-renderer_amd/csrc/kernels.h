@@ -72,3 +72,7 @@ hipError_t launch_svgf(const ViewImages &I, int cur, int width, int height, int 
 // Temporal upscaler stage (Upscaler::upscale, rt64_view.cpp:1584-1618): rtOutput + flow + masks + depth (render size rw x rh, jitter jx / jy)
 // and the previous upscaled image -> `out` (display size dw x dh, RGBA32F: colour + accumulated frame count).
 hipError_t launch_taa_upsample(const ViewImages &I, int cur, int rw, int rh, float jx, float jy, const float *prev, float *out, int dw, int dh, bool haveHistory, hipStream_t s);
+
+// ---- gather.hip -----------------------------------------------------------------------------------------------------
+// Rank 0 of a multi-GPU gather: frame row y <- row gather_row_owner(y) of the owner's packed buffer (`own` for rank 0, bucket + r * slotBytes for rank r).
+hipError_t launch_gather_assemble(const uint8_t *own, const uint8_t *bucket, size_t slotBytes, uint8_t *frame, int width, int height, int count, int bands, hipStream_t s);

@@ -162,6 +162,34 @@ struct ViewImages {
     uint32_t *klistCount;                // payload.nhits of the primary ray (per pixel)
 };
 
+// ---- image-tile partition of a frame over `count` devices -------------------------------------------------------------
+// bands == 0: interleaved 16-row strips -- rank r owns strips r, r + count, ... (RT64_SetDeviceInterleave); bands == 1: contiguous bands
+// of ceil(height / count) rows (RT64_SetDeviceTile; frames with a spatial filter).  A rank's buffer holds its rows packed in ascending order.
+#if defined(__HIPCC__)
+#define RT64_HD __host__ __device__ inline
+#else
+#define RT64_HD inline
+#endif
+RT64_HD int gather_band_rows(int height, int count) { return (height + count - 1) / count; }
+// the rank that owns frame row y, and (*packed) the row's position in that rank's packed buffer
+RT64_HD int gather_row_owner(int height, int count, int bands, int y, int *packed) {
+    if (count <= 1) { *packed = y; return 0; }
+    if (bands) { const int b = gather_band_rows(height, count); *packed = y % b; return y / b; }
+    const int strip = y / 16;
+    *packed = (strip / count) * 16 + (y & 15);
+    return strip % count;
+}
+// rows rank `rank` owns
+RT64_HD int gather_owned_rows(int height, int count, int bands, int rank) {
+    if (count <= 1) return height;
+    if (bands) { const int b = gather_band_rows(height, count), y0 = rank * b, y1 = (rank + 1) * b; return (y1 < height ? y1 : height) - (y0 < height ? y0 : height); }
+    int rows = 0;
+    for (int y = rank * 16; y < height; y += count * 16) rows += (y + 16 <= height ? 16 : height - y);
+    return rows;
+}
+// rows of the largest share (what every rank's slot of the bucket on rank 0 is sized for)
+RT64_HD int gather_max_owned_rows(int height, int count, int bands) { return bands ? gather_band_rows(height, count) : (((height + 15) / 16 + count - 1) / count) * 16; }
+
 #define RT_COUNTER_STRIPES 64          // copies of the counter block, chosen by workgroup number: the per-wave atomics of a counting frame spread over 64 lines
 enum { CTR_NODES = 0, CTR_TRIS, CTR_PRIMARY, CTR_SHADOW, CTR_INDIRECT, CTR_REFLECTION, CTR_REFRACTION,
        CTR_PASS_BASE,                    // then {nodes, triangles} per pass:

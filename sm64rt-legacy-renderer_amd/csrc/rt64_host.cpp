@@ -1536,6 +1536,175 @@ RT64_EXPORT size_t RT64_ReadbackViewAccel(RT64_VIEW *viewPtr, int what, void *ds
     RT64_CATCH(0)
 }
 
+// ---- multi-GPU: image-tile partition + RCCL gather of the composited back buffer (additive exports) -----------------------------
+// One process per GPU.  Every rank creates a gather with the same unique id (rank 0 makes it with RT64_GetGatherUniqueId and hands it
+// to the others over whatever channel the host has: a file, a pipe, MPI, torch.distributed's store); the gather sets the device's
+// partition (interleaved 16-row strips, or contiguous bands for frames with a spatial filter) and owns two slots of send / receive
+// buffers.  Per frame the host calls RT64_DrawDevice and RT64_SubmitGather: the frame's last kernel has written the rank's packed rows
+// straight into the slot's send buffer (RT64_SetDeviceGatherTarget; frames that do not honour it are copied), the exchange -- grouped
+// ncclSend / ncclRecv to rank 0, xGMI point to point -- and rank 0's reassembly run on the gather's own stream behind an event, so the
+// gather of frame k overlaps the rendering of frame k + 1; the slot is handed back to the renderer two frames later.
+// RCCL is bound at run time (dlopen of librccl.so.1): a single-GPU host never loads it and librt64.so does not link it.
+#include <rccl/rccl.h>
+
+namespace rt64 {
+
+struct RcclApi {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr; decltype(&ncclCommInitRank) CommInitRank = nullptr; decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr; decltype(&ncclGroupEnd) GroupEnd = nullptr; decltype(&ncclSend) Send = nullptr; decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+static RcclApi &rccl() {
+    static RcclApi api; static bool tried = false;
+    if (!tried) {
+        tried = true;
+        const char *names[] = { getenv("RT64_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+        for (const char *n : names) { if (n && *n && (api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break; }
+        if (api.handle) {
+#define RT64_RCCL_SYM(member, name) api.member = reinterpret_cast<decltype(api.member)>(dlsym(api.handle, name))
+            RT64_RCCL_SYM(GetUniqueId, "ncclGetUniqueId"); RT64_RCCL_SYM(CommInitRank, "ncclCommInitRank"); RT64_RCCL_SYM(CommDestroy, "ncclCommDestroy");
+            RT64_RCCL_SYM(GroupStart, "ncclGroupStart"); RT64_RCCL_SYM(GroupEnd, "ncclGroupEnd"); RT64_RCCL_SYM(Send, "ncclSend"); RT64_RCCL_SYM(Recv, "ncclRecv");
+            RT64_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef RT64_RCCL_SYM
+        }
+    }
+    if (!api.handle || !api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.GroupStart || !api.GroupEnd || !api.Send || !api.Recv)
+        throw std::runtime_error("RCCL (librccl.so.1) could not be loaded: the multi-GPU gather needs it.");
+    return api;
+}
+#define RCCL_CHECK(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { \
+    char msg_[512]; snprintf(msg_, sizeof(msg_), "RCCL call " #call " failed: %s", rccl().GetErrorString ? rccl().GetErrorString(r_) : "?"); throw std::runtime_error(msg_); } } while (0)
+
+struct Gather {
+    Device *dev; int rank, count, bands; int W, H; size_t slotBytes;
+    ncclComm_t comm = nullptr; hipStream_t commStream = nullptr;
+    struct Slot { uint8_t *local = nullptr, *bucket = nullptr, *frame = nullptr; hipEvent_t produced = nullptr, gathered = nullptr; bool pending = false; } slots[2];
+    int next = 0, last = -1;
+    Gather(Device *d, const ncclUniqueId &id, int rank_, int count_, int bands_);
+    ~Gather();
+    void prepare(int slot);
+    int submit();
+    void wait(int slot, bool host);
+};
+
+Gather::Gather(Device *d, const ncclUniqueId &id, int rank_, int count_, int bands_) : dev(d), rank(rank_), count(count_), bands(bands_) {
+    if (count < 1 || rank < 0 || rank >= count) throw std::runtime_error("RT64_CreateGather: rank / count out of range.");
+    dev->use();
+    W = dev->pendingWidth; H = dev->pendingHeight;
+    slotBytes = (size_t)gather_max_owned_rows(H, count, bands) * (size_t)W * 4;
+    // the device's share of the frame
+    if (bands) { const int b = gather_band_rows(H, count); dev->tileSet = true; dev->tileY0 = std::min(rank * b, H); dev->tileY1 = std::min((rank + 1) * b, H); dev->stripRank = 0; dev->stripCount = 1; }
+    else { dev->tileSet = false; dev->tileY0 = 0; dev->tileY1 = H; dev->stripRank = count > 1 ? rank : 0; dev->stripCount = count > 1 ? count : 1; }
+    HIP_CHECK(hipStreamCreateWithFlags(&commStream, hipStreamNonBlocking));
+    for (Slot &sl : slots) {
+        HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&sl.local), std::max<size_t>(slotBytes, 16)));
+        HIP_CHECK(hipMemsetAsync(sl.local, 0, std::max<size_t>(slotBytes, 16), dev->stream));
+        if (rank == 0) {
+            HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&sl.bucket), std::max<size_t>(slotBytes * (size_t)count, 16)));
+            HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&sl.frame), (size_t)W * H * 4));
+        }
+        HIP_CHECK(hipEventCreateWithFlags(&sl.produced, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&sl.gathered, hipEventDisableTiming));
+    }
+    HIP_CHECK(hipStreamSynchronize(dev->stream));
+    RCCL_CHECK(rccl().CommInitRank(&comm, count, id, rank));
+    prepare(0);
+}
+Gather::~Gather() {
+    hipSetDevice(dev->hipDevice);
+    hipStreamSynchronize(dev->stream); if (commStream) hipStreamSynchronize(commStream);
+    if (dev->gatherTarget == slots[0].local || dev->gatherTarget == slots[1].local) { dev->gatherTarget = nullptr; dev->gatherTargetBytes = 0; }
+    if (comm) rccl().CommDestroy(comm);
+    for (Slot &sl : slots) { if (sl.local) hipFree(sl.local); if (sl.bucket) hipFree(sl.bucket); if (sl.frame) hipFree(sl.frame); if (sl.produced) hipEventDestroy(sl.produced); if (sl.gathered) hipEventDestroy(sl.gathered); }
+    if (commStream) hipStreamDestroy(commStream);
+}
+// The renderer may write slot `slot` again: its previous exchange (two frames ago) is ordered before whatever the render stream does next.
+void Gather::prepare(int slot) {
+    Slot &sl = slots[slot];
+    if (sl.pending) { HIP_CHECK(hipStreamWaitEvent(dev->stream, sl.gathered, 0)); sl.pending = false; }
+    dev->gatherTarget = sl.local; dev->gatherTargetBytes = slotBytes;
+}
+// After RT64_DrawDevice: exchange the frame just drawn.  Returns the slot it travels in.
+int Gather::submit() {
+    dev->use();
+    if (dev->width != W || dev->height != H) throw std::runtime_error("RT64_SubmitGather: the device was resized after RT64_CreateGather.");
+    const int slot = next; Slot &sl = slots[slot];
+    View *v = first_view(dev);
+    if (!v) throw std::runtime_error("RT64_SubmitGather: the device has no view.");
+    const size_t mine = (size_t)gather_owned_rows(H, count, bands, rank) * (size_t)W * 4;
+    if (!(v->packedFinal && dev->gatherTarget == sl.local)) {        // this kind of frame did not write the send buffer itself: pack the owned rows now (same layout)
+        const bool sync = dev->opt.syncPresent; dev->opt.syncPresent = false;
+        const size_t got = mine ? readback(dev, RT64_IMAGE_FINAL_RGBA8, sl.local, slotBytes, true) : 0;
+        dev->opt.syncPresent = sync;
+        if (got != mine) throw std::runtime_error("RT64_SubmitGather: packing the owned rows failed.");
+    }
+    HIP_CHECK(hipEventRecord(sl.produced, dev->stream));
+    HIP_CHECK(hipStreamWaitEvent(commStream, sl.produced, 0));
+    if (count > 1) {
+        RcclApi &R = rccl();
+        RCCL_CHECK(R.GroupStart());
+        if (rank == 0) { for (int r = 1; r < count; r++) { const size_t n = (size_t)gather_owned_rows(H, count, bands, r) * (size_t)W * 4; if (n) RCCL_CHECK(R.Recv(sl.bucket + (size_t)r * slotBytes, n, ncclUint8, r, comm, commStream)); } }
+        else if (mine) RCCL_CHECK(R.Send(sl.local, mine, ncclUint8, 0, comm, commStream));
+        RCCL_CHECK(R.GroupEnd());
+    }
+    if (rank == 0) HIP_CHECK(launch_gather_assemble(sl.local, sl.bucket, slotBytes, sl.frame, W, H, count, bands, commStream));
+    HIP_CHECK(hipEventRecord(sl.gathered, commStream));
+    sl.pending = true; last = slot; next = slot ^ 1;
+    prepare(next);
+    return slot;
+}
+void Gather::wait(int slot, bool host) {
+    Slot &sl = slots[slot];
+    if (host) HIP_CHECK(hipEventSynchronize(sl.gathered));
+    else HIP_CHECK(hipStreamWaitEvent(dev->stream, sl.gathered, 0));
+}
+
+}  // namespace rt64
+
+RT64_EXPORT int RT64_GetGatherUniqueId(void *id, size_t idBytes) {
+    RT64_TRY
+    if (!id || idBytes < sizeof(ncclUniqueId)) throw std::runtime_error("RT64_GetGatherUniqueId: the id buffer needs RT64_GATHER_ID_BYTES bytes.");
+    ncclUniqueId u; RCCL_CHECK(rccl().GetUniqueId(&u)); memcpy(id, &u, sizeof(u)); return 1;
+    RT64_CATCH(0)
+}
+RT64_EXPORT RT64_GATHER *RT64_CreateGather(RT64_DEVICE *device, const void *id, size_t idBytes, int rank, int count, int bands) {
+    RT64_TRY
+    if (!device || !id || idBytes < sizeof(ncclUniqueId)) throw std::runtime_error("RT64_CreateGather: NULL device or id.");
+    ncclUniqueId u; memcpy(&u, id, sizeof(u));
+    return reinterpret_cast<RT64_GATHER *>(new Gather(reinterpret_cast<Device *>(device), u, rank, count, bands));
+    RT64_CATCH(nullptr)
+}
+RT64_EXPORT int RT64_SubmitGather(RT64_GATHER *gather) {
+    RT64_TRY if (!gather) throw std::runtime_error("RT64_SubmitGather: NULL gather."); return reinterpret_cast<Gather *>(gather)->submit(); RT64_CATCH(-1)
+}
+RT64_EXPORT size_t RT64_ReadbackGather(RT64_GATHER *gather, int slot, void *dst, size_t dstBytes, int toDevice) {
+    RT64_TRY
+    Gather *g = reinterpret_cast<Gather *>(gather);
+    if (!g) throw std::runtime_error("RT64_ReadbackGather: NULL gather.");
+    if (slot < 0) slot = g->last;
+    if (slot < 0 || slot > 1) throw std::runtime_error("RT64_ReadbackGather: no frame has been submitted.");
+    g->dev->use();
+    g->wait(slot, true);                                         // every rank: its part of the exchange has completed
+    if (g->rank != 0) return 0;
+    const size_t need = (size_t)g->W * g->H * 4;
+    if (!dst) return need;
+    if (dstBytes < need) throw std::runtime_error("RT64_ReadbackGather: destination buffer is too small.");
+    HIP_CHECK(hipMemcpy(dst, g->slots[slot].frame, need, toDevice ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    return need;
+    RT64_CATCH(0)
+}
+RT64_EXPORT void *RT64_GetGatherFrame(RT64_GATHER *gather, int slot) {           // rank 0: device pointer of the assembled RGBA8 frame of `slot` (valid once its gather has run)
+    Gather *g = reinterpret_cast<Gather *>(gather);
+    if (!g || g->rank != 0) return nullptr;
+    if (slot < 0) slot = g->last;
+    return (slot == 0 || slot == 1) ? g->slots[slot].frame : nullptr;
+}
+RT64_EXPORT void RT64_DestroyGather(RT64_GATHER *gather) { RT64_TRY delete reinterpret_cast<Gather *>(gather); RT64_CATCH_VOID }
+// Partition layout, as pure functions (no device needed): which rank owns frame row y and where the row sits in that rank's packed buffer.
+RT64_EXPORT int RT64_GatherRowOwner(int height, int count, int bands, int y, int *packedRow) { int p = 0; const int r = gather_row_owner(height, count, bands, y, &p); if (packedRow) *packedRow = p; return r; }
+RT64_EXPORT int RT64_GatherOwnedRows(int height, int count, int bands, int rank) { return gather_owned_rows(height, count, bands, rank); }
+RT64_EXPORT int RT64_GatherSlotRows(int height, int count, int bands) { return gather_max_owned_rows(height, count, bands); }
+
 // ---- inspector (rt64_inspector.cpp:469-515): the ImGui/Im3d debug UI is Win32-only; the exports exist so that hosts resolve all 33 symbols ----
 struct InspectorStub { Device *device; };
 RT64_EXPORT RT64_INSPECTOR *RT64_CreateInspector(RT64_DEVICE *devicePtr) { return reinterpret_cast<RT64_INSPECTOR *>(new InspectorStub{ reinterpret_cast<Device *>(devicePtr) }); }

@@ -193,7 +193,17 @@ EXT_API = [
     ("SetDeviceGatherTarget", "RT64_SetDeviceGatherTarget", None, [_P, _P, C.c_size_t]),
     ("ReadbackMeshAccel", "RT64_ReadbackMeshAccel", C.c_size_t, [_P, C.c_int, _P, C.c_size_t]),
     ("ReadbackViewAccel", "RT64_ReadbackViewAccel", C.c_size_t, [_P, C.c_int, _P, C.c_size_t]),
+    ("GetGatherUniqueId", "RT64_GetGatherUniqueId", C.c_int, [_P, C.c_size_t]),
+    ("CreateGather", "RT64_CreateGather", _P, [_P, _P, C.c_size_t, C.c_int, C.c_int, C.c_int]),
+    ("SubmitGather", "RT64_SubmitGather", C.c_int, [_P]),
+    ("ReadbackGather", "RT64_ReadbackGather", C.c_size_t, [_P, C.c_int, _P, C.c_size_t, C.c_int]),
+    ("GetGatherFrame", "RT64_GetGatherFrame", _P, [_P, C.c_int]),
+    ("DestroyGather", "RT64_DestroyGather", None, [_P]),
+    ("GatherRowOwner", "RT64_GatherRowOwner", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    ("GatherOwnedRows", "RT64_GatherOwnedRows", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("GatherSlotRows", "RT64_GatherSlotRows", C.c_int, [C.c_int, C.c_int, C.c_int]),
 ]
+GATHER_ID_BYTES = 128
 
 
 class Library:

@@ -67,6 +67,20 @@ def assemble_fast(packed, height, width, count, channels=4):
     return frame
 
 
+def assemble_by_library_layout(lib, packed, height, width, count, bands=False, channels=4):
+    """Reassemble the frame the way rank 0 of the in-library gather does (RT64_CreateGather / gather_assemble_kernel): row y comes from
+    row RT64_GatherRowOwner(..., y) -> (rank, packed row) of that rank's packed buffer.  `lib` is rt64.Library(); the layout exports are
+    pure host functions, so this runs without a GPU.  packed: [count, >= RT64_GatherSlotRows * width * channels]."""
+    import ctypes as C
+    frame = np.empty((height, width, channels), dtype=packed.dtype)
+    p = C.c_int()
+    row = width * channels
+    for y in range(height):
+        r = lib.GatherRowOwner(height, count, int(bands), y, C.byref(p))
+        frame[y] = np.asarray(packed[r][p.value * row:(p.value + 1) * row]).reshape(width, channels)
+    return frame
+
+
 def gather_frame(local, height, width, rank, count, group=None, fast=True):
     """Gather every rank's packed strips (1-D uint8 tensor padded to max_owned_rows) on rank 0 and reassemble.
     Returns the full frame on rank 0, None elsewhere.  One collective (dist.gather == ncclGather over send/recv)."""

@@ -40,6 +40,30 @@ def test_assemble_numpy_roundtrip():
         assert np.array_equal(tiles.assemble_fast(torch.from_numpy(packed), h, w, n).numpy(), frame)
 
 
+def test_library_layout_exports_agree_with_the_python_partition():
+    """RT64_GatherRowOwner / RT64_GatherOwnedRows / RT64_GatherSlotRows (the one layout definition behind RT64_CreateGather, shared with the
+    device-side reassembly kernel) against tiles.strip_ranges / band_range; pure host functions, no GPU."""
+    import ctypes as C
+    from sm64rt_legacy_renderer_amd import rt64
+    lib = rt64.Library()
+    p = C.c_int()
+    for h in (1, 15, 16, 17, 40, 270, 1080):
+        for n in (1, 2, 3, 8):
+            for bands in (0, 1):
+                owner = np.full(h, -1); packed_row = np.full(h, -1)
+                for r in range(n):
+                    ranges = [tiles.band_range(h, r, n)] if bands else tiles.strip_ranges(h, r, n)
+                    ranges = [(a, b) for a, b in ranges if b > a]
+                    k = 0
+                    for a, b in ranges:
+                        for y in range(a, b):
+                            owner[y] = r; packed_row[y] = k; k += 1
+                    assert lib.GatherOwnedRows(h, n, bands, r) == k
+                    assert lib.GatherSlotRows(h, n, bands) >= k
+                for y in range(h):
+                    assert lib.GatherRowOwner(h, n, bands, y, C.byref(p)) == owner[y] and p.value == packed_row[y], (h, n, bands, y)
+
+
 def _worker(rank, world, init_file, h, w, out_file):
     import torch
     import torch.distributed as dist
@@ -56,6 +80,16 @@ def _worker(rank, world, init_file, h, w, out_file):
             assert np.array_equal(full.numpy(), frame)
         else:
             assert full is None
+    # the same bucket reassembled by the layout the in-library RCCL gather uses on rank 0 (RT64_GatherRowOwner)
+    from sm64rt_legacy_renderer_amd import rt64
+    lib = rt64.Library()
+    assert lib.GatherSlotRows(h, world, 0) * w * 4 >= mx and lib.GatherOwnedRows(h, world, 0, rank) * w * 4 == mine.size
+    if rank == 0:
+        bucket = torch.empty((world, mx), dtype=torch.uint8)
+        dist.gather(local, list(bucket.unbind(0)), dst=0)
+        assert np.array_equal(tiles.assemble_by_library_layout(lib, bucket.numpy(), h, w, world), frame)
+    else:
+        dist.gather(local, None, dst=0)
     # pipelined gatherer (bench.py's N > 1 path): two slots, frames that differ per step, submit / wait in flight order
     g = tiles.FrameGatherer(h, w, rank, world, "cpu")
     assert g.local(0).numel() == tiles.strips_per_rank(h, world) * 16 * w * 4 >= mine.size == g.owned_bytes()

@@ -10,6 +10,11 @@
  * (RT64_ReadbackDevice, an additive export) and prints a checksum; tests/test_gpu_c_host.py compares it with the frame
  * the Python/ctypes harness renders.
  *
+ * `--ranks N` runs the multi-GPU path from C as well: N processes (one per GPU, forked BEFORE anything touches a GPU), rank r on HIP
+ * device r, the rendezvous id of RT64_GetGatherUniqueId handed from rank 0 to the others through a pipe; every rank creates the same
+ * scene, RT64_CreateGather partitions the frame's rows, and each frame is RT64_DrawDevice + RT64_SubmitGather; rank 0 prints the
+ * checksum of the gathered frame (`--ranks 1` runs the same calls with a world of one).
+ *
  * Only include/rt64.h is needed to build it -- the library is bound at run time with dlopen/dlsym like the game does:
  *     gcc -O2 -Iinclude tools/sample_host.c -o tools/sample_host -ldl -lz -lm
  *     RT64_LIBRARY_PATH=sm64rt-legacy-renderer_amd/librt64.so tools/sample_host --width 640 --height 360 --frames 3
@@ -21,6 +26,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/types.h>
+#include <sys/wait.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include "rt64.h"
@@ -265,7 +273,7 @@ static void drawFrame(void) {                                                   
 int main(int argc, char **argv) {
     int width = 1280, height = 720, frames = 3;                                  /* main.cpp:435-436: 1280 x 720 window */
     const char *assets = "assets/sample", *dump = NULL;
-    int selftest = 0;
+    int selftest = 0, ranks = 0, bands = 0;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--width") && i + 1 < argc) width = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--height") && i + 1 < argc) height = atoi(argv[++i]);
@@ -273,7 +281,9 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--assets") && i + 1 < argc) assets = argv[++i];
         else if (!strcmp(argv[i], "--dump") && i + 1 < argc) dump = argv[++i];
         else if (!strcmp(argv[i], "--selftest")) selftest = 1;
-        else { fprintf(stderr, "usage: %s [--width W] [--height H] [--frames N] [--assets DIR] [--dump frame.rgba] [--selftest]\n", argv[0]); return 2; }
+        else if (!strcmp(argv[i], "--ranks") && i + 1 < argc) ranks = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--bands")) bands = 1;
+        else { fprintf(stderr, "usage: %s [--width W] [--height H] [--frames N] [--assets DIR] [--dump frame.rgba] [--selftest] [--ranks N [--bands]]\n", argv[0]); return 2; }
     }
     if (selftest) {       /* the asset readers alone (no library, no GPU): byte sums the CPU test suite compares with the Python harness's loaders */
         static const char *pngs[6] = { "grass_nrm.png", "grass_spc.png", "clouds.png", "tiles_dif.png", "tiles_nrm.png", "tiles_spc.png" };
@@ -289,27 +299,59 @@ int main(int argc, char **argv) {
         printf("\"sphere.obj\": [%d, \"%016llx\"]}\n", n, fnv); free(v);
         return 0;
     }
+    /* multi-GPU: fork the other ranks now, before the library is loaded or any GPU call is made; ids travel over one pipe per rank */
+    int rank = 0, idPipe[64][2];
+    if (ranks > 64) ranks = 64;
+    if (ranks > 1) {
+        for (int r = 1; r < ranks; r++) if (pipe(idPipe[r]) != 0) die("pipe");
+        for (int r = 1; r < ranks; r++) {
+            pid_t pid = fork();
+            if (pid < 0) die("fork");
+            if (pid == 0) { rank = r; break; }
+        }
+    }
     RT64.lib = RT64_LoadLibrary();                                               /* main.cpp:419-432 */
     if (RT64.lib.handle == 0) die("failed to load the library (set RT64_LIBRARY_PATH)");
     RT64.ext = RT64_LoadLibraryExt(RT64.lib);
     if (!RT64.ext.CreateDeviceHeadless || !RT64.ext.ReadbackDevice) die("librt64.so lacks the headless extensions");
-    RT64.device = RT64.ext.CreateDeviceHeadless(width, height, -1);              /* stands in for CreateDevice(hwnd) of a width x height window */
+    RT64.device = RT64.ext.CreateDeviceHeadless(width, height, ranks > 0 ? rank : -1);   /* stands in for CreateDevice(hwnd) of a width x height window */
     if (!RT64.device) { fprintf(stderr, "sample_host: CreateDevice: %s\n", RT64.lib.GetLastError()); return 3; }
     setupRT64Scene(assets);
-    for (int f = 0; f < frames; f++) drawFrame();
-
     const size_t bytes = (size_t)width * height * 4;
     unsigned char *frame = (unsigned char *)malloc(bytes);
-    if (RT64.ext.ReadbackDevice(RT64.device, RT64_IMAGE_FINAL_RGBA8, frame, bytes) != bytes) { fprintf(stderr, "sample_host: readback: %s\n", RT64.lib.GetLastError()); return 4; }
+    if (ranks > 0) {                                                             /* the frame's rows over `ranks` GPUs, gathered on rank 0 */
+        unsigned char id[RT64_GATHER_ID_BYTES];
+        if (!RT64.ext.CreateGather || !RT64.ext.SubmitGather || !RT64.ext.ReadbackGather) die("librt64.so lacks the gather exports");
+        if (rank == 0) {
+            if (!RT64.ext.GetGatherUniqueId(id, sizeof(id))) die(RT64.lib.GetLastError());
+            for (int r = 1; r < ranks; r++) if (write(idPipe[r][1], id, sizeof(id)) != (ssize_t)sizeof(id)) die("id pipe");
+        }
+        else if (read(idPipe[rank][0], id, sizeof(id)) != (ssize_t)sizeof(id)) die("id pipe");
+        RT64_GATHER *gather = RT64.ext.CreateGather(RT64.device, id, sizeof(id), rank, ranks, bands);
+        if (!gather) { fprintf(stderr, "sample_host: CreateGather: %s\n", RT64.lib.GetLastError()); return 5; }
+        int slot = -1;
+        for (int f = 0; f < frames; f++) { drawFrame(); slot = RT64.ext.SubmitGather(gather); if (slot < 0) die(RT64.lib.GetLastError()); }
+        const size_t got = RT64.ext.ReadbackGather(gather, slot, frame, bytes, 0);          /* every rank waits for its part; rank 0 gets the frame */
+        RT64.ext.DestroyGather(gather);
+        if (rank != 0) { RT64.lib.DestroyDevice(RT64.device); return 0; }
+        if (got != bytes) { fprintf(stderr, "sample_host: ReadbackGather: %s\n", RT64.lib.GetLastError()); return 4; }
+        int failed = 0;
+        for (int r = 1; r < ranks; r++) { int st = 0; if (wait(&st) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) failed = 1; }
+        if (failed) die("a rank failed");
+    }
+    else {
+        for (int f = 0; f < frames; f++) drawFrame();
+        if (RT64.ext.ReadbackDevice(RT64.device, RT64_IMAGE_FINAL_RGBA8, frame, bytes) != bytes) { fprintf(stderr, "sample_host: readback: %s\n", RT64.lib.GetLastError()); return 4; }
+    }
     unsigned long long sum = 0, fnv = 1469598103934665603ull;
     for (size_t i = 0; i < bytes; i++) { sum += frame[i]; fnv = (fnv ^ frame[i]) * 1099511628211ull; }
-    RT64_INSTANCE *picked = RT64.lib.GetViewRaytracedInstanceAt(RT64.view, width / 2, height / 2);          /* right click of main.cpp:76-83 */
+    RT64_INSTANCE *picked = ranks > 1 ? NULL : RT64.lib.GetViewRaytracedInstanceAt(RT64.view, width / 2, height / 2);          /* right click of main.cpp:76-83 */
     const char *pickedName = picked == RT64.sphereInstance ? "sphere" : (picked == RT64.floorInstance ? "floor" : (picked ? "other" : "none"));
     RT64_FRAME_STATS st; memset(&st, 0, sizeof(st)); st.structSize = (unsigned int)sizeof(st);
     float gpuMs = 0.0f;
     if (RT64.ext.GetDeviceStats && RT64.ext.GetDeviceStats(RT64.device, &st)) gpuMs = st.msTotal;
-    printf("{\"host\": \"C (tools/sample_host.c)\", \"width\": %d, \"height\": %d, \"frames\": %d, \"checksum\": %llu, \"fnv1a\": \"%016llx\", \"picked_center\": \"%s\", \"gpu_ms_last_frame\": %.4f}\n",
-           width, height, frames, sum, fnv, pickedName, gpuMs);
+    printf("{\"host\": \"C (tools/sample_host.c)\", \"width\": %d, \"height\": %d, \"frames\": %d, \"ranks\": %d, \"checksum\": %llu, \"fnv1a\": \"%016llx\", \"picked_center\": \"%s\", \"gpu_ms_last_frame\": %.4f}\n",
+           width, height, frames, ranks, sum, fnv, pickedName, gpuMs);
     if (dump) { FILE *f = fopen(dump, "wb"); if (f) { fwrite(frame, 1, bytes, f); fclose(f); } }
     free(frame);
 
