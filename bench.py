@@ -150,6 +150,7 @@ def main():
     scene.option("count_traversal", 1)
     scene.draw()
     st_full = scene.stats()
+    first_frame_build_ms = float(st_full.msBuild)           # every BLAS build recorded by the RT64_SetMesh calls of the scene set-up + the TLAS build: they run at the first RT64_DrawDevice
     rays_total = int(st_full.primaryRays + st_full.shadowRays + st_full.indirectRays + st_full.reflectionRays + st_full.refractionRays)
     scene.option("count_traversal", 0)
     use_bands = N > 1 and args.gi_samples > 0 and args.denoiser
@@ -394,6 +395,8 @@ def main():
                                   "gather": "in-library (RT64_SubmitGather: grouped ncclSend / ncclRecv + reassembly kernel on the library's comm stream)" if native else "torch.distributed gather (tiles.FrameGatherer)",
                               "send_buffer": ("written by the frame kernel (RT64_SetDeviceGatherTarget)" if (packed[0] or (native and scene.stats().packedFinal)) else "packed after each frame (RT64_CopyDeviceImage layout)"),
                                   "host_ms_per_step": round(enqueue_ms, 5)}
+        result["accel_build"] = {"first_frame_ms": round(first_frame_build_ms, 4), "triangles": int(st_full.triangleCount), "blas_node_bytes": int(st_full.blasNodeBytes),
+                                 "what": "GPU time of all BLAS builds (LBVH: Morton, radix sort, Karras, fit, 4-wide nodes) + the TLAS build, executed at the first frame after the RT64_SetMesh calls"}
         if rebuild is not None:
             result["always_rebuild"] = rebuild
         result["frame_tables"] = "rebuilt every frame (always_rebuild)" if args.always_rebuild else "cached while the host re-sends identical descriptors (steady state of the sample host, main.cpp:97-134); `always_rebuild` holds the figure with the cache off"
