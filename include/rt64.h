@@ -338,8 +338,7 @@ enum {
     RT64_ACCEL_TRIANGLES = 1,          /* 48-byte leaves in Morton order: v0[3] prim v1[3] pad v2[3] pad (BLAS only) */
     RT64_ACCEL_SORTED_INDEX = 2,       /* u32[n]: leaf slot -> primitive (BLAS) / instance (TLAS) */
     RT64_ACCEL_MORTON = 3,             /* u32[n]: 30-bit Morton code per leaf slot */
-    RT64_ACCEL_HEADER = 4,             /* bmin[3] count bmax[3] pad */
-    RT64_ACCEL_WIDE_NODES = 5          /* 64-byte 4-wide traversal nodes, one per binary node: origin[3], quantum exponents[3] + child count, child[4], 8-bit boxes [4][6], pad[2] */
+    RT64_ACCEL_HEADER = 4              /* bmin[3] count bmax[3] pad */
 };
 
 /* Per-frame counters and GPU timings of the last RT64_DrawDevice (milliseconds, HIP events on the device stream). */

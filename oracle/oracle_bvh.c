@@ -22,15 +22,6 @@
  *   G5  node i stores the boxes of both children (ONode).  n == 1: node 0 = {left = leaf 0, right = none with an
  *       empty box (min=+inf, max=-inf)}.
  *   G6  refit keeps sort order and topology and recomputes boxes only.
- *   Wide spec (G7; the traversal representation, rebuilt after every build and refit).  Wide node i lies over binary node i:
- *       children = (left, right) without "none"; while fewer than four: the inner child with the largest box measure
- *       (dx*dy + dy*dz) + dz*dx (fp32, first one on ties; NaN / negative measures never win) is replaced, in place, by its own two
- *       children -- each child carries the box its binary parent stores for it.  origin_k = min of the children's lower bounds,
- *       e_k = (max of the upper bounds) - origin_k;  x = e_k / 254.0f;  quantum s_k = 2^(E+1) where x = 1.m * 2^E (fp32 exponent
- *       field of x, + 1), exponent byte clamped to [27, 250] (x <= 0 or tiny -> 27);  r = 1 / s (exact).
- *       qlo = clamp((int)floorf((lo - origin) * r), 0, 255), then qlo -= 1 if qlo > 0 and fmaf(qlo, s, origin) >= lo;
- *       qhi = clamp((int)ceilf((hi - origin) * r), 0, 255),  then qhi += 1 if qhi < 255 and fmaf(qhi, s, origin) <= hi
- *       (the dequantised box contains the child's box in real arithmetic).
  * ---------------------------------------------------------------------------------------------------
  */
 #include <stdlib.h>
@@ -63,7 +54,7 @@ static inline int delta(const uint64_t *keys, int n, int i, int j) {
 }
 
 void obvh_free(OBvh *b) {
-    free(b->nodes); free(b->sortedIndex); free(b->morton); free(b->wide);
+    free(b->nodes); free(b->sortedIndex); free(b->morton);
     memset(b, 0, sizeof(*b));
 }
 
@@ -107,60 +98,6 @@ void obvh_fit(OBvh *b, const float *leafMin, const float *leafMax) {
         }
     }
     free(done); free(nmin); free(nmax);
-}
-
-/* G7: the 4-wide nodes from the fitted binary nodes. */
-static float quantum_from_byte(uint8_t e) { uint32_t bits = (uint32_t)e << 23; float f; memcpy(&f, &bits, 4); return f; }
-void obvh_widen(OBvh *b) {
-    const uint32_t n = b->count, inner = n > 1 ? n - 1 : 1;
-    free(b->wide);
-    b->wide = (OWide *)calloc(inner, sizeof(OWide));
-    for (uint32_t i = 0; i < inner; i++) {
-        const ONode *nd = &b->nodes[i];
-        uint32_t child[4]; const float *lo[4], *hi[4]; int m = 0;
-        for (int side = 0; side < 2; side++) {
-            const uint32_t c = side ? nd->right : nd->left;
-            if (c == 0xFFFFFFFFu) continue;
-            child[m] = c; lo[m] = side ? nd->rmin : nd->lmin; hi[m] = side ? nd->rmax : nd->lmax; m++;
-        }
-        while (m < 4) {                 /* open the inner child with the largest box (first one on ties) until four slots are taken */
-            int best = -1; float bestArea = -1.0f;
-            for (int c = 0; c < m; c++) {
-                if (child[c] & 0x80000000u) continue;
-                const float dx = hi[c][0] - lo[c][0], dy = hi[c][1] - lo[c][1], dz = hi[c][2] - lo[c][2];
-                const float area = (dx * dy + dy * dz) + dz * dx;
-                if (area > bestArea) { bestArea = area; best = c; }
-            }
-            if (best < 0) break;
-            const ONode *cn = &b->nodes[child[best]];
-            for (int c = m; c > best + 1; c--) { child[c] = child[c - 1]; lo[c] = lo[c - 1]; hi[c] = hi[c - 1]; }
-            child[best] = cn->left; lo[best] = cn->lmin; hi[best] = cn->lmax;
-            child[best + 1] = cn->right; lo[best + 1] = cn->rmin; hi[best + 1] = cn->rmax;
-            m++;
-        }
-        OWide *w = &b->wide[i];
-        w->count = (uint8_t)m;
-        for (int c = 0; c < 4; c++) w->child[c] = c < m ? child[c] : 0xFFFFFFFFu;
-        for (int k = 0; k < 3; k++) {
-            float mn = INFINITY, mx = -INFINITY;
-            for (int c = 0; c < m; c++) { mn = fminf(mn, lo[c][k]); mx = fmaxf(mx, hi[c][k]); }
-            w->origin[k] = mn;
-            const float x = (mx - mn) / 254.0f;
-            uint32_t bits; memcpy(&bits, &x, 4);
-            int e = (x > 0.0f) ? (int)((bits >> 23) & 255u) + 1 : 27;
-            e = e < 27 ? 27 : (e > 250 ? 250 : e);
-            w->exp[k] = (uint8_t)e;
-            const float s = quantum_from_byte((uint8_t)e), r = 1.0f / s;
-            for (int c = 0; c < 4; c++) {
-                if (c >= m) { w->q[c][k] = 255; w->q[c][3 + k] = 0; continue; }
-                int ql = (int)floorf((lo[c][k] - mn) * r); ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql);
-                if (ql > 0 && fmaf((float)ql, s, mn) >= lo[c][k]) ql -= 1;
-                int qh = (int)ceilf((hi[c][k] - mn) * r); qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
-                if (qh < 255 && fmaf((float)qh, s, mn) <= hi[c][k]) qh += 1;
-                w->q[c][k] = (uint8_t)ql; w->q[c][3 + k] = (uint8_t)qh;
-            }
-        }
-    }
 }
 
 /* Build over n leaf boxes given in leaf-index order.  Returns sorted boxes through outMin/outMax (malloc'd, 3n floats). */
@@ -231,7 +168,6 @@ void obvh_build(OBvh *b, uint32_t n, const float *boxMin, const float *boxMax, f
         }
     }
     obvh_fit(b, smin, smax);
-    obvh_widen(b);
     free(keys);
     if (outMin) *outMin = smin; else free(smin);
     if (outMax) *outMax = smax; else free(smax);
@@ -303,7 +239,6 @@ void oracle_mesh_set(OMesh *m, const void *vertices, int vertexCount, int vertex
     }
     if (refit) {
         obvh_fit(&m->bvh, bmin, bmax);
-        obvh_widen(&m->bvh);
         for (int k = 0; k < 3; k++) { m->bvh.bmin[k] = INFINITY; m->bvh.bmax[k] = -INFINITY; }
         for (uint32_t s = 0; s < n; s++)
             for (int k = 0; k < 3; k++) {

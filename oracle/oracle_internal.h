@@ -108,7 +108,6 @@ struct OScene {
 void obvh_free(OBvh *b);
 void obvh_build(OBvh *b, uint32_t n, const float *boxMin, const float *boxMax, float **outMin, float **outMax);
 void obvh_fit(OBvh *b, const float *leafMin, const float *leafMax);
-void obvh_widen(OBvh *b);
 
 /* oracle_trace.c */
 typedef struct {

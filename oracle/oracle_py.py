@@ -89,13 +89,11 @@ class ONode(C.Structure):
 
 class OBvh(C.Structure):
     _fields_ = [("count", C.c_uint32), ("nodes", C.POINTER(ONode)), ("sortedIndex", C.POINTER(C.c_uint32)),
-                ("morton", C.POINTER(C.c_uint32)), ("bmin", C.c_float * 3), ("bmax", C.c_float * 3), ("wide", C.c_void_p)]
+                ("morton", C.POINTER(C.c_uint32)), ("bmin", C.c_float * 3), ("bmax", C.c_float * 3)]
 
 
 NODE_DTYPE = np.dtype([("lmin", "<f4", 3), ("lmax", "<f4", 3), ("rmin", "<f4", 3), ("rmax", "<f4", 3),
                        ("left", "<u4"), ("right", "<u4"), ("parent", "<u4"), ("pad", "<u4")])
-WIDE_DTYPE = np.dtype([("origin", "<f4", 3), ("exp", "u1", 3), ("count", "u1"), ("child", "<u4", 4), ("q", "u1", (4, 6)), ("pad", "<u4", 2)])
-assert WIDE_DTYPE.itemsize == 64
 TRI_DTYPE = np.dtype([("v0", "<f4", 3), ("prim", "<u4"), ("v1", "<f4", 3), ("pad1", "<u4"), ("v2", "<f4", 3), ("pad2", "<u4")])
 
 _lib = None
@@ -151,8 +149,7 @@ def bvh_to_numpy(bvh_ptr):
     nodes = np.ctypeslib.as_array(C.cast(b.nodes, C.POINTER(C.c_uint8)), shape=(inner * 64,)).view(NODE_DTYPE).copy()
     sorted_index = np.ctypeslib.as_array(b.sortedIndex, shape=(n,)).copy()
     morton = np.ctypeslib.as_array(b.morton, shape=(n,)).copy()
-    wide = np.ctypeslib.as_array(C.cast(b.wide, C.POINTER(C.c_uint8)), shape=(inner * 64,)).view(WIDE_DTYPE).copy() if b.wide else None
-    return {"count": n, "nodes": nodes, "sortedIndex": sorted_index, "morton": morton, "wide": wide,
+    return {"count": n, "nodes": nodes, "sortedIndex": sorted_index, "morton": morton,
             "bmin": np.array(list(b.bmin), dtype=np.float32), "bmax": np.array(list(b.bmax), dtype=np.float32)}
 
 

@@ -17,13 +17,8 @@
  *   R2 box test against [lo, hi]: a_k = fmaf(lo_k, inv_k, oi_k), b_k = fmaf(hi_k, inv_k, oi_k);
  *      tn = max(max(min(a_x,b_x), min(a_y,b_y)), max(min(a_z,b_z), tmin));
  *      tf = min(min(max(a_x,b_x), max(a_y,b_y)), min(max(a_z,b_z), tmax)) * 1.0000004f;   hit iff tn <= tf.
- *   R3 order: depth first with an explicit stack over the 4-WIDE nodes (oracle_bvh.c G7).  At wide node i:
- *      a_k = s_k * inv_k (s = the node's quantum, a power of two);  b_k = fmaf(origin_k, inv_k, oi_k);
- *      child c (c < count, in slot order): lo_k = fmaf((float)qlo_ck, a_k, b_k), hi_k = fmaf((float)qhi_ck, a_k, b_k), then tn / tf as R2
- *      with lo / hi in place of a / b.  The children that are hit are ordered by key = float((bits(tn) & ~3) | slot) ascending
- *      (distinct keys; tn values within 4 ulp of each other go by slot): the walk continues with the first and pushes the others
- *      so that they pop in that order; no child hit: pop.
- *      (The binary nodes are the build representation only; a "node visit" is a wide-node visit.)
+ *   R3 order: depth first with an explicit stack.  At an inner node test left then right; if both hit, continue
+ *      with the one with the smaller tn (ties: left) and push the other; if one hits continue with it; else pop.
  *      A TLAS leaf switches to object space (G8: o' = g_xform_point(worldToObject, o), d' = g_xform_vector(...))
  *      and walks the mesh's BLAS to exhaustion before the TLAS walk resumes.
  *   R4 triangle (Moller-Trumbore with fixed fma chains): e1 = v1-v0, e2 = v2-v0, p = g_cross3(d, e2),
@@ -79,43 +74,12 @@ static inline int tri_hit(const RaySpace *r, const OTri *tri, int cull, float tm
     return 1;
 }
 
-/* R3: one wide-node step.  Writes the hit children in visiting order to out[]; returns how many. */
-static inline int wide_step(const RaySpace *r, const OWide *w, float tmin, float tmax, uint32_t out[4]) {
-    float a[3], b[3];
-    for (int k = 0; k < 3; k++) {
-        uint32_t bits = (uint32_t)w->exp[k] << 23; float s; memcpy(&s, &bits, 4);
-        a[k] = s * r->inv[k];
-        b[k] = fmaf(w->origin[k], r->inv[k], r->oi[k]);
-    }
-    /* sort key of a child: its tnear with the two low mantissa bits replaced by the slot number (keys are distinct, near-ties go by
-     * slot); a child that is not hit sorts behind every hit one */
-    float key[4]; uint32_t child[4]; int nh = 0;
-    for (int c = 0; c < 4; c++) {
-        uint32_t kb = 0x7F000000u | (uint32_t)c;
-        if (c < w->count) {
-            float lo[3], hi[3];
-            for (int k = 0; k < 3; k++) { lo[k] = fmaf((float)w->q[c][k], a[k], b[k]); hi[k] = fmaf((float)w->q[c][3 + k], a[k], b[k]); }
-            float n = fmaxf(fmaxf(fminf(lo[0], hi[0]), fminf(lo[1], hi[1])), fmaxf(fminf(lo[2], hi[2]), tmin));
-            float f = fminf(fminf(fmaxf(lo[0], hi[0]), fmaxf(lo[1], hi[1])), fminf(fmaxf(lo[2], hi[2]), tmax)) * 1.0000004f;
-            if (n <= f) { uint32_t nb; memcpy(&nb, &n, 4); kb = (nb & ~3u) | (uint32_t)c; nh++; }
-        }
-        memcpy(&key[c], &kb, 4); child[c] = w->child[c];
-    }
-    for (int i = 1; i < 4; i++)                                   /* ascending by key (as floats), slots travel with their keys */
-        for (int j = i; j > 0 && key[j] < key[j - 1]; j--) {
-            float tk = key[j]; key[j] = key[j - 1]; key[j - 1] = tk;
-            uint32_t tc = child[j]; child[j] = child[j - 1]; child[j - 1] = tc;
-        }
-    for (int k = 0; k < nh; k++) out[k] = child[k];
-    return nh;
-}
-
 /* Walk one BLAS.  Returns 1 when the walk must terminate the whole trace. */
 static int walk_blas(const OMesh *mesh, const RaySpace *r, int cull, float tmin, float *tmax, uint32_t instance,
                      OAnyHitFn fn, void *user, OTraceCounters *ctr) {
     const OBvh *b = &mesh->bvh;
     uint32_t stack[STACK_MAX]; int sp = 0;
-    uint32_t cur = 0;                                   /* wide node index, or leaf with bit 31 */
+    uint32_t cur = 0;                                   /* inner node index, or leaf with bit 31 */
     for (;;) {
         if (cur & 0x80000000u) {
             if (cur != 0xFFFFFFFFu) {
@@ -133,16 +97,21 @@ static int walk_blas(const OMesh *mesh, const RaySpace *r, int cull, float tmin,
             cur = stack[--sp];
             continue;
         }
+        const ONode *nd = &b->nodes[cur];
         if (ctr) ctr->nodes++;
-        uint32_t order[4];
-        const int nh = wide_step(r, &b->wide[cur], tmin, *tmax, order);
-        if (nh == 0) {
+        float tl, tr;
+        int hl = box_hit(r, nd->lmin, nd->lmax, tmin, *tmax, &tl);
+        int hr = box_hit(r, nd->rmin, nd->rmax, tmin, *tmax, &tr);
+        if (hl && hr) {
+            if (tr < tl) { stack[sp++] = nd->left; cur = nd->right; }
+            else { stack[sp++] = nd->right; cur = nd->left; }
+        }
+        else if (hl) cur = nd->left;
+        else if (hr) cur = nd->right;
+        else {
             if (sp == 0) return 0;
             cur = stack[--sp];
-            continue;
         }
-        for (int k = nh - 1; k >= 1; k--) if (sp < STACK_MAX) stack[sp++] = order[k];
-        cur = order[0];
     }
 }
 
@@ -191,15 +160,20 @@ void otrace(const OScene *s, const ORay *ray, int bruteForce, OAnyHitFn fn, void
             cur = stack[--sp];
             continue;
         }
+        const ONode *nd = &b->nodes[cur];
         if (ctr) ctr->nodes++;
-        uint32_t order[4];
-        const int nh = wide_step(&r, &b->wide[cur], ray->tmin, tmax, order);
-        if (nh == 0) {
+        float tl, tr;
+        int hl = box_hit(&r, nd->lmin, nd->lmax, ray->tmin, tmax, &tl);
+        int hr = box_hit(&r, nd->rmin, nd->rmax, ray->tmin, tmax, &tr);
+        if (hl && hr) {
+            if (tr < tl) { stack[sp++] = nd->left; cur = nd->right; }
+            else { stack[sp++] = nd->right; cur = nd->left; }
+        }
+        else if (hl) cur = nd->left;
+        else if (hr) cur = nd->right;
+        else {
             if (sp == 0) return;
             cur = stack[--sp];
-            continue;
         }
-        for (int k = nh - 1; k >= 1; k--) if (sp < STACK_MAX) stack[sp++] = order[k];
-        cur = order[0];
     }
 }

@@ -83,17 +83,6 @@ typedef struct {
     uint32_t parent, pad;
 } ONode;
 
-/* 4-wide node laid over binary node i, 64 bytes: the children of i, each inner child replaced by ITS two children (order: left's, then
- * right's), boxes quantised to 8 bits per axis against the node's own box (oracle_bvh.c, "Wide spec").  Traversal walks these;
- * the binary nodes stay the build / refit representation. */
-typedef struct {
-    float origin[3];                              /* lower corner of the node's box */
-    uint8_t exp[3], count;                        /* biased fp32 exponent of the quantum per axis (a power of two); children in use */
-    uint32_t child[4];                            /* inner: binary node index; bit 31: leaf slot; 0xFFFFFFFF: none */
-    uint8_t q[4][6];                              /* child k spans origin + q[k][0..2] * quantum .. origin + q[k][3..5] * quantum (conservative) */
-    uint32_t pad[2];
-} OWide;
-
 typedef struct {                                  /* BLAS leaf payload in sorted order, 48 bytes */
     float v0[3]; uint32_t prim;
     float v1[3]; uint32_t pad1;
@@ -106,7 +95,6 @@ typedef struct {
     uint32_t *sortedIndex;                        /* leaf slot -> primitive (BLAS) / instance (TLAS) */
     uint32_t *morton;                             /* per leaf slot, after sort */
     float bmin[3], bmax[3];                       /* bounds of all leaves */
-    OWide *wide;                                  /* max(count-1, 1) wide nodes, index = binary node index, root = 0 */
 } OBvh;
 
 typedef struct {

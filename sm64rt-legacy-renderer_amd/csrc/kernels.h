@@ -16,7 +16,6 @@ struct LbvhArgs {
     const GpuInstance *instances;
     // outputs
     GpuNode *nodes;                   // max(n-1, 1)
-    GpuWide *wide;                    // max(n-1, 1): the 4-wide traversal nodes, rebuilt after every build / refit
     GpuTri *tris;                     // n (triangles mode)
     BlasHeader *header;
     uint32_t *sortedIndex, *morton, *leafParent;   // n each

@@ -83,67 +83,6 @@ DEV int delta64(const uint32_t *key, const uint32_t *val, int n, int i, int j) {
     return __clzll((long long)(a ^ b));
 }
 
-// G7 ("Wide spec", oracle/oracle_bvh.c): the 4-wide traversal node over binary node i.  Reads binary nodes that other threads fitted:
-// VOLATILE selects loads that bypass this CU's vector L1 (the single-workgroup builder calls this right after its bottom-up fit).
-struct NodeBox { float lo[3], hi[3]; };
-template <bool VOLATILE> DEV float ld_f(const float *p) { return VOLATILE ? *(volatile const float *)p : *p; }
-template <bool VOLATILE> DEV uint32_t ld_u(const uint32_t *p) { return VOLATILE ? *(volatile const uint32_t *)p : *p; }
-template <bool VOLATILE> DEV void widen_node(const LbvhArgs &a, uint32_t i) {
-    const GpuNode *nodes = a.nodes;
-    uint32_t child[4]; NodeBox box[4]; int m = 0;
-#pragma unroll
-    for (int side = 0; side < 2; side++) {
-        const GpuNode &nd = nodes[i];
-        const uint32_t c = ld_u<VOLATILE>(side ? &nd.right : &nd.left);
-        if (c == RT64_NO_CHILD) continue;
-        child[m] = c;
-#pragma unroll
-        for (int k = 0; k < 3; k++) { box[m].lo[k] = ld_f<VOLATILE>(side ? &nd.rmin[k] : &nd.lmin[k]); box[m].hi[k] = ld_f<VOLATILE>(side ? &nd.rmax[k] : &nd.lmax[k]); }
-        m++;
-    }
-    while (m < 4) {                  // open the inner child with the largest box (first one on ties) until four slots are taken
-        int best = -1; float bestArea = -1.0f;
-        for (int c = 0; c < m; c++) {
-            if (child[c] & RT64_LEAF_BIT) continue;
-            const float dx = box[c].hi[0] - box[c].lo[0], dy = box[c].hi[1] - box[c].lo[1], dz = box[c].hi[2] - box[c].lo[2];
-            const float area = (dx * dy + dy * dz) + dz * dx;
-            if (area > bestArea) { bestArea = area; best = c; }
-        }
-        if (best < 0) break;
-        const GpuNode &cn = nodes[child[best]];
-        for (int c = m; c > best + 1; c--) { child[c] = child[c - 1]; box[c] = box[c - 1]; }
-        child[best] = ld_u<VOLATILE>(&cn.left); child[best + 1] = ld_u<VOLATILE>(&cn.right);
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            box[best].lo[k] = ld_f<VOLATILE>(&cn.lmin[k]); box[best].hi[k] = ld_f<VOLATILE>(&cn.lmax[k]);
-            box[best + 1].lo[k] = ld_f<VOLATILE>(&cn.rmin[k]); box[best + 1].hi[k] = ld_f<VOLATILE>(&cn.rmax[k]);
-        }
-        m++;
-    }
-    GpuWide w; memset(&w, 0, sizeof(w));
-    w.count = (uint8_t)m;
-    for (int c = 0; c < 4; c++) w.child[c] = c < m ? child[c] : RT64_NO_CHILD;
-    for (int k = 0; k < 3; k++) {
-        float mn = INFINITY, mx = -INFINITY;
-        for (int c = 0; c < m; c++) { mn = fminf(mn, box[c].lo[k]); mx = fmaxf(mx, box[c].hi[k]); }
-        w.origin[k] = mn;
-        const float x = (mx - mn) / 254.0f;
-        int e = (x > 0.0f) ? (int)((__float_as_uint(x) >> 23) & 255u) + 1 : 27;
-        e = e < 27 ? 27 : (e > 250 ? 250 : e);
-        w.exp[k] = (uint8_t)e;
-        const float s = __uint_as_float((uint32_t)e << 23), r = 1.0f / s;
-        for (int c = 0; c < 4; c++) {
-            if (c >= m) { w.q[c][k] = 255; w.q[c][3 + k] = 0; continue; }
-            int ql = (int)floorf((box[c].lo[k] - mn) * r); ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql);
-            if (ql > 0 && fmaf((float)ql, s, mn) >= box[c].lo[k]) ql -= 1;
-            int qh = (int)ceilf((box[c].hi[k] - mn) * r); qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
-            if (qh < 255 && fmaf((float)qh, s, mn) <= box[c].hi[k]) qh += 1;
-            w.q[c][k] = (uint8_t)ql; w.q[c][3 + k] = (uint8_t)qh;
-        }
-    }
-    a.wide[i] = w;
-}
-
 // LDS carve (uint32 words): keyA[n] valA[n] keyB[n] valB[n] parentLeaf[n] parentNode[n] counters[n] scratch[64]
 DEV void lbvh_small_body(const LbvhArgs &a, uint32_t *lds) {
     const uint32_t n = a.n, tid = threadIdx.x, T = blockDim.x;
@@ -330,11 +269,6 @@ DEV void lbvh_small_body(const LbvhArgs &a, uint32_t *lds) {
             child = p; p = parentNode[p];
         }
     }
-    // ---- G7: the 4-wide traversal nodes.  Every box store above is followed by a workgroup-scope fence; the loads below bypass L1.
-    __threadfence_block();
-    __syncthreads();
-    const uint32_t inner = n > 1 ? n - 1 : 1;
-    for (uint32_t i = tid; i < inner; i += T) widen_node<true>(a, i);
 }
 
 __global__ __launch_bounds__(LBVH_THREADS) void lbvh_small_kernel(LbvhArgs a) {
@@ -618,10 +552,6 @@ __global__ __launch_bounds__(LG_THREADS) void lg_fit_kernel(LbvhArgs a, const fl
     }
 }
 
-__global__ __launch_bounds__(LG_THREADS) void lg_wide_kernel(LbvhArgs a) {
-    for (uint32_t i = blockIdx.x * LG_THREADS + threadIdx.x; i + 1 < a.n; i += gridDim.x * LG_THREADS) widen_node<false>(a, i);
-}
-
 }  // namespace
 
 size_t lbvh_large_scratch_bytes(uint32_t n) {
@@ -651,6 +581,5 @@ hipError_t lbvh_launch_large(const LbvhArgs &args, hipStream_t stream) {
     uint32_t depthBound = 32; { uint32_t m = n; while (m) { depthBound++; m >>= 1; } }      // 30 code bits + log2(n) index bits + slack
     for (uint32_t pass = 1; pass <= depthBound; pass++)
         hipLaunchKernelGGL(lg_fit_kernel, dim3(grid), dim3(LG_THREADS), 0, stream, args, L.leafBox, L.nodeBox, L.done, pass);
-    hipLaunchKernelGGL(lg_wide_kernel, dim3(grid), dim3(LG_THREADS), 0, stream, args);
     return hipGetLastError();
 }

@@ -25,18 +25,6 @@ struct alignas(16) GpuNode {
 };
 static_assert(sizeof(GpuNode) == 64, "GpuNode");
 
-// 4-wide traversal node laid over binary node i (same index), 64 B = four 16-byte loads: the children of i, the inner child with the
-// largest box opened in place until four slots are taken ("Wide spec" G7 in oracle/oracle_bvh.c), child boxes quantised to 8 bits per
-// axis against the node's own box, conservatively.  The walk visits these; GpuNode stays the build / refit representation.
-struct alignas(16) GpuWide {
-    float origin[3];                 // lower corner of the node's box
-    uint8_t exp[3], count;           // biased fp32 exponent of the quantum per axis (a power of two); children in use
-    uint32_t child[4];               // inner: binary node index; bit 31: leaf slot; RT64_NO_CHILD: none
-    uint8_t q[4][6];                 // child k: origin + q[k][0..2] * quantum .. origin + q[k][3..5] * quantum
-    uint32_t pad[2];
-};
-static_assert(sizeof(GpuWide) == 64, "GpuWide");
-
 // BLAS leaf: one triangle, positions only (Moller-Trumbore operands), 48 B = three 16-byte loads.
 struct alignas(16) GpuTri {
     float v0[3]; uint32_t prim;      // prim = PrimitiveIndex() (triangle number in the index buffer)
@@ -78,7 +66,7 @@ struct alignas(16) GpuInstance {
     float objectToWorldNormal[16];
     float objectToWorldPrevious[16];
     float worldToObject[16];
-    const GpuWide *nodes;                // the BLAS as the walk sees it (4-wide nodes)
+    const GpuNode *nodes;
     const GpuTri *tris;
     const uint8_t *vertices;
     const uint32_t *indices;
@@ -137,7 +125,7 @@ struct FrameParams {
     float skyBase[4];                    // ComputeSkyPlaneUV: base u, base v, 0.25 * ratioDivision, 0.25
     uint32_t lightCount, instanceCount, countTraversal;
     const GpuInstance *instances;
-    const GpuWide *tlasNodes;            // 4-wide nodes
+    const GpuNode *tlasNodes;
     const uint32_t *tlasIndex;           // TLAS leaf slot -> instance
     const GpuTexture *textures;
     const RT64_LIGHT *lights;

@@ -226,7 +226,7 @@ struct Mesh {
     int vertexCount = 0, vertexStride = 0, indexCount = 0;
     std::vector<uint8_t> hostVertices;                 // kept for the opacity rule (alpha bounds of the vertex inputs)
     DevArray<uint8_t> vertices; DevArray<uint32_t> indices;
-    DevArray<GpuNode> nodes; DevArray<GpuWide> wide; DevArray<GpuTri> tris; DevArray<BlasHeader> header;
+    DevArray<GpuNode> nodes; DevArray<GpuTri> tris; DevArray<BlasHeader> header;
     DevArray<uint32_t> sortedIndex, morton, leafParent; DevArray<uint8_t> buildScratch;
     uint32_t blasCount = 0;                            // leaves of the current BLAS (0 = none)
     bool buildPending = false, pendingRefit = false;   // RT64_SetMesh recorded a build / refit that Device::flushMeshBuilds has not run yet
@@ -299,7 +299,7 @@ struct View {
     template <class T> struct TablePtr { T *ptr = nullptr; };
     DevArray<uint8_t> dTables; TablePtr<GpuInstance> dInstances; TablePtr<GpuTexture> dTextures; TablePtr<RT64_LIGHT> dLights;
     std::vector<uint8_t> tableScratch;
-    DevArray<GpuNode> tlasNodes; DevArray<GpuWide> tlasWide; DevArray<uint32_t> tlasIndex, tlasMorton, tlasLeafParent; DevArray<BlasHeader> tlasHeader; DevArray<uint8_t> tlasScratch;
+    DevArray<GpuNode> tlasNodes; DevArray<uint32_t> tlasIndex, tlasMorton, tlasLeafParent; DevArray<BlasHeader> tlasHeader; DevArray<uint8_t> tlasScratch;
     std::vector<uint8_t> uploadedTables;      // bytes of the last uploaded instance/texture/light tables (cache key)
     float maxDepthBias = 0.0f;
     bool anyNonOpaque = false, anyReflection = false, anyRefraction = false, anyFog = false;
@@ -468,7 +468,7 @@ void Mesh::set(const void *vertexArray, int vcount, int vstride, const unsigned 
         const bool refit = (flags & RT64_MESH_RAYTRACE_UPDATABLE) && sameShape && blasCount == n;   // rt64_mesh.cpp:129,149-157
         // A refit keeps the topology of the tree that exists (or is about to exist, if its build is still pending).
         pendingRefit = buildPending ? (pendingRefit && refit) : refit;
-        nodes.reserve(std::max<size_t>(n - 1, 1)); wide.reserve(std::max<size_t>(n - 1, 1)); tris.reserve(n); header.reserve(1);
+        nodes.reserve(std::max<size_t>(n - 1, 1)); tris.reserve(n); header.reserve(1);
         sortedIndex.reserve(n); morton.reserve(n); leafParent.reserve(n);
         if (n > LBVH_SMALL_MAX) buildScratch.reserve(lbvh_large_scratch_bytes(n));
         blasCount = n;
@@ -490,7 +490,7 @@ void Device::flushMeshBuilds() {
         LbvhArgs a = {};
         a.mode = LBVH_MODE_TRIANGLES; a.refit = m->pendingRefit ? 1 : 0; a.n = m->blasCount;
         a.vertices = m->vertices.ptr; a.vertexStride = (uint32_t)m->vertexStride; a.indices = m->indices.ptr;
-        a.nodes = m->nodes.ptr; a.wide = m->wide.ptr; a.tris = m->tris.ptr; a.header = m->header.ptr; a.sortedIndex = m->sortedIndex.ptr; a.morton = m->morton.ptr; a.leafParent = m->leafParent.ptr;
+        a.nodes = m->nodes.ptr; a.tris = m->tris.ptr; a.header = m->header.ptr; a.sortedIndex = m->sortedIndex.ptr; a.morton = m->morton.ptr; a.leafParent = m->leafParent.ptr;
         if (a.n > LBVH_SMALL_MAX) { a.scratch = m->buildScratch.ptr; a.scratchBytes = m->buildScratch.bytes(); HIP_CHECK(lbvh_launch_large(a, stream)); }
         else { small.push_back(a); maxN = std::max(maxN, a.n); }
         m->buildPending = false; m->pendingRefit = false;
@@ -782,7 +782,7 @@ void View::update() {                          // View::update, rt64_view.cpp:10
         Mat4 w2o = mat_inverse(inst->transform);
         memcpy(g.worldToObject, w2o.m, 64);
         Mesh *mesh = inst->mesh;
-        g.nodes = mesh->wide.ptr; g.tris = mesh->tris.ptr; g.vertices = mesh->vertices.ptr; g.indices = mesh->indices.ptr; g.header = mesh->header.ptr;
+        g.nodes = mesh->nodes.ptr; g.tris = mesh->tris.ptr; g.vertices = mesh->vertices.ptr; g.indices = mesh->indices.ptr; g.header = mesh->header.ptr;
         g.material = inst->material;
         g.cc = inst->shader->cc;
         g.texDiffuse = g.material.diffuseTexIndex = inst->diffuse->currentIndex;      // rt64_view.cpp:1110-1112
@@ -829,10 +829,10 @@ void View::update() {                          // View::update, rt64_view.cpp:10
         // TLAS: full rebuild (rt64_view.cpp:412-452 rebuilds every frame, updateOnly = false).
         if (nInst) {
             const uint32_t n = (uint32_t)nInst;
-            tlasNodes.reserve(std::max<size_t>(n - 1, 1)); tlasWide.reserve(std::max<size_t>(n - 1, 1)); tlasIndex.reserve(n); tlasMorton.reserve(n); tlasLeafParent.reserve(n); tlasHeader.reserve(1);
+            tlasNodes.reserve(std::max<size_t>(n - 1, 1)); tlasIndex.reserve(n); tlasMorton.reserve(n); tlasLeafParent.reserve(n); tlasHeader.reserve(1);
             LbvhArgs a = {};
             a.mode = LBVH_MODE_INSTANCES; a.refit = 0; a.n = n; a.instances = dInstances.ptr;
-            a.nodes = tlasNodes.ptr; a.wide = tlasWide.ptr; a.tris = nullptr; a.header = tlasHeader.ptr; a.sortedIndex = tlasIndex.ptr; a.morton = tlasMorton.ptr; a.leafParent = tlasLeafParent.ptr;
+            a.nodes = tlasNodes.ptr; a.tris = nullptr; a.header = tlasHeader.ptr; a.sortedIndex = tlasIndex.ptr; a.morton = tlasMorton.ptr; a.leafParent = tlasLeafParent.ptr;
             if (n > LBVH_SMALL_MAX) { tlasScratch.reserve(lbvh_large_scratch_bytes(n)); a.scratch = tlasScratch.ptr; a.scratchBytes = tlasScratch.bytes(); }
             HIP_CHECK(lbvh_launch(a, dev->stream));
         }
@@ -932,7 +932,7 @@ void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64
     }
     P.lightCount = (uint32_t)scene->lights.size(); P.instanceCount = (uint32_t)rtInstances.size();
     P.countTraversal = dev->opt.countTraversal ? 1u : 0u;
-    P.instances = dInstances.ptr; P.tlasNodes = tlasWide.ptr; P.tlasIndex = tlasIndex.ptr; P.textures = dTextures.ptr; P.lights = dLights.ptr;
+    P.instances = dInstances.ptr; P.tlasNodes = tlasNodes.ptr; P.tlasIndex = tlasIndex.ptr; P.textures = dTextures.ptr; P.lights = dLights.ptr;
     dev->spillStack.reserve(rt_stack_spill_bytes(imgW, imgH) / sizeof(uint32_t));      // grows with the render size (no-op otherwise)
     P.blueNoise = dev->blueNoise.ptr; P.traversalStack = dev->spillStack.ptr; P.counters = dev->counters.ptr;
 }
@@ -1502,13 +1502,12 @@ RT64_EXPORT RT64_TEXTURE *RT64_CreateTexture(RT64_DEVICE *devicePtr, RT64_TEXTUR
 RT64_EXPORT void RT64_DestroyTexture(RT64_TEXTURE *texture) { RT64_TRY Texture *t = reinterpret_cast<Texture *>(texture); if (t) { t->device->use(); hipStreamSynchronize(t->device->stream); } delete t; RT64_CATCH_VOID }
 
 // ---- debug readback of acceleration structures (additive) ----
-static size_t accel_readback(Device *dev, int what, uint32_t n, const GpuNode *nodes, const GpuWide *wide, const GpuTri *tris, const uint32_t *sorted, const uint32_t *morton,
+static size_t accel_readback(Device *dev, int what, uint32_t n, const GpuNode *nodes, const GpuTri *tris, const uint32_t *sorted, const uint32_t *morton,
                              const BlasHeader *header, void *dst, size_t dstBytes) {
     dev->use();
     const void *src = nullptr; size_t bytes = 0;
     switch (what) {
     case RT64_ACCEL_NODES: src = nodes; bytes = (size_t)std::max<uint32_t>(n > 0 ? n - 1 : 0, 1) * sizeof(GpuNode); break;
-    case RT64_ACCEL_WIDE_NODES: src = wide; bytes = (size_t)std::max<uint32_t>(n > 0 ? n - 1 : 0, 1) * sizeof(GpuWide); break;
     case RT64_ACCEL_TRIANGLES: src = tris; bytes = (size_t)n * sizeof(GpuTri); break;
     case RT64_ACCEL_SORTED_INDEX: src = sorted; bytes = (size_t)n * 4; break;
     case RT64_ACCEL_MORTON: src = morton; bytes = (size_t)n * 4; break;
@@ -1526,14 +1525,14 @@ RT64_EXPORT size_t RT64_ReadbackMeshAccel(RT64_MESH *meshPtr, int what, void *ds
     RT64_TRY
     Mesh *m = reinterpret_cast<Mesh *>(meshPtr); if (!m) throw std::runtime_error("RT64_ReadbackMeshAccel: NULL mesh.");
     m->device->flushMeshBuilds();
-    return accel_readback(m->device, what, m->blasCount, m->nodes.ptr, m->wide.ptr, m->tris.ptr, m->sortedIndex.ptr, m->morton.ptr, m->header.ptr, dst, dstBytes);
+    return accel_readback(m->device, what, m->blasCount, m->nodes.ptr, m->tris.ptr, m->sortedIndex.ptr, m->morton.ptr, m->header.ptr, dst, dstBytes);
     RT64_CATCH(0)
 }
 RT64_EXPORT size_t RT64_ReadbackViewAccel(RT64_VIEW *viewPtr, int what, void *dst, size_t dstBytes) {
     RT64_TRY
     View *v = reinterpret_cast<View *>(viewPtr); if (!v) throw std::runtime_error("RT64_ReadbackViewAccel: NULL view.");
     if (what == RT64_ACCEL_TRIANGLES) throw std::runtime_error("RT64_ReadbackViewAccel: a TLAS has no triangle array.");
-    return accel_readback(v->scene->device, what, (uint32_t)v->rtInstances.size(), v->tlasNodes.ptr, v->tlasWide.ptr, nullptr, v->tlasIndex.ptr, v->tlasMorton.ptr, v->tlasHeader.ptr, dst, dstBytes);
+    return accel_readback(v->scene->device, what, (uint32_t)v->rtInstances.size(), v->tlasNodes.ptr, nullptr, v->tlasIndex.ptr, v->tlasMorton.ptr, v->tlasHeader.ptr, dst, dstBytes);
     RT64_CATCH(0)
 }
 

@@ -8,9 +8,7 @@
 // Geometry spec (every operation below is part of the bit-exact contract with the scalar reference tracer):
 //   R1 ds = |d| < 1e-20 ? copysign(1e-20, d) : d ; inv = 1/ds ; oi = -(o*inv)
 //   R2 slab test with fmaf(bound, inv, oi); tfar scaled by 1.0000004f; hit iff tnear <= tfar
-//   R3 depth-first over the 4-wide nodes (rt64_gpu.h GpuWide; "Wide spec" G7): a = quantum * inv, b = fmaf(origin, inv, oi), child planes
-//      fmaf((float)q, a, b), then R2; the hit children are ordered by key = float((bits(tnear) & ~3) | slot) ascending, the walk goes on
-//      with the first and pushes the others so that they pop in that order; a TLAS leaf walks its BLAS to exhaustion
+//   R3 depth-first, near child first (ties: left), far child pushed; a TLAS leaf walks its BLAS to exhaustion
 //   R4 Moller-Trumbore with the g_dot3 / g_cross3 fma chains; u,v >= 0, u+v <= 1, tmin < t < tmax
 //   R5 the hit handler may lower tmax or end the walk
 //
@@ -40,7 +38,7 @@ DEV PPtr kernel_params_here() { uint32_t z; asm volatile("s_mov_b32 %0, 0" : "=s
 #define RT_BLOCK 256                 // threads per workgroup of every ray kernel
 #define RT_STACK_LDS 24
 #define RT_STACK_SPILL 84               // entries per lane in the HBM slab behind the LDS entries
-#define RT_STACK_LDS_CACHED 12           // kernels that also hold the LDS scene cache: the cached scenes are small, their trees shallow (a 4-wide visit pushes up to three entries)
+#define RT_STACK_LDS_CACHED 8            // kernels that also hold the LDS scene cache: the cached scenes are small, their trees shallow
 
 struct RaySpace { float o[3], d[3], inv[3], oi[3]; };
 
@@ -119,53 +117,11 @@ template <class T> DEV T load_global(const T *p) {              // scalars / poi
 }
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));      // builtin vector: loads through address space 1 directly
 typedef const u32x4 __attribute__((address_space(1))) *GlobalU4;
-// One wide-node visit (R3).  Returns true and sets `cur` to the nearest hit child after pushing the others; false: no child is hit.
-struct WideWords { u32x4 a, b, c; uint32_t d0, d1; };       // the 56 meaningful bytes of a GpuWide
-DEV WideWords load_wide(const GpuWide *p) {                  // 3 x global_load_dwordx4 + 1 x global_load_dwordx2
+DEV GpuNode load_node(const GpuNode *p) {                         // 4 x global_load_dwordx4
     GlobalU4 q = reinterpret_cast<GlobalU4>(reinterpret_cast<uintptr_t>(p));
-    typedef const uint32_t __attribute__((address_space(1))) *GlobalU1;
-    GlobalU1 t = reinterpret_cast<GlobalU1>(reinterpret_cast<uintptr_t>(p));
-    WideWords w; w.a = q[0]; w.b = q[1]; w.c = q[2]; w.d0 = t[12]; w.d1 = t[13];
-    return w;
-}
-DEV float wide_qbyte(const WideWords &w, int B) {             // byte B of q[4][6] as a float (constant B: one v_cvt_f32_ubyteN)
-    const uint32_t d = B < 4 ? w.c.x : (B < 8 ? w.c.y : (B < 12 ? w.c.z : (B < 16 ? w.c.w : (B < 20 ? w.d0 : w.d1))));
-    return (float)((d >> ((B & 3) * 8)) & 0xFFu);
-}
-#define RT_WIDE_MISS_KEY 0x7F000000u                          // sort key of a child that is not hit: above every tnear, not a NaN with a slot in its low bits
-template <class Stack>
-DEV bool wide_visit(const RaySpace &R, const WideWords &w, float tmin, float tmax, const Stack &stk, int &sp, uint32_t &cur) {
-    const uint32_t hdr = w.a.w, count = hdr >> 24;
-    float qa[3], qb[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const float s = __uint_as_float(((hdr >> (8 * k)) & 0xFFu) << 23);
-        const float origin = __uint_as_float(k == 0 ? w.a.x : (k == 1 ? w.a.y : w.a.z));
-        qa[k] = s * R.inv[k];
-        qb[k] = fmaf(origin, R.inv[k], R.oi[k]);
-    }
-    float key[4];
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const float lx = fmaf(wide_qbyte(w, 6 * c + 0), qa[0], qb[0]), hx = fmaf(wide_qbyte(w, 6 * c + 3), qa[0], qb[0]);
-        const float ly = fmaf(wide_qbyte(w, 6 * c + 1), qa[1], qb[1]), hy = fmaf(wide_qbyte(w, 6 * c + 4), qa[1], qb[1]);
-        const float lz = fmaf(wide_qbyte(w, 6 * c + 2), qa[2], qb[2]), hz = fmaf(wide_qbyte(w, 6 * c + 5), qa[2], qb[2]);
-        const float tn = fmaxf(fmaxf(fminf(lx, hx), fminf(ly, hy)), fmaxf(fminf(lz, hz), tmin));
-        const float tf = fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fminf(fmaxf(lz, hz), tmax)) * 1.0000004f;
-        const bool hit = (uint32_t)c < count && tn <= tf;
-        key[c] = __uint_as_float(hit ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : (RT_WIDE_MISS_KEY | (uint32_t)c));
-    }
-    // four distinct keys through a 5-exchange sorting network
-#define RT_CE(i, j) { const float lo_ = fminf(key[i], key[j]), hi_ = fmaxf(key[i], key[j]); key[i] = lo_; key[j] = hi_; }
-    RT_CE(0, 1) RT_CE(2, 3) RT_CE(0, 2) RT_CE(1, 3) RT_CE(1, 2)
-#undef RT_CE
-    const float missKey = __uint_as_float(RT_WIDE_MISS_KEY);
-    auto childOf = [&](float k) -> uint32_t { const uint32_t slot = __float_as_uint(k) & 3u; return slot == 0 ? w.b.x : (slot == 1 ? w.b.y : (slot == 2 ? w.b.z : w.b.w)); };
-    if (key[3] < missKey) stk.push(sp, childOf(key[3]));
-    if (key[2] < missKey) stk.push(sp, childOf(key[2]));
-    if (key[1] < missKey) stk.push(sp, childOf(key[1]));
-    if (key[0] < missKey) { cur = childOf(key[0]); return true; }
-    return false;
+    union { u32x4 w[4]; GpuNode n; } u;
+    u.w[0] = q[0]; u.w[1] = q[1]; u.w[2] = q[2]; u.w[3] = q[3];
+    return u.n;
 }
 DEV GpuTri load_tri(const GpuTri *p) {                            // 3 x global_load_dwordx4
     GlobalU4 q = reinterpret_cast<GlobalU4>(reinterpret_cast<uintptr_t>(p));
@@ -185,11 +141,10 @@ DEV GpuTri load_tri(const GpuTri *p) {                            // 3 x global_
 // CACHED: the scene's nodes and per-instance records sit in LDS (stk.cache, layout in fill_scene_cache): a node visit and an
 // instance entry are ds_read_b128s (~100 cycles) instead of dependent global loads (~1 us each under load); only triangles still come
 // from HBM/L2.  Same data, same arithmetic, same order: results and visit counts are unchanged.
-DEV WideWords load_wide_lds(const u32x4_lds *q) {           // 3 x ds_read_b128 + 1 x ds_read_b64
-    WideWords w; w.a = q[0]; w.b = q[1]; w.c = q[2];
-    const uint32_t *t = reinterpret_cast<const uint32_t *>(q + 3);
-    w.d0 = t[0]; w.d1 = t[1];
-    return w;
+DEV GpuNode load_node_lds(const u32x4_lds *q) {
+    union { u32x4_lds w[4]; GpuNode n; } u;
+    u.w[0] = q[0]; u.w[1] = q[1]; u.w[2] = q[2]; u.w[3] = q[3];
+    return u.n;
 }
 
 template <bool CACHED = false, class OnHit>
@@ -199,7 +154,7 @@ DEV void trace_ray(PRef P, const float o[3], const float d[3], float tmin, float
     RaySpace W, R;
     make_ray_space(o, d, W);
     R = W;
-    const GpuWide *nodes = P.tlasNodes;
+    const GpuNode *nodes = P.tlasNodes;
     const uint32_t tlasOff = 4u * P.cacheInstances;          // CACHED: node arrays are addressed by their word offset in the cache
     uint32_t nodeOff = tlasOff;
     const GpuTri *tris = nullptr;
@@ -220,9 +175,18 @@ DEV void trace_ray(PRef P, const float o[3], const float d[3], float tmin, float
     while (alive) {
         // ---- inner nodes ----
         while (alive && !(cur & RT64_LEAF_BIT)) {
-            const WideWords nd = CACHED ? load_wide_lds(stk.cache + nodeOff + 4u * cur) : load_wide(nodes + cur);
+            const GpuNode nd = CACHED ? load_node_lds(stk.cache + nodeOff + 4u * cur) : load_node(nodes + cur);
             cnt.nodes++;
-            if (!wide_visit(R, nd, tmin, tmax, stk, sp, cur)) alive = popNext();
+            float tl, tr;
+            const bool hl = box_hit(R, nd.lmin, nd.lmax, tmin, tmax, tl);
+            const bool hr = box_hit(R, nd.rmin, nd.rmax, tmin, tmax, tr);
+            // same decisions as "both: push the farther, go to the nearer; one: go there; none: pop", as value selects with two
+            // predicated regions (push, pop) instead of a five-way branch nest: fewer exec-mask round trips per visited node
+            const bool both = hl && hr, rightFirst = tr < tl;
+            const uint32_t nearChild = both ? (rightFirst ? nd.right : nd.left) : (hl ? nd.left : nd.right);
+            if (both) stk.push(sp, rightFirst ? nd.left : nd.right);
+            if (hl || hr) cur = nearChild;
+            else alive = popNext();
         }
         if (!alive) break;
         // ---- leaf ----
@@ -283,7 +247,7 @@ DEV void trace_ray(PRef P, const float o[3], const float d[3], float tmin, float
 // with wave-ballot refill, used for incoherent secondary rays where one long ray would otherwise hold 63 finished lanes).
 struct RayWalk {
     RaySpace W, R;
-    const GpuWide *nodes; const GpuTri *tris;
+    const GpuNode *nodes; const GpuTri *tris;
     float tmin, tmax;
     int sp, blasBase;
     uint32_t inst, cur;
@@ -312,9 +276,16 @@ struct RayWalk {
         while (alive) {
             // ---- inner nodes ----
             while (alive && !(cur & RT64_LEAF_BIT)) {
-                const WideWords nd = load_wide(nodes + cur);
+                const GpuNode nd = load_node(nodes + cur);
                 cnt.nodes++;
-                if (!wide_visit(R, nd, tmin, tmax, stk, sp, cur)) alive = pop_next(P, stk);
+                float tl, tr;
+                const bool hl = box_hit(R, nd.lmin, nd.lmax, tmin, tmax, tl);
+                const bool hr = box_hit(R, nd.rmin, nd.rmax, tmin, tmax, tr);
+                const bool both = hl && hr, rightFirst = tr < tl;          // (value selects, as in trace_ray)
+                const uint32_t nearChild = both ? (rightFirst ? nd.right : nd.left) : (hl ? nd.left : nd.right);
+                if (both) stk.push(sp, rightFirst ? nd.left : nd.right);
+                if (hl || hr) cur = nearChild;
+                else alive = pop_next(P, stk);
             }
             if (!alive) break;
             // ---- leaf ----

@@ -22,7 +22,7 @@ TEXTURE_FORMAT_RGBA8, TEXTURE_FORMAT_DDS = 0x1, 0x2
 UPSCALER_OFF, UPSCALER_AUTO, UPSCALER_DLSS, UPSCALER_FSR, UPSCALER_XESS = range(5)
 (UPSCALER_MODE_AUTO, UPSCALER_MODE_ULTRA_PERFORMANCE, UPSCALER_MODE_PERFORMANCE, UPSCALER_MODE_BALANCED, UPSCALER_MODE_QUALITY,
  UPSCALER_MODE_ULTRA_QUALITY, UPSCALER_MODE_NATIVE) = range(7)
-ACCEL_NODES, ACCEL_TRIANGLES, ACCEL_SORTED_INDEX, ACCEL_MORTON, ACCEL_HEADER, ACCEL_WIDE_NODES = range(6)
+ACCEL_NODES, ACCEL_TRIANGLES, ACCEL_SORTED_INDEX, ACCEL_MORTON, ACCEL_HEADER = range(5)
 
 (IMAGE_FINAL_RGBA8, IMAGE_SHADING_POSITION, IMAGE_SHADING_NORMAL, IMAGE_SHADING_SPECULAR, IMAGE_DIFFUSE,
  IMAGE_INSTANCE_ID, IMAGE_DIRECT_LIGHT_RAW, IMAGE_DIRECT_LIGHT_FILTERED, IMAGE_INDIRECT_LIGHT_RAW,

@@ -131,9 +131,6 @@ def test_blas_tlas_bit_exact(scene_256, oracle_256):
         for f in ("lmin", "lmax", "rmin", "rmax", "left", "right"):
             assert np.array_equal(nodes[f], ref["nodes"][f]), (mesh_index, f)
         assert np.array_equal(nodes["parent"][1:], ref["nodes"]["parent"][1:])
-        wide = _accel(lib, lib.ReadbackMeshAccel, h, rt64.ACCEL_WIDE_NODES, oracle_py.WIDE_DTYPE)          # the 4-wide traversal nodes (Wide spec G7)
-        for f in ("origin", "exp", "count", "child", "q"):
-            assert np.array_equal(wide[f], ref["wide"][f]), (mesh_index, f)
         tris = _accel(lib, lib.ReadbackMeshAccel, h, rt64.ACCEL_TRIANGLES, oracle_py.TRI_DTYPE)
         rt = o.mesh_tris(mesh_index)
         for f in ("v0", "v1", "v2", "prim"):
@@ -145,9 +142,6 @@ def test_blas_tlas_bit_exact(scene_256, oracle_256):
     nodes = _accel(lib, lib.ReadbackViewAccel, scene_256.view, rt64.ACCEL_NODES, oracle_py.NODE_DTYPE)
     for f in ("lmin", "lmax", "rmin", "rmax", "left", "right"):
         assert np.array_equal(nodes[f], tl["nodes"][f]), f
-    wide = _accel(lib, lib.ReadbackViewAccel, scene_256.view, rt64.ACCEL_WIDE_NODES, oracle_py.WIDE_DTYPE)
-    for f in ("origin", "exp", "count", "child", "q"):
-        assert np.array_equal(wide[f], tl["wide"][f]), f
 
 
 @pytest.mark.parametrize("subdiv,grid", [(2, 1), (3, 64)])
@@ -171,9 +165,6 @@ def test_large_meshes_bit_exact(rt64_lib, oracle_lib, subdiv, grid):
             nodes = _accel(rt64_lib, rt64_lib.ReadbackMeshAccel, h, rt64.ACCEL_NODES, oracle_py.NODE_DTYPE)
             for f in ("lmin", "lmax", "rmin", "rmax", "left", "right"):
                 assert np.array_equal(nodes[f], rb["nodes"][f]), (mesh_index, f)
-            wide = _accel(rt64_lib, rt64_lib.ReadbackMeshAccel, h, rt64.ACCEL_WIDE_NODES, oracle_py.WIDE_DTYPE)
-            for f in ("origin", "exp", "count", "child", "q"):
-                assert np.array_equal(wide[f], rb["wide"][f]), (mesh_index, f)
         assert np.array_equal(s.readback(rt64.IMAGE_PRIMARY_HIT), ref["primaryHit"])
         st = s.stats()
         assert st.nodesVisited == ref["counters"]["nodesVisited"] and st.trianglesTested == ref["counters"]["trianglesTested"]

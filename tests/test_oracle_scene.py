@@ -167,49 +167,3 @@ def test_sample_scene_construction(sample_data):
     assert s.bluenoise.shape == (512, 512, 4)
     c = s.meshes[0].vertices["position"][:, :3]
     assert np.allclose(np.linalg.norm(c - np.array([0, 0.5, 0], dtype=np.float32), axis=1), 2.5455842, atol=1e-4)
-
-
-def test_wide_nodes_cover_their_binary_children(sample_data):
-    """Wide spec G7: every 4-wide node's children are the binary node's children with inner ones opened (never more than four, every leaf
-    of the binary subtree still reachable exactly once from the root), and each 8-bit box contains the box the binary tree stores for that
-    child -- checked in float64, independently of the builder's own rounding rule."""
-    from sm64rt_legacy_renderer_amd import sample_scene
-    from oracle import oracle_py
-    for data in (sample_data, sample_scene.make_sample_scene(subdiv=2, floor_grid=8)):
-        o = oracle_py.OracleScene(data)
-        try:
-            for k, m in enumerate(data.meshes):
-                if not (m.flags & 1):
-                    continue
-                b = o.mesh_bvh(k)
-                n, nodes, wide = b["count"], b["nodes"], b["wide"]
-                box = {}                                                # child id -> (lo, hi) as the binary tree stores it
-                for i in range(max(n - 1, 1)):
-                    for side, (lo, hi) in (("left", ("lmin", "lmax")), ("right", ("rmin", "rmax"))):
-                        c = int(nodes[side][i])
-                        if c != 0xFFFFFFFF:
-                            box[c] = (nodes[lo][i].astype(np.float64), nodes[hi][i].astype(np.float64))
-                seen = np.zeros(n, dtype=np.int32)
-                stack = [0]
-                visited = 0
-                while stack:
-                    i = stack.pop(); w = wide[i]; visited += 1
-                    cnt = int(w["count"])
-                    assert 1 <= cnt <= 4 and (w["child"][cnt:] == 0xFFFFFFFF).all()
-                    s = np.ldexp(1.0, w["exp"].astype(np.int64) - 127)
-                    for c in range(cnt):
-                        cid = int(w["child"][c])
-                        lo = w["origin"].astype(np.float64) + w["q"][c][:3].astype(np.float64) * s
-                        hi = w["origin"].astype(np.float64) + w["q"][c][3:].astype(np.float64) * s
-                        blo, bhi = box[cid]
-                        assert (lo <= blo).all() and (hi >= bhi).all(), (k, i, c)
-                        assert ((blo - lo) <= 2.0 * s + 1e-30).all() and ((hi - bhi) <= 2.0 * s + 1e-30).all()      # and is tight: within two quanta
-                        if cid & 0x80000000:
-                            seen[cid & 0x7FFFFFFF] += 1
-                        else:
-                            stack.append(cid)
-                assert (seen == 1).all() and visited <= max(n - 1, 1)
-                if n > 8:
-                    assert visited < 0.75 * (n - 1)                   # the walk only ever sees a subset of the nodes (about every other level)
-        finally:
-            o.close()
