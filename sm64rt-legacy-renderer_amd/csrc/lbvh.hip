@@ -240,7 +240,7 @@ DEV void lbvh_small_body(const LbvhArgs &a, uint32_t *lds) {
             GpuNode &nd = a.nodes[0];
 #pragma unroll
             for (int k = 0; k < 3; k++) { nd.lmin[k] = b.mn[k]; nd.lmax[k] = b.mx[k]; nd.rmin[k] = INFINITY; nd.rmax[k] = -INFINITY; a.header->bmin[k] = b.mn[k]; a.header->bmax[k] = b.mx[k]; }
-            a.header->count = 1; a.header->pad = 0;
+            a.header->count = 1; a.header->depth = 1;
             break;
         }
         uint32_t child = RT64_LEAF_BIT | s, p = parentLeaf[s];
@@ -263,11 +263,25 @@ DEV void lbvh_small_body(const LbvhArgs &a, uint32_t *lds) {
             if (p == 0) {
 #pragma unroll
                 for (int k = 0; k < 3; k++) { a.header->bmin[k] = b.mn[k]; a.header->bmax[k] = b.mx[k]; }
-                a.header->count = n; a.header->pad = 0;
+                a.header->count = n;
                 break;
             }
             child = p; p = parentNode[p];
         }
+    }
+    // tree depth (inner nodes on the longest root-to-leaf path): the host sizes the traversal stack of the LDS-cached kernels by it
+    if (n > 1) {
+        if (tid == 0) scratch[26] = 0;
+        __syncthreads();
+        uint32_t deepest = 0;
+        for (uint32_t s2 = tid; s2 < n; s2 += T) {
+            uint32_t d = 1, p = parentLeaf[s2];
+            while (p != 0) { p = parentNode[p]; d++; }
+            deepest = max(deepest, d);
+        }
+        atomicMax(&scratch[26], deepest);
+        __syncthreads();
+        if (tid == 0) a.header->depth = scratch[26];
     }
 }
 
@@ -546,7 +560,7 @@ __global__ __launch_bounds__(LG_THREADS) void lg_fit_kernel(LbvhArgs a, const fl
         if (i == 0) {
 #pragma unroll
             for (int k = 0; k < 3; k++) { a.header->bmin[k] = mn[k]; a.header->bmax[k] = mx[k]; }
-            a.header->count = a.n; a.header->pad = 0;
+            a.header->count = a.n; a.header->depth = 255;
         }
         done[i] = pass + 1;
     }

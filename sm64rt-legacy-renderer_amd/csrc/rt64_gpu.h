@@ -35,7 +35,7 @@ static_assert(sizeof(GpuTri) == 48, "GpuTri");
 
 struct BlasHeader {
     float bmin[3]; uint32_t count;
-    float bmax[3]; uint32_t pad;
+    float bmax[3]; uint32_t depth;   // inner nodes on the longest root-to-leaf path (single-workgroup builder; the multi-kernel path stores 255 = "deep")
 };
 
 struct GpuTexture {

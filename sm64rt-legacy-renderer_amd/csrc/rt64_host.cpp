@@ -229,6 +229,8 @@ struct Mesh {
     DevArray<GpuNode> nodes; DevArray<GpuTri> tris; DevArray<BlasHeader> header;
     DevArray<uint32_t> sortedIndex, morton, leafParent; DevArray<uint8_t> buildScratch;
     uint32_t blasCount = 0;                            // leaves of the current BLAS (0 = none)
+    uint32_t topologyVersion = 0, depthVersion = ~0u, depth = 255;      // tree depth (BlasHeader::depth), read back once per topology: refits keep it
+    uint32_t treeDepth();
     bool buildPending = false, pendingRefit = false;   // RT64_SetMesh recorded a build / refit that Device::flushMeshBuilds has not run yet
     ~Mesh();
     uint32_t version = 0;
@@ -493,6 +495,7 @@ void Device::flushMeshBuilds() {
         a.nodes = m->nodes.ptr; a.tris = m->tris.ptr; a.header = m->header.ptr; a.sortedIndex = m->sortedIndex.ptr; a.morton = m->morton.ptr; a.leafParent = m->leafParent.ptr;
         if (a.n > LBVH_SMALL_MAX) { a.scratch = m->buildScratch.ptr; a.scratchBytes = m->buildScratch.bytes(); HIP_CHECK(lbvh_launch_large(a, stream)); }
         else { small.push_back(a); maxN = std::max(maxN, a.n); }
+        if (!m->pendingRefit) m->topologyVersion++;
         m->buildPending = false; m->pendingRefit = false;
     }
     dirtyMeshes.clear();
@@ -506,6 +509,21 @@ void Device::flushMeshBuilds() {
         HIP_CHECK(lbvh_launch_batch(buildArgs.ptr, (uint32_t)small.size(), maxN, stream));
     }
     workSinceMark = true;
+}
+
+// Depth of the BLAS (inner nodes on the longest root-to-leaf path).  The builder leaves it in the header; read back (one stream wait) once
+// per topology -- a refit of an UPDATABLE mesh keeps the tree's shape.  Trees of the multi-kernel builder report 255 without asking.
+uint32_t Mesh::treeDepth() {
+    if (blasCount == 0) return 0;
+    if (blasCount > LBVH_SMALL_MAX) return 255;
+    if (depthVersion != topologyVersion) {
+        device->flushMeshBuilds();
+        BlasHeader h;
+        HIP_CHECK(hipMemcpyAsync(&h, header.ptr, sizeof(h), hipMemcpyDeviceToHost, device->stream));
+        HIP_CHECK(hipStreamSynchronize(device->stream));
+        depth = h.depth; depthVersion = topologyVersion;
+    }
+    return depth;
 }
 
 std::pair<float, float> Mesh::inputAlphaBounds(int offset) {
@@ -765,7 +783,10 @@ void View::update() {                          // View::update, rt64_view.cpp:10
     if (dev->opt.ldsCache && nInst >= 1 && nInst <= 16) {
         uint64_t words = 4 * nInst + 4 * std::max<size_t>(nInst - 1, 1);
         for (size_t i = 0; i < nInst; i++) { cacheOffset[i] = (uint32_t)words; words += 4ull * std::max<uint32_t>(rtInstances[i].instance->mesh->blasCount - 1, 1); }
-        if (words <= RT_CACHE_MAX_WORDS) cacheWords = (uint32_t)words;
+        // ... and the walk's stack (at most one entry per level: TLAS depth + the deepest BLAS) has to fit the LDS-only stack of the cached kernels
+        uint32_t deepest = 0;
+        if (words <= RT_CACHE_MAX_WORDS) for (size_t i = 0; i < nInst; i++) deepest = std::max(deepest, rtInstances[i].instance->mesh->treeDepth());
+        if (words <= RT_CACHE_MAX_WORDS && std::max<size_t>(nInst - 1, 1) + deepest <= RT_STACK_LDS_CACHED) cacheWords = (uint32_t)words;
     }
     maxDepthBias = nInst ? -INFINITY : 0.0f;
     anyNonOpaque = anyReflection = anyRefraction = anyFog = false;

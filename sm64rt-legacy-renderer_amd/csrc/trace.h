@@ -38,7 +38,10 @@ DEV PPtr kernel_params_here() { uint32_t z; asm volatile("s_mov_b32 %0, 0" : "=s
 #define RT_BLOCK 256                 // threads per workgroup of every ray kernel
 #define RT_STACK_LDS 24
 #define RT_STACK_SPILL 84               // entries per lane in the HBM slab behind the LDS entries
-#define RT_STACK_LDS_CACHED 8            // kernels that also hold the LDS scene cache: the cached scenes are small, their trees shallow
+#ifndef RT_STACK_LDS_CACHED
+#define RT_STACK_LDS_CACHED 16           // (kernels.h defines it for the host too) kernels that also hold the LDS scene cache: the host enables the cache only when TLAS depth + the deepest BLAS fit in these
+                                        // entries (BlasHeader::depth), so their push / pop are plain LDS accesses -- no spill branch in the node loop
+#endif
 
 struct RaySpace { float o[3], d[3], inv[3], oi[3]; };
 
@@ -95,14 +98,16 @@ struct TraceStack {
     GlobalU32Ptr spill;   // per-lane slab of RT_STACK_SPILL entries
     const u32x4_lds *cache;   // LDS scene cache (see fill_scene_cache), nullptr when the scene does not fit
     int ldsEntries;       // entries of this lane's stack that live in LDS (RT_STACK_LDS or RT_STACK_LDS_CACHED)
-    DEV void push(int &sp, uint32_t v) const {
+    template <bool LDS_ONLY = false> DEV void push(int &sp, uint32_t v) const {
+        if (LDS_ONLY) { lds[(sp & (RT_STACK_LDS_CACHED - 1)) * RT_BLOCK] = v; sp++; return; }      // depth checked by the host (the mask only keeps a wrong depth inside the array)
         if (sp < ldsEntries) lds[sp * RT_BLOCK] = v;
         else if (sp < ldsEntries + RT_STACK_SPILL) spill[sp - ldsEntries] = v;
         else return;      // deeper than any tree this builder produces for n < 2^20 leaves, m < 2^13 instances
         sp++;
     }
-    DEV uint32_t pop(int &sp) const {
+    template <bool LDS_ONLY = false> DEV uint32_t pop(int &sp) const {
         sp--;
+        if (LDS_ONLY) return lds[(sp & (RT_STACK_LDS_CACHED - 1)) * RT_BLOCK];
         return sp < ldsEntries ? lds[sp * RT_BLOCK] : spill[sp - ldsEntries];
     }
 };
@@ -169,7 +174,7 @@ DEV void trace_ray(PRef P, const float o[3], const float d[3], float tmin, float
             blasBase = -1; R = W; nodes = P.tlasNodes; nodeOff = tlasOff;
         }
         if (sp == 0) return false;
-        cur = stk.pop(sp);
+        cur = stk.template pop<CACHED>(sp);
         return true;
     };
     while (alive) {
@@ -184,7 +189,7 @@ DEV void trace_ray(PRef P, const float o[3], const float d[3], float tmin, float
             // predicated regions (push, pop) instead of a five-way branch nest: fewer exec-mask round trips per visited node
             const bool both = hl && hr, rightFirst = tr < tl;
             const uint32_t nearChild = both ? (rightFirst ? nd.right : nd.left) : (hl ? nd.left : nd.right);
-            if (both) stk.push(sp, rightFirst ? nd.left : nd.right);
+            if (both) stk.template push<CACHED>(sp, rightFirst ? nd.left : nd.right);
             if (hl || hr) cur = nearChild;
             else alive = popNext();
         }
