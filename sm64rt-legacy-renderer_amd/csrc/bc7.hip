@@ -124,3 +124,21 @@ hipError_t bc7_decode_launch(const uint8_t *blocks, uint8_t *rgba, uint32_t widt
                        reinterpret_cast<uint32_t *>(rgba), width, height, bw, bh, g_tables, g_tables + 1024, g_tables + 2048, g_tables + 2112, g_tables + 2176);
     return hipGetLastError();
 }
+
+// ---- 4 x 4-texel tiles ------------------------------------------------------------------------------------------------------------
+// dst[((y / 4) * (w / 4) + x / 4) * 16 + (y % 4) * 4 + x % 4] = src[y * w + x]: one 64-byte cache line per tile (FrameParams::skyTiled).
+namespace {
+__global__ __launch_bounds__(256) void tile_texture_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, uint32_t w, uint32_t h) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;            // index into dst: consecutive threads write consecutive words
+    if (i >= w * h) return;
+    const uint32_t tile = i >> 4, in = i & 15u, tilesX = w >> 2;
+    const uint32_t x = (tile % tilesX) * 4 + (in & 3u), y = (tile / tilesX) * 4 + (in >> 2);
+    dst[i] = src[(size_t)y * w + x];
+}
+}  // namespace
+
+hipError_t tile_texture_launch(const uint8_t *rgba, uint32_t *tiled, uint32_t width, uint32_t height, hipStream_t stream) {
+    if (width < 4 || height < 4 || (width & 3u) || (height & 3u)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(tile_texture_kernel, dim3((width * height + 255) / 256), dim3(256), 0, stream, reinterpret_cast<const uint32_t *>(rgba), tiled, width, height);
+    return hipGetLastError();
+}

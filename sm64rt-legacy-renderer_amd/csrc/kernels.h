@@ -31,6 +31,8 @@ hipError_t lbvh_launch_batch(const LbvhArgs *deviceArgs, uint32_t count, uint32_
 
 // ---- bc7.hip ------------------------------------------------------------------------------------------------------
 // Decode `blocksX * blocksY` BC7 blocks into an RGBA8 image of width x height texels.
+// RGBA8 image (row-major) -> the same texels in 4 x 4 tiles of 64 bytes (width, height multiples of 4).
+hipError_t tile_texture_launch(const uint8_t *rgba, uint32_t *tiled, uint32_t width, uint32_t height, hipStream_t stream);
 hipError_t bc7_decode_launch(const uint8_t *blocks, uint8_t *rgba, uint32_t width, uint32_t height, hipStream_t stream);
 
 // ---- passes.hip ---------------------------------------------------------------------------------------------------
@@ -53,6 +55,14 @@ hipError_t launch_compose_post(const FrameParams &P, const ViewImages &I, int cu
 // maxGroups: cap of the grid (RT_MAX_FRAME_GROUPS; device option max_frame_groups lowers it so that small frames exercise the several-tiles-per-workgroup walk)
 hipError_t launch_lean_frame(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, int cur, bool full, int ownedY0, int ownedY1, unsigned maxGroups, hipStream_t s);
 hipError_t launch_post_process(const FrameParams &P, const ViewImages &I, hipStream_t s);      // PostProcessPS as its own pass (resolution scale / motion blur)
+// passes_simple.hip: the same launchers over kernels compiled without non-power-of-two texture addressing and without the shadow any-hit
+// program; the launchers above route to them when FrameParams::simpleKernels is set
+hipError_t launch_primary_shade_simple(const FrameParams &P, const ViewImages &I, const int32_t *hitInstance, int cur, bool transparentLighting, bool lean, hipStream_t s);
+hipError_t launch_direct_simple(const FrameParams &P, const ViewImages &I, int cur, bool lean, hipStream_t s);
+hipError_t launch_indirect_simple(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, bool refill, hipStream_t s);
+hipError_t launch_refraction_simple(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s);
+hipError_t launch_reflection_simple(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s);
+hipError_t launch_lean_frame_simple(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, int cur, bool full, int ownedY0, int ownedY1, unsigned maxGroups, hipStream_t s);
 hipError_t launch_clear_final(const FrameParams &P, const ViewImages &I, hipStream_t s);
 
 // ---- raster.hip ----------------------------------------------------------------------------------------------------

@@ -19,6 +19,18 @@
 #include "shade.h"
 #include "raster_pixel.h"
 
+// This file is compiled twice.  passes_simple.hip defines RT_ASSUME_SIMPLE and includes it: the same ray kernels for frames whose
+// textures all have power-of-two sizes and whose instances are all shadow-opaque (rule O2) -- the non-power-of-two addressing and the
+// shadow any-hit program are not compiled in, which takes a third of the instructions and most of the register spills out of the
+// shading kernels (the sample scene is such a frame).  FrameParams::simpleKernels routes a launch to the `_simple` twin.
+#ifdef RT_ASSUME_SIMPLE
+#define RT_LAUNCHER(name) name##_simple
+#define RT_ROUTE_SIMPLE(call)
+#else
+#define RT_LAUNCHER(name) name
+#define RT_ROUTE_SIMPLE(call) if (P.simpleKernels) return call
+#endif
+
 namespace {
 
 struct Pixel { uint32_t x, y; bool valid; };
@@ -554,11 +566,11 @@ __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void direct_kernel(FramePar
 // refraction, fog, motion blur downstream): it writes the reference's whole G-buffer like primary_shade_kernel<.., FULL> and
 // DirectRayGen's two images like direct_kernel<true>, and leaves Compose to its own pass.  ownedY0 / ownedY1: the rows DirectRayGen
 // covers (the frame parameters may include a denoiser halo above and below them, which only the G-buffer part renders).
-template <bool CACHED, bool FULL>
+template <bool CACHED, bool FULL, int WAVES>
 #ifndef LEAN_WAVES
 #define LEAN_WAVES 3          // waves per SIMD of the one-kernel frame: 3 (168 VGPRs, ~30 spilled) measured 12 % faster than 2 (193 VGPRs, no spills) once the frame constants stopped occupying registers
 #endif
-__global__ __launch_bounds__(RT_BLOCK, LEAN_WAVES) void lean_frame_kernel(FrameParams Pv, ViewImages Iv, int32_t *hitInstance, int cur, int ownedY0, int ownedY1) {
+__global__ __launch_bounds__(RT_BLOCK, WAVES) void lean_frame_kernel(FrameParams Pv, ViewImages Iv, int32_t *hitInstance, int cur, int ownedY0, int ownedY1) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
     __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED : RT_STACK_LDS) * RT_BLOCK];
     __shared__ float ldsLightIntensity[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -1306,6 +1318,7 @@ __global__ __launch_bounds__(256) void clear_final_kernel(FrameParams Pv, ViewIm
 
 }  // namespace
 
+#ifndef RT_ASSUME_SIMPLE
 // One spill slab per lane of every workgroup of the largest grid a frame of `width` x `rows` can launch: the persistent kernels use
 // at most RT_GRID_BLOCKS workgroups, the one-kernel frame one per 16 x 16 tile.
 size_t rt_stack_spill_bytes(int width, int rows) {
@@ -1314,6 +1327,8 @@ size_t rt_stack_spill_bytes(int width, int rows) {
     if (blocks > RT_MAX_FRAME_GROUPS) blocks = RT_MAX_FRAME_GROUPS;       // no launch has more workgroups than that (launch_lean_frame, sparse_grid)
     return blocks * RT_BLOCK * RT_STACK_SPILL * sizeof(uint32_t);
 }
+#endif
+
 
 // Grid of a ray kernel: one persistent workgroup per CU slot (RT_GRID_BLOCKS), or one per tile when the device's share of the
 // frame has fewer tiles than that (small frames, a 1/8 strip share): workgroups without a tile only cost launch time.
@@ -1332,17 +1347,22 @@ static size_t cached_lds_bytes(const FrameParams &P, bool lights) {
 }
 #define LAUNCH_RAY_LDS(kernel, bytes, ...) do { hipLaunchKernelGGL(kernel, dim3(rt_grid(P)), dim3(RT_BLOCK), bytes, s, __VA_ARGS__); return hipGetLastError(); } while (0)
 
+#ifndef RT_ASSUME_SIMPLE
 hipError_t launch_primary_trace(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, bool klist, hipStream_t s) {
     if (klist) LAUNCH_RAY(primary_trace_kernel<true>, P, I, hitInstance);
     if (P.cacheWords) LAUNCH_RAY_LDS((primary_trace_kernel<false, true>), cached_lds_bytes(P, false), P, I, hitInstance);
     LAUNCH_RAY(primary_trace_kernel<false>, P, I, hitInstance);
 }
-hipError_t launch_primary_shade(const FrameParams &P, const ViewImages &I, const int32_t *hitInstance, int cur, bool transparentLighting, bool lean, hipStream_t s) {
+#endif
+
+hipError_t RT_LAUNCHER(launch_primary_shade)(const FrameParams &P, const ViewImages &I, const int32_t *hitInstance, int cur, bool transparentLighting, bool lean, hipStream_t s) {
+    RT_ROUTE_SIMPLE(launch_primary_shade_simple(P, I, hitInstance, cur, transparentLighting, lean, s));
     if (transparentLighting) LAUNCH_RAY((primary_shade_kernel<true, true, true>), P, I, hitInstance, cur);
     if (lean) LAUNCH_RAY((primary_shade_kernel<false, false, false>), P, I, hitInstance, cur);
     LAUNCH_RAY((primary_shade_kernel<false, false, true>), P, I, hitInstance, cur);
 }
-hipError_t launch_direct(const FrameParams &P, const ViewImages &I, int cur, bool lean, hipStream_t s) {
+hipError_t RT_LAUNCHER(launch_direct)(const FrameParams &P, const ViewImages &I, int cur, bool lean, hipStream_t s) {
+    RT_ROUTE_SIMPLE(launch_direct_simple(P, I, cur, lean, s));
     if (P.cacheWords) {
         if (lean) LAUNCH_RAY_LDS((direct_kernel<false, true>), cached_lds_bytes(P, true), P, I, cur);
         LAUNCH_RAY_LDS((direct_kernel<true, true>), cached_lds_bytes(P, true), P, I, cur);
@@ -1354,7 +1374,8 @@ hipError_t launch_direct(const FrameParams &P, const ViewImages &I, int cur, boo
 // CU), which together with the bottom-up tile order (geometry first) is a longest-job-first schedule; a resident round of
 // persistent workgroups with a static round-robin walk measured 8 % slower on the full frame (181 against 165 us) and keeps every
 // register file full until the launch ends, so nothing on another stream (the RCCL gather) can run beside it.
-hipError_t launch_lean_frame(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, int cur, bool full, int ownedY0, int ownedY1, unsigned maxGroups, hipStream_t s) {
+hipError_t RT_LAUNCHER(launch_lean_frame)(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, int cur, bool full, int ownedY0, int ownedY1, unsigned maxGroups, hipStream_t s) {
+    RT_ROUTE_SIMPLE(launch_lean_frame_simple(P, I, hitInstance, cur, full, ownedY0, ownedY1, maxGroups, s));
     const unsigned strips = (unsigned)(P.tileY1 - P.tileY0 + 15) / 16, owned = strips > (unsigned)P.stripRank ? (strips - (unsigned)P.stripRank + (unsigned)P.stripCount - 1) / (unsigned)P.stripCount : 0u;
     const unsigned tiles = (unsigned)((P.width + 15) / 16) * owned;
     // ... up to 8192 workgroups; bigger frames give every workgroup ceil(tiles / 8192) tiles (round-robin, same bottom-up order), which
@@ -1362,15 +1383,21 @@ hipError_t launch_lean_frame(const FrameParams &P, const ViewImages &I, int32_t 
     if (maxGroups < 1u || maxGroups > RT_MAX_FRAME_GROUPS) maxGroups = RT_MAX_FRAME_GROUPS;
     const unsigned perGroup = (tiles + maxGroups - 1u) / maxGroups, grid = tiles < 1u ? 1u : (tiles + perGroup - 1u) / perGroup;
     const size_t lds = P.cacheWords ? cached_lds_bytes(P, true) : 0;
+#ifdef RT_ASSUME_SIMPLE
+    static const bool four = getenv("RT64_LEAN_WAVES") && atoi(getenv("RT64_LEAN_WAVES")) == 4;      // experiment: 4 waves per SIMD (128 VGPRs, more spills)
+    if (four && P.cacheWords && !full) { hipLaunchKernelGGL((lean_frame_kernel<true, false, 4>), dim3(grid), dim3(RT_BLOCK), lds, s, P, I, hitInstance, cur, ownedY0, ownedY1); return hipGetLastError(); }
+    if (four && P.cacheWords && full) { hipLaunchKernelGGL((lean_frame_kernel<true, true, 4>), dim3(grid), dim3(RT_BLOCK), lds, s, P, I, hitInstance, cur, ownedY0, ownedY1); return hipGetLastError(); }
+#endif
     if (P.cacheWords) {
-        if (full) hipLaunchKernelGGL((lean_frame_kernel<true, true>), dim3(grid), dim3(RT_BLOCK), lds, s, P, I, hitInstance, cur, ownedY0, ownedY1);
-        else hipLaunchKernelGGL((lean_frame_kernel<true, false>), dim3(grid), dim3(RT_BLOCK), lds, s, P, I, hitInstance, cur, ownedY0, ownedY1);
+        if (full) hipLaunchKernelGGL((lean_frame_kernel<true, true, LEAN_WAVES>), dim3(grid), dim3(RT_BLOCK), lds, s, P, I, hitInstance, cur, ownedY0, ownedY1);
+        else hipLaunchKernelGGL((lean_frame_kernel<true, false, LEAN_WAVES>), dim3(grid), dim3(RT_BLOCK), lds, s, P, I, hitInstance, cur, ownedY0, ownedY1);
     }
-    else if (full) hipLaunchKernelGGL((lean_frame_kernel<false, true>), dim3(grid), dim3(RT_BLOCK), 0, s, P, I, hitInstance, cur, ownedY0, ownedY1);
-    else hipLaunchKernelGGL((lean_frame_kernel<false, false>), dim3(grid), dim3(RT_BLOCK), 0, s, P, I, hitInstance, cur, ownedY0, ownedY1);
+    else if (full) hipLaunchKernelGGL((lean_frame_kernel<false, true, LEAN_WAVES>), dim3(grid), dim3(RT_BLOCK), 0, s, P, I, hitInstance, cur, ownedY0, ownedY1);
+    else hipLaunchKernelGGL((lean_frame_kernel<false, false, LEAN_WAVES>), dim3(grid), dim3(RT_BLOCK), 0, s, P, I, hitInstance, cur, ownedY0, ownedY1);
     return hipGetLastError();
 }
-hipError_t launch_indirect(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, bool refill, hipStream_t s) {
+hipError_t RT_LAUNCHER(launch_indirect)(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, bool refill, hipStream_t s) {
+    RT_ROUTE_SIMPLE(launch_indirect_simple(P, I, cur, writeFiltered, klist, refill, s));
     if (klist) LAUNCH_RAY(indirect_kernel<true>, P, I, cur, writeFiltered ? 1 : 0);
     if (P.giSamples == 0 || !I.bounceRecords) LAUNCH_RAY(indirect_kernel<false>, P, I, cur, writeFiltered ? 1 : 0);
     if (refill) hipLaunchKernelGGL(bounce_trace_refill_kernel, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
@@ -1384,11 +1411,14 @@ hipError_t launch_indirect(const FrameParams &P, const ViewImages &I, int cur, b
     hipLaunchKernelGGL(bounce_resolve_kernel, grid, dim3(256), 0, s, P, I, cur, writeFiltered ? 1 : 0);
     return hipGetLastError();
 }
+#ifndef RT_ASSUME_SIMPLE
 hipError_t launch_indirect_constant(const FrameParams &P, const ViewImages &I, int cur, hipStream_t s) {
     dim3 grid((unsigned)(P.width + 31) / 32, (unsigned)(P.tileY1 - P.tileY0 + 7) / 8);
     hipLaunchKernelGGL(indirect_constant_kernel, grid, dim3(256), 0, s, P, I, cur);
     return hipGetLastError();
 }
+#endif
+
 // Refraction / reflection only have work where the primary hit has the factor: most tiles return at once, so these two take one
 // workgroup per tile (up to 8192) and let the dispatcher balance them (C5 reflection: 0.315 -> 0.26 ms against the persistent grid).
 static unsigned sparse_grid(const FrameParams &P) {
@@ -1397,17 +1427,20 @@ static unsigned sparse_grid(const FrameParams &P) {
     const unsigned tiles = (unsigned)((P.width + 15) / 16) * strips;
     return tiles < 1u ? 1u : (tiles < RT_MAX_FRAME_GROUPS ? tiles : RT_MAX_FRAME_GROUPS);
 }
-hipError_t launch_refraction(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s) {
+hipError_t RT_LAUNCHER(launch_refraction)(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s) {
+    RT_ROUTE_SIMPLE(launch_refraction_simple(P, I, klist, s));
     if (klist) hipLaunchKernelGGL(refraction_kernel<true>, dim3(sparse_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
     else hipLaunchKernelGGL(refraction_kernel<false>, dim3(sparse_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
     return hipGetLastError();
 }
-hipError_t launch_reflection(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s) {
+hipError_t RT_LAUNCHER(launch_reflection)(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s) {
+    RT_ROUTE_SIMPLE(launch_reflection_simple(P, I, klist, s));
     if (klist) hipLaunchKernelGGL(reflection_kernel<true>, dim3(sparse_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
     else hipLaunchKernelGGL(reflection_kernel<false>, dim3(sparse_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
     return hipGetLastError();
 }
 
+#ifndef RT_ASSUME_SIMPLE
 hipError_t launch_gaussian(const uint16_t *in, uint16_t *out, int width, int height, int y0, int y1, hipStream_t s) {
     dim3 grid((unsigned)(width + 31) / 32, (unsigned)(y1 - y0 + 7) / 8);
     hipLaunchKernelGGL(gaussian_kernel, grid, dim3(256), 0, s, in, out, width, height, y0, y1);
@@ -1430,3 +1463,5 @@ hipError_t launch_clear_final(const FrameParams &P, const ViewImages &I, hipStre
     hipLaunchKernelGGL(clear_final_kernel, grid, dim3(256), 0, s, P, I);
     return hipGetLastError();
 }
+#endif
+

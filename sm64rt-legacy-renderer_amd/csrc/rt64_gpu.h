@@ -117,12 +117,16 @@ struct FrameParams {
     // LDS scene cache (trace.h): when the TLAS + every BLAS node array + one 64-byte record per instance fit in LDS next to the
     // traversal stacks, the ray kernels copy them in once per workgroup and walk from there.  cacheWords = size in 16-byte words, 0 = off.
     uint32_t cacheWords, cacheInstances;
+    uint32_t simpleKernels;              // 1: every texture of the frame has power-of-two sizes and every instance is shadow-opaque: the launchers take the kernels of passes_simple.hip
     uint32_t separatePost;               // 1: render size != screen size or motion blur on -> PostProcessPS runs as post_process_kernel
     const float *postSource; int32_t postSourceW, postSourceH;      // image PostProcessPS samples: rtOutput (render size), or rtOutputUpscaled (screen size) behind an upscaler (rt64_view.cpp:800-801)
     // Foreground (HUD) raster list folded into the one-kernel lean frame: table + triangle records of raster.hip, 0 triangles = not folded.
     const GpuRasterInstance *rasterFg; const void *rasterFgTris; uint32_t rasterFgCount, rasterFgPad;
     uint32_t *finalPacked;               // RT64_SetDeviceGatherTarget: the owned rows of the back buffer, packed strip after strip (nullptr = off)
     float skyBase[4];                    // ComputeSkyPlaneUV: base u, base v, 0.25 * ratioDivision, 0.25
+    // Level 0 of the sky plane once more, in 4 x 4-texel tiles (64 B each): the environment lookups of bounce / reflection rays are random
+    // accesses, and a bilinear footprint then touches 1.56 cache lines on average instead of 2.1 (nullptr: not a power-of-two texture)
+    const uint32_t *skyTiled; uint32_t skyTiledLog2W, skyTiledLog2H;
     uint32_t lightCount, instanceCount, countTraversal;
     const GpuInstance *instances;
     const GpuNode *tlasNodes;

@@ -136,6 +136,7 @@ static GpuCombiner decode_combiner(uint32_t shaderId) {
 
 struct Options {
     bool countTraversal = false, profilePasses = true, syncPresent = true, alwaysRebuild = false, leanFrames = true, fusedLean = true, foldForeground = true;
+    bool simpleKernels = true;    // frames whose textures are all power-of-two sized and whose instances are all shadow-opaque run the kernels of passes_simple.hip
     bool ldsCache = true;         // small scenes: BVH nodes + instance records cached in LDS by the ray kernels (0: always walk from HBM/L2)
     bool spinPresent = true;      // RT64_DrawDevice waits for the frame by polling the stream (0: blocking hipStreamSynchronize)
     int bounceRefill = -1;        // bounce-ray traversal with wave-ballot refill: 1 on, 0 off, -1 auto (on when the scene has >= 64 Ki triangles)
@@ -269,6 +270,7 @@ struct View {
     bool upscaleActive = false; int jitterPhases = 1; float pixelJitter[2] = { 0.0f, 0.0f };
     float *upscaled[2] = { nullptr, nullptr }; int upW = 0, upH = 0, upSwap = 0; bool upValid = false;
     Texture *skyPlane = nullptr;
+    DevArray<uint32_t> skyTiled; uint32_t skyTiledSerial = 0; uint32_t skyTiledLog2[2] = { 0, 0 };     // level 0 of the sky plane in 4 x 4 tiles (FrameParams::skyTiled)
     Mat4 view = mat_identity(), projection = mat_identity(), viewI = mat_identity(), projectionI = mat_identity(), viewProj = mat_identity(), prevViewI = mat_identity(), prevViewProj = mat_identity();
     float fov = 0.0f, nearDist = 0.0f, farDist = 0.0f; bool canReproject = true, matricesValid = false, perspectiveSet = false;
     uint32_t frameCount = 0; bool rtSwap = false, skipReprojection = true;
@@ -305,6 +307,7 @@ struct View {
     std::vector<uint8_t> uploadedTables;      // bytes of the last uploaded instance/texture/light tables (cache key)
     float maxDepthBias = 0.0f;
     bool anyNonOpaque = false, anyReflection = false, anyRefraction = false, anyFog = false;
+    bool simpleFrame = false;                 // every texture of the frame is a power of two in both sizes and every instance is shadow-opaque (passes_simple.hip)
     bool leanFrame = false;                   // last frame skipped the images no pass consumed (see materialise)
     bool fusedFullFrame = false;              // full frame whose primary + direct passes ran as lean_frame_kernel<.., FULL>
     bool packedFinal = false;                 // the frame also wrote its owned back-buffer rows to the device's gather target
@@ -790,6 +793,7 @@ void View::update() {                          // View::update, rt64_view.cpp:10
     }
     maxDepthBias = nInst ? -INFINITY : 0.0f;
     anyNonOpaque = anyReflection = anyRefraction = anyFog = false;
+    simpleFrame = dev->opt.simpleKernels && nInst > 0;
     for (size_t i = 0; i < nInst; i++) {
         Instance *inst = rtInstances[i].instance;
         GpuInstance &g = hInst[i];
@@ -816,6 +820,7 @@ void View::update() {                          // View::update, rt64_view.cpp:10
         if (inst->shader->flags & RT64_SHADER_NORMAL_MAP_ENABLED) g.flags |= GPU_INST_NORMAL_MAP;
         if (inst->shader->flags & RT64_SHADER_SPECULAR_MAP_ENABLED) g.flags |= GPU_INST_SPECULAR_MAP;
         if (instance_is_shadow_opaque(inst, g.cc)) g.flags |= GPU_INST_SHADOW_OPAQUE;
+        else simpleFrame = false;
         g.triCount = mesh->blasCount;
         g.meshVersion = mesh->version;
         g.cacheNodeOffset = cacheWords ? cacheOffset[i] : 0u;
@@ -831,6 +836,7 @@ void View::update() {                          // View::update, rt64_view.cpp:10
         GpuTexture &g = hTex[i];
         g.texels = t->texels.ptr; g.width = (uint32_t)t->width; g.height = (uint32_t)t->height; g.mips = (uint32_t)t->mips;
         g.pow2 = ((t->width & (t->width - 1)) == 0 && (t->height & (t->height - 1)) == 0) ? 1u : 0u;
+        if (!g.pow2) simpleFrame = false;
         memcpy(g.mipOffset, t->mipOffset, sizeof(g.mipOffset));
     }
     if (nLights) memcpy(hLights, scene->lights.data(), lightBytes);
@@ -917,6 +923,18 @@ void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64
     P.pixelJitter[0] = pixelJitter[0]; P.pixelJitter[1] = pixelJitter[1];
     P.motionBlurStrength = motionBlurStrength; P.motionBlurSamples = motionBlurSamples;
     P.skyPlaneTexIndex = skyPlane ? 0 : -1;
+    P.skyTiled = nullptr; P.skyTiledLog2W = P.skyTiledLog2H = 0;
+    // the tiled copy only pays for random lookups (bounce / reflection rays): frames without GI or reflections never make them
+    if (skyPlane && (giSamples > 0 || anyReflection) && skyPlane->width >= 4 && skyPlane->height >= 4 &&
+        (skyPlane->width & (skyPlane->width - 1)) == 0 && (skyPlane->height & (skyPlane->height - 1)) == 0) {
+        if (skyTiledSerial != skyPlane->serial) {
+            skyTiled.reserve((size_t)skyPlane->width * skyPlane->height);
+            HIP_CHECK(tile_texture_launch(skyPlane->texels.ptr, skyTiled.ptr, (uint32_t)skyPlane->width, (uint32_t)skyPlane->height, dev->stream));
+            skyTiledSerial = skyPlane->serial;
+            skyTiledLog2[0] = (uint32_t)__builtin_ctz((unsigned)skyPlane->width); skyTiledLog2[1] = (uint32_t)__builtin_ctz((unsigned)skyPlane->height);
+        }
+        P.skyTiled = skyTiled.ptr; P.skyTiledLog2W = skyTiledLog2[0]; P.skyTiledLog2H = skyTiledLog2[1];
+    }
     P.randomSeed = frameCount; P.frameCount = frameCount;
     P.diSamples = diSamples; P.giSamples = giSamples; P.maxLights = maxLights;
     P.diReproject = 0;                                        // DI_REPROJECTION_SUPPORT undefined (:1012-1016)
@@ -926,6 +944,7 @@ void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64
     P.width = imgW; P.height = imgH; P.tileY0 = dev->tileY0; P.tileY1 = dev->tileY1; P.stripRank = dev->stripRank; P.stripCount = dev->stripCount;
     P.cacheWords = cacheWords; P.cacheInstances = cacheWords ? (uint32_t)rtInstances.size() : 0u;
     P.separatePost = separatePost() ? 1u : 0u;
+    P.simpleKernels = simpleFrame ? 1u : 0u;
     P.postSource = img.output; P.postSourceW = imgW; P.postSourceH = imgH;
     P.rasterFg = nullptr; P.rasterFgTris = nullptr; P.rasterFgCount = 0; P.rasterFgPad = 0; P.finalPacked = nullptr;
     memset(&P.background, 0, sizeof(P.background));
@@ -1402,6 +1421,7 @@ RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, doubl
     else if (k == "bounce_refill") d->opt.bounceRefill = (int)value;
     else if (k == "spin_present") d->opt.spinPresent = value != 0.0;
     else if (k == "lds_cache") d->opt.ldsCache = value != 0.0;
+    else if (k == "simple_kernels") d->opt.simpleKernels = value != 0.0;       // 0: every frame runs the general kernels (A/B tests)
     else if (k == "reset_accum") { d->finishStats(); d->accum = RT64_FRAME_STATS(); }
     else if (k == "fold_foreground") d->opt.foldForeground = value != 0.0;        // 0: the foreground (HUD) list keeps its own raster_draw launch after a one-kernel frame
     else if (k == "fused_lean") d->opt.fusedLean = value != 0.0;                  // 0: a lean frame runs as primary_trace + primary_shade + direct instead of lean_frame_kernel

@@ -100,7 +100,14 @@ DEV f4 tex_sample_level_impl(const TexView &t, float u, float v, uint32_t level,
     { float top = c00.w + fx * (c10.w - c00.w), bot = c01.w + fx * (c11.w - c01.w); r.w = top + fy * (bot - top); }
     return r;
 }
+// gBackground has the screen's size, whatever that is: its sampler keeps both addressing forms in every build
+DEV f4 tex_sample_level_any(const TexView &t, float u, float v, uint32_t level, uint32_t filter, uint32_t hAddr, uint32_t vAddr) {
+    return t.pow2 ? tex_sample_level_impl<true>(t, u, v, level, filter, hAddr, vAddr) : tex_sample_level_impl<false>(t, u, v, level, filter, hAddr, vAddr);
+}
 DEV f4 tex_sample_level(const TexView &t, float u, float v, uint32_t level, uint32_t filter, uint32_t hAddr, uint32_t vAddr) {
+#ifdef RT_ASSUME_SIMPLE
+    return tex_sample_level_impl<true>(t, u, v, level, filter, hAddr, vAddr);       // the host checked: every texture of the frame is a power of two in both sizes
+#endif
     return t.pow2 ? tex_sample_level_impl<true>(t, u, v, level, filter, hAddr, vAddr) : tex_sample_level_impl<false>(t, u, v, level, filter, hAddr, vAddr);
 }
 
@@ -180,21 +187,45 @@ DEV f4 sample_sky_2d(PRef P, f2 screenUV) {                       // SampleSky2D
     f2 uv = sky_plane_uv(P, screenUV);
     return sky_finish(P, tex_sample_level(tex_view(P.textures + P.skyPlaneTexIndex), uv.x, uv.y, 0, 1, 0, 0));
 }
+// LINEAR / WRAP sample of level 0 from the tiled copy of the sky plane: the arithmetic of tex_sample_level_impl<true> (same values, bit for
+// bit), only the texel address differs.
+DEV f4 sky_tiled_sample(PRef P, float u, float v) {
+    const uint32_t lw = P.skyTiledLog2W, lh = P.skyTiledLog2H;
+    const int w = 1 << lw, h = 1 << lh;
+    float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    float x0f = floorf(x), y0f = floorf(y);
+    float fx = x - x0f, fy = y - y0f;
+    const int x0 = (int)x0f & (w - 1), x1 = ((int)x0f + 1) & (w - 1), y0 = (int)y0f & (h - 1), y1 = ((int)y0f + 1) & (h - 1);
+    auto texel = [&](int tx, int ty) -> f4 {
+        const uint32_t idx = ((((uint32_t)ty >> 2) << (lw - 2)) + ((uint32_t)tx >> 2)) * 16u + (((uint32_t)ty & 3u) << 2) + ((uint32_t)tx & 3u);
+        const uint32_t t = P.skyTiled[idx];
+        const float k = 1.0f / 255.0f;
+        return mk4((float)(t & 0xFF) * k, (float)((t >> 8) & 0xFF) * k, (float)((t >> 16) & 0xFF) * k, (float)(t >> 24) * k);
+    };
+    f4 c00 = texel(x0, y0), c10 = texel(x1, y0), c01 = texel(x0, y1), c11 = texel(x1, y1);
+    f4 r;
+    { float top = c00.x + fx * (c10.x - c00.x), bot = c01.x + fx * (c11.x - c01.x); r.x = top + fy * (bot - top); }
+    { float top = c00.y + fx * (c10.y - c00.y), bot = c01.y + fx * (c11.y - c01.y); r.y = top + fy * (bot - top); }
+    { float top = c00.z + fx * (c10.z - c00.z), bot = c01.z + fx * (c11.z - c01.z); r.z = top + fy * (bot - top); }
+    { float top = c00.w + fx * (c10.w - c00.w), bot = c01.w + fx * (c11.w - c01.w); r.w = top + fy * (bot - top); }
+    return r;
+}
 DEV f4 sample_sky_plane(PRef P, f3 rayDirection) {                // SampleSkyPlane :72-87
     if (P.skyPlaneTexIndex < 0) return mk4(0, 0, 0, 0);
     f2 uv = fake_envmap_uv(rayDirection, P.skyYawOffset);
+    if (P.skyTiled) return sky_finish(P, sky_tiled_sample(P, uv.x, uv.y));
     return sky_finish(P, tex_sample_level(tex_view(P.textures + P.skyPlaneTexIndex), uv.x, uv.y, 0, 1, 0, 0));
 }
 // gBackground: the raster background instances drawn into a screen-size RGBA8 target (rt64_view.cpp:1296-1319, raster.hip),
 // sampled with the static LINEAR / WRAP sampler (BgSky.hlsli:89-95).  No background instance => transparent black.
 DEV f3 sample_background_2d(PRef P, f2 screenUV) {
     if (!P.background.texels) return mk3s(0.0f);
-    return xyz(tex_sample_level(tex_view_arg(P.background), screenUV.x, screenUV.y, 0, 1, 0, 0));
+    return xyz(tex_sample_level_any(tex_view_arg(P.background), screenUV.x, screenUV.y, 0, 1, 0, 0));
 }
 DEV f3 sample_background_envmap(PRef P, f3 rayDirection) {
     if (!P.background.texels) return mk3s(0.0f);
     const f2 uv = fake_envmap_uv(rayDirection, 0.0f);
-    return xyz(tex_sample_level(tex_view_arg(P.background), uv.x, uv.y, 0, 1, 0, 0));
+    return xyz(tex_sample_level_any(tex_view_arg(P.background), uv.x, uv.y, 0, 1, 0, 0));
 }
 
 DEV f4 fog_from_camera(PRef P, const RT64_MATERIAL &m, f3 position) {    // Fog.hlsli:5-18
@@ -520,6 +551,9 @@ DEV float trace_shadow(PRef P, ShadeEnv &env, f3 origin, f3 dir, float tmin, flo
     trace_ray<CACHED>(P, o, d, tmin, tmax, false /* SKIP_BACKFACE_SHADOWS undefined */, env.stk,
               [&](float, float u, float v, uint32_t instance, uint32_t prim, float &, uint32_t instFlags, float) -> bool {
                   if (instFlags & GPU_INST_SHADOW_OPAQUE) { shadowHit = 0.0f; return true; }   // payload.shadowHit = 0 (:661)
+#ifdef RT_ASSUME_SIMPLE
+                  shadowHit = 0.0f; return true;          // the host checked: every instance of the frame is shadow-opaque, the any-hit program is never needed
+#endif
                   float a = shadow_anyhit_alpha(P, instance, prim, u, v, px, py);
                   if (a < 0.0f) return false;
                   shadowHit = fmaxf(shadowHit - a, 0.0f);

@@ -203,3 +203,16 @@ def test_background_texture_swapped_in_the_same_slot_redraws_gbackground(rt64_li
         assert np.abs(final.astype(np.int32) - rb["final"].astype(np.int32)).max() <= 1
     finally:
         s.close(); oa.close(); ob.close()
+
+
+@pytest.mark.parametrize("config", ["C2", "C3", "C5"])
+def test_simple_frame_kernels_equal_the_general_kernels(rt64_lib, sample_data, config):
+    """The sample scene is a "simple" frame (every texture a power of two in both sizes, every instance shadow-opaque): it runs the kernels of
+    passes_simple.hip, compiled without non-power-of-two addressing and without the shadow any-hit program.  Device option simple_kernels = 0
+    sends the same frames through the general kernels: every image and every counter is identical."""
+    a, _, sa = _bench_pair(rt64_lib, sample_data, config, frames=3)
+    b, _, sb = _bench_pair(rt64_lib, sample_data, config, frames=3, options={"simple_kernels": 0})
+    for k in a:
+        assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), k
+    assert (sa[0].primaryRays, sa[0].shadowRays, sa[0].indirectRays, sa[0].reflectionRays, sa[0].nodesVisited, sa[0].trianglesTested) == \
+           (sb[0].primaryRays, sb[0].shadowRays, sb[0].indirectRays, sb[0].reflectionRays, sb[0].nodesVisited, sb[0].trianglesTested)
