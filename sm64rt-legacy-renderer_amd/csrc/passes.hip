@@ -568,7 +568,7 @@ __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void direct_kernel(FramePar
 // covers (the frame parameters may include a denoiser halo above and below them, which only the G-buffer part renders).
 template <bool CACHED, bool FULL, int WAVES>
 #ifndef LEAN_WAVES
-#define LEAN_WAVES 3          // waves per SIMD of the one-kernel frame: 3 (168 VGPRs, ~30 spilled) measured 12 % faster than 2 (193 VGPRs, no spills) once the frame constants stopped occupying registers
+#define LEAN_WAVES 3          // waves per SIMD of the one-kernel frame: 3 (168 VGPRs) measured 12 % faster than 2 (193 VGPRs, no spills); 4 (128 VGPRs, 62 spilled dwords in the simple build) measured 30 % slower
 #endif
 __global__ __launch_bounds__(RT_BLOCK, WAVES) void lean_frame_kernel(FrameParams Pv, ViewImages Iv, int32_t *hitInstance, int cur, int ownedY0, int ownedY1) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
@@ -1383,11 +1383,6 @@ hipError_t RT_LAUNCHER(launch_lean_frame)(const FrameParams &P, const ViewImages
     if (maxGroups < 1u || maxGroups > RT_MAX_FRAME_GROUPS) maxGroups = RT_MAX_FRAME_GROUPS;
     const unsigned perGroup = (tiles + maxGroups - 1u) / maxGroups, grid = tiles < 1u ? 1u : (tiles + perGroup - 1u) / perGroup;
     const size_t lds = P.cacheWords ? cached_lds_bytes(P, true) : 0;
-#ifdef RT_ASSUME_SIMPLE
-    static const bool four = getenv("RT64_LEAN_WAVES") && atoi(getenv("RT64_LEAN_WAVES")) == 4;      // experiment: 4 waves per SIMD (128 VGPRs, more spills)
-    if (four && P.cacheWords && !full) { hipLaunchKernelGGL((lean_frame_kernel<true, false, 4>), dim3(grid), dim3(RT_BLOCK), lds, s, P, I, hitInstance, cur, ownedY0, ownedY1); return hipGetLastError(); }
-    if (four && P.cacheWords && full) { hipLaunchKernelGGL((lean_frame_kernel<true, true, 4>), dim3(grid), dim3(RT_BLOCK), lds, s, P, I, hitInstance, cur, ownedY0, ownedY1); return hipGetLastError(); }
-#endif
     if (P.cacheWords) {
         if (full) hipLaunchKernelGGL((lean_frame_kernel<true, true, LEAN_WAVES>), dim3(grid), dim3(RT_BLOCK), lds, s, P, I, hitInstance, cur, ownedY0, ownedY1);
         else hipLaunchKernelGGL((lean_frame_kernel<true, false, LEAN_WAVES>), dim3(grid), dim3(RT_BLOCK), lds, s, P, I, hitInstance, cur, ownedY0, ownedY1);
