@@ -176,7 +176,8 @@ def main():
             uid_dev = uid.cuda()
             dist.broadcast(uid_dev, 0)
             uid = uid_dev.cpu()
-        gather = lib.CreateGather(scene.device, uid.data_ptr(), uid.numel(), rank, N, int(use_bands))       # also sets this device's share of the frame
+        # frames with GI + denoiser: contiguous bands of about equal modelled cost (cut from the whole frame every rank has just rendered)
+        gather = lib.CreateGather(scene.device, uid.data_ptr(), uid.numel(), rank, N, 2 if use_bands else 0)       # also sets this device's share of the frame
         if not gather:
             raise SystemExit("RT64_CreateGather: " + lib.last_error())
 
@@ -194,7 +195,14 @@ def main():
     gatherer = tiles.FrameGatherer(H, W, rank, N, comm_device, stream=ext_stream, bands=use_bands) if (G and not native) else None
     staging = torch.zeros(max(tiles.strips_per_rank(H, N) * 16, tiles.band_rows(H, N)) * W * 4, dtype=torch.uint8, device="cuda") if (G and not pipelined) else None
     local = torch.zeros(max(tiles.max_owned_rows(H, N), 1) * W * 4, dtype=torch.uint8, device="cuda")
-    my_bytes = (gatherer.owned_bytes() if gatherer else lib.GatherOwnedRows(H, N, int(use_bands), rank) * W * 4) if G else H * W * 4
+    if native and use_bands:
+        band_starts = (C.c_int * (N + 1))()
+        if lib.GetGatherBands(gather, band_starts, N + 1) != N:
+            raise SystemExit("RT64_GetGatherBands failed")
+        my_rows = band_starts[rank + 1] - band_starts[rank]
+    elif native:
+        my_rows = lib.GatherOwnedRows(H, N, 0, rank)
+    my_bytes = (gatherer.owned_bytes() if gatherer else my_rows * W * 4) if G else H * W * 4
     if PR > 1:
         my_bytes = ((tiles.band_range(H, 0, PR)[1] - tiles.band_range(H, 0, PR)[0]) if (args.gi_samples > 0 and args.denoiser) else tiles.owned_rows(H, 0, PR)) * W * 4
 
@@ -341,7 +349,7 @@ def main():
     if rank == 0:
         K = float(stat_frames)
         kms = {k: v / K for k, v in acc.items()}
-        my_pixels = (tiles.band_range(H, 0, N)[1] if use_bands else tiles.owned_rows(H, 0, N)) * W
+        my_pixels = my_bytes // 4 if native else (tiles.band_range(H, 0, N)[1] if use_bands else tiles.owned_rows(H, 0, N)) * W
         if PR > 1:
             my_pixels = my_bytes // 4
         kernels = {
@@ -387,7 +395,7 @@ def main():
                 args.config, W, H, "" if not (args.gi_samples or args.subdiv or args.floor_grid > 1) else " [gi=%d denoiser=%d subdiv=%d floor_grid=%d]" % (
                     args.gi_samples, int(args.denoiser), args.subdiv, args.floor_grid)),
                 "rays_per_frame": int(rays_total), "width": W, "height": H,
-                "partition": ("DIAGNOSIS: rank 0's share of a %d-way partition only, no gather" % PR) if PR > 1 else ("%s x%d + RCCL gather of RGBA8" % ("contiguous bands with denoiser halo" if use_bands else "interleaved 16-row strips", N)) if N > 1 else "single GPU"},
+                "partition": ("DIAGNOSIS: rank 0's share of a %d-way partition only, no gather" % PR) if PR > 1 else ("%s x%d + RCCL gather of RGBA8" % (("cost-balanced contiguous bands %s with denoiser halo" % (list(band_starts) if native else "")) if use_bands else "interleaved 16-row strips", N)) if N > 1 else "single GPU"},
             "roofline": roofline,
         }
         if G:

@@ -417,7 +417,13 @@ typedef struct {
        packed buffer; rows a rank owns; rows every rank's slot is sized for */ \
     X(GatherRowOwner, RT64_GatherRowOwner, int, (int height, int count, int bands, int y, int *packedRow)) \
     X(GatherOwnedRows, RT64_GatherOwnedRows, int, (int height, int count, int bands, int rank)) \
-    X(GatherSlotRows, RT64_GatherSlotRows, int, (int height, int count, int bands))
+    X(GatherSlotRows, RT64_GatherSlotRows, int, (int height, int count, int bands)) \
+    /* bands = 2 in RT64_CreateGather: contiguous bands of about equal COST instead of equal height -- cost of a row = its pixels, those whose \
+       primary ray hit geometry in the device's last (whole) frame counted 6 times; every rank must have rendered that frame, so that all \
+       derive the same boundaries.  RT64_GetGatherBands reads the boundaries of a gather (starts[0..count]); RT64_BalanceGatherBands is the cut \
+       itself as a pure function of per-row hit counts. */ \
+    X(GetGatherBands, RT64_GetGatherBands, int, (RT64_GATHER *gather, int *starts, int capacity)) \
+    X(BalanceGatherBands, RT64_BalanceGatherBands, void, (const unsigned int *hitCounts, int width, int height, int count, int *starts))
 
 typedef struct RT64_GATHER RT64_GATHER;
 #define RT64_GATHER_ID_BYTES 128       /* size of the rendezvous id (an ncclUniqueId) */

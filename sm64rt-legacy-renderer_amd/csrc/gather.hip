@@ -12,11 +12,11 @@ namespace {
 
 // One workgroup per frame row: 16-byte copies of the row from the owner's packed buffer (rank 0's own rows come from its send buffer).
 __global__ __launch_bounds__(256) void gather_assemble_kernel(const uint8_t *__restrict__ own, const uint8_t *__restrict__ bucket, size_t slotBytes,
-                                                              uint8_t *__restrict__ frame, int width, int height, int count, int bands) {
-    const int y = blockIdx.x;
+                                                              uint8_t *__restrict__ frame, int width, GatherLayout L) {
+    const int y = blockIdx.x, height = L.height;
     if (y >= height) return;
     int packed;
-    const int owner = gather_row_owner(height, count, bands, y, &packed);
+    const int owner = gather_row_owner(L, y, &packed);
     const uint8_t *src = (owner == 0 ? own : bucket + (size_t)owner * slotBytes) + (size_t)packed * (size_t)width * 4;
     uint8_t *dst = frame + (size_t)y * (size_t)width * 4;
     const int bytes = width * 4;
@@ -32,7 +32,26 @@ __global__ __launch_bounds__(256) void gather_assemble_kernel(const uint8_t *__r
 
 }  // namespace
 
-hipError_t launch_gather_assemble(const uint8_t *own, const uint8_t *bucket, size_t slotBytes, uint8_t *frame, int width, int height, int count, int bands, hipStream_t s) {
-    hipLaunchKernelGGL(gather_assemble_kernel, dim3((unsigned)height), dim3(256), 0, s, own, bucket, slotBytes, frame, width, height, count, bands);
+hipError_t launch_gather_assemble(const uint8_t *own, const uint8_t *bucket, size_t slotBytes, uint8_t *frame, int width, const GatherLayout &L, hipStream_t s) {
+    hipLaunchKernelGGL(gather_assemble_kernel, dim3((unsigned)L.height), dim3(256), 0, s, own, bucket, slotBytes, frame, width, L);
+    return hipGetLastError();
+}
+
+// Pixels per row whose primary ray hit geometry (the cost model of the cost-balanced bands): one workgroup per row.
+namespace {
+__global__ __launch_bounds__(256) void row_hit_count_kernel(const int32_t *__restrict__ hitInstance, uint32_t *__restrict__ counts, int width) {
+    __shared__ uint32_t total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    uint32_t n = 0;
+    for (int x = threadIdx.x; x < width; x += 256) n += hitInstance[(size_t)blockIdx.x * width + x] >= 0 ? 1u : 0u;
+    for (int d = 32; d >= 1; d >>= 1) n += __shfl_down(n, d, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&total, n);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = total;
+}
+}  // namespace
+hipError_t launch_row_hit_count(const int32_t *hitInstance, uint32_t *counts, int width, int height, hipStream_t s) {
+    hipLaunchKernelGGL(row_hit_count_kernel, dim3((unsigned)height), dim3(256), 0, s, hitInstance, counts, width);
     return hipGetLastError();
 }

@@ -86,4 +86,5 @@ hipError_t launch_taa_upsample(const ViewImages &I, int cur, int rw, int rh, flo
 
 // ---- gather.hip -----------------------------------------------------------------------------------------------------
 // Rank 0 of a multi-GPU gather: frame row y <- row gather_row_owner(y) of the owner's packed buffer (`own` for rank 0, bucket + r * slotBytes for rank r).
-hipError_t launch_gather_assemble(const uint8_t *own, const uint8_t *bucket, size_t slotBytes, uint8_t *frame, int width, int height, int count, int bands, hipStream_t s);
+hipError_t launch_gather_assemble(const uint8_t *own, const uint8_t *bucket, size_t slotBytes, uint8_t *frame, int width, const GatherLayout &L, hipStream_t s);
+hipError_t launch_row_hit_count(const int32_t *hitInstance, uint32_t *counts, int width, int height, hipStream_t s);      // counts[y] = pixels of row y whose primary ray hit geometry

@@ -174,25 +174,33 @@ struct ViewImages {
 #else
 #define RT64_HD inline
 #endif
+#define RT64_GATHER_MAX_RANKS 64
+struct GatherLayout { int height, count, mode; int starts[RT64_GATHER_MAX_RANKS + 1]; };   // mode 2 (cost-balanced bands): rank r owns rows [starts[r], starts[r + 1])
 RT64_HD int gather_band_rows(int height, int count) { return (height + count - 1) / count; }
 // the rank that owns frame row y, and (*packed) the row's position in that rank's packed buffer
-RT64_HD int gather_row_owner(int height, int count, int bands, int y, int *packed) {
-    if (count <= 1) { *packed = y; return 0; }
-    if (bands) { const int b = gather_band_rows(height, count); *packed = y % b; return y / b; }
+RT64_HD int gather_row_owner(const GatherLayout &L, int y, int *packed) {
+    if (L.count <= 1) { *packed = y; return 0; }
+    if (L.mode == 2) { int r = 0; while (r + 1 < L.count && y >= L.starts[r + 1]) r++; *packed = y - L.starts[r]; return r; }
+    if (L.mode == 1) { const int b = gather_band_rows(L.height, L.count); *packed = y % b; return y / b; }
     const int strip = y / 16;
-    *packed = (strip / count) * 16 + (y & 15);
-    return strip % count;
+    *packed = (strip / L.count) * 16 + (y & 15);
+    return strip % L.count;
 }
 // rows rank `rank` owns
-RT64_HD int gather_owned_rows(int height, int count, int bands, int rank) {
-    if (count <= 1) return height;
-    if (bands) { const int b = gather_band_rows(height, count), y0 = rank * b, y1 = (rank + 1) * b; return (y1 < height ? y1 : height) - (y0 < height ? y0 : height); }
+RT64_HD int gather_owned_rows(const GatherLayout &L, int rank) {
+    if (L.count <= 1) return L.height;
+    if (L.mode == 2) return L.starts[rank + 1] - L.starts[rank];
+    if (L.mode == 1) { const int b = gather_band_rows(L.height, L.count), y0 = rank * b, y1 = (rank + 1) * b; return (y1 < L.height ? y1 : L.height) - (y0 < L.height ? y0 : L.height); }
     int rows = 0;
-    for (int y = rank * 16; y < height; y += count * 16) rows += (y + 16 <= height ? 16 : height - y);
+    for (int y = rank * 16; y < L.height; y += L.count * 16) rows += (y + 16 <= L.height ? 16 : L.height - y);
     return rows;
 }
 // rows of the largest share (what every rank's slot of the bucket on rank 0 is sized for)
-RT64_HD int gather_max_owned_rows(int height, int count, int bands) { return bands ? gather_band_rows(height, count) : (((height + 15) / 16 + count - 1) / count) * 16; }
+RT64_HD int gather_max_owned_rows(const GatherLayout &L) {
+    if (L.mode == 2) { int m = 0; for (int r = 0; r < L.count; r++) { const int n = L.starts[r + 1] - L.starts[r]; m = n > m ? n : m; } return m; }
+    return L.mode == 1 ? gather_band_rows(L.height, L.count) : (((L.height + 15) / 16 + L.count - 1) / L.count) * 16;
+}
+RT64_HD GatherLayout gather_layout(int height, int count, int mode) { GatherLayout L; L.height = height; L.count = count < 1 ? 1 : count; L.mode = mode; for (int i = 0; i <= RT64_GATHER_MAX_RANKS; i++) L.starts[i] = 0; return L; }
 
 #define RT_COUNTER_STRIPES 64          // copies of the counter block, chosen by workgroup number: the per-wave atomics of a counting frame spread over 64 lines
 enum { CTR_NODES = 0, CTR_TRIS, CTR_PRIMARY, CTR_SHADOW, CTR_INDIRECT, CTR_REFLECTION, CTR_REFRACTION,

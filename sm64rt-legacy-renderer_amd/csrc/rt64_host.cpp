@@ -1617,8 +1617,28 @@ static RcclApi &rccl() {
 #define RCCL_CHECK(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { \
     char msg_[512]; snprintf(msg_, sizeof(msg_), "RCCL call " #call " failed: %s", rccl().GetErrorString ? rccl().GetErrorString(r_) : "?"); throw std::runtime_error(msg_); } } while (0)
 
+// Boundaries of `count` contiguous bands of about equal cost: cost(row) = width + RT64_BAND_HIT_WEIGHT * (pixels of the row that hit geometry).
+// Greedy cut at the running cost's crossings of k / count of the total; every band keeps at least RT64_BAND_MIN_ROWS rows (while the frame has them).
+#define RT64_BAND_HIT_WEIGHT 6
+#define RT64_BAND_MIN_ROWS 16
+static void gather_balanced_bands(const uint32_t *hitCounts, int width, int height, int count, int *starts) {
+    std::vector<double> prefix((size_t)height + 1, 0.0);
+    for (int y = 0; y < height; y++) prefix[(size_t)y + 1] = prefix[(size_t)y] + (double)width + (double)RT64_BAND_HIT_WEIGHT * (double)hitCounts[y];
+    const double total = prefix[(size_t)height];
+    const int minRows = height >= count * RT64_BAND_MIN_ROWS ? RT64_BAND_MIN_ROWS : std::max(height / count, 1);
+    starts[0] = 0;
+    for (int r = 1; r < count; r++) {
+        const double target = total * (double)r / (double)count;
+        int y = (int)(std::lower_bound(prefix.begin(), prefix.end(), target) - prefix.begin());
+        y = std::max(y, starts[r - 1] + minRows);                       // not thinner than the minimum ...
+        y = std::min(y, height - (count - r) * minRows);                // ... and leave the minimum for every band still to come
+        starts[r] = std::max(y, starts[r - 1]);
+    }
+    starts[count] = height;
+}
+
 struct Gather {
-    Device *dev; int rank, count, bands; int W, H; size_t slotBytes;
+    Device *dev; int rank, count, bands; int W, H; size_t slotBytes; GatherLayout layout;
     ncclComm_t comm = nullptr; hipStream_t commStream = nullptr;
     struct Slot { uint8_t *local = nullptr, *bucket = nullptr, *frame = nullptr; hipEvent_t produced = nullptr, gathered = nullptr; bool pending = false; } slots[2];
     int next = 0, last = -1;
@@ -1633,9 +1653,27 @@ Gather::Gather(Device *d, const ncclUniqueId &id, int rank_, int count_, int ban
     if (count < 1 || rank < 0 || rank >= count) throw std::runtime_error("RT64_CreateGather: rank / count out of range.");
     dev->use();
     W = dev->pendingWidth; H = dev->pendingHeight;
-    slotBytes = (size_t)gather_max_owned_rows(H, count, bands) * (size_t)W * 4;
+    if (count > RT64_GATHER_MAX_RANKS) throw std::runtime_error("RT64_CreateGather: more ranks than RT64_GATHER_MAX_RANKS.");
+    if (bands < 0 || bands > 2) throw std::runtime_error("RT64_CreateGather: bands must be 0 (interleaved strips), 1 (equal bands) or 2 (cost-balanced bands).");
+    layout = gather_layout(H, count, bands);
+    if (bands == 2) {
+        // Cost-balanced contiguous bands.  Cost model of a row: its pixels, the ones whose primary ray hits geometry weighted RT64_BAND_HIT_WEIGHT
+        // times (a GI + denoiser pixel costs several times a sky pixel), counted on the last frame this device rendered -- which has to be
+        // a whole frame, the same on every rank (every rank renders the same scene), so that all ranks derive the same boundaries.
+        View *v = first_view(dev);
+        if (!v || v->frameCount == 0 || v->imgW != W || v->imgH != H || dev->tileY0 != 0 || dev->tileY1 != dev->height || dev->stripCount > 1)
+            throw std::runtime_error("RT64_CreateGather: cost-balanced bands are cut from the device's last frame: render one whole frame (no tile / interleave) before creating the gather.");
+        DevArray<uint32_t> dCounts; dCounts.reserve((size_t)H);
+        HIP_CHECK(launch_row_hit_count(v->hitInstance.ptr, dCounts.ptr, W, H, dev->stream));
+        std::vector<uint32_t> counts((size_t)H);
+        HIP_CHECK(hipMemcpyAsync(counts.data(), dCounts.ptr, (size_t)H * 4, hipMemcpyDeviceToHost, dev->stream));
+        HIP_CHECK(hipStreamSynchronize(dev->stream));
+        gather_balanced_bands(counts.data(), W, H, count, layout.starts);
+    }
+    slotBytes = (size_t)gather_max_owned_rows(layout) * (size_t)W * 4;
     // the device's share of the frame
-    if (bands) { const int b = gather_band_rows(H, count); dev->tileSet = true; dev->tileY0 = std::min(rank * b, H); dev->tileY1 = std::min((rank + 1) * b, H); dev->stripRank = 0; dev->stripCount = 1; }
+    if (bands == 2) { dev->tileSet = true; dev->tileY0 = layout.starts[rank]; dev->tileY1 = layout.starts[rank + 1]; dev->stripRank = 0; dev->stripCount = 1; }
+    else if (bands) { const int b = gather_band_rows(H, count); dev->tileSet = true; dev->tileY0 = std::min(rank * b, H); dev->tileY1 = std::min((rank + 1) * b, H); dev->stripRank = 0; dev->stripCount = 1; }
     else { dev->tileSet = false; dev->tileY0 = 0; dev->tileY1 = H; dev->stripRank = count > 1 ? rank : 0; dev->stripCount = count > 1 ? count : 1; }
     HIP_CHECK(hipStreamCreateWithFlags(&commStream, hipStreamNonBlocking));
     for (Slot &sl : slots) {
@@ -1672,7 +1710,7 @@ int Gather::submit() {
     const int slot = next; Slot &sl = slots[slot];
     View *v = first_view(dev);
     if (!v) throw std::runtime_error("RT64_SubmitGather: the device has no view.");
-    const size_t mine = (size_t)gather_owned_rows(H, count, bands, rank) * (size_t)W * 4;
+    const size_t mine = (size_t)gather_owned_rows(layout, rank) * (size_t)W * 4;
     if (!(v->packedFinal && dev->gatherTarget == sl.local)) {        // this kind of frame did not write the send buffer itself: pack the owned rows now (same layout)
         const bool sync = dev->opt.syncPresent; dev->opt.syncPresent = false;
         const size_t got = mine ? readback(dev, RT64_IMAGE_FINAL_RGBA8, sl.local, slotBytes, true) : 0;
@@ -1684,11 +1722,11 @@ int Gather::submit() {
     if (count > 1) {
         RcclApi &R = rccl();
         RCCL_CHECK(R.GroupStart());
-        if (rank == 0) { for (int r = 1; r < count; r++) { const size_t n = (size_t)gather_owned_rows(H, count, bands, r) * (size_t)W * 4; if (n) RCCL_CHECK(R.Recv(sl.bucket + (size_t)r * slotBytes, n, ncclUint8, r, comm, commStream)); } }
+        if (rank == 0) { for (int r = 1; r < count; r++) { const size_t n = (size_t)gather_owned_rows(layout, r) * (size_t)W * 4; if (n) RCCL_CHECK(R.Recv(sl.bucket + (size_t)r * slotBytes, n, ncclUint8, r, comm, commStream)); } }
         else if (mine) RCCL_CHECK(R.Send(sl.local, mine, ncclUint8, 0, comm, commStream));
         RCCL_CHECK(R.GroupEnd());
     }
-    if (rank == 0) HIP_CHECK(launch_gather_assemble(sl.local, sl.bucket, slotBytes, sl.frame, W, H, count, bands, commStream));
+    if (rank == 0) HIP_CHECK(launch_gather_assemble(sl.local, sl.bucket, slotBytes, sl.frame, W, layout, commStream));
     HIP_CHECK(hipEventRecord(sl.gathered, commStream));
     sl.pending = true; last = slot; next = slot ^ 1;
     prepare(next);
@@ -1742,9 +1780,20 @@ RT64_EXPORT void *RT64_GetGatherFrame(RT64_GATHER *gather, int slot) {          
 }
 RT64_EXPORT void RT64_DestroyGather(RT64_GATHER *gather) { RT64_TRY delete reinterpret_cast<Gather *>(gather); RT64_CATCH_VOID }
 // Partition layout, as pure functions (no device needed): which rank owns frame row y and where the row sits in that rank's packed buffer.
-RT64_EXPORT int RT64_GatherRowOwner(int height, int count, int bands, int y, int *packedRow) { int p = 0; const int r = gather_row_owner(height, count, bands, y, &p); if (packedRow) *packedRow = p; return r; }
-RT64_EXPORT int RT64_GatherOwnedRows(int height, int count, int bands, int rank) { return gather_owned_rows(height, count, bands, rank); }
-RT64_EXPORT int RT64_GatherSlotRows(int height, int count, int bands) { return gather_max_owned_rows(height, count, bands); }
+RT64_EXPORT int RT64_GatherRowOwner(int height, int count, int bands, int y, int *packedRow) { int p = 0; const int r = gather_row_owner(gather_layout(height, count, bands ? 1 : 0), y, &p); if (packedRow) *packedRow = p; return r; }
+RT64_EXPORT int RT64_GatherOwnedRows(int height, int count, int bands, int rank) { return gather_owned_rows(gather_layout(height, count, bands ? 1 : 0), rank); }
+RT64_EXPORT int RT64_GatherSlotRows(int height, int count, int bands) { return gather_max_owned_rows(gather_layout(height, count, bands ? 1 : 0)); }
+// The band boundaries of an existing gather (bands = 1 or 2): starts[0 .. count], rank r owns rows [starts[r], starts[r + 1]).  Returns count, 0 for interleaved strips.
+RT64_EXPORT int RT64_GetGatherBands(RT64_GATHER *gather, int *starts, int capacity) {
+    Gather *g = reinterpret_cast<Gather *>(gather);
+    if (!g || !starts || g->bands == 0 || capacity < g->count + 1) return 0;
+    for (int r = 0; r <= g->count; r++) starts[r] = g->bands == 2 ? g->layout.starts[r] : std::min(r * gather_band_rows(g->H, g->count), g->H);
+    return g->count;
+}
+// The same cut as a pure function: boundaries of `count` cost-balanced bands from per-row hit counts (what RT64_CreateGather(bands = 2) computes from its last frame).
+RT64_EXPORT void RT64_BalanceGatherBands(const unsigned int *hitCounts, int width, int height, int count, int *starts) {
+    if (hitCounts && starts && width > 0 && height > 0 && count >= 1 && count <= RT64_GATHER_MAX_RANKS) gather_balanced_bands(hitCounts, width, height, count, starts);
+}
 
 // ---- inspector (rt64_inspector.cpp:469-515): the ImGui/Im3d debug UI is Win32-only; the exports exist so that hosts resolve all 33 symbols ----
 struct InspectorStub { Device *device; };

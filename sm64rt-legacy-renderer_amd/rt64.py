@@ -202,6 +202,8 @@ EXT_API = [
     ("GatherRowOwner", "RT64_GatherRowOwner", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     ("GatherOwnedRows", "RT64_GatherOwnedRows", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     ("GatherSlotRows", "RT64_GatherSlotRows", C.c_int, [C.c_int, C.c_int, C.c_int]),
+    ("GetGatherBands", "RT64_GetGatherBands", C.c_int, [_P, C.POINTER(C.c_int), C.c_int]),
+    ("BalanceGatherBands", "RT64_BalanceGatherBands", None, [C.POINTER(C.c_uint), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
 ]
 GATHER_ID_BYTES = 128
 

@@ -57,3 +57,45 @@ def test_c_host_gathers_through_the_c_abi(rt64_lib):
     a = json.loads(next(l for l in subprocess.run(base, env=env, capture_output=True, text=True, timeout=300, check=True).stdout.splitlines() if l.startswith("{")))
     b = json.loads(next(l for l in subprocess.run(base + ["--ranks", "1"], env=env, capture_output=True, text=True, timeout=300, check=True).stdout.splitlines() if l.startswith("{")))
     assert b["ranks"] == 1 and (a["checksum"], a["fnv1a"]) == (b["checksum"], b["fnv1a"])
+
+
+def test_cost_balanced_bands_reassemble_the_whole_frame(rt64_lib, sample_data):
+    """bands = 2: RT64_CreateGather cuts contiguous bands of about equal modelled cost from the device's last whole frame.  With a world of one
+    the gather itself is trivial, so the cut is checked through RT64_BalanceGatherBands on the same hit counts: three devices rendering those
+    bands (GI + SVGF, with the denoiser halo) reassemble the single-device frame bit for bit, and the geometry-heavy bottom bands are thinner."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    W, H, N = 320, 180, 3
+    whole = sample_scene.Rt64Scene(rt64_lib, sample_data, W, H, hip_device=0)
+    parts = []
+    try:
+        whole.set_view_description(gi_samples=1, denoiser=True)
+        whole.draw()
+        hits = (whole.readback(rt64.IMAGE_FIRST_INSTANCE_ID) >= 0).sum(axis=1).astype(np.uint32)
+        starts = (C.c_int * (N + 1))()
+        rt64_lib.BalanceGatherBands(hits.ctypes.data_as(C.POINTER(C.c_uint)), W, H, N, starts)
+        s = list(starts)
+        assert s[0] == 0 and s[-1] == H and (s[1] - s[0]) > (s[3] - s[2])                      # sky band on top is taller than the geometry band at the bottom
+        # a gather created on the device after that whole frame derives the same boundaries (world of one: [0, H])
+        uid = (C.c_uint8 * rt64.GATHER_ID_BYTES)()
+        assert rt64_lib.GetGatherUniqueId(uid, len(uid)) == 1
+        g = rt64_lib.CreateGather(whole.device, uid, len(uid), 0, 1, 2)
+        assert g, rt64_lib.last_error()
+        got = (C.c_int * 2)()
+        assert rt64_lib.GetGatherBands(g, got, 2) == 1 and list(got) == [0, H]
+        rt64_lib.DestroyGather(g)
+        parts = [sample_scene.Rt64Scene(rt64_lib, sample_data, W, H, hip_device=0) for _ in range(N)]
+        for p, (a, b) in zip(parts, zip(s, s[1:])):
+            p.set_view_description(gi_samples=1, denoiser=True)
+            p.set_tile(a, b)
+        for _ in range(3):
+            for p in parts:
+                p.draw()
+        for _ in range(2):
+            whole.draw()
+        for image in (rt64.IMAGE_FINAL_RGBA8, rt64.IMAGE_INDIRECT_LIGHT_FILTERED):
+            tiled = np.concatenate([p.readback(image) for p in parts], axis=0)
+            assert np.array_equal(tiled, whole.readback(image))
+    finally:
+        whole.close()
+        for p in parts:
+            p.close()

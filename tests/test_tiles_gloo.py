@@ -130,3 +130,34 @@ def test_gather_frame_gloo_world2(h, w):
         init_file = os.path.join(d, "init"); out_file = os.path.join(d, "out")
         mp.spawn(_worker, args=(2, init_file, h, w, out_file), nprocs=2, join=True)
         assert open(out_file).read() == "ok"
+
+
+def test_cost_balanced_bands_are_balanced_deterministic_and_cover_the_frame():
+    """RT64_BalanceGatherBands (the cut behind RT64_CreateGather(bands = 2)): contiguous bands whose modelled cost -- a row's pixels, the ones
+    that hit geometry weighted 6x -- is about equal, on a frame whose top half is sky (the sample scene's shape)."""
+    import ctypes as C
+    from sm64rt_legacy_renderer_amd import rt64
+    lib = rt64.Library()
+    H, W = 2160, 3840
+    hits = np.zeros(H, dtype=np.uint32)
+    hits[980:] = (W * np.clip(np.linspace(0.3, 1.0, H - 980), 0, 1)).astype(np.uint32)          # geometry only below the horizon
+    cost = W + 6.0 * hits.astype(np.float64)
+    for n in (1, 2, 3, 8):
+        starts = (C.c_int * (n + 1))()
+        lib.BalanceGatherBands(hits.ctypes.data_as(C.POINTER(C.c_uint)), W, H, n, starts)
+        s = list(starts)
+        assert s[0] == 0 and s[-1] == H and all(b - a >= 16 for a, b in zip(s, s[1:]))
+        band_cost = np.array([cost[a:b].sum() for a, b in zip(s, s[1:])])
+        assert band_cost.max() <= 1.05 * cost.sum() / n + cost.max()                           # within a row of the ideal share
+        equal = np.array([cost[a:b].sum() for a, b in (tiles.band_range(H, r, n) for r in range(n))])
+        if n >= 2:
+            assert band_cost.max() < 0.75 * equal.max()                                         # equal heights leave the sky bands idle
+        again = (C.c_int * (n + 1))()
+        lib.BalanceGatherBands(hits.ctypes.data_as(C.POINTER(C.c_uint)), W, H, n, again)
+        assert list(again) == s
+    # degenerate inputs: nothing hit (equal heights), fewer rows than 16 per band
+    starts = (C.c_int * 9)()
+    zero = np.zeros(100, dtype=np.uint32)
+    lib.BalanceGatherBands(zero.ctypes.data_as(C.POINTER(C.c_uint)), 64, 100, 8, starts)
+    s = list(starts)
+    assert s[0] == 0 and s[-1] == 100 and all(b > a for a, b in zip(s, s[1:]))
