@@ -404,7 +404,7 @@ def main():
                               "send_buffer": ("written by the frame kernel (RT64_SetDeviceGatherTarget)" if (packed[0] or (native and scene.stats().packedFinal)) else "packed after each frame (RT64_CopyDeviceImage layout)"),
                                   "host_ms_per_step": round(enqueue_ms, 5)}
         result["accel_build"] = {"first_frame_ms": round(first_frame_build_ms, 4), "triangles": int(st_full.triangleCount), "blas_node_bytes": int(st_full.blasNodeBytes),
-                                 "what": "GPU time of all BLAS builds (LBVH: Morton, radix sort, Karras, fit, 4-wide nodes) + the TLAS build, executed at the first frame after the RT64_SetMesh calls"}
+                                 "what": "GPU time of all BLAS builds (LBVH: Morton, radix sort, Karras, fit) + the TLAS build, executed at the first frame after the RT64_SetMesh calls"}
         if rebuild is not None:
             result["always_rebuild"] = rebuild
         result["frame_tables"] = "rebuilt every frame (always_rebuild)" if args.always_rebuild else "cached while the host re-sends identical descriptors (steady state of the sample host, main.cpp:97-134); `always_rebuild` holds the figure with the cache off"

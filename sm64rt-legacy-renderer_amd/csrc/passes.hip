@@ -206,11 +206,8 @@ __global__ __launch_bounds__(RT_BLOCK, KLIST ? 2 : TRACE_WAVES) void primary_tra
     __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED : RT_STACK_LDS) * RT_BLOCK];
     extern __shared__ u32x4_lds dynLds[];
     if (CACHED) fill_scene_cache(P, dynLds);
-    __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
-    __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
-    env.lightIntensity = ldsLightIntensity + threadIdx.x; env.lightIndex = ldsLightIndex + threadIdx.x;
-    env.lightIntensity = nullptr; env.lightIndex = nullptr;
+    env.lightIntensity = nullptr; env.lightIndex = nullptr;              // pure visibility: no light is picked in this kernel
     if (CACHED) { env.stk.cache = dynLds; env.stk.ldsEntries = RT_STACK_LDS_CACHED; }
     uint32_t rays = 0;
     const uint32_t tiles = tile_count(P);

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "device_math.h"
 
 #define RT64_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -136,6 +137,7 @@ static GpuCombiner decode_combiner(uint32_t shaderId) {
 
 struct Options {
     bool countTraversal = false, profilePasses = true, syncPresent = true, alwaysRebuild = false, leanFrames = true, fusedLean = true, foldForeground = true;
+    bool hostTlas = true;         // the TLAS of up to RT64_HOST_TLAS_MAX instances is built on the host and travels in the table upload (0: always the GPU builder)
     bool simpleKernels = true;    // frames whose textures are all power-of-two sized and whose instances are all shadow-opaque run the kernels of passes_simple.hip
     bool ldsCache = true;         // small scenes: BVH nodes + instance records cached in LDS by the ray kernels (0: always walk from HBM/L2)
     bool spinPresent = true;      // RT64_DrawDevice waits for the frame by polling the stream (0: blocking hipStreamSynchronize)
@@ -230,6 +232,7 @@ struct Mesh {
     DevArray<GpuNode> nodes; DevArray<GpuTri> tris; DevArray<BlasHeader> header;
     DevArray<uint32_t> sortedIndex, morton, leafParent; DevArray<uint8_t> buildScratch;
     uint32_t blasCount = 0;                            // leaves of the current BLAS (0 = none)
+    float hostBmin[3] = { 0, 0, 0 }, hostBmax[3] = { 0, 0, 0 };     // bounds of the indexed positions (== BlasHeader bounds: a min / max over the same floats), for the host-side TLAS build
     uint32_t topologyVersion = 0, depthVersion = ~0u, depth = 255;      // tree depth (BlasHeader::depth), read back once per topology: refits keep it
     uint32_t treeDepth();
     bool buildPending = false, pendingRefit = false;   // RT64_SetMesh recorded a build / refit that Device::flushMeshBuilds has not run yet
@@ -304,6 +307,8 @@ struct View {
     DevArray<uint8_t> dTables; TablePtr<GpuInstance> dInstances; TablePtr<GpuTexture> dTextures; TablePtr<RT64_LIGHT> dLights;
     std::vector<uint8_t> tableScratch;
     DevArray<GpuNode> tlasNodes; DevArray<uint32_t> tlasIndex, tlasMorton, tlasLeafParent; DevArray<BlasHeader> tlasHeader; DevArray<uint8_t> tlasScratch;
+    // where the current TLAS lives: the arrays above (GPU build), or the tail of dTables (a few instances: built on the host, uploaded with the tables)
+    const GpuNode *tlasNodesAt = nullptr; const uint32_t *tlasIndexAt = nullptr, *tlasMortonAt = nullptr; const BlasHeader *tlasHeaderAt = nullptr;
     std::vector<uint8_t> uploadedTables;      // bytes of the last uploaded instance/texture/light tables (cache key)
     float maxDepthBias = 0.0f;
     bool anyNonOpaque = false, anyReflection = false, anyRefraction = false, anyFog = false;
@@ -453,7 +458,16 @@ void Texture::setDDS(const void *data, int byteCount) {
 void Mesh::set(const void *vertexArray, int vcount, int vstride, const unsigned int *indexArray, int icount) {
     if (!vertexArray || !indexArray || vcount <= 0 || icount <= 0 || vstride < 12) throw std::runtime_error("RT64_SetMesh: invalid arguments.");
     // An index past the vertex array would make the BLAS builder and the any-hit vertex fetches read outside the buffer (a GPU memory fault).
-    for (int i = 0; i < icount; i++) if (indexArray[i] >= (unsigned int)vcount) throw std::runtime_error("RT64_SetMesh: index " + std::to_string(i) + " (" + std::to_string(indexArray[i]) + ") is out of range for " + std::to_string(vcount) + " vertices.");
+    float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+    const int usedIndices = (flags & RT64_MESH_RAYTRACE_ENABLED) ? (icount / 3) * 3 : icount;
+    for (int i = 0; i < icount; i++) {
+        if (indexArray[i] >= (unsigned int)vcount) throw std::runtime_error("RT64_SetMesh: index " + std::to_string(i) + " (" + std::to_string(indexArray[i]) + ") is out of range for " + std::to_string(vcount) + " vertices.");
+        if (i < usedIndices) {
+            float p[3]; memcpy(p, static_cast<const uint8_t *>(vertexArray) + (size_t)indexArray[i] * vstride, 12);
+            for (int k = 0; k < 3; k++) { mn[k] = fminf(mn[k], p[k]); mx[k] = fmaxf(mx[k], p[k]); }
+        }
+    }
+    memcpy(hostBmin, mn, 12); memcpy(hostBmax, mx, 12);
     device->use();
     // rt64_mesh.cpp:30-39,76-82: a change of counts/stride discards the BLAS even if updatable.
     const bool sameShape = vertices.ptr && vertexCount == vcount && vertexStride == vstride && indexCount == icount;
@@ -724,6 +738,94 @@ void View::drawRasterList(RasterList &rl, uint8_t *target) {
     dev->workSinceMark = true;
 }
 
+// ---- TLAS of a few instances, built on the host ----------------------------------------------------------------------------------------
+// The same tree the GPU builder makes (Geometry spec G1-G6 of oracle/oracle_bvh.c / lbvh.hip: instance boxes from the eight transformed
+// corners, 30-bit Morton codes of the box centres, stable sort by (code, instance), Karras' radix tree, children's boxes in the parent),
+// bit for bit -- the operations are IEEE min / max / fma in the same order.  For the handful of instances of a small frame it costs a few
+// microseconds of host time and travels in the frame-table upload, where the single-workgroup kernel costs ~17 us of serial GPU time
+// (dependent cold loads) plus a launch on every frame whose tables changed.
+#define RT64_HOST_TLAS_MAX 64
+// v_min_f32 / v_max_f32 order -0 below +0; the host's fminf / fmaxf may return either.  (No NaN reaches here that the GPU builder would survive.)
+static inline float gmin(float a, float b) { return (a < b || (a == b && std::signbit(a))) ? a : b; }
+static inline float gmax(float a, float b) { return (a > b || (a == b && !std::signbit(a))) ? a : b; }
+static uint32_t host_morton30(uint32_t x, uint32_t y, uint32_t z) {
+    uint32_t v[3] = { x & 1023u, y & 1023u, z & 1023u }, code = 0;
+    for (int k = 0; k < 3; k++) {
+        uint32_t t = v[k];
+        t = (t | (t << 16)) & 0x030000FFu; t = (t | (t << 8)) & 0x0300F00Fu; t = (t | (t << 4)) & 0x030C30C3u; t = (t | (t << 2)) & 0x09249249u;
+        code |= t << k;
+    }
+    return code;
+}
+static void host_build_tlas(const GpuInstance *inst, const float (*meshMin)[3], const float (*meshMax)[3], uint32_t n,
+                            GpuNode *nodes, uint32_t *sortedIndex, uint32_t *morton, BlasHeader *header) {
+    std::vector<float> lo(3 * (size_t)n), hi(3 * (size_t)n);
+    float smin[3] = { INFINITY, INFINITY, INFINITY }, smax[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (uint32_t i = 0; i < n; i++) {                                    // G1
+        float bmn[3] = { INFINITY, INFINITY, INFINITY }, bmx[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for (int c = 0; c < 8; c++) {
+            const float p[3] = { (c & 1) ? meshMax[i][0] : meshMin[i][0], (c & 2) ? meshMax[i][1] : meshMin[i][1], (c & 4) ? meshMax[i][2] : meshMin[i][2] };
+            float w[3]; g_xform_point(inst[i].objectToWorld, p, w);
+            for (int k = 0; k < 3; k++) { bmn[k] = gmin(bmn[k], w[k]); bmx[k] = gmax(bmx[k], w[k]); }
+        }
+        for (int k = 0; k < 3; k++) { lo[3 * i + k] = bmn[k]; hi[3 * i + k] = bmx[k]; smin[k] = gmin(smin[k], bmn[k]); smax[k] = gmax(smax[k], bmx[k]); }
+    }
+    std::vector<unsigned long long> keys(n);                             // G2, G3
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t q[3];
+        for (int k = 0; k < 3; k++) {
+            const float ext = smax[k] - smin[k], scale = ext > 0.0f ? 1024.0f / ext : 0.0f;
+            const float c = (lo[3 * i + k] + hi[3 * i + k]) * 0.5f, f = (c - smin[k]) * scale;
+            const int qi = (int)f;
+            q[k] = (uint32_t)(qi < 0 ? 0 : (qi > 1023 ? 1023 : qi));
+        }
+        keys[i] = ((unsigned long long)host_morton30(q[0], q[1], q[2]) << 32) | i;
+    }
+    std::sort(keys.begin(), keys.end());
+    for (uint32_t s = 0; s < n; s++) { sortedIndex[s] = (uint32_t)(keys[s] & 0xFFFFFFFFull); morton[s] = (uint32_t)(keys[s] >> 32); }
+    memset(nodes, 0, sizeof(GpuNode) * std::max<uint32_t>(n - 1, 1));
+    auto leafLo = [&](uint32_t s) { return &lo[3 * (size_t)sortedIndex[s]]; };
+    auto leafHi = [&](uint32_t s) { return &hi[3 * (size_t)sortedIndex[s]]; };
+    if (n == 1) {                                                        // G5, single leaf
+        GpuNode &nd = nodes[0];
+        nd.left = RT64_LEAF_BIT; nd.right = RT64_NO_CHILD; nd.parent = RT64_NO_CHILD;
+        for (int k = 0; k < 3; k++) { nd.lmin[k] = leafLo(0)[k]; nd.lmax[k] = leafHi(0)[k]; nd.rmin[k] = INFINITY; nd.rmax[k] = -INFINITY; header->bmin[k] = nd.lmin[k]; header->bmax[k] = nd.lmax[k]; }
+        header->count = 1; header->depth = 1;
+        return;
+    }
+    const int N = (int)n;                                                // G4
+    auto delta = [&](int i, int j) -> int { return (j < 0 || j >= N) ? -1 : __builtin_clzll(keys[(size_t)i] ^ keys[(size_t)j]); };
+    nodes[0].parent = RT64_NO_CHILD;
+    for (int i = 0; i < N - 1; i++) {
+        const int d = (delta(i, i + 1) - delta(i, i - 1)) >= 0 ? 1 : -1, dmin = delta(i, i - d);
+        int lmax = 2;
+        while (delta(i, i + lmax * d) > dmin) lmax *= 2;
+        int l = 0;
+        for (int t = lmax / 2; t >= 1; t /= 2) if (delta(i, i + (l + t) * d) > dmin) l += t;
+        const int j = i + l * d, dnode = delta(i, j);
+        int s = 0;
+        for (int div = 2;; div *= 2) { const int t = (l + div - 1) / div; if (delta(i, i + (s + t) * d) > dnode) s += t; if (t <= 1) break; }
+        const int g = i + s * d + (d < 0 ? -1 : 0), lo_ = i < j ? i : j, hi_ = i < j ? j : i;
+        if (lo_ == g) nodes[i].left = RT64_LEAF_BIT | (uint32_t)g; else { nodes[i].left = (uint32_t)g; nodes[g].parent = (uint32_t)i; }
+        if (hi_ == g + 1) nodes[i].right = RT64_LEAF_BIT | (uint32_t)(g + 1); else { nodes[i].right = (uint32_t)(g + 1); nodes[g + 1].parent = (uint32_t)i; }
+    }
+    struct Fit { static uint32_t run(GpuNode *nodes, uint32_t i, const std::vector<float> &lo, const std::vector<float> &hi, const uint32_t *sorted, float *mn, float *mx) {
+        GpuNode &nd = nodes[i]; uint32_t depth = 0;                      // G5: children's boxes in the parent; returns the subtree's depth in inner nodes
+        for (int side = 0; side < 2; side++) {
+            const uint32_t c = side ? nd.right : nd.left;
+            float *cmn = side ? nd.rmin : nd.lmin, *cmx = side ? nd.rmax : nd.lmax;
+            if (c & RT64_LEAF_BIT) { const size_t inst = sorted[c & 0x7FFFFFFFu]; for (int k = 0; k < 3; k++) { cmn[k] = lo[3 * inst + k]; cmx[k] = hi[3 * inst + k]; } }
+            else depth = std::max(depth, run(nodes, c, lo, hi, sorted, cmn, cmx));
+        }
+        for (int k = 0; k < 3; k++) { mn[k] = gmin(nd.lmin[k], nd.rmin[k]); mx[k] = gmax(nd.lmax[k], nd.rmax[k]); }
+        return depth + 1;
+    } };
+    float rmn[3], rmx[3];
+    header->depth = Fit::run(nodes, 0, lo, hi, sortedIndex, rmn, rmx);
+    for (int k = 0; k < 3; k++) { header->bmin[k] = rmn[k]; header->bmax[k] = rmx[k]; }
+    header->count = n;
+}
+
 void View::update() {                          // View::update, rt64_view.cpp:1053-1178
     Device *dev = scene->device;
     {   // View::createOutputBuffers: render size = lround(screen * resolutionScale) (rt64_view.cpp:138-139)
@@ -845,23 +947,39 @@ void View::update() {                          // View::update, rt64_view.cpp:10
     const size_t tableBytes = instBytes + texBytes + lightBytes;
     const bool unchanged = uploadedTables.size() == tableBytes && tableBytes && memcmp(uploadedTables.data(), stage, tableBytes) == 0 && !dev->opt.alwaysRebuild;
     if (!unchanged) {
-        dTables.reserve(std::max<size_t>(tableBytes, 4096));
+        // TLAS: full rebuild (rt64_view.cpp:412-452 rebuilds every frame, updateOnly = false) -- of a few instances on the host, into the same upload
+        const uint32_t n = (uint32_t)nInst;
+        const bool hostTlas = n >= 1 && n <= RT64_HOST_TLAS_MAX && dev->opt.hostTlas;
+        const size_t tlasAt = (tableBytes + 63) & ~(size_t)63, nodeBytes = sizeof(GpuNode) * std::max<size_t>(n ? n - 1 : 0, 1);
+        const size_t uploadBytes = hostTlas ? tlasAt + nodeBytes + sizeof(BlasHeader) + 2 * sizeof(uint32_t) * n : tableBytes;
+        dTables.reserve(std::max<size_t>(uploadBytes, 4096));
         dInstances.ptr = reinterpret_cast<GpuInstance *>(dTables.ptr); dTextures.ptr = reinterpret_cast<GpuTexture *>(dTables.ptr + instBytes);
         dLights.ptr = reinterpret_cast<RT64_LIGHT *>(dTables.ptr + instBytes + texBytes);
-        if (tableBytes) {       // staged in the pinned upload ring: no wait before the region is reused (a wrap-around of the ring drains the stream)
-            void *pinnedStage = dev->ringAlloc(tableBytes);
+        if (uploadBytes) {       // staged in the pinned upload ring: no wait before the region is reused (a wrap-around of the ring drains the stream)
+            uint8_t *pinnedStage = static_cast<uint8_t *>(dev->ringAlloc(uploadBytes));
             memcpy(pinnedStage, stage, tableBytes);
-            HIP_CHECK(hipMemcpyAsync(dTables.ptr, pinnedStage, tableBytes, hipMemcpyHostToDevice, dev->stream));
+            if (hostTlas) {
+                memset(pinnedStage + tableBytes, 0, tlasAt - tableBytes);
+                GpuNode *hn = reinterpret_cast<GpuNode *>(pinnedStage + tlasAt);
+                BlasHeader *hh = reinterpret_cast<BlasHeader *>(pinnedStage + tlasAt + nodeBytes);
+                uint32_t *hi = reinterpret_cast<uint32_t *>(hh + 1), *hm = hi + n;
+                float mn[RT64_HOST_TLAS_MAX][3], mx[RT64_HOST_TLAS_MAX][3];
+                for (uint32_t i = 0; i < n; i++) { memcpy(mn[i], rtInstances[i].instance->mesh->hostBmin, 12); memcpy(mx[i], rtInstances[i].instance->mesh->hostBmax, 12); }
+                host_build_tlas(hInst, mn, mx, n, hn, hi, hm, hh);
+                uint8_t *base = dTables.ptr + tlasAt;
+                tlasNodesAt = reinterpret_cast<const GpuNode *>(base); tlasHeaderAt = reinterpret_cast<const BlasHeader *>(base + nodeBytes);
+                tlasIndexAt = reinterpret_cast<const uint32_t *>(tlasHeaderAt + 1); tlasMortonAt = tlasIndexAt + n;
+            }
+            HIP_CHECK(hipMemcpyAsync(dTables.ptr, pinnedStage, uploadBytes, hipMemcpyHostToDevice, dev->stream));
         }
-        // TLAS: full rebuild (rt64_view.cpp:412-452 rebuilds every frame, updateOnly = false).
-        if (nInst) {
-            const uint32_t n = (uint32_t)nInst;
+        if (n && !hostTlas) {
             tlasNodes.reserve(std::max<size_t>(n - 1, 1)); tlasIndex.reserve(n); tlasMorton.reserve(n); tlasLeafParent.reserve(n); tlasHeader.reserve(1);
             LbvhArgs a = {};
             a.mode = LBVH_MODE_INSTANCES; a.refit = 0; a.n = n; a.instances = dInstances.ptr;
             a.nodes = tlasNodes.ptr; a.tris = nullptr; a.header = tlasHeader.ptr; a.sortedIndex = tlasIndex.ptr; a.morton = tlasMorton.ptr; a.leafParent = tlasLeafParent.ptr;
             if (n > LBVH_SMALL_MAX) { tlasScratch.reserve(lbvh_large_scratch_bytes(n)); a.scratch = tlasScratch.ptr; a.scratchBytes = tlasScratch.bytes(); }
             HIP_CHECK(lbvh_launch(a, dev->stream));
+            tlasNodesAt = tlasNodes.ptr; tlasIndexAt = tlasIndex.ptr; tlasMortonAt = tlasMorton.ptr; tlasHeaderAt = tlasHeader.ptr;
         }
         uploadedTables.assign(stage, stage + tableBytes);
         dev->workSinceMark = true;
@@ -972,7 +1090,7 @@ void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64
     }
     P.lightCount = (uint32_t)scene->lights.size(); P.instanceCount = (uint32_t)rtInstances.size();
     P.countTraversal = dev->opt.countTraversal ? 1u : 0u;
-    P.instances = dInstances.ptr; P.tlasNodes = tlasNodes.ptr; P.tlasIndex = tlasIndex.ptr; P.textures = dTextures.ptr; P.lights = dLights.ptr;
+    P.instances = dInstances.ptr; P.tlasNodes = tlasNodesAt; P.tlasIndex = tlasIndexAt; P.textures = dTextures.ptr; P.lights = dLights.ptr;
     dev->spillStack.reserve(rt_stack_spill_bytes(imgW, imgH) / sizeof(uint32_t));      // grows with the render size (no-op otherwise)
     P.blueNoise = dev->blueNoise.ptr; P.traversalStack = dev->spillStack.ptr; P.counters = dev->counters.ptr;
 }
@@ -1421,6 +1539,7 @@ RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, doubl
     else if (k == "bounce_refill") d->opt.bounceRefill = (int)value;
     else if (k == "spin_present") d->opt.spinPresent = value != 0.0;
     else if (k == "lds_cache") d->opt.ldsCache = value != 0.0;
+    else if (k == "host_tlas") d->opt.hostTlas = value != 0.0;
     else if (k == "simple_kernels") d->opt.simpleKernels = value != 0.0;       // 0: every frame runs the general kernels (A/B tests)
     else if (k == "reset_accum") { d->finishStats(); d->accum = RT64_FRAME_STATS(); }
     else if (k == "fold_foreground") d->opt.foldForeground = value != 0.0;        // 0: the foreground (HUD) list keeps its own raster_draw launch after a one-kernel frame
@@ -1573,7 +1692,7 @@ RT64_EXPORT size_t RT64_ReadbackViewAccel(RT64_VIEW *viewPtr, int what, void *ds
     RT64_TRY
     View *v = reinterpret_cast<View *>(viewPtr); if (!v) throw std::runtime_error("RT64_ReadbackViewAccel: NULL view.");
     if (what == RT64_ACCEL_TRIANGLES) throw std::runtime_error("RT64_ReadbackViewAccel: a TLAS has no triangle array.");
-    return accel_readback(v->scene->device, what, (uint32_t)v->rtInstances.size(), v->tlasNodes.ptr, nullptr, v->tlasIndex.ptr, v->tlasMorton.ptr, v->tlasHeader.ptr, dst, dstBytes);
+    return accel_readback(v->scene->device, what, (uint32_t)v->rtInstances.size(), v->tlasNodesAt, nullptr, v->tlasIndexAt, v->tlasMortonAt, v->tlasHeaderAt, dst, dstBytes);
     RT64_CATCH(0)
 }
 

@@ -144,6 +144,60 @@ def test_blas_tlas_bit_exact(scene_256, oracle_256):
         assert np.array_equal(nodes[f], tl["nodes"][f]), f
 
 
+@pytest.mark.parametrize("extra", [0, 1, 37, 62, 80])
+def test_tlas_host_and_gpu_builders_agree(rt64_lib, oracle_lib, extra):
+    """The TLAS of a few instances is built on the host and uploaded with the frame tables (rt64_host.cpp host_build_tlas); above
+    RT64_HOST_TLAS_MAX = 64 the GPU builder runs.  Both must give the oracle's tree bit for bit (Geometry spec G1-G6), and the frames
+    rendered through either must be identical.  `extra` rotated / scaled / translated copies of the sphere are added to the sample scene
+    (2 + 62 = the last host-built size; 0 with the floor removed = the single-leaf tree)."""
+    import copy
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    from oracle import oracle_py
+    data = sample_scene.make_sample_scene()
+    rng = np.random.default_rng(1234 + extra)
+    sphere = next(i for i in data.instances if i.name == "sphere")
+    if extra == 0:
+        data.instances = [i for i in data.instances if i.name != "floor"]
+    for k in range(extra):
+        a, b = rng.uniform(0, 2 * np.pi, 2)
+        ca, sa, cb, sb = np.cos(a), np.sin(a), np.cos(b), np.sin(b)
+        rot = np.array([[ca, sa, 0, 0], [-sa, ca, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]]) @ np.array([[1, 0, 0, 0], [0, cb, sb, 0], [0, -sb, cb, 0], [0, 0, 0, 1]])
+        m = np.diag(list(rng.uniform(0.1, 0.6, 3)) + [1.0]) @ rot
+        m[3, :3] = rng.uniform(-6, 6, 3) * (1.0, 0.3, 1.0) + (0.0, 2.0, 0.0)
+        t = m.astype(np.float32)
+        if k % 7 == 3:
+            t = data.instances[-1].transform.copy()                        # the same box again: equal Morton codes, ordered by instance index (G3)
+        data.instances.append(sample_scene.InstanceData("copy%d" % k, sphere.mesh, t, t, sphere.diffuse, sphere.normal, sphere.specular, sample_scene.copy_material(sphere.material), 0))
+    o = oracle_py.OracleScene(data)
+    ref = o.render(160, 90)                                                # builds the oracle's TLAS
+    tl = o.tlas()
+    s = sample_scene.Rt64Scene(rt64_lib, data, 160, 90, hip_device=0)
+    try:
+        got = {}
+        for host in (1, 0):
+            s.option("host_tlas", host); s.option("always_rebuild", 1)
+            s.draw()
+            got[host] = dict(index=_accel(rt64_lib, rt64_lib.ReadbackViewAccel, s.view, rt64.ACCEL_SORTED_INDEX, np.uint32).copy(),
+                             morton=_accel(rt64_lib, rt64_lib.ReadbackViewAccel, s.view, rt64.ACCEL_MORTON, np.uint32).copy(),
+                             nodes=_accel(rt64_lib, rt64_lib.ReadbackViewAccel, s.view, rt64.ACCEL_NODES, oracle_py.NODE_DTYPE).copy(),
+                             header=_accel(rt64_lib, rt64_lib.ReadbackViewAccel, s.view, rt64.ACCEL_HEADER, np.uint32).copy(),
+                             frame=s.readback(rt64.IMAGE_FINAL_RGBA8).copy(), hit=s.readback(rt64.IMAGE_PRIMARY_HIT).copy())
+        assert np.array_equal(got[1]["hit"], ref["primaryHit"])              # many-instance traversal (TLAS stack, LDS cache off above 16 instances)
+        for host in (1, 0):
+            g = got[host]
+            assert np.array_equal(g["index"], tl["sortedIndex"]), host
+            assert np.array_equal(g["morton"], tl["morton"]), host
+            for f in ("lmin", "lmax", "rmin", "rmax", "left", "right"):
+                assert np.array_equal(g["nodes"][f].view(np.uint32), tl["nodes"][f].view(np.uint32)), (host, f)
+        assert np.array_equal(got[0]["nodes"]["parent"][1:], got[1]["nodes"]["parent"][1:])
+        assert np.array_equal(got[0]["header"][[0, 1, 2, 3, 4, 5, 6]], got[1]["header"][[0, 1, 2, 3, 4, 5, 6]])      # bounds + count
+        if len(tl["sortedIndex"]) <= 64:
+            assert got[0]["header"][7] == got[1]["header"][7]                                                        # tree depth (single-workgroup builder)
+        assert np.array_equal(got[0]["frame"], got[1]["frame"]) and np.array_equal(got[0]["hit"], got[1]["hit"])
+    finally:
+        s.close(); o.close()
+
+
 @pytest.mark.parametrize("subdiv,grid", [(2, 1), (3, 64)])
 def test_large_meshes_bit_exact(rt64_lib, oracle_lib, subdiv, grid):
     """Stress variant of the sample scene: 5 120 / 20 480-triangle spheres (multi-block radix path above 4096
