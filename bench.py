@@ -59,6 +59,7 @@ def parse_args():
     ap.add_argument("--floor-grid", type=int, default=1, help="stress variant: floor tessellation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--always-rebuild", action="store_true", help="upload the frame tables and rebuild the TLAS every frame (the reference's behaviour)")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE", help="RT64_SetDeviceOption(key, value) before the run (A/B measurements; the line records them under config.options)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU-staged rehearsal of the N>1 path")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a 1-GPU box: every rank renders on device 0")
     ap.add_argument("--force-gather", action="store_true", help="rehearsal: run the N > 1 code path (enqueued frames + pipelined RCCL gather) with a world of 1")
@@ -257,6 +258,9 @@ def main():
     # --- instrumented frame (untimed): ray / node / triangle counts of this rank's strips ---
     if args.always_rebuild:
         scene.option("always_rebuild", 1)
+    for kv in args.option:
+        k, _, v = kv.partition("=")
+        scene.option(k, float(v))
     if os.environ.get("RT64_LDS_CACHE"):
         scene.option("lds_cache", int(os.environ["RT64_LDS_CACHE"]))
     if os.environ.get("RT64_FUSED_LEAN"):
@@ -398,6 +402,8 @@ def main():
                 "partition": ("DIAGNOSIS: rank 0's share of a %d-way partition only, no gather" % PR) if PR > 1 else ("%s x%d + RCCL gather of RGBA8" % (("cost-balanced contiguous bands %s with denoiser halo" % (list(band_starts) if native else "")) if use_bands else "interleaved 16-row strips", N)) if N > 1 else "single GPU"},
             "roofline": roofline,
         }
+        if args.option:
+            result["config"]["options"] = list(args.option)      # non-default library options: an A/B line, not the headline
         if G:
             result["pipeline"] = {"frames": "enqueued (sync_present=0), 2 gather slots" if pipelined else "synchronous, CPU-staged gather (rehearsal)",
                                   "gather": "in-library (RT64_SubmitGather: grouped ncclSend / ncclRecv + reassembly kernel on the library's comm stream)" if native else "torch.distributed gather (tiles.FrameGatherer)",

@@ -81,33 +81,44 @@ DEV TraceStack make_stack(PRef P, uint32_t *ldsStack) {
 //   [4m, 4m + 4 nT)    TLAS nodes, nT = max(m - 1, 1)
 //   [cacheNodeOffset)  the BLAS nodes of every instance (offsets assigned by View::update)
 // The host enables it (FrameParams::cacheWords != 0) when all of that is at most RT_CACHE_MAX_WORDS: small scenes, like the sample.
-DEV void fill_scene_cache(PRef P, u32x4_lds *cache) {
-    const uint32_t m = P.cacheInstances, T = blockDim.x, tid = threadIdx.x;
+// The image is assembled once per table change in HBM (scene_cache_image_kernel: the pointer chase tlasIndex -> instance -> node array
+// happens there, three dependent round trips); a workgroup's fill is then one flat copy whose loads are all in flight together.
+#ifndef RT_ASSUME_SIMPLE
+__global__ __launch_bounds__(RT_BLOCK) void scene_cache_image_kernel(const GpuInstance *instances, const uint32_t *tlasIndex, const GpuNode *tlasNodes, uint32_t m, u32x4 *cache) {
+    typedef u32x4 W4;
+    const uint32_t T = blockDim.x, tid = threadIdx.x;
     typedef const u32x4 __attribute__((address_space(1))) *G4;
     for (uint32_t k = tid; k < m; k += T) {
-        const uint32_t inst = P.tlasIndex[k];
-        const GpuInstance &in = P.instances[inst];
+        const uint32_t inst = tlasIndex[k];
+        const GpuInstance &in = instances[inst];
         const float *M = in.worldToObject;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            u32x4_lds w; w.x = __float_as_uint(M[c]); w.y = __float_as_uint(M[4 + c]); w.z = __float_as_uint(M[8 + c]); w.w = __float_as_uint(M[12 + c]);
+            W4 w; w.x = __float_as_uint(M[c]); w.y = __float_as_uint(M[4 + c]); w.z = __float_as_uint(M[8 + c]); w.w = __float_as_uint(M[12 + c]);
             cache[4 * k + c] = w;
         }
         const uint64_t tp = reinterpret_cast<uint64_t>(in.tris);
-        u32x4_lds info; info.x = inst | ((in.flags & 0xFFu) << 8) | (in.cacheNodeOffset << 16); info.y = __float_as_uint(in.material.depthBias); info.z = (uint32_t)tp; info.w = (uint32_t)(tp >> 32);
+        W4 info; info.x = inst | ((in.flags & 0xFFu) << 8) | (in.cacheNodeOffset << 16); info.y = __float_as_uint(in.material.depthBias); info.z = (uint32_t)tp; info.w = (uint32_t)(tp >> 32);
         cache[4 * k + 3] = info;
     }
     {
         const uint32_t words = 4u * (m > 1 ? m - 1 : 1u);
-        G4 src = reinterpret_cast<G4>(reinterpret_cast<uintptr_t>(P.tlasNodes));
+        G4 src = reinterpret_cast<G4>(reinterpret_cast<uintptr_t>(tlasNodes));
         for (uint32_t t = tid; t < words; t += T) cache[4 * m + t] = src[t];
     }
     for (uint32_t k = 0; k < m; k++) {                       // uniform: every thread walks the same instance list
-        const GpuInstance &in = P.instances[P.tlasIndex[k]];
+        const GpuInstance &in = instances[tlasIndex[k]];
         const uint32_t words = 4u * (in.triCount > 1 ? in.triCount - 1 : 1u), off = in.cacheNodeOffset;
         G4 src = reinterpret_cast<G4>(reinterpret_cast<uintptr_t>(in.nodes));
         for (uint32_t t = tid; t < words; t += T) cache[off + t] = src[t];
     }
+}
+#endif
+DEV void fill_scene_cache(PRef P, u32x4_lds *cache) {
+    typedef const u32x4 __attribute__((address_space(1))) *G4;
+    G4 src = reinterpret_cast<G4>(reinterpret_cast<uintptr_t>(P.cacheImage));
+    const uint32_t words = P.cacheWords;
+    for (uint32_t t = threadIdx.x; t < words; t += RT_BLOCK) cache[t] = src[t];
     __syncthreads();
 }
 
@@ -1345,6 +1356,10 @@ static size_t cached_lds_bytes(const FrameParams &P, bool lights) {
 #define LAUNCH_RAY_LDS(kernel, bytes, ...) do { hipLaunchKernelGGL(kernel, dim3(rt_grid(P)), dim3(RT_BLOCK), bytes, s, __VA_ARGS__); return hipGetLastError(); } while (0)
 
 #ifndef RT_ASSUME_SIMPLE
+hipError_t launch_scene_cache_image(const GpuInstance *instances, const uint32_t *tlasIndex, const GpuNode *tlasNodes, uint32_t cacheInstances, void *image, hipStream_t s) {
+    hipLaunchKernelGGL(scene_cache_image_kernel, dim3(1), dim3(RT_BLOCK), 0, s, instances, tlasIndex, tlasNodes, cacheInstances, static_cast<u32x4 *>(image));
+    return hipGetLastError();
+}
 hipError_t launch_primary_trace(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, bool klist, hipStream_t s) {
     if (klist) LAUNCH_RAY(primary_trace_kernel<true>, P, I, hitInstance);
     if (P.cacheWords) LAUNCH_RAY_LDS((primary_trace_kernel<false, true>), cached_lds_bytes(P, false), P, I, hitInstance);

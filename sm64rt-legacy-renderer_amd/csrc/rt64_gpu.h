@@ -117,6 +117,7 @@ struct FrameParams {
     // LDS scene cache (trace.h): when the TLAS + every BLAS node array + one 64-byte record per instance fit in LDS next to the
     // traversal stacks, the ray kernels copy them in once per workgroup and walk from there.  cacheWords = size in 16-byte words, 0 = off.
     uint32_t cacheWords, cacheInstances;
+    const void *cacheImage;              // the cache's contents as one flat array in HBM (cacheWords x 16 B, built by scene_cache_image_kernel when the tables change): a workgroup fills its LDS copy with independent loads
     uint32_t simpleKernels;              // 1: every texture of the frame has power-of-two sizes and every instance is shadow-opaque: the launchers take the kernels of passes_simple.hip
     uint32_t separatePost;               // 1: render size != screen size or motion blur on -> PostProcessPS runs as post_process_kernel
     const float *postSource; int32_t postSourceW, postSourceH;      // image PostProcessPS samples: rtOutput (render size), or rtOutputUpscaled (screen size) behind an upscaler (rt64_view.cpp:800-801)

@@ -281,6 +281,7 @@ struct View {
     int finalW = 0, finalH = 0;               // back buffer = screen size
     // rectangle of the ray-traced picture: the first ray-traced instance's scissor / viewport when it has any (rt64_view.cpp:1258-1271)
     float rtViewport[4] = { 0, 0, 0, 0 }; int rtScissor[4] = { 0, 0, 0, 0 }; bool rtRect = false;
+    DevArray<uint8_t> cacheImage; bool cacheImageValid = false;      // FrameParams::cacheImage: rebuilt after every table upload that leaves the cache enabled
     uint32_t cacheWords = 0;                   // LDS scene cache size in 16-byte words (0: the scene does not fit / option lds_cache = 0)
     bool separatePost() const { return upscaleActive || rtRect || imgW != finalW || imgH != finalH || (motionBlurStrength > 0.0f && motionBlurSamples > 0); }
     // device images
@@ -981,8 +982,14 @@ void View::update() {                          // View::update, rt64_view.cpp:10
             HIP_CHECK(lbvh_launch(a, dev->stream));
             tlasNodesAt = tlasNodes.ptr; tlasIndexAt = tlasIndex.ptr; tlasMortonAt = tlasMorton.ptr; tlasHeaderAt = tlasHeader.ptr;
         }
+        cacheImageValid = false;
         uploadedTables.assign(stage, stage + tableBytes);
         dev->workSinceMark = true;
+    }
+    if (cacheWords && !cacheImageValid) {
+        cacheImage.reserve((size_t)cacheWords * 16);
+        HIP_CHECK(launch_scene_cache_image(dInstances.ptr, tlasIndexAt, tlasNodesAt, (uint32_t)nInst, cacheImage.ptr, dev->stream));
+        cacheImageValid = true;
     }
     // Raster lists (background first, then foreground; rt64_view.cpp:1138-1147).  They are a handful of HUD instances: uploaded every frame.
     {
@@ -1060,7 +1067,7 @@ void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64
     P.binaryLockMask = upscaleActive ? 0u : 1u;               // rtUpscaleMode != FSR (:1018): the built-in stage stands where FSR does and takes the continuous mask
     P.visualizationMode = 0;
     P.width = imgW; P.height = imgH; P.tileY0 = dev->tileY0; P.tileY1 = dev->tileY1; P.stripRank = dev->stripRank; P.stripCount = dev->stripCount;
-    P.cacheWords = cacheWords; P.cacheInstances = cacheWords ? (uint32_t)rtInstances.size() : 0u;
+    P.cacheWords = cacheWords; P.cacheInstances = cacheWords ? (uint32_t)rtInstances.size() : 0u; P.cacheImage = cacheWords ? cacheImage.ptr : nullptr;
     P.separatePost = separatePost() ? 1u : 0u;
     P.simpleKernels = simpleFrame ? 1u : 0u;
     P.postSource = img.output; P.postSourceW = imgW; P.postSourceH = imgH;

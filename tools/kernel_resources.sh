@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../sm64rt-legacy-renderer_amd/csrc"
 import re, sys
 cur = None; rows = []
 for line in sys.stdin:
-    m = re.search(r"remark: +([A-Za-z][\w \[\]/]*?): *(\S+)", line)
+    m = re.search(r"remark:\s+([A-Za-z][\w \[\]/]*?):\s*(\S+)", line)
     if not m: continue
     k, v = m.group(1).strip(), m.group(2)
     if k == "Function Name" or k == "Name":
