@@ -36,7 +36,7 @@ hipError_t tile_texture_launch(const uint8_t *rgba, uint32_t *tiled, uint32_t wi
 hipError_t bc7_decode_launch(const uint8_t *blocks, uint8_t *rgba, uint32_t width, uint32_t height, hipStream_t stream);
 
 // ---- passes.hip ---------------------------------------------------------------------------------------------------
-#define RT_CACHE_MAX_WORDS 1536       // LDS scene cache: at most 24 KB next to the 24 KB of traversal stacks (3 workgroups per CU)
+#define RT_CACHE_MAX_WORDS 1536       // LDS scene cache, nodes + instance records: at most 24 KB next to the 8 KB stack (int16 entries) and the light columns of a workgroup, four workgroups per CU
 #define RT_STACK_LDS_CACHED 16        // traversal stack entries (LDS only, no spill path) of the kernels that hold the LDS scene cache: a power of two
 #define RT_GRID_BLOCKS 2048           // persistent grid of every ray kernel (8 workgroups of 256 per CU)
 #define RT_MAX_FRAME_GROUPS 8192u     // largest grid of the one-workgroup-per-tile kernels (bigger frames give every workgroup a few tiles)
@@ -46,7 +46,8 @@ hipError_t launch_scene_cache_image(const GpuInstance *instances, const uint32_t
 hipError_t launch_primary_trace(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, bool klist, hipStream_t s);
 hipError_t launch_primary_shade(const FrameParams &P, const ViewImages &I, const int32_t *hitInstance, int cur, bool transparentLighting, bool lean, hipStream_t s);
 hipError_t launch_direct(const FrameParams &P, const ViewImages &I, int cur, bool lean, hipStream_t s);
-hipError_t launch_indirect(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, bool refill, hipStream_t s);
+enum { BOUNCE_WALK_PLAIN = 0, BOUNCE_WALK_REFILL = 1, BOUNCE_WALK_BINNED = 2 };      // how bounce_trace hands rays to lanes (passes.hip)
+hipError_t launch_indirect(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, int walk, hipStream_t s);
 hipError_t launch_indirect_constant(const FrameParams &P, const ViewImages &I, int cur, hipStream_t s);
 hipError_t launch_refraction(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s);
 hipError_t launch_reflection(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s);
@@ -60,7 +61,7 @@ hipError_t launch_post_process(const FrameParams &P, const ViewImages &I, hipStr
 // program; the launchers above route to them when FrameParams::simpleKernels is set
 hipError_t launch_primary_shade_simple(const FrameParams &P, const ViewImages &I, const int32_t *hitInstance, int cur, bool transparentLighting, bool lean, hipStream_t s);
 hipError_t launch_direct_simple(const FrameParams &P, const ViewImages &I, int cur, bool lean, hipStream_t s);
-hipError_t launch_indirect_simple(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, bool refill, hipStream_t s);
+hipError_t launch_indirect_simple(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, int walk, hipStream_t s);
 hipError_t launch_refraction_simple(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s);
 hipError_t launch_reflection_simple(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s);
 hipError_t launch_lean_frame_simple(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, int cur, bool full, int ownedY0, int ownedY1, unsigned maxGroups, hipStream_t s);

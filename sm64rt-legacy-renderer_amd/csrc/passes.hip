@@ -71,7 +71,7 @@ DEV TraceStack make_stack(PRef P, uint32_t *ldsStack) {
     TraceStack s;
     s.lds = (LdsU32Ptr)(ldsStack + threadIdx.x);
     s.spill = (GlobalU32Ptr)(P.traversalStack + ((size_t)blockIdx.x * RT_BLOCK + threadIdx.x) * RT_STACK_SPILL);
-    s.cache = nullptr; s.ldsEntries = RT_STACK_LDS;
+    s.cache = nullptr; s.ldsEntries = RT_STACK_LDS; s.lds16 = nullptr;
     return s;
 }
 
@@ -84,10 +84,20 @@ DEV TraceStack make_stack(PRef P, uint32_t *ldsStack) {
 // The image is assembled once per table change in HBM (scene_cache_image_kernel: the pointer chase tlasIndex -> instance -> node array
 // happens there, three dependent round trips); a workgroup's fill is then one flat copy whose loads are all in flight together.
 #ifndef RT_ASSUME_SIMPLE
+DEV uint32_t cache_child_ref(uint32_t c) { return (c & RT64_LEAF_BIT) ? (c == RT64_NO_CHILD ? c : (0xFFFF8000u | (c & RT_CACHE_INDEX_MASK))) : c; }
+DEV void copy_cache_nodes(const GpuNode *nodes, uint32_t count, u32x4 *dst) {      // word 3 of a node = (left, right, parent, pad): the child references become 16-bit
+    typedef const u32x4 __attribute__((address_space(1))) *G4;
+    G4 src = reinterpret_cast<G4>(reinterpret_cast<uintptr_t>(nodes));
+    for (uint32_t t = threadIdx.x; t < 4u * count; t += blockDim.x) {
+        u32x4 w = src[t];
+        if ((t & 3u) == 3u) { w.x = cache_child_ref(w.x); w.y = cache_child_ref(w.y); }
+        dst[t] = w;
+    }
+}
 __global__ __launch_bounds__(RT_BLOCK) void scene_cache_image_kernel(const GpuInstance *instances, const uint32_t *tlasIndex, const GpuNode *tlasNodes, uint32_t m, u32x4 *cache) {
     typedef u32x4 W4;
     const uint32_t T = blockDim.x, tid = threadIdx.x;
-    typedef const u32x4 __attribute__((address_space(1))) *G4;
+
     for (uint32_t k = tid; k < m; k += T) {
         const uint32_t inst = tlasIndex[k];
         const GpuInstance &in = instances[inst];
@@ -101,16 +111,10 @@ __global__ __launch_bounds__(RT_BLOCK) void scene_cache_image_kernel(const GpuIn
         W4 info; info.x = inst | ((in.flags & 0xFFu) << 8) | (in.cacheNodeOffset << 16); info.y = __float_as_uint(in.material.depthBias); info.z = (uint32_t)tp; info.w = (uint32_t)(tp >> 32);
         cache[4 * k + 3] = info;
     }
-    {
-        const uint32_t words = 4u * (m > 1 ? m - 1 : 1u);
-        G4 src = reinterpret_cast<G4>(reinterpret_cast<uintptr_t>(tlasNodes));
-        for (uint32_t t = tid; t < words; t += T) cache[4 * m + t] = src[t];
-    }
+    copy_cache_nodes(tlasNodes, m > 1 ? m - 1 : 1u, cache + 4 * m);
     for (uint32_t k = 0; k < m; k++) {                       // uniform: every thread walks the same instance list
         const GpuInstance &in = instances[tlasIndex[k]];
-        const uint32_t words = 4u * (in.triCount > 1 ? in.triCount - 1 : 1u), off = in.cacheNodeOffset;
-        G4 src = reinterpret_cast<G4>(reinterpret_cast<uintptr_t>(in.nodes));
-        for (uint32_t t = tid; t < words; t += T) cache[off + t] = src[t];
+        copy_cache_nodes(in.nodes, in.triCount > 1 ? in.triCount - 1 : 1u, cache + in.cacheNodeOffset);
     }
 }
 #endif
@@ -214,12 +218,12 @@ DEV bool surface_record(PRef P, IRef I, size_t pixel, uint32_t hit, const Surfac
 template <bool KLIST, bool CACHED = false>
 __global__ __launch_bounds__(RT_BLOCK, KLIST ? 2 : TRACE_WAVES) void primary_trace_kernel(FrameParams Pv, ViewImages Iv, int32_t *hitInstance) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
-    __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED : RT_STACK_LDS) * RT_BLOCK];
+    __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED / 2 : RT_STACK_LDS) * RT_BLOCK];
     extern __shared__ u32x4_lds dynLds[];
     if (CACHED) fill_scene_cache(P, dynLds);
     ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
     env.lightIntensity = nullptr; env.lightIndex = nullptr;              // pure visibility: no light is picked in this kernel
-    if (CACHED) { env.stk.cache = dynLds; env.stk.ldsEntries = RT_STACK_LDS_CACHED; }
+    if (CACHED) env.stk.use_cache(dynLds);
     uint32_t rays = 0;
     const uint32_t tiles = tile_count(P);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
@@ -499,7 +503,7 @@ DEV void compose_lean_pixel(PRef P, IRef I, size_t i, f3 directStored) {
 DEV uint32_t light_slots(PRef P) { return (P.lightCount < RT64_MAX_LIGHTS ? P.lightCount : (uint32_t)RT64_MAX_LIGHTS) + 1u; }
 DEV void cached_env(PRef P, ShadeEnv &env, u32x4_lds *dynLds) {
     fill_scene_cache(P, dynLds);
-    env.stk.cache = dynLds; env.stk.ldsEntries = RT_STACK_LDS_CACHED;
+    env.stk.use_cache(dynLds);
     float *li = reinterpret_cast<float *>(dynLds + P.cacheWords);
     env.lightIntensity = li + threadIdx.x;
     env.lightIndex = reinterpret_cast<uint8_t *>(li + light_slots(P) * RT_BLOCK) + threadIdx.x;
@@ -522,7 +526,7 @@ DEV f3 direct_light_pixel(PRef P, ShadeEnv &env, uint32_t px, uint32_t py, f3 ra
 template <bool FULL, bool CACHED = false>
 __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void direct_kernel(FrameParams Pv, ViewImages Iv, int cur) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
-    __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED : RT_STACK_LDS) * RT_BLOCK];
+    __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED / 2 : RT_STACK_LDS) * RT_BLOCK];
     __shared__ float ldsLightIntensity[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     extern __shared__ u32x4_lds dynLds[];
@@ -580,7 +584,7 @@ template <bool CACHED, bool FULL, int WAVES>
 #endif
 __global__ __launch_bounds__(RT_BLOCK, WAVES) void lean_frame_kernel(FrameParams Pv, ViewImages Iv, int32_t *hitInstance, int cur, int ownedY0, int ownedY1) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
-    __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED : RT_STACK_LDS) * RT_BLOCK];
+    __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED / 2 : RT_STACK_LDS) * RT_BLOCK];
     __shared__ float ldsLightIntensity[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     extern __shared__ u32x4_lds dynLds[];
@@ -778,7 +782,7 @@ DEV size_t bounce_miss_base(PRef P, uint32_t segment) { return (size_t)gridDim.x
 template <bool CACHED>
 __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kernel(FrameParams Pv, ViewImages Iv) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
-    __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED : RT_STACK_LDS) * RT_BLOCK];
+    __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED / 2 : RT_STACK_LDS) * RT_BLOCK];
     __shared__ uint32_t ldsCount[2];
     extern __shared__ u32x4_lds dynLds[];
     if (threadIdx.x < 2) ldsCount[threadIdx.x] = 0;
@@ -787,7 +791,7 @@ __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kern
     const uint32_t segment = bounce_segment_size(P); const size_t missBase = bounce_miss_base(P, segment);
     ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
     env.lightIntensity = nullptr; env.lightIndex = nullptr;
-    if (CACHED) { env.stk.cache = dynLds; env.stk.ldsEntries = RT_STACK_LDS_CACHED; }
+    if (CACHED) env.stk.use_cache(dynLds);
     uint32_t rays = 0;
     const size_t stride = (size_t)P.width * (size_t)P.height;
     const uint32_t tiles = tile_count(P);
@@ -814,6 +818,104 @@ __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kern
             uint4 *rec = I.bounceRecords + ((size_t)(smp - 1) * stride + i) * 2;
             rec[0] = a; rec[1] = b;
             bounce_append(I, ldsCount, segment, missBase, best.hit, (uint32_t)((size_t)(smp - 1) * stride + i));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) I.bounceCounts[2 * blockIdx.x + threadIdx.x] = ldsCount[threadIdx.x];
+    flush_env(P, env, PASS_INDIRECT, CTR_INDIRECT, rays);
+}
+
+// The same walk with the rays of a tile handed to the lanes in DIRECTION order.  A wave of the plain kernel holds the 64 rays of an
+// 8 x 8 pixel block: cosine-hemisphere directions, so one lane leaves through the sky after two box tests while its neighbour walks a
+// BLAS, and the wave executes the union of their code paths (measured 26 % VALU lane utilisation, SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU).
+// Here the workgroup generates BOUNCE_BIN_SAMPLES samples of its 256 pixels at once, counts them into 32 direction bins (8 levels of
+// d.y, the signs of d.x and d.z) with LDS atomics, and walks them bin after bin: the rays of a wave start close together and point the
+// same way, so they enter the same instances and end together.  Every ray is the ray the plain kernel traces -- same origin, direction,
+// record slot -- only which lane walks it changes: records, images and visit counts are identical; the order inside the hit / miss
+// lists is not (nothing reads it as an order).
+#define BOUNCE_BINS 32
+#define BOUNCE_BIN_SAMPLES 2
+template <bool CACHED>
+__global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_binned_kernel(FrameParams Pv, ViewImages Iv) {
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
+    __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED / 2 : RT_STACK_LDS) * RT_BLOCK];
+    __shared__ uint32_t ldsCount[2];
+    __shared__ float ldsDir[3][BOUNCE_BIN_SAMPLES * RT_BLOCK];
+    __shared__ uint16_t ldsOrder[BOUNCE_BIN_SAMPLES * RT_BLOCK];
+    __shared__ uint32_t ldsBin[BOUNCE_BINS + 1];
+    extern __shared__ u32x4_lds dynLds[];
+    if (threadIdx.x < 2) ldsCount[threadIdx.x] = 0;
+    if (CACHED) fill_scene_cache(P, dynLds);
+    __syncthreads();
+    const uint32_t segment = bounce_segment_size(P); const size_t missBase = bounce_miss_base(P, segment);
+    ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
+    env.lightIntensity = nullptr; env.lightIndex = nullptr;
+    if (CACHED) env.stk.use_cache(dynLds);
+    uint32_t rays = 0;
+    const size_t stride = (size_t)P.width * (size_t)P.height;
+    const uint32_t tiles = tile_count(P);
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        for (uint32_t first = 0; first < P.giSamples; first += BOUNCE_BIN_SAMPLES) {      // samples S - first, S - first - 1, ... (the reference's loop counts down)
+            PRef P = *kernel_params_here(); IRef I = *kernel_images_here();
+            if (threadIdx.x <= BOUNCE_BINS) ldsBin[threadIdx.x] = 0;
+            __syncthreads();
+            // ---- generate: this thread's pixel, BOUNCE_BIN_SAMPLES directions -> LDS, bin + rank inside the bin ----
+            uint32_t slotKey[BOUNCE_BIN_SAMPLES];
+            {
+                const Pixel p = tile_pixel(P, tile);
+                const size_t i = (size_t)p.y * (size_t)P.width + p.x;
+                const bool lit = p.valid && I.instanceId[i] >= 0;
+                f3 shadingNormal = mk3s(0.0f);
+                if (lit) shadingNormal = xyz(load_rgba16f(I.shadingNormal, i));
+                const uint32_t blueNoiseMult = 64u / P.giSamples;
+#pragma unroll
+                for (uint32_t c = 0; c < BOUNCE_BIN_SAMPLES; c++) {
+                    slotKey[c] = 0xFFFFFFFFu;
+                    if (!lit || first + c >= P.giSamples) continue;
+                    const uint32_t smp = P.giSamples - first - c;
+                    const f3 d = cos_hemisphere_blue_noise(P, p.x, p.y, P.frameCount + smp * blueNoiseMult, shadingNormal);
+                    const uint32_t e = c * RT_BLOCK + threadIdx.x;
+                    ldsDir[0][e] = d.x; ldsDir[1][e] = d.y; ldsDir[2][e] = d.z;
+                    int level = (int)((d.y * 0.5f + 0.5f) * 8.0f); level = level < 0 ? 0 : (level > 7 ? 7 : level);      // NaN -> 0: any bin is a correct bin
+                    const uint32_t bin = ((uint32_t)level << 2) | (d.x < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 1u : 0u);
+                    slotKey[c] = (bin << 16) | atomicAdd(&ldsBin[bin], 1u);
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x < 64) {           // exclusive scan of the 32 counts; entry BOUNCE_BINS = rays of this round
+                const uint32_t lane = threadIdx.x, own = lane < BOUNCE_BINS ? ldsBin[lane] : 0u;
+                uint32_t incl = own;
+#pragma unroll
+                for (int dlt = 1; dlt < BOUNCE_BINS; dlt <<= 1) { const uint32_t o = __shfl_up(incl, dlt, 64); if ((int)lane >= dlt) incl += o; }
+                if (lane < BOUNCE_BINS) ldsBin[lane] = incl - own;
+                if (lane == BOUNCE_BINS - 1) ldsBin[BOUNCE_BINS] = incl;
+            }
+            __syncthreads();
+#pragma unroll
+            for (uint32_t c = 0; c < BOUNCE_BIN_SAMPLES; c++)
+                if (slotKey[c] != 0xFFFFFFFFu) ldsOrder[ldsBin[slotKey[c] >> 16] + (slotKey[c] & 0xFFFFu)] = (uint16_t)(c * RT_BLOCK + threadIdx.x);
+            __syncthreads();
+            // ---- walk, in bin order ----
+            const uint32_t total = ldsBin[BOUNCE_BINS];
+            for (uint32_t r = threadIdx.x; r < total; r += RT_BLOCK) {
+                const uint32_t e = ldsOrder[r], slot = e % RT_BLOCK, c = e / RT_BLOCK, smp = P.giSamples - first - c;
+                const Pixel p = tile_pixel_at(P, tile, slot >> 6, slot & 63u);
+                const size_t i = (size_t)p.y * (size_t)P.width + p.x;
+                const float4 pos4 = reinterpret_cast<const float4 *>(I.shadingPosition)[i];
+                const f3 rayOrigin = mk3(pos4.x, pos4.y, pos4.z), rayDirection = mk3(ldsDir[0][e], ldsDir[1][e], ldsDir[2][e]);
+                RayDiff rd; rd.dOdx = rd.dOdy = rd.dDdx = rd.dDdy = mk3s(0.0f);
+                SurfaceHit best;
+                trace_surface<false, CACHED>(P, env, I, i, rayOrigin, rayDirection, rd, p.x, p.y, best);
+                rays++;
+                uint4 a, b;
+                a.x = __float_as_uint(best.t); a.y = __float_as_uint(best.u); a.z = __float_as_uint(best.v); a.w = best.prim;
+                b.x = __float_as_uint(rayDirection.x); b.y = __float_as_uint(rayDirection.y); b.z = __float_as_uint(rayDirection.z);
+                b.w = best.hit ? best.instance : 0xFFFFFFFFu;
+                uint4 *rec = I.bounceRecords + ((size_t)(smp - 1) * stride + i) * 2;
+                rec[0] = a; rec[1] = b;
+                bounce_append(I, ldsCount, segment, missBase, best.hit, (uint32_t)((size_t)(smp - 1) * stride + i));
+            }
+            __syncthreads();
         }
     }
     __syncthreads();
@@ -910,7 +1012,7 @@ DEV f3 bounce_sky_term(PRef P, f3 rayDirection) {
 template <bool CACHED>
 __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void bounce_hit_kernel(FrameParams Pv, ViewImages Iv) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
-    __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED : RT_STACK_LDS) * RT_BLOCK];
+    __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED / 2 : RT_STACK_LDS) * RT_BLOCK];
     __shared__ float ldsLightIntensity[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     extern __shared__ u32x4_lds dynLds[];
@@ -1403,11 +1505,13 @@ hipError_t RT_LAUNCHER(launch_lean_frame)(const FrameParams &P, const ViewImages
     else hipLaunchKernelGGL((lean_frame_kernel<false, false, LEAN_WAVES>), dim3(grid), dim3(RT_BLOCK), 0, s, P, I, hitInstance, cur, ownedY0, ownedY1);
     return hipGetLastError();
 }
-hipError_t RT_LAUNCHER(launch_indirect)(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, bool refill, hipStream_t s) {
-    RT_ROUTE_SIMPLE(launch_indirect_simple(P, I, cur, writeFiltered, klist, refill, s));
+hipError_t RT_LAUNCHER(launch_indirect)(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, int walk, hipStream_t s) {
+    RT_ROUTE_SIMPLE(launch_indirect_simple(P, I, cur, writeFiltered, klist, walk, s));
     if (klist) LAUNCH_RAY(indirect_kernel<true>, P, I, cur, writeFiltered ? 1 : 0);
     if (P.giSamples == 0 || !I.bounceRecords) LAUNCH_RAY(indirect_kernel<false>, P, I, cur, writeFiltered ? 1 : 0);
-    if (refill) hipLaunchKernelGGL(bounce_trace_refill_kernel, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
+    if (walk == BOUNCE_WALK_REFILL) hipLaunchKernelGGL(bounce_trace_refill_kernel, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
+    else if (walk == BOUNCE_WALK_BINNED && P.cacheWords) hipLaunchKernelGGL(bounce_trace_binned_kernel<true>, dim3(rt_grid(P)), dim3(RT_BLOCK), cached_lds_bytes(P, false), s, P, I);
+    else if (walk == BOUNCE_WALK_BINNED) hipLaunchKernelGGL(bounce_trace_binned_kernel<false>, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
     else if (P.cacheWords) hipLaunchKernelGGL(bounce_trace_plain_kernel<true>, dim3(rt_grid(P)), dim3(RT_BLOCK), cached_lds_bytes(P, false), s, P, I);
     else hipLaunchKernelGGL(bounce_trace_plain_kernel<false>, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
     // same grid for the three kernels: workgroup b shades the segments workgroup b of bounce_trace filled (lengths stay on the device)

@@ -93,13 +93,24 @@ typedef uint32_t u32x4_lds __attribute__((ext_vector_type(4)));      // a 16-byt
 // addresser's queue) -- on every pop of the node loop.  Typed, the LDS half is a ds_read_b32 / ds_write_b32.
 typedef uint32_t __attribute__((address_space(3))) *LdsU32Ptr;
 typedef uint32_t __attribute__((address_space(1))) *GlobalU32Ptr;
+typedef int16_t __attribute__((address_space(3))) *LdsI16Ptr;
+// Child references inside the LDS scene cache are 16-bit values, sign-extended: inner node = its index, leaf = 0xFFFF8000 | index,
+// no child = 0xFFFFFFFF (scene_cache_image_kernel rewrites the node arrays that way; the host enables the cache only below 2^15 - 1
+// leaves and nodes per tree).  Bit 31 still says "leaf" and RT64_NO_CHILD is unchanged, the index is `& RT_CACHE_INDEX_MASK`, and
+// the stack of the cached kernels holds int16 entries: ds_write_b16 truncates, ds_read_i16 sign-extends -- half the LDS of a uint32 stack.
+#define RT_CACHE_INDEX_MASK 0x7FFFu
 struct TraceStack {
     LdsU32Ptr lds;        // &ldsStack[threadIdx.x], stride RT_BLOCK
+    LdsI16Ptr lds16;      // the same array as int16 entries (cached kernels): &((int16 *)ldsStack)[threadIdx.x], stride RT_BLOCK
     GlobalU32Ptr spill;   // per-lane slab of RT_STACK_SPILL entries
     const u32x4_lds *cache;   // LDS scene cache (see fill_scene_cache), nullptr when the scene does not fit
     int ldsEntries;       // entries of this lane's stack that live in LDS (RT_STACK_LDS or RT_STACK_LDS_CACHED)
+    DEV void use_cache(const u32x4_lds *c) {
+        cache = c; ldsEntries = RT_STACK_LDS_CACHED;
+        lds16 = (LdsI16Ptr)(lds - threadIdx.x) + threadIdx.x;
+    }
     template <bool LDS_ONLY = false> DEV void push(int &sp, uint32_t v) const {
-        if (LDS_ONLY) { lds[(sp & (RT_STACK_LDS_CACHED - 1)) * RT_BLOCK] = v; sp++; return; }      // depth checked by the host (the mask only keeps a wrong depth inside the array)
+        if (LDS_ONLY) { lds16[(sp & (RT_STACK_LDS_CACHED - 1)) * RT_BLOCK] = (int16_t)v; sp++; return; }      // depth checked by the host (the mask only keeps a wrong depth inside the array)
         if (sp < ldsEntries) lds[sp * RT_BLOCK] = v;
         else if (sp < ldsEntries + RT_STACK_SPILL) spill[sp - ldsEntries] = v;
         else return;      // deeper than any tree this builder produces for n < 2^20 leaves, m < 2^13 instances
@@ -107,7 +118,7 @@ struct TraceStack {
     }
     template <bool LDS_ONLY = false> DEV uint32_t pop(int &sp) const {
         sp--;
-        if (LDS_ONLY) return lds[(sp & (RT_STACK_LDS_CACHED - 1)) * RT_BLOCK];
+        if (LDS_ONLY) return (uint32_t)(int32_t)lds16[(sp & (RT_STACK_LDS_CACHED - 1)) * RT_BLOCK];
         return sp < ldsEntries ? lds[sp * RT_BLOCK] : spill[sp - ldsEntries];
     }
 };
@@ -145,12 +156,15 @@ DEV GpuTri load_tri(const GpuTri *p) {                            // 3 x global_
 //
 // CACHED: the scene's nodes and per-instance records sit in LDS (stk.cache, layout in fill_scene_cache): a node visit and an
 // instance entry are ds_read_b128s (~100 cycles) instead of dependent global loads (~1 us each under load); only triangles still come
-// from HBM/L2.  Same data, same arithmetic, same order: results and visit counts are unchanged.
+// from HBM/L2 (with them in LDS too -- 36 KB per workgroup instead of 21 -- the longer fill of every workgroup cost more than the L2
+// round trips it saved: C2 0.158 against 0.153 ms, profiles/r02_experiments/lds_triangles_*).  Same data, same arithmetic, same order:
+// results and visit counts are unchanged.
 DEV GpuNode load_node_lds(const u32x4_lds *q) {
     union { u32x4_lds w[4]; GpuNode n; } u;
     u.w[0] = q[0]; u.w[1] = q[1]; u.w[2] = q[2]; u.w[3] = q[3];
     return u.n;
 }
+
 
 template <bool CACHED = false, class OnHit>
 DEV void trace_ray(PRef P, const float o[3], const float d[3], float tmin, float tmax, bool cullBackFaces,
@@ -163,6 +177,7 @@ DEV void trace_ray(PRef P, const float o[3], const float d[3], float tmin, float
     const uint32_t tlasOff = 4u * P.cacheInstances;          // CACHED: node arrays are addressed by their word offset in the cache
     uint32_t nodeOff = tlasOff;
     const GpuTri *tris = nullptr;
+    const uint32_t indexMask = CACHED ? RT_CACHE_INDEX_MASK : 0x7FFFFFFFu;
     int sp = 0, blasBase = -1;
     uint32_t inst = 0, instFlags = 0;
     float instDepthBias = 0.0f;            // of the instance being walked: handed to the hit handler (no table lookup per hit)
@@ -202,7 +217,7 @@ DEV void trace_ray(PRef P, const float o[3], const float d[3], float tmin, float
                 uint32_t flags;
                 if (CACHED) {
                     // 64-byte record of leaf slot `cur`: three words (M[c], M[4+c], M[8+c], M[12+c]), then (instance | flags << 8 | node offset << 16, depth bias, tris pointer)
-                    const u32x4_lds *rec = stk.cache + 4u * (cur & 0x7FFFFFFFu);
+                    const u32x4_lds *rec = stk.cache + 4u * (cur & indexMask);
                     const u32x4_lds info = rec[3];
 #pragma unroll
                     for (int c = 0; c < 3; c++) {
@@ -235,7 +250,7 @@ DEV void trace_ray(PRef P, const float o[3], const float d[3], float tmin, float
                 cur = 0;
                 continue;
             }
-            const GpuTri tri = load_tri(tris + (cur & 0x7FFFFFFFu));
+            const GpuTri tri = load_tri(tris + (cur & indexMask));
             cnt.tris++;
             float t, u, v;
             if (tri_hit(R, tri, cull, tmin, tmax, t, u, v))

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Extra SQ counter passes for one kernel family (diagnosis, not the judged profile):  tools/pmc_extra.sh <tag> <kernel-substring> [bench flags]
-# One rocprofv3 --kernel-trace --pmc pass per counter set; prints the per-launch averages of the kernels whose name holds the substring.
+# Extra SQ counter passes for some kernels (diagnosis, not the judged profile):  tools/pmc_extra.sh <tag> <kernel-name-regex> [bench flags]
+# One rocprofv3 --kernel-trace --pmc pass per counter set; prints the per-launch averages of the kernels whose name matches.
 set -e
 TAG=${1:-x}; KERN=${2:-lean_frame}; shift 2 || true
 REPO=$(pwd); OUT=$REPO/gpurun_out; mkdir -p "$OUT"
@@ -19,12 +19,14 @@ do
   f=$(find "$D" -name '*counter_collection.csv' | head -1)
   python3 - "$f" "$KERN" <<'PY'
 import csv, sys, collections
+import re
 tot, cnt = collections.defaultdict(float), collections.Counter()
 for r in csv.DictReader(open(sys.argv[1])):
-    if sys.argv[2] in r["Kernel_Name"]:
-        tot[r["Counter_Name"]] += float(r["Counter_Value"]); cnt[r["Counter_Name"]] += 1
+    if re.search(sys.argv[2], r["Kernel_Name"]):
+        name = re.sub(r"\(anonymous namespace\)::|^void ", "", r["Kernel_Name"]).split("(")[0]
+        tot[(name, r["Counter_Name"])] += float(r["Counter_Value"]); cnt[(name, r["Counter_Name"])] += 1
 for k in sorted(tot):
-    print("%-28s %16.1f  (%d launches)" % (k, tot[k] / cnt[k], cnt[k]))
+    print("%-44s %-28s %16.1f  (%d launches)" % (k[0][:44], k[1], tot[k] / cnt[k], cnt[k]))
 PY
   rm -rf "$D"
 done
