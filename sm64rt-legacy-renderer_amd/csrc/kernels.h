@@ -46,7 +46,7 @@ hipError_t launch_scene_cache_image(const GpuInstance *instances, const uint32_t
 hipError_t launch_primary_trace(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, bool klist, hipStream_t s);
 hipError_t launch_primary_shade(const FrameParams &P, const ViewImages &I, const int32_t *hitInstance, int cur, bool transparentLighting, bool lean, hipStream_t s);
 hipError_t launch_direct(const FrameParams &P, const ViewImages &I, int cur, bool lean, hipStream_t s);
-enum { BOUNCE_WALK_PLAIN = 0, BOUNCE_WALK_REFILL = 1, BOUNCE_WALK_BINNED = 2 };      // how bounce_trace hands rays to lanes (passes.hip)
+enum { BOUNCE_WALK_PLAIN = 0, BOUNCE_WALK_REFILL = 1 };      // how bounce_trace hands rays to lanes (passes.hip)
 hipError_t launch_indirect(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, int walk, hipStream_t s);
 hipError_t launch_indirect_constant(const FrameParams &P, const ViewImages &I, int cur, hipStream_t s);
 hipError_t launch_refraction(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s);

@@ -825,104 +825,11 @@ __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kern
     flush_env(P, env, PASS_INDIRECT, CTR_INDIRECT, rays);
 }
 
-// The same walk with the rays of a tile handed to the lanes in DIRECTION order.  A wave of the plain kernel holds the 64 rays of an
-// 8 x 8 pixel block: cosine-hemisphere directions, so one lane leaves through the sky after two box tests while its neighbour walks a
-// BLAS, and the wave executes the union of their code paths (measured 26 % VALU lane utilisation, SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU).
-// Here the workgroup generates BOUNCE_BIN_SAMPLES samples of its 256 pixels at once, counts them into 32 direction bins (8 levels of
-// d.y, the signs of d.x and d.z) with LDS atomics, and walks them bin after bin: the rays of a wave start close together and point the
-// same way, so they enter the same instances and end together.  Every ray is the ray the plain kernel traces -- same origin, direction,
-// record slot -- only which lane walks it changes: records, images and visit counts are identical; the order inside the hit / miss
-// lists is not (nothing reads it as an order).
-#define BOUNCE_BINS 32
-#define BOUNCE_BIN_SAMPLES 2
-template <bool CACHED>
-__global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_binned_kernel(FrameParams Pv, ViewImages Iv) {
-    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
-    __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED / 2 : RT_STACK_LDS) * RT_BLOCK];
-    __shared__ uint32_t ldsCount[2];
-    __shared__ float ldsDir[3][BOUNCE_BIN_SAMPLES * RT_BLOCK];
-    __shared__ uint16_t ldsOrder[BOUNCE_BIN_SAMPLES * RT_BLOCK];
-    __shared__ uint32_t ldsBin[BOUNCE_BINS + 1];
-    extern __shared__ u32x4_lds dynLds[];
-    if (threadIdx.x < 2) ldsCount[threadIdx.x] = 0;
-    if (CACHED) fill_scene_cache(P, dynLds);
-    __syncthreads();
-    const uint32_t segment = bounce_segment_size(P); const size_t missBase = bounce_miss_base(P, segment);
-    ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
-    env.lightIntensity = nullptr; env.lightIndex = nullptr;
-    if (CACHED) env.stk.use_cache(dynLds);
-    uint32_t rays = 0;
-    const size_t stride = (size_t)P.width * (size_t)P.height;
-    const uint32_t tiles = tile_count(P);
-    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        for (uint32_t first = 0; first < P.giSamples; first += BOUNCE_BIN_SAMPLES) {      // samples S - first, S - first - 1, ... (the reference's loop counts down)
-            PRef P = *kernel_params_here(); IRef I = *kernel_images_here();
-            if (threadIdx.x <= BOUNCE_BINS) ldsBin[threadIdx.x] = 0;
-            __syncthreads();
-            // ---- generate: this thread's pixel, BOUNCE_BIN_SAMPLES directions -> LDS, bin + rank inside the bin ----
-            uint32_t slotKey[BOUNCE_BIN_SAMPLES];
-            {
-                const Pixel p = tile_pixel(P, tile);
-                const size_t i = (size_t)p.y * (size_t)P.width + p.x;
-                const bool lit = p.valid && I.instanceId[i] >= 0;
-                f3 shadingNormal = mk3s(0.0f);
-                if (lit) shadingNormal = xyz(load_rgba16f(I.shadingNormal, i));
-                const uint32_t blueNoiseMult = 64u / P.giSamples;
-#pragma unroll
-                for (uint32_t c = 0; c < BOUNCE_BIN_SAMPLES; c++) {
-                    slotKey[c] = 0xFFFFFFFFu;
-                    if (!lit || first + c >= P.giSamples) continue;
-                    const uint32_t smp = P.giSamples - first - c;
-                    const f3 d = cos_hemisphere_blue_noise(P, p.x, p.y, P.frameCount + smp * blueNoiseMult, shadingNormal);
-                    const uint32_t e = c * RT_BLOCK + threadIdx.x;
-                    ldsDir[0][e] = d.x; ldsDir[1][e] = d.y; ldsDir[2][e] = d.z;
-                    int level = (int)((d.y * 0.5f + 0.5f) * 8.0f); level = level < 0 ? 0 : (level > 7 ? 7 : level);      // NaN -> 0: any bin is a correct bin
-                    const uint32_t bin = ((uint32_t)level << 2) | (d.x < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 1u : 0u);
-                    slotKey[c] = (bin << 16) | atomicAdd(&ldsBin[bin], 1u);
-                }
-            }
-            __syncthreads();
-            if (threadIdx.x < 64) {           // exclusive scan of the 32 counts; entry BOUNCE_BINS = rays of this round
-                const uint32_t lane = threadIdx.x, own = lane < BOUNCE_BINS ? ldsBin[lane] : 0u;
-                uint32_t incl = own;
-#pragma unroll
-                for (int dlt = 1; dlt < BOUNCE_BINS; dlt <<= 1) { const uint32_t o = __shfl_up(incl, dlt, 64); if ((int)lane >= dlt) incl += o; }
-                if (lane < BOUNCE_BINS) ldsBin[lane] = incl - own;
-                if (lane == BOUNCE_BINS - 1) ldsBin[BOUNCE_BINS] = incl;
-            }
-            __syncthreads();
-#pragma unroll
-            for (uint32_t c = 0; c < BOUNCE_BIN_SAMPLES; c++)
-                if (slotKey[c] != 0xFFFFFFFFu) ldsOrder[ldsBin[slotKey[c] >> 16] + (slotKey[c] & 0xFFFFu)] = (uint16_t)(c * RT_BLOCK + threadIdx.x);
-            __syncthreads();
-            // ---- walk, in bin order ----
-            const uint32_t total = ldsBin[BOUNCE_BINS];
-            for (uint32_t r = threadIdx.x; r < total; r += RT_BLOCK) {
-                const uint32_t e = ldsOrder[r], slot = e % RT_BLOCK, c = e / RT_BLOCK, smp = P.giSamples - first - c;
-                const Pixel p = tile_pixel_at(P, tile, slot >> 6, slot & 63u);
-                const size_t i = (size_t)p.y * (size_t)P.width + p.x;
-                const float4 pos4 = reinterpret_cast<const float4 *>(I.shadingPosition)[i];
-                const f3 rayOrigin = mk3(pos4.x, pos4.y, pos4.z), rayDirection = mk3(ldsDir[0][e], ldsDir[1][e], ldsDir[2][e]);
-                RayDiff rd; rd.dOdx = rd.dOdy = rd.dDdx = rd.dDdy = mk3s(0.0f);
-                SurfaceHit best;
-                trace_surface<false, CACHED>(P, env, I, i, rayOrigin, rayDirection, rd, p.x, p.y, best);
-                rays++;
-                uint4 a, b;
-                a.x = __float_as_uint(best.t); a.y = __float_as_uint(best.u); a.z = __float_as_uint(best.v); a.w = best.prim;
-                b.x = __float_as_uint(rayDirection.x); b.y = __float_as_uint(rayDirection.y); b.z = __float_as_uint(rayDirection.z);
-                b.w = best.hit ? best.instance : 0xFFFFFFFFu;
-                uint4 *rec = I.bounceRecords + ((size_t)(smp - 1) * stride + i) * 2;
-                rec[0] = a; rec[1] = b;
-                bounce_append(I, ldsCount, segment, missBase, best.hit, (uint32_t)((size_t)(smp - 1) * stride + i));
-            }
-            __syncthreads();
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 2) I.bounceCounts[2 * blockIdx.x + threadIdx.x] = ldsCount[threadIdx.x];
-    flush_env(P, env, PASS_INDIRECT, CTR_INDIRECT, rays);
-}
-
+// (Handing the rays of a tile to the lanes in direction order instead -- 32 bins of (d.y level, sign d.x, sign d.z), counted and
+// ranked in LDS, bit-identical results -- was measured and removed: C5 indirect 2.52 against 2.34 ms, commit 10c0030 and
+// profiles/r02_experiments/bounce_binned_*.  The lanes of a wave diverge by WHICH of the three code paths -- node test, instance
+// entry, triangle test -- their next step needs, and rays that start together and point the same way still take those steps at
+// different trips.)
 // Bounce rays are incoherent: in a plain one-ray-per-lane walk the wave waits for its longest ray (measured 27 % VALU lane
 // utilisation).  Each wave therefore streams through its work list -- (tile, pixel slot, sample) in tile order -- and lanes whose
 // ray has finished are REFILLED: when fewer than BOUNCE_MIN_LIVE lanes are still walking, the walk pauses (RayWalk::run), the
@@ -1510,8 +1417,6 @@ hipError_t RT_LAUNCHER(launch_indirect)(const FrameParams &P, const ViewImages &
     if (klist) LAUNCH_RAY(indirect_kernel<true>, P, I, cur, writeFiltered ? 1 : 0);
     if (P.giSamples == 0 || !I.bounceRecords) LAUNCH_RAY(indirect_kernel<false>, P, I, cur, writeFiltered ? 1 : 0);
     if (walk == BOUNCE_WALK_REFILL) hipLaunchKernelGGL(bounce_trace_refill_kernel, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
-    else if (walk == BOUNCE_WALK_BINNED && P.cacheWords) hipLaunchKernelGGL(bounce_trace_binned_kernel<true>, dim3(rt_grid(P)), dim3(RT_BLOCK), cached_lds_bytes(P, false), s, P, I);
-    else if (walk == BOUNCE_WALK_BINNED) hipLaunchKernelGGL(bounce_trace_binned_kernel<false>, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
     else if (P.cacheWords) hipLaunchKernelGGL(bounce_trace_plain_kernel<true>, dim3(rt_grid(P)), dim3(RT_BLOCK), cached_lds_bytes(P, false), s, P, I);
     else hipLaunchKernelGGL(bounce_trace_plain_kernel<false>, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
     // same grid for the three kernels: workgroup b shades the segments workgroup b of bounce_trace filled (lengths stay on the device)

@@ -141,7 +141,6 @@ struct Options {
     bool simpleKernels = true;    // frames whose textures are all power-of-two sized and whose instances are all shadow-opaque run the kernels of passes_simple.hip
     bool ldsCache = true;         // small scenes: BVH nodes + instance records cached in LDS by the ray kernels (0: always walk from HBM/L2)
     bool spinPresent = true;      // RT64_DrawDevice waits for the frame by polling the stream (0: blocking hipStreamSynchronize)
-    bool bounceBinned = false;    // bounce rays of a tile are walked in direction-bin order (measured slower: profiles/r02_experiments/bounce_binned_*)
     int bounceRefill = -1;        // bounce-ray traversal with wave-ballot refill: 1 on, 0 off, -1 auto (on when the scene has >= 64 Ki triangles)
     int denoiserMode = 1;          // 0 = reference 5x Gaussian, 1 = SVGF
     int maxReflections = 2;        // rt64_view.cpp:60 (inspector-only knob in the reference)
@@ -1209,7 +1208,7 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         else {
             bool refill = dev->opt.bounceRefill == 1;
             if (dev->opt.bounceRefill < 0) { size_t tri = 0; for (auto &ri : rtInstances) tri += ri.instance->mesh->blasCount; refill = tri >= 65536; }
-            const int walk = refill ? BOUNCE_WALK_REFILL : (dev->opt.bounceBinned ? BOUNCE_WALK_BINNED : BOUNCE_WALK_PLAIN);
+            const int walk = refill ? BOUNCE_WALK_REFILL : BOUNCE_WALK_PLAIN;
             L(launch_indirect(X, img, cur, !denoiseGI, klist, walk, s));
         }
         mark(Device::EV_INDIRECT);
@@ -1545,7 +1544,6 @@ RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, doubl
     else if (k == "profile_passes") d->opt.profilePasses = value != 0.0;
     else if (k == "sync_present") d->opt.syncPresent = value != 0.0;
     else if (k == "denoiser_mode") d->opt.denoiserMode = (int)value;
-    else if (k == "bounce_binned") d->opt.bounceBinned = value != 0.0;
     else if (k == "bounce_refill") d->opt.bounceRefill = (int)value;
     else if (k == "spin_present") d->opt.spinPresent = value != 0.0;
     else if (k == "lds_cache") d->opt.ldsCache = value != 0.0;

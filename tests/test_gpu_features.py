@@ -193,23 +193,6 @@ def test_c3_bounce_traversal_with_wave_refill_matches_plain_walk(rt64_lib, sampl
     assert (st1.nodesVisited, st1.trianglesTested, st1.indirectRays) == (st0.nodesVisited, st0.trianglesTested, st0.indirectRays)
 
 
-@pytest.mark.parametrize("samples,cache", [(1, 1), (3, 1), (4, 0)])
-def test_bounce_rays_walked_in_direction_bins_match_pixel_order(rt64_lib, sample_data, samples, cache):
-    """Option bounce_binned (default 1): a workgroup sorts the bounce rays of its tile into 32 direction bins and walks them bin after
-    bin (passes.hip bounce_trace_binned_kernel).  The rays are the plain kernel's rays, so images and traversal counters must be
-    bit-identical to bounce_binned = 0 -- with an odd sample count (a half-filled last round), with and without the LDS scene cache --
-    and the frame must equal the oracle's."""
-    res = {}
-    for binned in (1, 0):
-        res[binned] = _render_pair(rt64_lib, sample_data, frames=3, view_desc=dict(gi_samples=samples, denoiser=True),
-                                   options={"bounce_binned": binned, "bounce_refill": 0, "lds_cache": cache, "denoiser_mode": 1})
-    (got1, ref, st1), (got0, _, st0) = res[1], res[0]
-    assert np.array_equal(got1["INDIRECT_LIGHT_RAW"], got0["INDIRECT_LIGHT_RAW"]) and np.array_equal(got1["OUTPUT_RGBA32F"], got0["OUTPUT_RGBA32F"])
-    assert (st1.nodesVisited, st1.trianglesTested, st1.indirectRays) == (st0.nodesVisited, st0.trianglesTested, st0.indirectRays)
-    assert st1.indirectRays == ref["counters"]["indirectRays"] > 0
-    assert _rmse(got1["OUTPUT_RGBA32F"][..., :3], ref["output"][..., :3]) <= 1e-3
-
-
 def test_resolution_scale_resamples_the_render_target_to_the_screen(rt64_lib, sample_data):
     """RT64_VIEW_DESC.resolutionScale (rt64_view.cpp:138-139): every image is lround(screen x scale), PostProcessPS.hlsl resamples the
     composed output to the screen-size back buffer with the LINEAR/WRAP static sampler.  0.75 (upsample) and 1.5 (supersample)."""
