@@ -380,9 +380,7 @@ DEV void resolve_primary(PRef P, IRef I, ShadeEnv &env, uint32_t px, uint32_t py
     }
     resReactiveMask += fmaxf(resTransparent.x, fmaxf(resTransparent.y, resTransparent.z));
     if (resColor.w != 0.0f) {
-        const f4 skyColor = sample_sky_2d(P, screenUV);
-        // lerp(background, sky, 1) is the sky itself up to one rounding of (sky - bg) + bg: skip the gBackground fetch under an opaque sky
-        f3 bgColor = skyColor.w >= 1.0f ? xyz(skyColor) : lerp3(sample_background_2d(P, screenUV), xyz(skyColor), skyColor.w);
+        const f3 bgColor = sky_over_background_2d(P, screenUV);
         resColor.x += bgColor.x * resColor.w; resColor.y += bgColor.y * resColor.w; resColor.z += bgColor.z * resColor.w;
     }
     resColor.w = 1.0f - resColor.w;
@@ -701,9 +699,7 @@ __global__ __launch_bounds__(RT_BLOCK, 3) void indirect_kernel(FrameParams Pv, V
             SurfaceHit best;
             const uint32_t nhits = trace_surface<KLIST>(P, env, I, i, rayOrigin, rayDirection, rd, px, py, best);
             rays++;
-            f3 bgColor = sample_background_envmap(P, rayDirection);
-            f4 sky = sample_sky_plane(P, rayDirection);
-            bgColor = lerp3(bgColor, xyz(sky), sky.w);
+            const f3 bgColor = sky_over_background_envmap(P, rayDirection);
             f3 resPosition = mk3s(0.0f), resNormal = mk3s(0.0f), resSpecular = mk3s(0.0f); f4 resColor = mk4(0, 0, 0, 1); int resInstanceId = -1;
             for (uint32_t hit = 0; hit < nhits; hit++) {
                 HitRecord r;
@@ -911,9 +907,7 @@ __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_refill_ker
 // bounce_resolve_kernel: per pixel, samples in the reference's order: temporal accumulation, luminance moments, stores.
 // Per-sample arithmetic and its order are those of indirect_kernel<false>.
 DEV f3 bounce_sky_term(PRef P, f3 rayDirection) {
-    f3 bgColor = sample_background_envmap(P, rayDirection);
-    f4 sky = sample_sky_plane(P, rayDirection);
-    return lerp3(bgColor, xyz(sky), sky.w);
+    return sky_over_background_envmap(P, rayDirection);
 }
 
 template <bool CACHED>
@@ -1050,9 +1044,7 @@ __global__ __launch_bounds__(RT_BLOCK) void refraction_kernel(FrameParams Pv, Vi
         f3 rayOrigin = mk3(pos4.x, pos4.y, pos4.z), viewDirection = xyz(load_rgba16f(I.viewDirection, i)), shadingNormal = xyz(load_rgba16f(I.shadingNormal, i));
         f3 rayDirection = hlsl_refract(viewDirection, shadingNormal, P.instances[instanceId].material.refractionFactor);
         f2 screenUV; screenUV.x = ((float)px + P.pixelJitter[0]) / (float)P.width; screenUV.y = ((float)py + P.pixelJitter[1]) / (float)P.height;
-        f3 bgColor = sample_background_2d(P, screenUV);
-        f4 sky = sample_sky_2d(P, screenUV);
-        bgColor = lerp3(bgColor, xyz(sky), sky.w);
+        const f3 bgColor = sky_over_background_2d(P, screenUV);
         RayDiff rd; rd.dOdx = rd.dOdy = rd.dDdx = rd.dDdy = mk3s(0.0f);
         SurfaceHit best;
         const uint32_t nhits = trace_surface<KLIST>(P, env, I, i, rayOrigin, rayDirection, rd, px, py, best);
@@ -1117,9 +1109,7 @@ __global__ __launch_bounds__(RT_BLOCK) void reflection_kernel(FrameParams Pv, Vi
         f3 shadingPosition = mk3(pos4.x, pos4.y, pos4.z), viewDirection = xyz(load_rgba16f(I.viewDirection, i)), shadingNormal = xyz(load_rgba16f(I.shadingNormal, i));
         f3 rayDirection = reflect3(viewDirection, shadingNormal);
         float newReflectionAlpha = 0.0f;
-        f3 bgColor = sample_background_envmap(P, rayDirection);
-        f4 sky = sample_sky_plane(P, rayDirection);
-        bgColor = lerp3(bgColor, xyz(sky), sky.w);
+        const f3 bgColor = sky_over_background_envmap(P, rayDirection);
         RayDiff rd; rd.dOdx = rd.dOdy = rd.dDdx = rd.dDdy = mk3s(0.0f);
         SurfaceHit best;
         const uint32_t nhits = trace_surface<KLIST>(P, env, I, i, shadingPosition, rayDirection, rd, px, py, best);

@@ -228,6 +228,20 @@ DEV f3 sample_background_envmap(PRef P, f3 rayDirection) {
     return xyz(tex_sample_level_any(tex_view_arg(P.background), uv.x, uv.y, 0, 1, 0, 0));
 }
 
+// lerp(background, sky, sky.a) as the ray-gen shaders write it (BgSky.hlsli:89-95 with SampleSkyPlane / SampleSky2D).  Under an opaque sky
+// texel (a >= 1) that is the sky itself up to one rounding of (sky - bg) + bg, so the gBackground fetch is skipped there: for a bounce
+// ray it is a random access into a screen-size image (C5: 4.2 GB of bounce_miss_kernel's fetches), for nothing.
+DEV f3 sky_over_background_envmap(PRef P, f3 rayDirection) {
+    const f4 sky = sample_sky_plane(P, rayDirection);
+    if (sky.w >= 1.0f) return xyz(sky);
+    return lerp3(sample_background_envmap(P, rayDirection), xyz(sky), sky.w);
+}
+DEV f3 sky_over_background_2d(PRef P, f2 screenUV) {
+    const f4 sky = sample_sky_2d(P, screenUV);
+    if (sky.w >= 1.0f) return xyz(sky);
+    return lerp3(sample_background_2d(P, screenUV), xyz(sky), sky.w);
+}
+
 DEV f4 fog_from_camera(PRef P, const RT64_MATERIAL &m, f3 position) {    // Fog.hlsli:5-18
     f4 clip = mul4(cmat(P.viewProj).m, mk4(position.x, position.y, position.z, 1.0f));
     clip.z = clip.z * 2.0f - clip.w;
