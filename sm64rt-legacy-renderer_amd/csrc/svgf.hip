@@ -18,6 +18,10 @@
 // taps per pixel instead of 25).  Measured at 1080p (five iterations + guide + variance): 4 rows 0.240 ms (133 VGPRs, 3 waves/SIMD),
 // 2 rows 0.223 ms, 1 row 0.210 ms (68 VGPRs, 7 waves/SIMD): the pass is latency-bound and occupancy beats tap reuse, so 1 it is.
 // Sky pixels (56 % of the sample frame) copy through.
+// Round 2 measured the other way to reuse taps as well: steps 1 and 2 with the workgroup's (64 + 4S) x (8 + 4S) input pixels staged in LDS
+// (1.6 / 2.3 global loads per output instead of 50, same values into the same arithmetic).  Slower again -- C3 SVGF 0.240 against 0.210 ms,
+// C5 0.800 against 0.751 (profiles/r02_experiments/atrous_lds_tiled*, the patch is there too): the staging barrier and 5 instead of 8
+// waves per SIMD cost more than the loads they replace, which the L1 serves at its hit rate anyway.
 #include "kernels.h"
 #include "device_math.h"
 
