@@ -94,6 +94,11 @@ def main():
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         spawn_ranks(args)
+    # stdout carries ONE JSON line.  The library reports like the reference does ("Render buffer: WxH", rt64_view.cpp:150) with printf on
+    # stdout: from here on file descriptor 1 is stderr, and the line goes out through a duplicate of the real stdout.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
     import __graft_entry__ as graft
@@ -422,7 +427,7 @@ def main():
             result["frame_checksum"] = int(frame.to(torch.int64).sum().item())
         else:
             result["frame_checksum"] = gathered_checksum
-        print(json.dumps(result), flush=True)
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
 
     if gatherer:
         gatherer.close()                 # torch's current stream goes back to the default one before the renderer's stream is destroyed
@@ -527,7 +532,13 @@ def roofline_object(dominant, d_ms, d_bytes, kernels):
     out["counters"] = detail
     if "SQ_WAVE_CYCLES" in c and c.get("SQ_WAVE_CYCLES"):
         wc = float(c["SQ_WAVE_CYCLES"])
-        out["counters"]["wave"]["share_of_wave_cycles"] = {k: round(c[k] / wc, 3) for k in ("SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if k in c}
+        share = {k: round(c[k] / wc, 3) for k in ("SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if k in c}
+        out["counters"]["wave"]["share_of_wave_cycles"] = share
+        # `bound` names the busier of the two pipes; when neither is busy, what holds the kernel is how long a wave waits, and this says so
+        resident = wc * 4.0 / (SIMDS * secs * CLOCK_HZ)          # SQ_WAVE_CYCLES counts quad-cycles: average waves resident per SIMD
+        if out["frac"] is not None and out["frac"] < 0.5 and "SQ_WAIT_ANY" in share:
+            out["limiter"] = ("latency: a wave spends %.0f %% of its cycles in s_waitcnt (memory) and %.0f %% issuing VALU; %.1f waves per SIMD are resident on average, too few to fill the "
+                              "gaps, so neither the VALU (%.0f %%) nor HBM (%.0f %%) is the limit" % (100 * share["SQ_WAIT_ANY"], 100 * share.get("SQ_ACTIVE_INST_VALU", 0), resident, 100 * valu_frac, 100 * hbm_frac))
     return out
 
 

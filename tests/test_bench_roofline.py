@@ -43,6 +43,9 @@ def test_roofline_uses_the_matching_profile_and_stays_below_one(bench, tmp_path,
     assert r["bound"] == "valu" and r["unit"] == "TFLOP/s"
     # the SURVEY 8(d) figure is still there, named for what it is (8.8 TB/s "achieved" on algorithmic bytes would be 1.1 x the HBM peak)
     assert r["algorithmic"]["bytes_per_launch"] == 1_456_816_660 and r["algorithmic"]["GBps"] > 8000.0 and "frac" not in r["algorithmic"]
+    # neither pipe is half busy: the line has to say what holds the kernel instead (wait share of the wave cycles, waves resident per SIMD)
+    if "SQ_WAIT_ANY" in LEAN and "SQ_WAVE_CYCLES" in LEAN:
+        assert r["limiter"].startswith("latency") and "waves per SIMD" in r["limiter"]
 
 
 def test_roofline_refuses_a_profile_of_other_sources(bench, tmp_path, monkeypatch):
