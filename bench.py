@@ -184,8 +184,20 @@ def main():
             uid = uid_dev.cpu()
         # frames with GI + denoiser: contiguous bands of about equal modelled cost (cut from the whole frame every rank has just rendered)
         gather = lib.CreateGather(scene.device, uid.data_ptr(), uid.numel(), rank, N, 2 if use_bands else 0)       # also sets this device's share of the frame
-        if not gather:
-            raise SystemExit("RT64_CreateGather: " + lib.last_error())
+        # every rank has to have it, or none uses it: a rank without RCCL behind the library falls back to the torch.distributed gatherer
+        # of tiles.py (same layout, same pipelining) -- together with all the others, and the line says which one ran
+        ok = torch.tensor([1 if gather else 0], dtype=torch.int32, device="cuda")
+        if N > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if not int(ok.item()):
+            print("bench.py: rank %d: RT64_CreateGather unavailable on some rank (%s): torch.distributed gather instead" % (rank, lib.last_error() if not gather else "ok here"), file=sys.stderr)
+            if gather:
+                lib.DestroyGather(gather)
+            gather, native = None, False
+            if use_bands:
+                scene.set_tile(*tiles.band_range(H, rank, N))
+            else:
+                scene.set_interleave(rank, N)
 
     # N > 1: frames are ENQUEUED (sync_present = 0) on the renderer's stream, the strips are copied into a gather slot on the same
     # stream, and the RCCL gather of frame k runs beside the rendering of frame k+1 (two slots).  Everything is complete at the
@@ -342,6 +354,24 @@ def main():
         rebuild = {"ms_per_step": round(r_ms, 5), "value": round(rays_total / (r_ms * 1e-3) / 1e6, 2), "build_ms": round(sr.accumMsBuild / max(sr.accumFrames, 1), 5),
                    "what": "always_rebuild=1: frame tables uploaded + TLAS rebuilt + raster lists re-staged every frame, as the reference does (rt64_view.cpp:451,1150-1152)"}
         scene.option("always_rebuild", 0)
+    # ... and with RT64_DrawDevice only enqueueing (sync_present = 0, what the N > 1 path runs): K frames back to back on the stream, one wait
+    # at the end.  `value` above keeps the reference's frame-by-frame wait (rt64_device.cpp:1006-1025); this is the same work without the
+    # launch-to-completion round trip between frames.
+    enqueued = None
+    if not G and PR <= 1 and anim is None:
+        scene.option("sync_present", 0)
+        for _ in range(min(args.warmup, 5)):
+            step()
+        barrier()
+        te = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        e_ms = (time.perf_counter() - te) * 1e3 / args.steps
+        enqueued = {"ms_per_step": round(e_ms, 5), "value": round(rays_total / (e_ms * 1e-3) / 1e6, 2),
+                    "what": "sync_present=0: RT64_DrawDevice enqueues, frames run back to back on the library's stream, one wait after the K-th (cached tables)"}
+        scene.option("sync_present", 1)
+        step(); barrier()
     if G or PR > 1:                  # per-kernel timings of this rank's strips from a few untimed frames (reading them synchronises)
         stat_frames = 10
         for _ in range(stat_frames):
@@ -416,6 +446,8 @@ def main():
                                   "host_ms_per_step": round(enqueue_ms, 5)}
         result["accel_build"] = {"first_frame_ms": round(first_frame_build_ms, 4), "triangles": int(st_full.triangleCount), "blas_node_bytes": int(st_full.blasNodeBytes),
                                  "what": "GPU time of all BLAS builds (LBVH: Morton, radix sort, Karras, fit) + the TLAS build, executed at the first frame after the RT64_SetMesh calls"}
+        if enqueued is not None:
+            result["enqueued_frames"] = enqueued
         if rebuild is not None:
             result["always_rebuild"] = rebuild
         result["frame_tables"] = "rebuilt every frame (always_rebuild)" if args.always_rebuild else "cached while the host re-sends identical descriptors (steady state of the sample host, main.cpp:97-134); `always_rebuild` holds the figure with the cache off"

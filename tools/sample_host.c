@@ -26,6 +26,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <sys/types.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -270,20 +271,23 @@ static void drawFrame(void) {                                                   
     RT64.lib.DrawDevice(RT64.device, 1, 1000.0f / 60.0f);
 }
 
+static double now_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
+
 int main(int argc, char **argv) {
-    int width = 1280, height = 720, frames = 3;                                  /* main.cpp:435-436: 1280 x 720 window */
+    int width = 1280, height = 720, frames = 3, warmup = 0;                      /* main.cpp:435-436: 1280 x 720 window */
     const char *assets = "assets/sample", *dump = NULL;
     int selftest = 0, ranks = 0, bands = 0;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--width") && i + 1 < argc) width = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--height") && i + 1 < argc) height = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--frames") && i + 1 < argc) frames = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--warmup") && i + 1 < argc) warmup = atoi(argv[++i]);             /* untimed frames before the `frames` timed ones */
         else if (!strcmp(argv[i], "--assets") && i + 1 < argc) assets = argv[++i];
         else if (!strcmp(argv[i], "--dump") && i + 1 < argc) dump = argv[++i];
         else if (!strcmp(argv[i], "--selftest")) selftest = 1;
         else if (!strcmp(argv[i], "--ranks") && i + 1 < argc) ranks = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--bands")) bands = 1;
-        else { fprintf(stderr, "usage: %s [--width W] [--height H] [--frames N] [--assets DIR] [--dump frame.rgba] [--selftest] [--ranks N [--bands]]\n", argv[0]); return 2; }
+        else { fprintf(stderr, "usage: %s [--width W] [--height H] [--frames N] [--warmup W] [--assets DIR] [--dump frame.rgba] [--selftest] [--ranks N [--bands]]\n", argv[0]); return 2; }
     }
     if (selftest) {       /* the asset readers alone (no library, no GPU): byte sums the CPU test suite compares with the Python harness's loaders */
         static const char *pngs[6] = { "grass_nrm.png", "grass_spc.png", "clouds.png", "tiles_dif.png", "tiles_nrm.png", "tiles_spc.png" };
@@ -319,6 +323,7 @@ int main(int argc, char **argv) {
     setupRT64Scene(assets);
     const size_t bytes = (size_t)width * height * 4;
     unsigned char *frame = (unsigned char *)malloc(bytes);
+    double msPerFrame = 0.0;
     if (ranks > 0) {                                                             /* the frame's rows over `ranks` GPUs, gathered on rank 0 */
         unsigned char id[RT64_GATHER_ID_BYTES];
         if (!RT64.ext.CreateGather || !RT64.ext.SubmitGather || !RT64.ext.ReadbackGather) die("librt64.so lacks the gather exports");
@@ -330,8 +335,12 @@ int main(int argc, char **argv) {
         RT64_GATHER *gather = RT64.ext.CreateGather(RT64.device, id, sizeof(id), rank, ranks, bands);
         if (!gather) { fprintf(stderr, "sample_host: CreateGather: %s\n", RT64.lib.GetLastError()); return 5; }
         int slot = -1;
+        for (int f = 0; f < warmup; f++) { drawFrame(); slot = RT64.ext.SubmitGather(gather); if (slot < 0) die(RT64.lib.GetLastError()); }
+        if (warmup) RT64.ext.ReadbackGather(gather, slot, frame, bytes, 0);
+        const double t0 = now_ms();
         for (int f = 0; f < frames; f++) { drawFrame(); slot = RT64.ext.SubmitGather(gather); if (slot < 0) die(RT64.lib.GetLastError()); }
         const size_t got = RT64.ext.ReadbackGather(gather, slot, frame, bytes, 0);          /* every rank waits for its part; rank 0 gets the frame */
+        msPerFrame = (now_ms() - t0) / (frames > 0 ? frames : 1);
         RT64.ext.DestroyGather(gather);
         if (rank != 0) { RT64.lib.DestroyDevice(RT64.device); return 0; }
         if (got != bytes) { fprintf(stderr, "sample_host: ReadbackGather: %s\n", RT64.lib.GetLastError()); return 4; }
@@ -340,7 +349,10 @@ int main(int argc, char **argv) {
         if (failed) die("a rank failed");
     }
     else {
-        for (int f = 0; f < frames; f++) drawFrame();
+        for (int f = 0; f < warmup; f++) drawFrame();
+        const double t0 = now_ms();
+        for (int f = 0; f < frames; f++) drawFrame();                          /* RT64_DrawDevice returns when the frame is in the back buffer */
+        msPerFrame = (now_ms() - t0) / (frames > 0 ? frames : 1);
         if (RT64.ext.ReadbackDevice(RT64.device, RT64_IMAGE_FINAL_RGBA8, frame, bytes) != bytes) { fprintf(stderr, "sample_host: readback: %s\n", RT64.lib.GetLastError()); return 4; }
     }
     unsigned long long sum = 0, fnv = 1469598103934665603ull;
@@ -350,8 +362,8 @@ int main(int argc, char **argv) {
     RT64_FRAME_STATS st; memset(&st, 0, sizeof(st)); st.structSize = (unsigned int)sizeof(st);
     float gpuMs = 0.0f;
     if (RT64.ext.GetDeviceStats && RT64.ext.GetDeviceStats(RT64.device, &st)) gpuMs = st.msTotal;
-    printf("{\"host\": \"C (tools/sample_host.c)\", \"width\": %d, \"height\": %d, \"frames\": %d, \"ranks\": %d, \"checksum\": %llu, \"fnv1a\": \"%016llx\", \"picked_center\": \"%s\", \"gpu_ms_last_frame\": %.4f}\n",
-           width, height, frames, ranks, sum, fnv, pickedName, gpuMs);
+    printf("{\"host\": \"C (tools/sample_host.c)\", \"width\": %d, \"height\": %d, \"frames\": %d, \"ranks\": %d, \"checksum\": %llu, \"fnv1a\": \"%016llx\", \"picked_center\": \"%s\", \"gpu_ms_last_frame\": %.4f, \"ms_per_frame\": %.5f}\n",
+           width, height, frames, ranks, sum, fnv, pickedName, gpuMs, msPerFrame);
     if (dump) { FILE *f = fopen(dump, "wb"); if (f) { fwrite(frame, 1, bytes, f); fclose(f); } }
     free(frame);
 
