@@ -506,7 +506,8 @@ def load_counters(workload):
 
 COUNTER_WORKLOAD = [None]
 # bench.py's kernel groups -> (profile kernel, launches per frame)
-GROUPS = {"indirect": [("bounce_trace", 1), ("bounce_hit", 1), ("bounce_miss", 1), ("bounce_resolve", 1)],
+GROUPS = {"indirect": [("bounce_trace", 1), ("bounce_hit", 1), ("bounce_miss", 1), ("bounce_resolve", 1)],        # bounce_miss: only behind the refill walk
+          "_optional": {"bounce_miss"},
           "svgf_denoise": [("svgf_guide", 1), ("svgf_variance", 1), ("svgf_atrous", 5)], "reflection_refraction": [("reflection", 2)]}
 
 
@@ -514,11 +515,11 @@ def group_counters(kernels, key):
     """Counters of one bench.py kernel group per frame: a single profiled kernel, or the sum over the launches the group stands for."""
     if key in kernels:
         return kernels[key]
-    if key not in GROUPS or any(k not in kernels for k, _ in GROUPS[key]):
+    if key not in GROUPS or any(k not in kernels and k not in GROUPS["_optional"] for k, _ in GROUPS[key]):
         return None
     out = {}
     for k, n in GROUPS[key]:
-        for c, v in kernels[k].items():
+        for c, v in kernels.get(k, {}).items():
             if c.startswith("SQ_") or c in ("hbm_bytes", "fetch_bytes_x2", "write_bytes", "avg_ns"):
                 out[c] = out.get(c, 0.0) + n * v
     return out

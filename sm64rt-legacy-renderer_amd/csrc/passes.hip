@@ -775,6 +775,8 @@ DEV void bounce_append(IRef I, uint32_t *ldsCount, uint32_t segment, size_t miss
 }
 DEV size_t bounce_miss_base(PRef P, uint32_t segment) { return (size_t)gridDim.x * segment; }
 
+DEV f3 bounce_sky_term(PRef P, f3 rayDirection);
+
 template <bool CACHED>
 __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kernel(FrameParams Pv, ViewImages Iv) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
@@ -800,6 +802,7 @@ __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kern
         if (I.instanceId[i] < 0) continue;
         const float4 pos4 = reinterpret_cast<const float4 *>(I.shadingPosition)[i];
         const f3 rayOrigin = mk3(pos4.x, pos4.y, pos4.z), shadingNormal = xyz(load_rgba16f(I.shadingNormal, i));
+        const f3 ambientBase = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]);
         const uint32_t blueNoiseMult = 64u / P.giSamples;
         for (uint32_t smp = P.giSamples; smp > 0; smp--) {
             const f3 rayDirection = cos_hemisphere_blue_noise(P, px, py, P.frameCount + smp * blueNoiseMult, shadingNormal);
@@ -807,13 +810,21 @@ __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kern
             SurfaceHit best;
             trace_surface<false, CACHED>(P, env, I, i, rayOrigin, rayDirection, rd, px, py, best);
             rays++;
+            const size_t id = (size_t)(smp - 1) * stride + i;
+            if (!best.hit) {
+                // a ray that leaves the scene is finished here: its radiance is the sky term (what bounce_miss_kernel computes from a record and a
+                // list entry -- one 16-byte store instead of a 32-byte record, a list append, and a kernel that reads both back)
+                const f3 resIndirect = ambientBase + bounce_sky_term(P, rayDirection) * (P.giSkyStrength * 1.0f);
+                I.bounceResults[id] = make_float4(resIndirect.x, resIndirect.y, resIndirect.z, 0.0f);
+                continue;
+            }
             uint4 a, b;
             a.x = __float_as_uint(best.t); a.y = __float_as_uint(best.u); a.z = __float_as_uint(best.v); a.w = best.prim;
             b.x = __float_as_uint(rayDirection.x); b.y = __float_as_uint(rayDirection.y); b.z = __float_as_uint(rayDirection.z);
-            b.w = best.hit ? best.instance : 0xFFFFFFFFu;
-            uint4 *rec = I.bounceRecords + ((size_t)(smp - 1) * stride + i) * 2;
+            b.w = best.instance;
+            uint4 *rec = I.bounceRecords + id * 2;
             rec[0] = a; rec[1] = b;
-            bounce_append(I, ldsCount, segment, missBase, best.hit, (uint32_t)((size_t)(smp - 1) * stride + i));
+            bounce_append(I, ldsCount, segment, missBase, true, (uint32_t)id);
         }
     }
     __syncthreads();
@@ -1412,7 +1423,7 @@ hipError_t RT_LAUNCHER(launch_indirect)(const FrameParams &P, const ViewImages &
     // same grid for the three kernels: workgroup b shades the segments workgroup b of bounce_trace filled (lengths stay on the device)
     if (P.cacheWords) hipLaunchKernelGGL(bounce_hit_kernel<true>, dim3(rt_grid(P)), dim3(RT_BLOCK), cached_lds_bytes(P, true), s, P, I);
     else hipLaunchKernelGGL(bounce_hit_kernel<false>, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
-    hipLaunchKernelGGL(bounce_miss_kernel, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
+    if (walk == BOUNCE_WALK_REFILL) hipLaunchKernelGGL(bounce_miss_kernel, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, P, I);      // the plain walk finishes its misses itself
     dim3 grid((unsigned)(P.width + 31) / 32, (unsigned)(P.tileY1 - P.tileY0 + 7) / 8);
     hipLaunchKernelGGL(bounce_resolve_kernel, grid, dim3(256), 0, s, P, I, cur, writeFiltered ? 1 : 0);
     return hipGetLastError();
