@@ -21,7 +21,8 @@
 // Round 2 measured the other way to reuse taps as well: steps 1 and 2 with the workgroup's (64 + 4S) x (8 + 4S) input pixels staged in LDS
 // (1.6 / 2.3 global loads per output instead of 50, same values into the same arithmetic).  Slower again -- C3 SVGF 0.240 against 0.210 ms,
 // C5 0.800 against 0.751 (profiles/r02_experiments/atrous_lds_tiled*, the patch is there too): the staging barrier and 5 instead of 8
-// waves per SIMD cost more than the loads they replace, which the L1 serves at its hit rate anyway.
+// waves per SIMD cost more than the loads they replace, which the L1 serves at its hit rate anyway.  Nor is it the bytes per tap: 12-byte guide
+// records (`global_load_dwordx3`, the depth gradient moved to its own array; 20 instead of 24 B per tap) measured 0.212 / 0.753 ms.
 #include "kernels.h"
 #include "device_math.h"
 
