@@ -18,7 +18,8 @@
  *   G3  leaves sorted ascending by key.
  *   G4  inner node i in [0, n-2] by Karras' range/split search with delta(i,j) = clz64(key_i ^ key_j),
  *       delta = -1 outside [0, n-1].  Children: split g -> left = (min(range)==g ? leaf g : inner g),
- *       right = (max(range)==g+1 ? leaf g+1 : inner g+1).  Root = inner 0.
+ *       right = (max(range)==g+1 ? leaf g+1 : inner g+1).  Root = inner 0.  The node's `pad` word keeps j, the other end of
+ *       its leaf range [min(i, j), max(i, j)] (0 in a single-leaf tree).
  *   G5  node i stores the boxes of both children (ONode).  n == 1: node 0 = {left = leaf 0, right = none with an
  *       empty box (min=+inf, max=-inf)}.
  *   G6  refit keeps sort order and topology and recomputes boxes only.
@@ -165,6 +166,7 @@ void obvh_build(OBvh *b, uint32_t n, const float *boxMin, const float *boxMax, f
             ONode *nd = &b->nodes[i];
             if (lo == g) nd->left = 0x80000000u | (uint32_t)g; else { nd->left = (uint32_t)g; b->nodes[g].parent = (uint32_t)i; }
             if (hi == g + 1) nd->right = 0x80000000u | (uint32_t)(g + 1); else { nd->right = (uint32_t)(g + 1); b->nodes[g + 1].parent = (uint32_t)i; }
+            nd->pad = (uint32_t)j;          /* G4: the node keeps the other end of its leaf range [min(i, j), max(i, j)] (the GPU's chunked box fit asks for it) */
         }
     }
     obvh_fit(b, smin, smax);

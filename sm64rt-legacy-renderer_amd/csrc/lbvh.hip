@@ -210,7 +210,7 @@ DEV void lbvh_small_body(const LbvhArgs &a, uint32_t *lds) {
                 else { left = (uint32_t)g; parentNode[g] = (uint32_t)i; a.nodes[g].parent = (uint32_t)i; }
                 if (hi == g + 1) { right = RT64_LEAF_BIT | (uint32_t)(g + 1); parentLeaf[g + 1] = (uint32_t)i; a.leafParent[g + 1] = (uint32_t)i; }
                 else { right = (uint32_t)(g + 1); parentNode[g + 1] = (uint32_t)i; a.nodes[g + 1].parent = (uint32_t)i; }
-                a.nodes[i].left = left; a.nodes[i].right = right; a.nodes[i].pad = 0;
+                a.nodes[i].left = left; a.nodes[i].right = right; a.nodes[i].pad = (uint32_t)j;      // the other end of the leaf range (G4)
             }
         }
     }
@@ -342,20 +342,28 @@ hipError_t lbvh_launch_batch(const LbvhArgs *deviceArgs, uint32_t count, uint32_
 // ---- large trees (n > LBVH_SMALL_MAX) -----------------------------------------------------------------------------------------
 // Same Geometry spec (G1-G6), spread over the whole chip:
 //   bounds (ordered-uint atomics) -> Morton keys -> 4 x 8-bit stable LSD radix passes {histogram, scan, scatter} -> Karras
-//   nodes -> leaves in Morton order -> level-synchronous box fit (one launch per tree level, <= 30 + log2(n) + 2 launches;
-//   kernel boundaries give the cross-XCD visibility the bottom-up atomic version would need fences for).
+//   nodes -> leaves in Morton order -> bottom-up box fit in two launches (chunk-local nodes by one workgroup per chunk, the nodes that
+//   span chunks by a single workgroup: no fence ever has to cross an XCD, see lg_fit_local_kernel).
 // Scratch (caller-allocated, lbvh_large_scratch_bytes): keys/vals x2, histogram, bounds, leaf boxes, node boxes, done stamps.
 namespace {
 
 #define LG_THREADS 256
 #define LG_TILE 2048            // keys per workgroup in the radix passes
+#define LG_CHUNK 2048           // leaves (in Morton order) per workgroup of the box fit
+#define LG_ROOT_SLOTS 192       // list entries per chunk: the maximal subtrees inside an interval of leaves number at most 2 x depth (depth <= 62 key bits + 1)
 
 struct LargeScratch {
-    uint32_t *keyA, *valA, *keyB, *valB, *hist, *bounds, *done;
+    uint32_t *keyA, *valA, *keyB, *valB, *hist, *bounds, *done, *rootList, *rootCount;
     float *leafBox, *nodeBox;   // [n][6]
     uint32_t blocks;
 };
 
+#define LG_FAN_LISTS 64          // = LG_FAN (defined with the fit kernels): lists one workgroup of a level takes from the level below
+__host__ __device__ inline size_t lg_lists_all_levels(uint32_t n) {      // root lists of every level of the fit, back to back: chunks, groups of chunks, ... , 1 (+ the unused list of the last level)
+    size_t total = 0, lists = ((size_t)n + LG_CHUNK - 1) / LG_CHUNK;
+    for (;;) { total += lists; if (lists == 1) break; lists = (lists + LG_FAN_LISTS - 1) / LG_FAN_LISTS; }
+    return total + 1;
+}
 __host__ __device__ inline LargeScratch carve(void *base, uint32_t n) {
     LargeScratch L;
     const uint32_t blocks = (n + LG_TILE - 1) / LG_TILE;
@@ -363,10 +371,12 @@ __host__ __device__ inline LargeScratch carve(void *base, uint32_t n) {
     auto take = [&](size_t bytes) { uint8_t *r = p; p += (bytes + 255) & ~(size_t)255; return r; };
     L.keyA = reinterpret_cast<uint32_t *>(take((size_t)n * 4)); L.valA = reinterpret_cast<uint32_t *>(take((size_t)n * 4));
     L.keyB = reinterpret_cast<uint32_t *>(take((size_t)n * 4)); L.valB = reinterpret_cast<uint32_t *>(take((size_t)n * 4));
-    L.hist = reinterpret_cast<uint32_t *>(take((size_t)blocks * 256 * 4));
+    L.hist = reinterpret_cast<uint32_t *>(take(((size_t)blocks + 1) * 256 * 4));      // [digit][block] counts, then the 256 row totals
     L.bounds = reinterpret_cast<uint32_t *>(take(64));
     L.done = reinterpret_cast<uint32_t *>(take((size_t)n * 4));
     L.leafBox = reinterpret_cast<float *>(take((size_t)n * 24)); L.nodeBox = reinterpret_cast<float *>(take((size_t)n * 24));
+    const size_t listsAllLevels = lg_lists_all_levels(n);
+    L.rootList = reinterpret_cast<uint32_t *>(take(listsAllLevels * LG_ROOT_SLOTS * 4)); L.rootCount = reinterpret_cast<uint32_t *>(take(listsAllLevels * 4));
     L.blocks = blocks;
     return L;
 }
@@ -426,31 +436,30 @@ __global__ __launch_bounds__(LG_THREADS) void lg_hist_kernel(const uint32_t *key
     hist[threadIdx.x * blocks + blockIdx.x] = h[threadIdx.x];
 }
 
-// exclusive scan of hist[0 .. 256*blocks) in place (single workgroup of 1024)
-__global__ __launch_bounds__(1024) void lg_scan_kernel(uint32_t *hist, uint32_t total) {
-    __shared__ uint32_t waveTot[16];
+// Exclusive scan of the histogram in (digit, block) order, in two levels: workgroup d scans row d (the `blocks` counts of digit d) in
+// place and leaves the row's total in hist[256 * blocks + d]; the scatter kernel adds the exclusive scan of those 256 totals itself.
+// (One workgroup over all 256 * blocks entries -- 1.3 M for 5 M triangles -- took 308 us per radix pass.)
+__global__ __launch_bounds__(LG_THREADS) void lg_scan_rows_kernel(uint32_t *hist, uint32_t blocks) {
+    __shared__ uint32_t waveTot[LG_THREADS / 64];
     __shared__ uint32_t carry;
+    uint32_t *row = hist + (size_t)blockIdx.x * blocks;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < total; base += 1024) {
-        uint32_t i = base + threadIdx.x;
-        uint32_t v = i < total ? hist[i] : 0u;
-        uint32_t incl = wave_inclusive_scan(v, lane);
+    for (uint32_t base = 0; base < blocks; base += LG_THREADS) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < blocks ? row[i] : 0u;
+        const uint32_t incl = wave_inclusive_scan(v, lane);
         if (lane == 63) waveTot[wave] = incl;
         __syncthreads();
-        if (wave == 0) {
-            uint32_t w = lane < 16 ? waveTot[lane] : 0u;
-            uint32_t s2 = wave_inclusive_scan(w, lane);
-            if (lane < 16) waveTot[lane] = s2 - w;
-        }
+        uint32_t before = carry;
+        for (int w = 0; w < wave; w++) before += waveTot[w];
+        if (i < blocks) row[i] = before + incl - v;
         __syncthreads();
-        const uint32_t c = carry;
-        if (i < total) hist[i] = c + waveTot[wave] + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = c + waveTot[15] + incl;
+        if (threadIdx.x == LG_THREADS - 1) carry = before + incl;
         __syncthreads();
     }
+    if (threadIdx.x == 0) hist[(size_t)256 * blocks + blockIdx.x] = carry;
 }
 
 // stable scatter of one tile: rounds of 256 keys in index order; rank inside a wave by ballot matching
@@ -459,7 +468,16 @@ __global__ __launch_bounds__(LG_THREADS) void lg_scatter_kernel(const uint32_t *
     __shared__ uint32_t digitOffset[256];
     __shared__ uint32_t waveCount[4][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    digitOffset[threadIdx.x] = hist[threadIdx.x * blocks + blockIdx.x];
+    {   // where this tile's keys of digit d go: keys of smaller digits (exclusive scan of the 256 row totals) + keys of digit d in earlier tiles
+        const uint32_t total = hist[(size_t)256 * blocks + threadIdx.x];
+        const uint32_t incl = wave_inclusive_scan(total, lane);
+        if (lane == 63) waveCount[0][wave] = incl;
+        __syncthreads();
+        uint32_t before = 0;
+        for (int w = 0; w < wave; w++) before += waveCount[0][w];
+        digitOffset[threadIdx.x] = before + incl - total + hist[(size_t)threadIdx.x * blocks + blockIdx.x];
+        __syncthreads();
+    }
     const uint32_t base = blockIdx.x * LG_TILE;
     for (uint32_t r = 0; r < LG_TILE / LG_THREADS; r++) {
         for (int w = 0; w < 4; w++) waveCount[w][threadIdx.x] = 0;
@@ -515,7 +533,7 @@ __global__ __launch_bounds__(LG_THREADS) void lg_karras_kernel(LbvhArgs a, const
         uint32_t left, right;
         if (lo == g) { left = RT64_LEAF_BIT | (uint32_t)g; a.leafParent[g] = (uint32_t)i; } else { left = (uint32_t)g; a.nodes[g].parent = (uint32_t)i; }
         if (hi == g + 1) { right = RT64_LEAF_BIT | (uint32_t)(g + 1); a.leafParent[g + 1] = (uint32_t)i; } else { right = (uint32_t)(g + 1); a.nodes[g + 1].parent = (uint32_t)i; }
-        a.nodes[i].left = left; a.nodes[i].right = right; a.nodes[i].pad = 0;
+        a.nodes[i].left = left; a.nodes[i].right = right; a.nodes[i].pad = (uint32_t)j;      // pad = the other end of the node's leaf range [min(i, j), max(i, j)]: the fit asks whether a node lies inside one chunk
     }
 }
 
@@ -539,38 +557,106 @@ __global__ __launch_bounds__(LG_THREADS) void lg_leaves_kernel(LbvhArgs a, float
     }
 }
 
-// One tree level: an inner node whose children were finished by EARLIER launches (stamp in [1, pass]) takes their boxes.
-__global__ __launch_bounds__(LG_THREADS) void lg_fit_kernel(LbvhArgs a, const float *leafBox, float *nodeBox, uint32_t *done, uint32_t pass) {
-    for (uint32_t i = blockIdx.x * LG_THREADS + threadIdx.x; i + 1 < a.n; i += gridDim.x * LG_THREADS) {
-        if (done[i]) continue;
-        GpuNode &nd = a.nodes[i];
-        const uint32_t l = nd.left, r = nd.right;
-        const bool lLeaf = l & RT64_LEAF_BIT, rLeaf = r & RT64_LEAF_BIT;
-        if (!lLeaf) { uint32_t st = done[l]; if (st == 0 || st > pass) continue; }
-        if (!rLeaf) { uint32_t st = done[r]; if (st == 0 || st > pass) continue; }
-        const float *lb = lLeaf ? leafBox + 6 * (size_t)(l & 0x7FFFFFFFu) : nodeBox + 6 * (size_t)l;
-        const float *rb = rLeaf ? leafBox + 6 * (size_t)(r & 0x7FFFFFFFu) : nodeBox + 6 * (size_t)r;
-        float mn[3], mx[3];
+// Box fit in a few launches instead of one per tree level.  The leaves (Morton order) are cut into chunks of LG_CHUNK, chunks into groups
+// of LG_FAN chunks, groups into groups of groups ...; an inner node is LOCAL at granularity G when its leaf range [min(i, pad), max(i, pad)]
+// lies inside one interval of G leaves, and then both of its subtrees do.
+//   lg_fit_local_kernel : one workgroup per chunk fits the chunk's local nodes bottom-up -- a lane climbs from its leaf, the first arrival
+//                         at a node leaves its box there and stops, the second merges and goes on (arrival counters in LDS: a local node's
+//                         index lies inside the chunk; workgroup-scope fences: both arrivals belong to this workgroup).  A climb stops below
+//                         the first node that is not local and puts the subtree it finished (a leaf or an inner node: a "root") on the
+//                         chunk's list.
+//   lg_fit_group_kernel : one workgroup per group of LG_FAN lists climbs from every listed root through the nodes local at the group's
+//                         granularity, same protocol (counters in HBM now), and lists what it finished for the next level; the last
+//                         level is one workgroup for which every node is local.
+// No fence ever has to cross an XCD: a node is fitted by exactly one workgroup, and what that workgroup reads from earlier levels was
+// written by earlier launches.  Unions of boxes do not depend on the order of arrival: the boxes are the ones the level-by-level fit
+// produced (105 launches, 2.1 ms for the 5.4 M-triangle stress scene; a single workgroup for everything above the chunks: 3.2 ms).
+static_assert(LG_FAN_LISTS == 64, "LG_FAN");
+#define LG_FAN LG_FAN_LISTS
+DEV bool lg_is_local(const GpuNode &nd, uint32_t i, uint32_t granule) {
+    const uint32_t lo = i < nd.pad ? i : nd.pad, hi = i < nd.pad ? nd.pad : i;
+    return lo / granule == hi / granule;
+}
+// climbs from `child` (box b) through the nodes local at `granule`; ended = it stopped below a node that is not (child / b then describe a root)
+template <class Counter>
+DEV void lg_climb(LbvhArgs a, float *nodeBox, Counter &&counter, uint32_t granule, uint32_t &child, uint32_t p, Box &b, bool &ended) {
+    ended = false;
+    for (;;) {
+        GpuNode &nd = a.nodes[p];
+        if (!lg_is_local(nd, p, granule)) { ended = true; return; }
+        const bool isLeft = nd.left == child;
+        float *dmn = isLeft ? nd.lmin : nd.rmin, *dmx = isLeft ? nd.lmax : nd.rmax;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { dmn[k] = b.mn[k]; dmx[k] = b.mx[k]; }
+        __threadfence_block();
+        if (atomicAdd(counter(p), 1u) == 0) return;             // the sibling subtree finishes this node
+        __threadfence_block();
+        const float *smn = isLeft ? nd.rmin : nd.lmin, *smx = isLeft ? nd.rmax : nd.lmax;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            nd.lmin[k] = lb[k]; nd.lmax[k] = lb[3 + k]; nd.rmin[k] = rb[k]; nd.rmax[k] = rb[3 + k];
-            mn[k] = fminf(lb[k], rb[k]); mx[k] = fmaxf(lb[3 + k], rb[3 + k]);
-            nodeBox[6 * (size_t)i + k] = mn[k]; nodeBox[6 * (size_t)i + 3 + k] = mx[k];
+            const float omn = *(volatile const float *)&smn[k], omx = *(volatile const float *)&smx[k];
+            b.mn[k] = fminf(b.mn[k], omn); b.mx[k] = fmaxf(b.mx[k], omx);
         }
-        if (i == 0) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) { a.header->bmin[k] = mn[k]; a.header->bmax[k] = mx[k]; }
+        for (int k = 0; k < 3; k++) { nodeBox[6 * (size_t)p + k] = b.mn[k]; nodeBox[6 * (size_t)p + 3 + k] = b.mx[k]; }
+        if (p == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { a.header->bmin[k] = b.mn[k]; a.header->bmax[k] = b.mx[k]; }
             a.header->count = a.n; a.header->depth = 255;
+            return;
         }
-        done[i] = pass + 1;
+        child = p; p = nd.parent;
     }
+}
+#define LG_FIT_THREADS 1024      // two leaves per lane: a climb is a chain of L2 round trips, so the chunk wants lanes, not trips
+__global__ __launch_bounds__(LG_FIT_THREADS) void lg_fit_local_kernel(LbvhArgs a, const float *leafBox, float *nodeBox, uint32_t *rootList, uint32_t *rootCount) {
+    __shared__ uint32_t arrivals[LG_CHUNK];
+    __shared__ uint32_t listed;
+    for (uint32_t k = threadIdx.x; k < LG_CHUNK; k += LG_FIT_THREADS) arrivals[k] = 0;
+    if (threadIdx.x == 0) listed = 0;
+    __syncthreads();
+    const uint32_t first = blockIdx.x * LG_CHUNK;
+    for (uint32_t s = first + threadIdx.x; s < first + LG_CHUNK && s < a.n; s += LG_FIT_THREADS) {
+        Box b;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { b.mn[k] = leafBox[6 * (size_t)s + k]; b.mx[k] = leafBox[6 * (size_t)s + 3 + k]; }
+        uint32_t child = RT64_LEAF_BIT | s;
+        bool ended;
+        lg_climb(a, nodeBox, [&](uint32_t p) { return &arrivals[p - first]; }, LG_CHUNK, child, a.leafParent[s], b, ended);
+        if (ended) { const uint32_t k = atomicAdd(&listed, 1u); if (k < LG_ROOT_SLOTS) rootList[(size_t)blockIdx.x * LG_ROOT_SLOTS + k] = child; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) rootCount[blockIdx.x] = listed < LG_ROOT_SLOTS ? listed : LG_ROOT_SLOTS;
+}
+// lists [blockIdx.x * LG_FAN, + LG_FAN) of the level below -> the nodes local at `granule` (0xFFFFFFFF: all of them) -> this group's list
+__global__ __launch_bounds__(1024) void lg_fit_group_kernel(LbvhArgs a, const float *leafBox, float *nodeBox, uint32_t *counter, const uint32_t *inList, const uint32_t *inCount,
+                                                            uint32_t inLists, uint32_t granule, uint32_t *outList, uint32_t *outCount) {
+    __shared__ uint32_t listed;
+    if (threadIdx.x == 0) listed = 0;
+    __syncthreads();
+    const uint32_t firstList = blockIdx.x * LG_FAN, lists = inLists - firstList < LG_FAN ? inLists - firstList : LG_FAN;
+    for (uint32_t e = threadIdx.x; e < lists * LG_ROOT_SLOTS; e += 1024) {
+        const uint32_t list = firstList + e / LG_ROOT_SLOTS, k = e % LG_ROOT_SLOTS;
+        if (k >= inCount[list]) continue;
+        uint32_t child = inList[(size_t)list * LG_ROOT_SLOTS + k];
+        const float *src = (child & RT64_LEAF_BIT) ? leafBox + 6 * (size_t)(child & 0x7FFFFFFFu) : nodeBox + 6 * (size_t)child;
+        Box b;
+#pragma unroll
+        for (int q = 0; q < 3; q++) { b.mn[q] = src[q]; b.mx[q] = src[3 + q]; }
+        const uint32_t p = (child & RT64_LEAF_BIT) ? a.leafParent[child & 0x7FFFFFFFu] : a.nodes[child].parent;
+        bool ended;
+        lg_climb(a, nodeBox, [&](uint32_t q) { return &counter[q]; }, granule, child, p, b, ended);
+        if (ended) { const uint32_t slot = atomicAdd(&listed, 1u); if (slot < LG_ROOT_SLOTS) outList[(size_t)blockIdx.x * LG_ROOT_SLOTS + slot] = child; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) outCount[blockIdx.x] = listed < LG_ROOT_SLOTS ? listed : LG_ROOT_SLOTS;
 }
 
 }  // namespace
 
 size_t lbvh_large_scratch_bytes(uint32_t n) {
     const size_t blocks = ((size_t)n + LG_TILE - 1) / LG_TILE;
-    return (size_t)n * (4 * 4 + 4 + 24 + 24) + blocks * 256 * 4 + 64 + 16 * 256;
+    return (size_t)n * (4 * 4 + 4 + 24 + 24) + (blocks + 1) * 256 * 4 + 64 + 16 * 256 + lg_lists_all_levels(n) * (LG_ROOT_SLOTS + 1) * 4 + 2 * 256;
 }
 
 hipError_t lbvh_launch_large(const LbvhArgs &args, hipStream_t stream) {
@@ -585,15 +671,23 @@ hipError_t lbvh_launch_large(const LbvhArgs &args, hipStream_t stream) {
         uint32_t *kin = L.keyA, *vin = L.valA, *kout = L.keyB, *vout = L.valB;
         for (int shift = 0; shift < 32; shift += 8) {      // 30 code bits: four 8-bit digits
             hipLaunchKernelGGL(lg_hist_kernel, dim3(L.blocks), dim3(LG_THREADS), 0, stream, kin, n, shift, L.hist, L.blocks);
-            hipLaunchKernelGGL(lg_scan_kernel, dim3(1), dim3(1024), 0, stream, L.hist, L.blocks * 256u);
+            hipLaunchKernelGGL(lg_scan_rows_kernel, dim3(256), dim3(LG_THREADS), 0, stream, L.hist, L.blocks);
             hipLaunchKernelGGL(lg_scatter_kernel, dim3(L.blocks), dim3(LG_THREADS), 0, stream, kin, vin, kout, vout, n, shift, L.hist, L.blocks);
             std::swap(kin, kout); std::swap(vin, vout);
         }
         hipLaunchKernelGGL(lg_karras_kernel, dim3(grid), dim3(LG_THREADS), 0, stream, args, kin, vin);
     }
     hipLaunchKernelGGL(lg_leaves_kernel, dim3(grid), dim3(LG_THREADS), 0, stream, args, L.leafBox, L.done);
-    uint32_t depthBound = 32; { uint32_t m = n; while (m) { depthBound++; m >>= 1; } }      // 30 code bits + log2(n) index bits + slack
-    for (uint32_t pass = 1; pass <= depthBound; pass++)
-        hipLaunchKernelGGL(lg_fit_kernel, dim3(grid), dim3(LG_THREADS), 0, stream, args, L.leafBox, L.nodeBox, L.done, pass);
+    uint32_t lists = (n + LG_CHUNK - 1) / LG_CHUNK;
+    uint32_t *inList = L.rootList, *inCount = L.rootCount;
+    hipLaunchKernelGGL(lg_fit_local_kernel, dim3(lists), dim3(LG_FIT_THREADS), 0, stream, args, L.leafBox, L.nodeBox, inList, inCount);
+    for (uint64_t granule = (uint64_t)LG_CHUNK * LG_FAN;; granule *= LG_FAN) {         // levels above the chunks: 2 560 chunks -> 40 groups -> 1
+        const uint32_t groups = (lists + LG_FAN - 1) / LG_FAN;
+        uint32_t *outList = inList + (size_t)lists * LG_ROOT_SLOTS, *outCount = inCount + lists;
+        hipLaunchKernelGGL(lg_fit_group_kernel, dim3(groups), dim3(1024), 0, stream, args, L.leafBox, L.nodeBox, L.done, inList, inCount, lists,
+                           groups == 1 ? 0xFFFFFFFFu : (uint32_t)granule, outList, outCount);
+        if (groups == 1) break;
+        lists = groups; inList = outList; inCount = outCount;
+    }
     return hipGetLastError();
 }

@@ -21,7 +21,7 @@
 struct alignas(16) GpuNode {
     float lmin[3], lmax[3];
     float rmin[3], rmax[3];
-    uint32_t left, right, parent, pad;
+    uint32_t left, right, parent, pad;   // pad: the other end j of the node's leaf range [min(i, j), max(i, j)] (Karras' split search; 0 in a single-leaf tree)
 };
 static_assert(sizeof(GpuNode) == 64, "GpuNode");
 

@@ -809,6 +809,7 @@ static void host_build_tlas(const GpuInstance *inst, const float (*meshMin)[3], 
         const int g = i + s * d + (d < 0 ? -1 : 0), lo_ = i < j ? i : j, hi_ = i < j ? j : i;
         if (lo_ == g) nodes[i].left = RT64_LEAF_BIT | (uint32_t)g; else { nodes[i].left = (uint32_t)g; nodes[g].parent = (uint32_t)i; }
         if (hi_ == g + 1) nodes[i].right = RT64_LEAF_BIT | (uint32_t)(g + 1); else { nodes[i].right = (uint32_t)(g + 1); nodes[g + 1].parent = (uint32_t)i; }
+        nodes[i].pad = (uint32_t)j;
     }
     struct Fit { static uint32_t run(GpuNode *nodes, uint32_t i, const std::vector<float> &lo, const std::vector<float> &hi, const uint32_t *sorted, float *mn, float *mx) {
         GpuNode &nd = nodes[i]; uint32_t depth = 0;                      // G5: children's boxes in the parent; returns the subtree's depth in inner nodes

@@ -168,7 +168,8 @@ def test_many_meshes_set_between_frames_build_in_one_batch(rt64_lib, sample_data
         return v, np.arange(3 * n_tri, dtype=np.uint32)
 
     def mod(d):
-        sizes = [1, 2, 7, 64, 300, 1024, 1500, 4096, 5000] + [int(x) for x in rng.integers(3, 200, size=24)]
+        # index 11 (6000 triangles) is UPDATABLE and refitted in frame 1: the multi-kernel path's refit (leaf boxes + the chunked bottom-up fit on the kept topology)
+        sizes = [1, 2, 7, 64, 300, 1024, 1500, 4096, 5000, 33, 77, 6000] + [int(x) for x in rng.integers(3, 200, size=21)]
         for k, n in enumerate(sizes):
             v, i = blob(-6.0 + 1.5 * (k % 9), -2.0 + 1.5 * (k // 9), n)
             d.meshes.append(sample_scene.MeshData("blob%d" % k, rt64.MESH_RAYTRACE_ENABLED | (rt64.MESH_RAYTRACE_UPDATABLE if k % 2 else 0), v, i))

@@ -128,7 +128,7 @@ def test_blas_tlas_bit_exact(scene_256, oracle_256):
         assert np.array_equal(_accel(lib, lib.ReadbackMeshAccel, h, rt64.ACCEL_MORTON, np.uint32), ref["morton"])
         assert np.array_equal(_accel(lib, lib.ReadbackMeshAccel, h, rt64.ACCEL_SORTED_INDEX, np.uint32), ref["sortedIndex"])
         nodes = _accel(lib, lib.ReadbackMeshAccel, h, rt64.ACCEL_NODES, oracle_py.NODE_DTYPE)
-        for f in ("lmin", "lmax", "rmin", "rmax", "left", "right"):
+        for f in ("lmin", "lmax", "rmin", "rmax", "left", "right", "pad"):
             assert np.array_equal(nodes[f], ref["nodes"][f]), (mesh_index, f)
         assert np.array_equal(nodes["parent"][1:], ref["nodes"]["parent"][1:])
         tris = _accel(lib, lib.ReadbackMeshAccel, h, rt64.ACCEL_TRIANGLES, oracle_py.TRI_DTYPE)
@@ -187,7 +187,7 @@ def test_tlas_host_and_gpu_builders_agree(rt64_lib, oracle_lib, extra):
             g = got[host]
             assert np.array_equal(g["index"], tl["sortedIndex"]), host
             assert np.array_equal(g["morton"], tl["morton"]), host
-            for f in ("lmin", "lmax", "rmin", "rmax", "left", "right"):
+            for f in ("lmin", "lmax", "rmin", "rmax", "left", "right", "pad"):
                 assert np.array_equal(g["nodes"][f].view(np.uint32), tl["nodes"][f].view(np.uint32)), (host, f)
         assert np.array_equal(got[0]["nodes"]["parent"][1:], got[1]["nodes"]["parent"][1:])
         assert np.array_equal(got[0]["header"][[0, 1, 2, 3, 4, 5, 6]], got[1]["header"][[0, 1, 2, 3, 4, 5, 6]])      # bounds + count
