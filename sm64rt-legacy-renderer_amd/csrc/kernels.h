@@ -70,6 +70,8 @@ hipError_t launch_clear_final(const FrameParams &P, const ViewImages &I, hipStre
 // ---- raster.hip ----------------------------------------------------------------------------------------------------
 size_t raster_tri_bytes(uint32_t triTotal);       // setup records of a draw list
 // Triangle setup of a draw list for a w x h target, rows [y0, y1); `apply` = drawInstances' applyScissorsAndViewports (rt64_view.cpp:1225).
+bool raster_setup_takes_table_inline(uint32_t instanceCount);      // short lists: the table travels in the kernel arguments (launch_raster_setup_inline), no copy
+hipError_t launch_raster_setup_inline(const GpuRasterInstance *hostTable, GpuRasterInstance *deviceTable, uint32_t instanceCount, uint32_t triTotal, void *tris, int w, int h, int y0, int y1, bool apply, hipStream_t s);
 hipError_t launch_raster_setup(const GpuRasterInstance *instances, uint32_t instanceCount, uint32_t triTotal, void *tris, int w, int h, int y0, int y1, bool apply, hipStream_t s);
 // Shade + blend the list, in order, into the RGBA8 target; `bounds` = pixel rectangle [x0, y0, x1, y1) the list can touch.
 hipError_t launch_raster_draw(const GpuRasterInstance *instances, const void *tris, uint32_t triTotal, const GpuTexture *textures, uint8_t *target,

@@ -14,6 +14,7 @@
 // pixels costs a few SALU instructions -- and keeps the destination pixel in registers until the list is exhausted
 // (one read + one write of the target per pixel, however many layers blend).  HUD lists are hundreds of triangles; no binning.
 #include <algorithm>
+#include <cstring>
 #include "kernels.h"
 #include "shade.h"
 #include "raster_pixel.h"
@@ -78,8 +79,14 @@ DEV bool raster_setup_record(RasterTri &r, const ClipVertex v[3], const uint32_t
     return ok;
 }
 
-__global__ __launch_bounds__(256) void raster_setup_kernel(const GpuRasterInstance *instances, uint32_t instanceCount, uint32_t triTotal,
-                                                           RasterTri *tris, int w, int h, int y0, int y1, int apply) {
+// Short draw lists (a HUD is one or two instances) hand their instance table to the setup kernel BY VALUE, in the kernel arguments: the
+// kernel reads it from there and writes the device copy the draw kernel (or the frame kernel, when the HUD is folded into it) reads
+// afterwards -- a frame that re-stages its lists then has no table copy in front of the setup launch (5.6 us each on the stream).
+#define RASTER_INLINE_MAX 16
+struct RasterInlineTable { GpuRasterInstance inst[RASTER_INLINE_MAX]; };
+
+template <class Table>
+DEV void raster_setup_triangle(const Table &instances, uint32_t instanceCount, uint32_t triTotal, RasterTri *tris, int w, int h, int y0, int y1, int apply) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= triTotal) return;
     uint32_t lo = 0, hi = instanceCount - 1;                                  // last instance with firstTri <= t
@@ -148,6 +155,19 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(const GpuRasterInstan
     first.extraCount = pieces;
     tris[t] = first;
 }
+__global__ __launch_bounds__(256) void raster_setup_kernel(const GpuRasterInstance *instances, uint32_t instanceCount, uint32_t triTotal,
+                                                           RasterTri *tris, int w, int h, int y0, int y1, int apply) {
+    raster_setup_triangle(instances, instanceCount, triTotal, tris, w, h, y0, y1, apply);
+}
+__global__ __launch_bounds__(256) void raster_setup_inline_kernel(RasterInlineTable table, GpuRasterInstance *deviceTable, uint32_t instanceCount, uint32_t triTotal,
+                                                                  RasterTri *tris, int w, int h, int y0, int y1, int apply) {
+    if (blockIdx.x == 0) {
+        const uint32_t words = instanceCount * (uint32_t)(sizeof(GpuRasterInstance) / 4);
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(&table);
+        for (uint32_t k = threadIdx.x; k < words; k += 256) reinterpret_cast<uint32_t *>(deviceTable)[k] = src[k];
+    }
+    raster_setup_triangle(table.inst, instanceCount, triTotal, tris, w, h, y0, y1, apply);
+}
 
 __global__ __launch_bounds__(256) void raster_draw_kernel(const GpuRasterInstance *__restrict__ instances, const RasterTri *__restrict__ tris, uint32_t triTotal,
                                                           const GpuTexture *__restrict__ textures, uint8_t *target, int w, int y0, int y1, int gx0, int gy0, int stripRank, int stripCount) {
@@ -169,6 +189,16 @@ size_t raster_tri_bytes(uint32_t triTotal) { return (size_t)triTotal * (1 + RAST
 hipError_t launch_raster_setup(const GpuRasterInstance *instances, uint32_t instanceCount, uint32_t triTotal, void *tris, int w, int h, int y0, int y1, bool apply, hipStream_t s) {
     if (instanceCount == 0 || triTotal == 0) return hipSuccess;
     hipLaunchKernelGGL(raster_setup_kernel, dim3((triTotal + 255) / 256), dim3(256), 0, s, instances, instanceCount, triTotal, static_cast<RasterTri *>(tris), w, h, y0, y1, apply ? 1 : 0);
+    return hipGetLastError();
+}
+bool raster_setup_takes_table_inline(uint32_t instanceCount) { return instanceCount >= 1 && instanceCount <= RASTER_INLINE_MAX; }
+// hostTable: the list's instances in host memory (copied into the launch); deviceTable: where the kernel leaves them for the draw
+hipError_t launch_raster_setup_inline(const GpuRasterInstance *hostTable, GpuRasterInstance *deviceTable, uint32_t instanceCount, uint32_t triTotal, void *tris, int w, int h, int y0, int y1, bool apply, hipStream_t s) {
+    if (!raster_setup_takes_table_inline(instanceCount)) return hipErrorInvalidValue;
+    RasterInlineTable table;
+    memset(&table, 0, sizeof(table));
+    memcpy(table.inst, hostTable, (size_t)instanceCount * sizeof(GpuRasterInstance));
+    hipLaunchKernelGGL(raster_setup_inline_kernel, dim3(triTotal ? (triTotal + 255) / 256 : 1u), dim3(256), 0, s, table, deviceTable, instanceCount, triTotal, static_cast<RasterTri *>(tris), w, h, y0, y1, apply ? 1 : 0);
     return hipGetLastError();
 }
 

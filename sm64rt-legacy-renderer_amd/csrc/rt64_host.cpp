@@ -722,14 +722,18 @@ void View::prepareRasterList(const std::vector<RenderInstance> &list, RasterList
                       rl.w == w && rl.h == h && rl.y0 == y0 && rl.y1 == y1 && rl.apply == apply && !dev->opt.alwaysRebuild;
     if (same) return;
     rl.table.reserve(hst.size()); rl.tris.reserve(std::max<size_t>(raster_tri_bytes(triTotal), 16));
-    uint8_t *stage = static_cast<uint8_t *>(dev->ringAlloc(bytes));       // pinned upload ring: queued without a wait
-    memcpy(stage, hst.data(), bytes);
-    HIP_CHECK(hipMemcpyAsync(rl.table.ptr, stage, bytes, hipMemcpyHostToDevice, dev->stream));
+    const bool inlineTable = raster_setup_takes_table_inline((uint32_t)hst.size());      // a short list rides in the setup kernel's arguments: no copy on the stream
+    if (!inlineTable) {
+        uint8_t *stage = static_cast<uint8_t *>(dev->ringAlloc(bytes));       // pinned upload ring: queued without a wait
+        memcpy(stage, hst.data(), bytes);
+        HIP_CHECK(hipMemcpyAsync(rl.table.ptr, stage, bytes, hipMemcpyHostToDevice, dev->stream));
+    }
     rl.uploaded.assign(reinterpret_cast<uint8_t *>(hst.data()), reinterpret_cast<uint8_t *>(hst.data()) + bytes);
     rl.triTotal = triTotal; rl.w = w; rl.h = h; rl.y0 = y0; rl.y1 = y1; rl.apply = apply; rl.ready = true; rl.changed = true;
     rl.bounds[0] = std::max(0, (int)std::floor(std::min(bx0, 1e9f)) - 1); rl.bounds[1] = std::max(y0, (int)std::floor(std::min(by0, 1e9f)) - 1);
     rl.bounds[2] = std::min(w, (int)std::ceil(std::max(bx1, -1e9f)) + 2); rl.bounds[3] = std::min(y1, (int)std::ceil(std::max(by1, -1e9f)) + 2);
-    HIP_CHECK(launch_raster_setup(rl.table.ptr, (uint32_t)hst.size(), triTotal, rl.tris.ptr, w, h, y0, y1, apply, dev->stream));
+    if (inlineTable) HIP_CHECK(launch_raster_setup_inline(hst.data(), rl.table.ptr, (uint32_t)hst.size(), triTotal, rl.tris.ptr, w, h, y0, y1, apply, dev->stream));
+    else HIP_CHECK(launch_raster_setup(rl.table.ptr, (uint32_t)hst.size(), triTotal, rl.tris.ptr, w, h, y0, y1, apply, dev->stream));
 }
 
 void View::drawRasterList(RasterList &rl, uint8_t *target) {
