@@ -608,10 +608,15 @@ __global__ __launch_bounds__(RT_BLOCK, WAVES) void lean_frame_kernel(FrameParams
         const uint32_t nhits = trace_surface<false, CACHED>(P, env, I, i, o, rayDirection, noDiff, px, py, h);
         primaryCnt.nodes += env.cnt.nodes - before.nodes; primaryCnt.tris += env.cnt.tris - before.tris;
         rays++;
-        uint4 rec;
-        if (h.hit) { rec.x = __float_as_uint(h.t); rec.y = __float_as_uint(h.u); rec.z = __float_as_uint(h.v); rec.w = h.prim; hitInstance[i] = (int32_t)h.instance; }
-        else { rec.x = rec.y = rec.z = rec.w = 0xFFFFFFFFu; hitInstance[i] = -1; }
-        reinterpret_cast<uint4 *>(I.primaryHit)[i] = rec;
+        // A lean frame keeps nothing but the back buffer: hitInstance == nullptr says so, and a reader of any other image gets it from
+        // View::materialise, which runs the FULL variant of this kernel on the kept frame parameters (same rays, same arithmetic).
+        const bool keepRecords = FULL || hitInstance != nullptr;
+        if (keepRecords) {
+            uint4 rec;
+            if (h.hit) { rec.x = __float_as_uint(h.t); rec.y = __float_as_uint(h.u); rec.z = __float_as_uint(h.v); rec.w = h.prim; hitInstance[i] = (int32_t)h.instance; }
+            else { rec.x = rec.y = rec.z = rec.w = 0xFFFFFFFFu; hitInstance[i] = -1; }
+            reinterpret_cast<uint4 *>(I.primaryHit)[i] = rec;
+        }
 
         PrimaryResolve R;
         resolve_primary<false, false, FULL>(P, I, env, px, py, i, o, rayDirection, ndc, h, nhits, R);
@@ -628,7 +633,7 @@ __global__ __launch_bounds__(RT_BLOCK, WAVES) void lean_frame_kernel(FrameParams
             historyLength = 1.0f;
             direct = lerp3(mk3s(0.0f), resDirect, s_rcp(historyLength));
         }
-        store_rgba16f(I.directLight[cur], i, direct.x, direct.y, direct.z, historyLength);
+        if (keepRecords) store_rgba16f(I.directLight[cur], i, direct.x, direct.y, direct.z, historyLength);
         if (FULL) { store_rgba16f(I.filteredDirect[1], i, direct.x, direct.y, direct.z, historyLength); continue; }
         const f3 result = compose_lean_value(P, diffuse, mk3(q_f16(direct.x), q_f16(direct.y), q_f16(direct.z)));
         if (P.separatePost) reinterpret_cast<float4 *>(I.output)[i] = make_float4(result.x, result.y, result.z, 1.0f);

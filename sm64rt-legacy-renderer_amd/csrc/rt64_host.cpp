@@ -137,6 +137,7 @@ static GpuCombiner decode_combiner(uint32_t shaderId) {
 
 struct Options {
     bool countTraversal = false, profilePasses = true, syncPresent = true, alwaysRebuild = false, leanFrames = true, fusedLean = true, foldForeground = true;
+    bool leanRecords = false;     // 1: the one-kernel lean frame also stores the hit records and the direct-light image (otherwise View::materialise re-traces them on demand)
     bool hostTlas = true;         // the TLAS of up to RT64_HOST_TLAS_MAX instances is built on the host and travels in the table upload (0: always the GPU builder)
     bool simpleKernels = true;    // frames whose textures are all power-of-two sized and whose instances are all shadow-opaque run the kernels of passes_simple.hip
     bool ldsCache = true;         // small scenes: BVH nodes + instance records cached in LDS by the ray kernels (0: always walk from HBM/L2)
@@ -317,6 +318,7 @@ struct View {
     bool leanFrame = false;                   // last frame skipped the images no pass consumed (see materialise)
     bool fusedFullFrame = false;              // full frame whose primary + direct passes ran as lean_frame_kernel<.., FULL>
     bool packedFinal = false;                 // the frame also wrote its owned back-buffer rows to the device's gather target
+    bool fusedStoreless = false;              // ... and that kernel stored the back buffer only (no hit records, no direct-light image)
     bool fusedFrame = false;                  // ... and ran as lean_frame_kernel: rtOutput was not written either (unless PostProcess ran separately)
     FrameParams lastParams; int lastCur = 0;
 
@@ -1190,7 +1192,9 @@ void View::render() {                          // View::render, rt64_view.cpp:11
             packedFinal = true;
         }
         if (fused) {
-            L(launch_lean_frame(P, img, hitInstance.ptr, cur, false, 0, imgH, dev->opt.maxFrameGroups, s));
+            // nullptr: the frame stores its back buffer only (hit records and the direct-light image come back through materialise); option lean_records = 1 keeps them
+            L(launch_lean_frame(P, img, dev->opt.leanRecords ? hitInstance.ptr : nullptr, cur, false, 0, imgH, dev->opt.maxFrameGroups, s));
+            fusedStoreless = !dev->opt.leanRecords;
             mark(Device::EV_PRIMARY_TRACE); mark(Device::EV_PRIMARY); mark(Device::EV_DIRECT);
         }
         else if (fusedFull) {
@@ -1257,10 +1261,19 @@ void View::materialise() {
     if (!leanFrame) return;
     Device *dev = scene->device;
     dev->use();
-    HIP_CHECK(launch_primary_shade(lastParams, img, hitInstance.ptr, lastCur, false, false, dev->stream));
-    HIP_CHECK(launch_indirect_constant(lastParams, img, lastCur, dev->stream));
-    const size_t rowBytes = (size_t)imgW * 8, off = (size_t)lastParams.tileY0 * rowBytes, bytes = (size_t)(lastParams.tileY1 - lastParams.tileY0) * rowBytes;
-    HIP_CHECK(hipMemcpyAsync(reinterpret_cast<uint8_t *>(img.filteredDirect[1]) + off, reinterpret_cast<uint8_t *>(img.directLight[lastCur]) + off, bytes, hipMemcpyDeviceToDevice, dev->stream));
+    if (fusedFrame && fusedStoreless) {
+        // the frame kept no records: the FULL variant of the frame kernel traces the same rays again and writes the whole G-buffer and DirectRayGen's two images
+        FrameParams Q = lastParams;
+        Q.rasterFg = nullptr; Q.rasterFgTris = nullptr; Q.rasterFgCount = 0; Q.finalPacked = nullptr;
+        HIP_CHECK(launch_lean_frame(Q, img, hitInstance.ptr, lastCur, true, Q.tileY0, Q.tileY1, dev->opt.maxFrameGroups, dev->stream));
+        HIP_CHECK(launch_indirect_constant(lastParams, img, lastCur, dev->stream));
+    }
+    else {
+        HIP_CHECK(launch_primary_shade(lastParams, img, hitInstance.ptr, lastCur, false, false, dev->stream));
+        HIP_CHECK(launch_indirect_constant(lastParams, img, lastCur, dev->stream));
+        const size_t rowBytes = (size_t)imgW * 8, off = (size_t)lastParams.tileY0 * rowBytes, bytes = (size_t)(lastParams.tileY1 - lastParams.tileY0) * rowBytes;
+        HIP_CHECK(hipMemcpyAsync(reinterpret_cast<uint8_t *>(img.filteredDirect[1]) + off, reinterpret_cast<uint8_t *>(img.directLight[lastCur]) + off, bytes, hipMemcpyDeviceToDevice, dev->stream));
+    }
     // the one-kernel lean frame kept the composed colour in registers: rtOutput from the images just rebuilt (the back buffer already has the foreground drawn over it)
     if (fusedFrame && !lastParams.separatePost) HIP_CHECK(launch_compose_post(lastParams, img, lastCur, true, false, dev->stream));
     HIP_CHECK(hipStreamSynchronize(dev->stream));
@@ -1552,6 +1565,7 @@ RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, doubl
     else if (k == "bounce_refill") d->opt.bounceRefill = (int)value;
     else if (k == "spin_present") d->opt.spinPresent = value != 0.0;
     else if (k == "lds_cache") d->opt.ldsCache = value != 0.0;
+    else if (k == "lean_records") d->opt.leanRecords = value != 0.0;
     else if (k == "host_tlas") d->opt.hostTlas = value != 0.0;
     else if (k == "simple_kernels") d->opt.simpleKernels = value != 0.0;       // 0: every frame runs the general kernels (A/B tests)
     else if (k == "reset_accum") { d->finishStats(); d->accum = RT64_FRAME_STATS(); }
