@@ -1265,6 +1265,7 @@ void View::materialise() {
         // the frame kept no records: the FULL variant of the frame kernel traces the same rays again and writes the whole G-buffer and DirectRayGen's two images
         FrameParams Q = lastParams;
         Q.rasterFg = nullptr; Q.rasterFgTris = nullptr; Q.rasterFgCount = 0; Q.finalPacked = nullptr;
+        Q.countTraversal = 0;        // the frame's rays were counted when the frame ran
         HIP_CHECK(launch_lean_frame(Q, img, hitInstance.ptr, lastCur, true, Q.tileY0, Q.tileY1, dev->opt.maxFrameGroups, dev->stream));
         HIP_CHECK(launch_indirect_constant(lastParams, img, lastCur, dev->stream));
     }
@@ -1809,6 +1810,7 @@ Gather::Gather(Device *d, const ncclUniqueId &id, int rank_, int count_, int ban
         View *v = first_view(dev);
         if (!v || v->frameCount == 0 || v->imgW != W || v->imgH != H || dev->tileY0 != 0 || dev->tileY1 != dev->height || dev->stripCount > 1)
             throw std::runtime_error("RT64_CreateGather: cost-balanced bands are cut from the device's last frame: render one whole frame (no tile / interleave) before creating the gather.");
+        v->materialise();            // a pixel-local frame keeps no hit records: this brings them back (no-op after a frame that stored its G-buffer)
         DevArray<uint32_t> dCounts; dCounts.reserve((size_t)H);
         HIP_CHECK(launch_row_hit_count(v->hitInstance.ptr, dCounts.ptr, W, H, dev->stream));
         std::vector<uint32_t> counts((size_t)H);
