@@ -37,6 +37,7 @@ hipError_t bc7_decode_launch(const uint8_t *blocks, uint8_t *rgba, uint32_t widt
 
 // ---- passes.hip ---------------------------------------------------------------------------------------------------
 #define RT_CACHE_MAX_WORDS 1536       // LDS scene cache, nodes + instance records: at most 24 KB next to the 8 KB stack (int16 entries) and the light columns of a workgroup, four workgroups per CU
+#define RT_STACK_LDS 24               // traversal stack entries per lane in LDS of the kernels without the scene cache; deeper levels go to the HBM spill slab
 #define RT_STACK_LDS_CACHED 16        // traversal stack entries (LDS only, no spill path) of the kernels that hold the LDS scene cache: a power of two
 #define RT_GRID_BLOCKS 2048           // persistent grid of every ray kernel (8 workgroups of 256 per CU)
 #define RT_MAX_FRAME_GROUPS 8192u     // largest grid of the one-workgroup-per-tile kernels (bigger frames give every workgroup a few tiles)

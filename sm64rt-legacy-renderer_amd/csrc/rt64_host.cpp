@@ -283,6 +283,7 @@ struct View {
     // rectangle of the ray-traced picture: the first ray-traced instance's scissor / viewport when it has any (rt64_view.cpp:1258-1271)
     float rtViewport[4] = { 0, 0, 0, 0 }; int rtScissor[4] = { 0, 0, 0, 0 }; bool rtRect = false;
     DevArray<uint8_t> cacheImage; bool cacheImageValid = false;      // FrameParams::cacheImage: rebuilt after every table upload that leaves the cache enabled
+    bool needSpillSlab = false;                // some walk of this frame can outgrow its LDS stack entries (see View::update)
     uint32_t cacheWords = 0;                   // LDS scene cache size in 16-byte words (0: the scene does not fit / option lds_cache = 0)
     bool separatePost() const { return upscaleActive || rtRect || imgW != finalW || imgH != finalH || (motionBlurStrength > 0.0f && motionBlurSamples > 0); }
     // device images
@@ -360,7 +361,6 @@ Device::Device(int w, int h, int dev) {
     width = pendingWidth = w; height = pendingHeight = h; tileY0 = 0; tileY1 = h;
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     for (auto &ev : events) HIP_CHECK(hipEventCreate(&ev));
-    spillStack.reserve(rt_stack_spill_bytes(w, h) / sizeof(uint32_t));
     counters.reserve((size_t)CTR_COUNT * RT_COUNTER_STRIPES);
     HIP_CHECK(hipMemsetAsync(counters.ptr, 0, counters.bytes(), stream));
     // Blue-noise table (Device::loadBlueNoise, rt64_device.cpp:794-797): 512x512 RGBA8.
@@ -901,6 +901,12 @@ void View::update() {                          // View::update, rt64_view.cpp:10
         if (words <= RT_CACHE_MAX_WORDS) for (size_t i = 0; i < nInst; i++) deepest = std::max(deepest, rtInstances[i].instance->mesh->treeDepth());
         if (words <= RT_CACHE_MAX_WORDS && std::max<size_t>(nInst - 1, 1) + deepest <= RT_STACK_LDS_CACHED) cacheWords = (uint32_t)words;
     }
+    {   // The HBM spill slab behind the LDS stacks (84 entries per resident lane: 0.7 GB) is only needed when a walk can go deeper than the LDS
+        // entries: TLAS depth (at most nInst - 1) + the deepest BLAS (the builders leave it in the header; 255 = "deep" for the multi-kernel path).
+        uint32_t deepest = 0;
+        for (size_t i = 0; i < nInst; i++) deepest = std::max(deepest, rtInstances[i].instance->mesh->treeDepth());
+        needSpillSlab = nInst > 0 && std::max<size_t>(nInst - 1, 1) + deepest > RT_STACK_LDS;
+    }
     maxDepthBias = nInst ? -INFINITY : 0.0f;
     anyNonOpaque = anyReflection = anyRefraction = anyFog = false;
     simpleFrame = dev->opt.simpleKernels && nInst > 0;
@@ -1105,7 +1111,7 @@ void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64
     P.lightCount = (uint32_t)scene->lights.size(); P.instanceCount = (uint32_t)rtInstances.size();
     P.countTraversal = dev->opt.countTraversal ? 1u : 0u;
     P.instances = dInstances.ptr; P.tlasNodes = tlasNodesAt; P.tlasIndex = tlasIndexAt; P.textures = dTextures.ptr; P.lights = dLights.ptr;
-    dev->spillStack.reserve(rt_stack_spill_bytes(imgW, imgH) / sizeof(uint32_t));      // grows with the render size (no-op otherwise)
+    if (needSpillSlab) dev->spillStack.reserve(rt_stack_spill_bytes(imgW, imgH) / sizeof(uint32_t));      // grows with the render size (no-op otherwise); never allocated for shallow scenes
     P.blueNoise = dev->blueNoise.ptr; P.traversalStack = dev->spillStack.ptr; P.counters = dev->counters.ptr;
 }
 

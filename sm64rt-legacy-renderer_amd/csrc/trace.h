@@ -36,7 +36,9 @@ DEV PPtr kernel_params() { return (PPtr)__builtin_amdgcn_kernarg_segment_ptr(); 
 // Same, through an offset the compiler cannot see through (always 0): loads that depend on it stay inside the loop iteration that made it.
 DEV PPtr kernel_params_here() { uint32_t z; asm volatile("s_mov_b32 %0, 0" : "=s"(z)); return (PPtr)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + z); }
 #define RT_BLOCK 256                 // threads per workgroup of every ray kernel
-#define RT_STACK_LDS 24
+#ifndef RT_STACK_LDS
+#define RT_STACK_LDS 24                 // (kernels.h defines it for the host too)
+#endif
 #define RT_STACK_SPILL 84               // entries per lane in the HBM slab behind the LDS entries
 #ifndef RT_STACK_LDS_CACHED
 #define RT_STACK_LDS_CACHED 16           // (kernels.h defines it for the host too) kernels that also hold the LDS scene cache: the host enables the cache only when TLAS depth + the deepest BLAS fit in these
