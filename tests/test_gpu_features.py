@@ -331,6 +331,38 @@ def test_one_kernel_lean_frame_matches_the_three_kernel_path(rt64_lib, sample_da
 
 
 @pytest.mark.gpu
+def test_lean_frame_without_stored_records_materialises_the_same_images(rt64_lib, sample_data):
+    """The one-kernel lean frame stores the back buffer only (option lean_records, default 0); every other image comes from
+    View::materialise re-running the FULL frame kernel.  With lean_records = 1 the frame stores its hit records and direct light itself
+    (round-1 behaviour).  Both must give the same bytes in every image, the same counters, and the counters of the frame must not move
+    when an image is read back (the re-traced rays are not counted) -- synchronous and enqueued frames."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    images = [rt64.IMAGE_FINAL_RGBA8, rt64.IMAGE_OUTPUT_RGBA32F, rt64.IMAGE_PRIMARY_HIT, rt64.IMAGE_INSTANCE_ID, rt64.IMAGE_DIFFUSE, rt64.IMAGE_DIRECT_LIGHT_RAW,
+              rt64.IMAGE_DIRECT_LIGHT_FILTERED, rt64.IMAGE_SHADING_POSITION, rt64.IMAGE_SHADING_NORMAL, rt64.IMAGE_FIRST_INSTANCE_ID]
+    got = {}
+    for records in (0, 1):
+        for sync in (1, 0):
+            s = sample_scene.Rt64Scene(rt64_lib, sample_data, 333, 187, hip_device=0)
+            try:
+                s.option("lean_records", records); s.option("count_traversal", 1); s.option("sync_present", sync)
+                s.draw(); s.draw()
+                imgs = [s.readback(i) for i in images]          # the first readback of a non-final image materialises
+                st = s.stats()                                    # enqueued frames: counters are read now, after the re-trace
+                assert st.leanFrame == 1 and st.fusedFrame == 1
+                got[(records, sync)] = (imgs, (st.primaryRays, st.shadowRays, st.nodesVisited, st.trianglesTested))
+                picked = rt64_lib.GetViewRaytracedInstanceAt(s.view, 166, 110)
+                assert picked == s.instances[1]                   # the sphere, through firstInstanceId of the materialised G-buffer
+            finally:
+                s.close()
+    ref_imgs, ref_ctr = got[(1, 1)]
+    assert ref_ctr[0] == 333 * 187
+    for key, (imgs, ctr) in got.items():
+        assert ctr == ref_ctr, key
+        for a, b in zip(imgs, ref_imgs):
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), key
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("band", [None, (48, 128)])
 def test_one_kernel_full_frame_matches_the_separate_kernels(rt64_lib, sample_data, band):
     """Full (non-lean) frames whose instances are all opaque -- here 1 GI sample + SVGF -- run primary visibility, the G-buffer and
