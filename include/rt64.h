@@ -338,7 +338,8 @@ enum {
     RT64_ACCEL_TRIANGLES = 1,          /* 48-byte leaves in Morton order: v0[3] prim v1[3] pad v2[3] pad (BLAS only) */
     RT64_ACCEL_SORTED_INDEX = 2,       /* u32[n]: leaf slot -> primitive (BLAS) / instance (TLAS) */
     RT64_ACCEL_MORTON = 3,             /* u32[n]: 30-bit Morton code per leaf slot */
-    RT64_ACCEL_HEADER = 4              /* bmin[3] count bmax[3] pad */
+    RT64_ACCEL_HEADER = 4,             /* bmin[3] count bmax[3] depth (inner nodes on the longest root-to-leaf path; 255 = built by the multi-kernel path) */
+    RT64_ACCEL_HOST_DEPTH = 5          /* u32 (BLAS only): the depth the host computed from the triangles at RT64_SetMesh -- what sizes the traversal stacks; equals the header's */
 };
 
 /* Per-frame counters and GPU timings of the last RT64_DrawDevice (milliseconds, HIP events on the device stream). */
@@ -399,6 +400,9 @@ typedef struct {
        Returns bytes written (0 on error); pass dst = NULL to query the size. */ \
     X(ReadbackMeshAccel, RT64_ReadbackMeshAccel, size_t, (RT64_MESH *mesh, int what, void *dst, size_t dstBytes)) \
     X(ReadbackViewAccel, RT64_ReadbackViewAccel, size_t, (RT64_VIEW *view, int what, void *dst, size_t dstBytes)) \
+    /* Depth of the BLAS RT64_SetMesh will build over these triangles (pure host function, no device; 0 = invalid arguments, 255 = a tree \
+       of the multi-kernel builder): the library sizes its traversal stacks by it without waiting for the build. */ \
+    X(MeshTreeDepth, RT64_MeshTreeDepth, unsigned int, (const void *vertexArray, int vertexCount, int vertexStride, const unsigned int *indexArray, int indexCount)) \
     /* ---- multi-GPU: one process per GPU, the frame's rows partitioned over `count` devices, ONE gather of the composited RGBA8 back buffer \
        to rank 0 per frame over RCCL / xGMI (the reference is single-GPU: NodeMask 0, rt64_device.cpp:753).  Rank 0 fills an id with \
        RT64_GetGatherUniqueId and passes it to the other ranks (file, pipe, MPI, ...); every rank then calls RT64_CreateGather on its own \
@@ -418,6 +422,11 @@ typedef struct {
     X(GatherRowOwner, RT64_GatherRowOwner, int, (int height, int count, int bands, int y, int *packedRow)) \
     X(GatherOwnedRows, RT64_GatherOwnedRows, int, (int height, int count, int bands, int rank)) \
     X(GatherSlotRows, RT64_GatherSlotRows, int, (int height, int count, int bands)) \
+    /* (bands = 0 or 1 only; they return -1 for bands = 2, whose boundaries are not a function of height and count.)  The same three for a \
+       layout given by its band boundaries starts[0 .. count] -- what RT64_GetGatherBands / RT64_BalanceGatherBands produce: */ \
+    X(GatherRowOwnerOf, RT64_GatherRowOwnerOf, int, (int height, int count, const int *starts, int y, int *packedRow)) \
+    X(GatherOwnedRowsOf, RT64_GatherOwnedRowsOf, int, (int height, int count, const int *starts, int rank)) \
+    X(GatherSlotRowsOf, RT64_GatherSlotRowsOf, int, (int height, int count, const int *starts)) \
     /* bands = 2 in RT64_CreateGather: contiguous bands of about equal COST instead of equal height -- cost of a row = its pixels, those whose \
        primary ray hit geometry in the device's last (whole) frame counted 6 times; every rank must have rendered that frame, so that all \
        derive the same boundaries.  RT64_GetGatherBands reads the boundaries of a gather (starts[0..count]); RT64_BalanceGatherBands is the cut \

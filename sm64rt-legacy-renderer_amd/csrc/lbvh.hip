@@ -351,6 +351,12 @@ namespace {
 #define LG_TILE 2048            // keys per workgroup in the radix passes
 #define LG_CHUNK 2048           // leaves (in Morton order) per workgroup of the box fit
 #define LG_ROOT_SLOTS 192       // list entries per chunk: the maximal subtrees inside an interval of leaves number at most 2 x depth (depth <= 62 key bits + 1)
+// Why a list can never overflow: the maximal subtrees of a radix tree that lie inside one interval of leaves hang off the two root-to-leaf
+// paths that bound the interval, at most one per level and side, and a path of the tree over LG_KEY_BITS-bit unique keys has at most
+// LG_KEY_BITS inner nodes.  A wider key needs more slots: the assertion keeps the two numbers together (the `k < LG_ROOT_SLOTS` tests in the
+// fit kernels only keep a wrong bound inside the arrays).
+#define LG_KEY_BITS 62           // 30-bit Morton code << 32 | 32-bit leaf number: bits 61..0 can differ
+static_assert(LG_ROOT_SLOTS >= 2 * (LG_KEY_BITS + 1), "LG_ROOT_SLOTS must hold 2 x (key bits + 1) roots per chunk");
 
 struct LargeScratch {
     uint32_t *keyA, *valA, *keyB, *valB, *hist, *bounds, *done, *rootList, *rootCount;

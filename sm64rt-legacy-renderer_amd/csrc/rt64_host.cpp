@@ -135,6 +135,8 @@ static GpuCombiner decode_combiner(uint32_t shaderId) {
 
 // ---- objects ---------------------------------------------------------------------------------------------------------------
 
+#define RT64_LEAN_HOLDOFF_FRAMES 4     // frames that store their whole G-buffer after a scene change had to materialise a lean frame (Device::beforeSceneMutation)
+
 struct Options {
     bool countTraversal = false, profilePasses = true, syncPresent = true, alwaysRebuild = false, leanFrames = true, fusedLean = true, foldForeground = true;
     bool leanRecords = false;     // 1: the one-kernel lean frame also stores the hit records and the direct-light image (otherwise View::materialise re-traces them on demand)
@@ -201,6 +203,11 @@ struct Device {
     // next frame (or before anything else reads a BLAS) -- small trees in ONE launch, one workgroup each.
     std::vector<Mesh *> dirtyMeshes; DevArray<LbvhArgs> buildArgs;
     void flushMeshBuilds();
+    // A lean frame keeps its G-buffer implicit: View::materialise re-reads the frame's meshes, textures and tables.  Whoever is about to change
+    // or free one of them calls this first, so the images are produced from the bytes the frame was rendered with; the next few frames then
+    // store their whole G-buffer themselves (a host that changes its scene every frame pays for one materialise, not one per frame).
+    void beforeSceneMutation();
+    unsigned leanHoldoff = 0;
     void draw(int vsyncInterval, float deltaTimeMs);
     float aspect() const { return (float)width / (float)height; }
     // Rows of [tileY0, tileY1) in strips stripRank, stripRank + stripCount, ... (16 rows each).
@@ -234,8 +241,8 @@ struct Mesh {
     DevArray<uint32_t> sortedIndex, morton, leafParent; DevArray<uint8_t> buildScratch;
     uint32_t blasCount = 0;                            // leaves of the current BLAS (0 = none)
     float hostBmin[3] = { 0, 0, 0 }, hostBmax[3] = { 0, 0, 0 };     // bounds of the indexed positions (== BlasHeader bounds: a min / max over the same floats), for the host-side TLAS build
-    uint32_t topologyVersion = 0, depthVersion = ~0u, depth = 255;      // tree depth (BlasHeader::depth), read back once per topology: refits keep it
-    uint32_t treeDepth();
+    uint32_t topologyVersion = 0, depth = 255;      // tree depth (== BlasHeader::depth), computed on the host when the topology is decided (Mesh::set): refits keep it
+    uint32_t treeDepth() const { return blasCount == 0 ? 0u : depth; }
     bool buildPending = false, pendingRefit = false;   // RT64_SetMesh recorded a build / refit that Device::flushMeshBuilds has not run yet
     ~Mesh();
     uint32_t version = 0;
@@ -297,6 +304,7 @@ struct View {
         DevArray<GpuRasterInstance> table; DevArray<uint8_t> tris;      // device instance table + triangle setup records
         std::vector<uint8_t> uploaded;                                   // bytes of the table the records were built from (cache key)
         uint32_t triTotal = 0; int w = 0, h = 0, y0 = 0, y1 = 0; bool apply = false, ready = false, changed = false;
+        bool contentChanged = false;                                     // `changed` and the bytes really differ (always_rebuild re-stages identical lists)
         int bounds[4] = { 0, 0, 0, 0 };                                  // conservative pixel rectangle [x0, y0, x1, y1) the list can touch
     };
     RasterList rasterBgEnv, rasterBgScreen, rasterFgScreen;             // bg -> gBackground (no scissors), bg -> back buffer, fg -> back buffer
@@ -458,6 +466,60 @@ void Texture::setDDS(const void *data, int byteCount) {
 
 // ---- Mesh -------------------------------------------------------------------------------------------------------------------
 
+static uint32_t host_morton30(uint32_t x, uint32_t y, uint32_t z) {
+    uint32_t v[3] = { x & 1023u, y & 1023u, z & 1023u }, code = 0;
+    for (int k = 0; k < 3; k++) {
+        uint32_t t = v[k];
+        t = (t | (t << 16)) & 0x030000FFu; t = (t | (t << 8)) & 0x0300F00Fu; t = (t | (t << 4)) & 0x030C30C3u; t = (t | (t << 2)) & 0x09249249u;
+        code |= t << k;
+    }
+    return code;
+}
+// Depth of the LBVH the device builder will make over these triangles (inner nodes on the longest root-to-leaf path == BlasHeader::depth),
+// computed on the host so that View::update never waits for a build to learn it: the same leaf boxes, scene box, Morton keys and key order as
+// lbvh.hip (Geometry spec G1-G3: IEEE min / max, (c - min) * scale truncated, 62-bit keys code << 32 | triangle), then the depth of the radix
+// tree over the sorted keys -- Karras' tree splits a key range where the highest differing bit of its end keys flips, so the depth follows from
+// the keys alone.  A few microseconds for the few hundred triangles of a game mesh; trees of the multi-kernel builder report 255 ("deep").
+static uint32_t host_blas_depth(const uint8_t *vertices, size_t stride, const unsigned int *indices, uint32_t n) {
+    if (n <= 1) return 1;
+    if (n > LBVH_SMALL_MAX) return 255;
+    std::vector<float> lo(3 * (size_t)n), hi(3 * (size_t)n);
+    float smin[3] = { INFINITY, INFINITY, INFINITY }, smax[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (uint32_t t = 0; t < n; t++) {
+        float v[3][3];
+        for (int k = 0; k < 3; k++) memcpy(v[k], vertices + (size_t)indices[3 * t + k] * stride, 12);
+        for (int k = 0; k < 3; k++) {
+            const float mn = fminf(fminf(v[0][k], v[1][k]), v[2][k]), mx = fmaxf(fmaxf(v[0][k], v[1][k]), v[2][k]);
+            lo[3 * (size_t)t + k] = mn; hi[3 * (size_t)t + k] = mx; smin[k] = fminf(smin[k], mn); smax[k] = fmaxf(smax[k], mx);
+        }
+    }
+    std::vector<unsigned long long> keys(n);
+    float scale[3];
+    for (int k = 0; k < 3; k++) { const float ext = smax[k] - smin[k]; scale[k] = ext > 0.0f ? 1024.0f / ext : 0.0f; }
+    for (uint32_t t = 0; t < n; t++) {
+        uint32_t q[3];
+        for (int k = 0; k < 3; k++) {
+            const float c = (lo[3 * (size_t)t + k] + hi[3 * (size_t)t + k]) * 0.5f, f = (c - smin[k]) * scale[k];
+            q[k] = !(f >= 1.0f) ? 0u : (f >= 1023.0f ? 1023u : (uint32_t)(int)f);       // (int)f clamped to [0, 1023]; NaN -> 0 like v_cvt_i32_f32
+        }
+        keys[t] = ((unsigned long long)host_morton30(q[0], q[1], q[2]) << 32) | t;
+    }
+    std::sort(keys.begin(), keys.end());
+    struct Range { uint32_t l, r, d; };
+    std::vector<Range> todo; todo.push_back({ 0u, n - 1, 1u });
+    uint32_t deepest = 1;
+    while (!todo.empty()) {
+        const Range g = todo.back(); todo.pop_back();
+        deepest = std::max(deepest, g.d);
+        const unsigned long long bit = 1ull << (63 - __builtin_clzll(keys[g.l] ^ keys[g.r]));
+        uint32_t a = g.l, b = g.r;                      // first key of the range with `bit` set (keys[l] has it clear, keys[r] set)
+        while (a + 1 < b) { const uint32_t m = a + (b - a) / 2; if (keys[m] & bit) b = m; else a = m; }
+        if (a > g.l) todo.push_back({ g.l, a, g.d + 1 });
+        if (b < g.r) todo.push_back({ b, g.r, g.d + 1 });
+    }
+    return deepest;
+}
+
 void Mesh::set(const void *vertexArray, int vcount, int vstride, const unsigned int *indexArray, int icount) {
     if (!vertexArray || !indexArray || vcount <= 0 || icount <= 0 || vstride < 12) throw std::runtime_error("RT64_SetMesh: invalid arguments.");
     // An index past the vertex array would make the BLAS builder and the any-hit vertex fetches read outside the buffer (a GPU memory fault).
@@ -472,6 +534,7 @@ void Mesh::set(const void *vertexArray, int vcount, int vstride, const unsigned 
     }
     memcpy(hostBmin, mn, 12); memcpy(hostBmax, mx, 12);
     device->use();
+    if (vertices.ptr) device->beforeSceneMutation();       // a kept lean frame may still read this mesh's arrays (a first upload changes nothing a frame has seen)
     // rt64_mesh.cpp:30-39,76-82: a change of counts/stride discards the BLAS even if updatable.
     const bool sameShape = vertices.ptr && vertexCount == vcount && vertexStride == vstride && indexCount == icount;
     const size_t vbytes = (size_t)vcount * vstride, ibytes = (size_t)icount * 4;
@@ -490,6 +553,7 @@ void Mesh::set(const void *vertexArray, int vcount, int vstride, const unsigned 
         const bool refit = (flags & RT64_MESH_RAYTRACE_UPDATABLE) && sameShape && blasCount == n;   // rt64_mesh.cpp:129,149-157
         // A refit keeps the topology of the tree that exists (or is about to exist, if its build is still pending).
         pendingRefit = buildPending ? (pendingRefit && refit) : refit;
+        if (!pendingRefit) depth = host_blas_depth(static_cast<const uint8_t *>(vertexArray), (size_t)vstride, indexArray, n);
         nodes.reserve(std::max<size_t>(n - 1, 1)); tris.reserve(n); header.reserve(1);
         sortedIndex.reserve(n); morton.reserve(n); leafParent.reserve(n);
         if (n > LBVH_SMALL_MAX) buildScratch.reserve(lbvh_large_scratch_bytes(n));
@@ -531,19 +595,8 @@ void Device::flushMeshBuilds() {
     workSinceMark = true;
 }
 
-// Depth of the BLAS (inner nodes on the longest root-to-leaf path).  The builder leaves it in the header; read back (one stream wait) once
-// per topology -- a refit of an UPDATABLE mesh keeps the tree's shape.  Trees of the multi-kernel builder report 255 without asking.
-uint32_t Mesh::treeDepth() {
-    if (blasCount == 0) return 0;
-    if (blasCount > LBVH_SMALL_MAX) return 255;
-    if (depthVersion != topologyVersion) {
-        device->flushMeshBuilds();
-        BlasHeader h;
-        HIP_CHECK(hipMemcpyAsync(&h, header.ptr, sizeof(h), hipMemcpyDeviceToHost, device->stream));
-        HIP_CHECK(hipStreamSynchronize(device->stream));
-        depth = h.depth; depthVersion = topologyVersion;
-    }
-    return depth;
+void Device::beforeSceneMutation() {
+    for (Scene *sc : scenes) for (View *v : sc->views) if (v->leanFrame) { v->materialise(); leanHoldoff = RT64_LEAN_HOLDOFF_FRAMES; }
 }
 
 std::pair<float, float> Mesh::inputAlphaBounds(int offset) {
@@ -687,8 +740,8 @@ static bool instance_is_shadow_opaque(const Instance *inst, const GpuCombiner &c
 // Build (or reuse) the device table and the triangle setup records of one raster draw list.  The records only depend on the
 // table bytes, the target size, the row range and the scissor mode: an unchanged HUD costs nothing here after its first frame.
 void View::prepareRasterList(const std::vector<RenderInstance> &list, RasterList &rl, int w, int h, int y0, int y1, bool apply) {
-    rl.changed = false;
-    if (list.empty()) { rl.triTotal = 0; rl.ready = false; rl.uploaded.clear(); return; }
+    rl.changed = false; rl.contentChanged = false;
+    if (list.empty()) { rl.contentChanged = rl.ready; rl.triTotal = 0; rl.ready = false; rl.uploaded.clear(); return; }
     Device *dev = scene->device;
     std::vector<GpuRasterInstance> hst(list.size());
     uint32_t triTotal = 0;
@@ -720,9 +773,10 @@ void View::prepareRasterList(const std::vector<RenderInstance> &list, RasterList
         }
     }
     const size_t bytes = hst.size() * sizeof(GpuRasterInstance);
-    const bool same = rl.ready && rl.uploaded.size() == bytes && memcmp(rl.uploaded.data(), hst.data(), bytes) == 0 &&
-                      rl.w == w && rl.h == h && rl.y0 == y0 && rl.y1 == y1 && rl.apply == apply && !dev->opt.alwaysRebuild;
-    if (same) return;
+    const bool sameContent = rl.ready && rl.uploaded.size() == bytes && memcmp(rl.uploaded.data(), hst.data(), bytes) == 0 &&
+                             rl.w == w && rl.h == h && rl.y0 == y0 && rl.y1 == y1 && rl.apply == apply;
+    if (sameContent && !dev->opt.alwaysRebuild) return;
+    rl.contentChanged = !sameContent;
     rl.table.reserve(hst.size()); rl.tris.reserve(std::max<size_t>(raster_tri_bytes(triTotal), 16));
     const bool inlineTable = raster_setup_takes_table_inline((uint32_t)hst.size());      // a short list rides in the setup kernel's arguments: no copy on the stream
     if (!inlineTable) {
@@ -755,15 +809,6 @@ void View::drawRasterList(RasterList &rl, uint8_t *target) {
 // v_min_f32 / v_max_f32 order -0 below +0; the host's fminf / fmaxf may return either.  (No NaN reaches here that the GPU builder would survive.)
 static inline float gmin(float a, float b) { return (a < b || (a == b && std::signbit(a))) ? a : b; }
 static inline float gmax(float a, float b) { return (a > b || (a == b && !std::signbit(a))) ? a : b; }
-static uint32_t host_morton30(uint32_t x, uint32_t y, uint32_t z) {
-    uint32_t v[3] = { x & 1023u, y & 1023u, z & 1023u }, code = 0;
-    for (int k = 0; k < 3; k++) {
-        uint32_t t = v[k];
-        t = (t | (t << 16)) & 0x030000FFu; t = (t | (t << 8)) & 0x0300F00Fu; t = (t | (t << 4)) & 0x030C30C3u; t = (t | (t << 2)) & 0x09249249u;
-        code |= t << k;
-    }
-    return code;
-}
 static void host_build_tlas(const GpuInstance *inst, const float (*meshMin)[3], const float (*meshMax)[3], uint32_t n,
                             GpuNode *nodes, uint32_t *sortedIndex, uint32_t *morton, BlasHeader *header) {
     std::vector<float> lo(3 * (size_t)n), hi(3 * (size_t)n);
@@ -959,7 +1004,11 @@ void View::update() {                          // View::update, rt64_view.cpp:10
     // The tables (and with them the TLAS) only change when the host changed an instance, a mesh, a texture binding or a light.
     // Identical bytes => the device copies and the TLAS of the previous frame are still exact: skip upload and rebuild.
     const size_t tableBytes = instBytes + texBytes + lightBytes;
-    const bool unchanged = uploadedTables.size() == tableBytes && tableBytes && memcmp(uploadedTables.data(), stage, tableBytes) == 0 && !dev->opt.alwaysRebuild;
+    const bool sameContent = uploadedTables.size() == tableBytes && tableBytes && memcmp(uploadedTables.data(), stage, tableBytes) == 0;
+    const bool unchanged = sameContent && !dev->opt.alwaysRebuild;
+    // A kept lean frame re-reads the tables, the TLAS and the cache image it was rendered with (View::materialise): its images are produced
+    // before new contents overwrite them.  (always_rebuild re-uploads identical bytes to the same places: nothing to save.)
+    if (!sameContent && leanFrame) { materialise(); dev->leanHoldoff = RT64_LEAN_HOLDOFF_FRAMES; }
     if (!unchanged) {
         // TLAS: full rebuild (rt64_view.cpp:412-452 rebuilds every frame, updateOnly = false) -- of a few instances on the host, into the same upload
         const uint32_t n = (uint32_t)nInst;
@@ -1011,7 +1060,8 @@ void View::update() {                          // View::update, rt64_view.cpp:10
         prepareRasterList(rasterBg, rasterBgEnv, finalW, finalH, 0, finalH, false);               // gBackground: every rank needs all of it (env-map lookups)
         prepareRasterList((rtInstances.empty() || rtRect) ? rasterBg : std::vector<RenderInstance>(), rasterBgScreen, finalW, finalH, sy0, sy1, true);
         prepareRasterList(rasterFg, rasterFgScreen, finalW, finalH, sy0, sy1, true);
-        if (!rasterBg.empty() && (backgroundW != finalW || backgroundH != finalH)) { background.reserve((size_t)finalW * finalH * 4); backgroundW = finalW; backgroundH = finalH; rasterBgEnv.changed = true; }
+        if (!rasterBg.empty() && (backgroundW != finalW || backgroundH != finalH)) { background.reserve((size_t)finalW * finalH * 4); backgroundW = finalW; backgroundH = finalH; rasterBgEnv.changed = true; }      // (a resize has dropped every kept frame: View::createImages)
+        if (leanFrame && (rasterBgEnv.contentChanged || (!rasterBgEnv.ready && lastParams.background.texels))) { materialise(); dev->leanHoldoff = RT64_LEAN_HOLDOFF_FRAMES; }      // the kept frame's sky pixels read gBackground
         if (rasterBgEnv.ready && rasterBgEnv.changed) {        // gBackground: cleared to 0, drawn without scissors / viewports (rt64_view.cpp:1298-1319)
             HIP_CHECK(hipMemsetAsync(background.ptr, 0, (size_t)finalW * finalH * 4, dev->stream));
             const int sr = dev->stripRank, sc = dev->stripCount; dev->stripRank = 0; dev->stripCount = 1;
@@ -1135,7 +1185,7 @@ void View::render() {                          // View::render, rt64_view.cpp:11
     // Lean frame: nothing downstream reads the view direction, the reflection / refraction / transparent accumulators, motion
     // vectors, upscaler masks, history guides or a GI buffer.  A full frame after lean ones reads the previous frame's guides and
     // history (temporal reprojection), so what that lean frame skipped is produced first, while its hit records still exist.
-    const bool leanNow = !rtInstances.empty() && dev->opt.leanFrames && !upscaleActive && !anyNonOpaque && !anyReflection && !anyRefraction && !anyFog && giSamples == 0 && motionBlurStrength <= 0.0f;
+    const bool leanNow = !rtInstances.empty() && dev->opt.leanFrames && !upscaleActive && !anyNonOpaque && !anyReflection && !anyRefraction && !anyFog && giSamples == 0 && motionBlurStrength <= 0.0f && dev->leanHoldoff == 0;
     if (leanFrame && !leanNow) materialise();
     FrameParams P;
     fillParams(P);
@@ -1303,6 +1353,7 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
     for (Scene *sc : scenes) for (View *v : sc->views) v->update();
     auto tu1 = std::chrono::steady_clock::now();
     for (Scene *sc : scenes) for (View *v : sc->views) v->render();
+    if (leanHoldoff) leanHoldoff--;
     auto tu2 = std::chrono::steady_clock::now();
     hostUpdateUs += std::chrono::duration<double, std::micro>(tu1 - tu0).count(); hostRenderUs += std::chrono::duration<double, std::micro>(tu2 - tu1).count(); hostFrames++;
     if (opt.profilePasses) {             // the end mark shares the last mark's event when nothing was launched after it (one barrier packet less per frame)
@@ -1653,7 +1704,7 @@ RT64_EXPORT RT64_MESH *RT64_CreateMesh(RT64_DEVICE *devicePtr, int flags) {
 RT64_EXPORT void RT64_SetMesh(RT64_MESH *meshPtr, void *vertexArray, int vertexCount, int vertexStride, unsigned int *indexArray, int indexCount) {
     RT64_TRY if (!meshPtr) throw std::runtime_error("RT64_SetMesh: NULL mesh."); reinterpret_cast<Mesh *>(meshPtr)->set(vertexArray, vertexCount, vertexStride, indexArray, indexCount); RT64_CATCH_VOID
 }
-RT64_EXPORT void RT64_DestroyMesh(RT64_MESH *meshPtr) { RT64_TRY Mesh *m = reinterpret_cast<Mesh *>(meshPtr); if (m) { m->device->use(); hipStreamSynchronize(m->device->stream); } delete m; RT64_CATCH_VOID }
+RT64_EXPORT void RT64_DestroyMesh(RT64_MESH *meshPtr) { RT64_TRY Mesh *m = reinterpret_cast<Mesh *>(meshPtr); if (m) { m->device->use(); m->device->beforeSceneMutation(); hipStreamSynchronize(m->device->stream); } delete m; RT64_CATCH_VOID }
 
 // ---- shader (rt64_shader.cpp:810-824) ----
 RT64_EXPORT RT64_SHADER *RT64_CreateShader(RT64_DEVICE *devicePtr, unsigned int shaderId, unsigned int filter, unsigned int hAddr, unsigned int vAddr, int flags) {
@@ -1693,7 +1744,7 @@ RT64_EXPORT RT64_TEXTURE *RT64_CreateTexture(RT64_DEVICE *devicePtr, RT64_TEXTUR
     return reinterpret_cast<RT64_TEXTURE *>(t);
     } catch (const std::exception &e) { GlobalLastError = e.what(); fprintf(stderr, "%s\n", e.what()); delete t; return nullptr; }
 }
-RT64_EXPORT void RT64_DestroyTexture(RT64_TEXTURE *texture) { RT64_TRY Texture *t = reinterpret_cast<Texture *>(texture); if (t) { t->device->use(); hipStreamSynchronize(t->device->stream); } delete t; RT64_CATCH_VOID }
+RT64_EXPORT void RT64_DestroyTexture(RT64_TEXTURE *texture) { RT64_TRY Texture *t = reinterpret_cast<Texture *>(texture); if (t) { t->device->use(); t->device->beforeSceneMutation(); hipStreamSynchronize(t->device->stream); } delete t; RT64_CATCH_VOID }
 
 // ---- debug readback of acceleration structures (additive) ----
 static size_t accel_readback(Device *dev, int what, uint32_t n, const GpuNode *nodes, const GpuTri *tris, const uint32_t *sorted, const uint32_t *morton,
@@ -1718,9 +1769,21 @@ static size_t accel_readback(Device *dev, int what, uint32_t n, const GpuNode *n
 RT64_EXPORT size_t RT64_ReadbackMeshAccel(RT64_MESH *meshPtr, int what, void *dst, size_t dstBytes) {
     RT64_TRY
     Mesh *m = reinterpret_cast<Mesh *>(meshPtr); if (!m) throw std::runtime_error("RT64_ReadbackMeshAccel: NULL mesh.");
+    if (what == RT64_ACCEL_HOST_DEPTH) {
+        if (m->blasCount == 0) throw std::runtime_error("RT64_ReadbackMeshAccel: no acceleration structure.");
+        if (!dst) return sizeof(uint32_t);
+        if (dstBytes < sizeof(uint32_t)) throw std::runtime_error("RT64_ReadbackMeshAccel: destination buffer is too small.");
+        const uint32_t d = m->treeDepth(); memcpy(dst, &d, sizeof(d)); return sizeof(d);
+    }
     m->device->flushMeshBuilds();
     return accel_readback(m->device, what, m->blasCount, m->nodes.ptr, m->tris.ptr, m->sortedIndex.ptr, m->morton.ptr, m->header.ptr, dst, dstBytes);
     RT64_CATCH(0)
+}
+// The depth RT64_SetMesh derives for the BLAS of these triangles, as a pure host function (no device): what RT64_ACCEL_HOST_DEPTH reports for a mesh.
+RT64_EXPORT unsigned int RT64_MeshTreeDepth(const void *vertexArray, int vertexCount, int vertexStride, const unsigned int *indexArray, int indexCount) {
+    if (!vertexArray || !indexArray || vertexCount <= 0 || vertexStride < 12 || indexCount < 3) return 0;
+    for (int i = 0; i < indexCount; i++) if (indexArray[i] >= (unsigned int)vertexCount) return 0;
+    return host_blas_depth(static_cast<const uint8_t *>(vertexArray), (size_t)vertexStride, indexArray, (uint32_t)indexCount / 3);
 }
 RT64_EXPORT size_t RT64_ReadbackViewAccel(RT64_VIEW *viewPtr, int what, void *dst, size_t dstBytes) {
     RT64_TRY
@@ -1739,7 +1802,25 @@ RT64_EXPORT size_t RT64_ReadbackViewAccel(RT64_VIEW *viewPtr, int what, void *ds
 // ncclSend / ncclRecv to rank 0, xGMI point to point -- and rank 0's reassembly run on the gather's own stream behind an event, so the
 // gather of frame k overlaps the rendering of frame k + 1; the slot is handed back to the renderer two frames later.
 // RCCL is bound at run time (dlopen of librccl.so.1): a single-GPU host never loads it and librt64.so does not link it.
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// A build host without the RCCL headers (single-GPU deployments): the handful of declarations the gather binds with dlsym, as RCCL 2.x declares them.
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1 } ncclDataType_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId *);
+ncclResult_t ncclCommInitRank(ncclComm_t *, int, ncclUniqueId, int);
+ncclResult_t ncclCommDestroy(ncclComm_t);
+ncclResult_t ncclGroupStart();
+ncclResult_t ncclGroupEnd();
+ncclResult_t ncclSend(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+ncclResult_t ncclRecv(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+const char *ncclGetErrorString(ncclResult_t);
+}
+#endif
 
 namespace rt64 {
 
@@ -1866,9 +1947,9 @@ int Gather::submit() {
     if (!v) throw std::runtime_error("RT64_SubmitGather: the device has no view.");
     const size_t mine = (size_t)gather_owned_rows(layout, rank) * (size_t)W * 4;
     if (!(v->packedFinal && dev->gatherTarget == sl.local)) {        // this kind of frame did not write the send buffer itself: pack the owned rows now (same layout)
-        const bool sync = dev->opt.syncPresent; dev->opt.syncPresent = false;
-        const size_t got = mine ? readback(dev, RT64_IMAGE_FINAL_RGBA8, sl.local, slotBytes, true) : 0;
-        dev->opt.syncPresent = sync;
+        struct Enqueued { Device *d; bool sync; explicit Enqueued(Device *dv) : d(dv), sync(dv->opt.syncPresent) { d->opt.syncPresent = false; } ~Enqueued() { d->opt.syncPresent = sync; } };
+        size_t got = 0;
+        { Enqueued guard(dev); got = mine ? readback(dev, RT64_IMAGE_FINAL_RGBA8, sl.local, slotBytes, true) : 0; }      // the copy is ordered on the stream, not waited for; the option comes back even if the copy throws
         if (got != mine) throw std::runtime_error("RT64_SubmitGather: packing the owned rows failed.");
     }
     HIP_CHECK(hipEventRecord(sl.produced, dev->stream));
@@ -1934,9 +2015,27 @@ RT64_EXPORT void *RT64_GetGatherFrame(RT64_GATHER *gather, int slot) {          
 }
 RT64_EXPORT void RT64_DestroyGather(RT64_GATHER *gather) { RT64_TRY delete reinterpret_cast<Gather *>(gather); RT64_CATCH_VOID }
 // Partition layout, as pure functions (no device needed): which rank owns frame row y and where the row sits in that rank's packed buffer.
-RT64_EXPORT int RT64_GatherRowOwner(int height, int count, int bands, int y, int *packedRow) { int p = 0; const int r = gather_row_owner(gather_layout(height, count, bands ? 1 : 0), y, &p); if (packedRow) *packedRow = p; return r; }
-RT64_EXPORT int RT64_GatherOwnedRows(int height, int count, int bands, int rank) { return gather_owned_rows(gather_layout(height, count, bands ? 1 : 0), rank); }
-RT64_EXPORT int RT64_GatherSlotRows(int height, int count, int bands) { return gather_max_owned_rows(gather_layout(height, count, bands ? 1 : 0)); }
+// bands = 0 (interleaved strips) and 1 (equal bands) are functions of (height, count) alone.  bands = 2 (cost-balanced) is not: its boundaries are
+// cut from a frame, so these three answer -1 for it and the *Of forms below take the boundaries (RT64_GetGatherBands / RT64_BalanceGatherBands).
+RT64_EXPORT int RT64_GatherRowOwner(int height, int count, int bands, int y, int *packedRow) {
+    if (bands < 0 || bands > 1 || height < 1 || count < 1 || y < 0 || y >= height) return -1;
+    int p = 0; const int r = gather_row_owner(gather_layout(height, count, bands), y, &p); if (packedRow) *packedRow = p; return r;
+}
+RT64_EXPORT int RT64_GatherOwnedRows(int height, int count, int bands, int rank) { return (bands < 0 || bands > 1 || height < 1 || count < 1 || rank < 0 || rank >= count) ? -1 : gather_owned_rows(gather_layout(height, count, bands), rank); }
+RT64_EXPORT int RT64_GatherSlotRows(int height, int count, int bands) { return (bands < 0 || bands > 1 || height < 1 || count < 1) ? -1 : gather_max_owned_rows(gather_layout(height, count, bands)); }
+// The same three for a layout given by its band boundaries starts[0 .. count] (cost-balanced bands; also valid for equal bands).
+static bool gather_layout_of(int height, int count, const int *starts, GatherLayout &L) {
+    if (!starts || height < 1 || count < 1 || count > RT64_GATHER_MAX_RANKS || starts[0] != 0 || starts[count] != height) return false;
+    L = gather_layout(height, count, 2);
+    for (int r = 0; r <= count; r++) { if (r && starts[r] < starts[r - 1]) return false; L.starts[r] = starts[r]; }
+    return true;
+}
+RT64_EXPORT int RT64_GatherRowOwnerOf(int height, int count, const int *starts, int y, int *packedRow) {
+    GatherLayout L; if (!gather_layout_of(height, count, starts, L) || y < 0 || y >= height) return -1;
+    int p = 0; const int r = gather_row_owner(L, y, &p); if (packedRow) *packedRow = p; return r;
+}
+RT64_EXPORT int RT64_GatherOwnedRowsOf(int height, int count, const int *starts, int rank) { GatherLayout L; return (!gather_layout_of(height, count, starts, L) || rank < 0 || rank >= count) ? -1 : gather_owned_rows(L, rank); }
+RT64_EXPORT int RT64_GatherSlotRowsOf(int height, int count, const int *starts) { GatherLayout L; return !gather_layout_of(height, count, starts, L) ? -1 : gather_max_owned_rows(L); }
 // The band boundaries of an existing gather (bands = 1 or 2): starts[0 .. count], rank r owns rows [starts[r], starts[r + 1]).  Returns count, 0 for interleaved strips.
 RT64_EXPORT int RT64_GetGatherBands(RT64_GATHER *gather, int *starts, int capacity) {
     Gather *g = reinterpret_cast<Gather *>(gather);

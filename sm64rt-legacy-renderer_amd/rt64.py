@@ -22,7 +22,7 @@ TEXTURE_FORMAT_RGBA8, TEXTURE_FORMAT_DDS = 0x1, 0x2
 UPSCALER_OFF, UPSCALER_AUTO, UPSCALER_DLSS, UPSCALER_FSR, UPSCALER_XESS = range(5)
 (UPSCALER_MODE_AUTO, UPSCALER_MODE_ULTRA_PERFORMANCE, UPSCALER_MODE_PERFORMANCE, UPSCALER_MODE_BALANCED, UPSCALER_MODE_QUALITY,
  UPSCALER_MODE_ULTRA_QUALITY, UPSCALER_MODE_NATIVE) = range(7)
-ACCEL_NODES, ACCEL_TRIANGLES, ACCEL_SORTED_INDEX, ACCEL_MORTON, ACCEL_HEADER = range(5)
+ACCEL_NODES, ACCEL_TRIANGLES, ACCEL_SORTED_INDEX, ACCEL_MORTON, ACCEL_HEADER, ACCEL_HOST_DEPTH = range(6)
 
 (IMAGE_FINAL_RGBA8, IMAGE_SHADING_POSITION, IMAGE_SHADING_NORMAL, IMAGE_SHADING_SPECULAR, IMAGE_DIFFUSE,
  IMAGE_INSTANCE_ID, IMAGE_DIRECT_LIGHT_RAW, IMAGE_DIRECT_LIGHT_FILTERED, IMAGE_INDIRECT_LIGHT_RAW,
@@ -193,6 +193,7 @@ EXT_API = [
     ("SetDeviceGatherTarget", "RT64_SetDeviceGatherTarget", None, [_P, _P, C.c_size_t]),
     ("ReadbackMeshAccel", "RT64_ReadbackMeshAccel", C.c_size_t, [_P, C.c_int, _P, C.c_size_t]),
     ("ReadbackViewAccel", "RT64_ReadbackViewAccel", C.c_size_t, [_P, C.c_int, _P, C.c_size_t]),
+    ("MeshTreeDepth", "RT64_MeshTreeDepth", C.c_uint, [_P, C.c_int, C.c_int, _P, C.c_int]),
     ("GetGatherUniqueId", "RT64_GetGatherUniqueId", C.c_int, [_P, C.c_size_t]),
     ("CreateGather", "RT64_CreateGather", _P, [_P, _P, C.c_size_t, C.c_int, C.c_int, C.c_int]),
     ("SubmitGather", "RT64_SubmitGather", C.c_int, [_P]),
@@ -202,6 +203,9 @@ EXT_API = [
     ("GatherRowOwner", "RT64_GatherRowOwner", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     ("GatherOwnedRows", "RT64_GatherOwnedRows", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     ("GatherSlotRows", "RT64_GatherSlotRows", C.c_int, [C.c_int, C.c_int, C.c_int]),
+    ("GatherRowOwnerOf", "RT64_GatherRowOwnerOf", C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
+    ("GatherOwnedRowsOf", "RT64_GatherOwnedRowsOf", C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
+    ("GatherSlotRowsOf", "RT64_GatherSlotRowsOf", C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
     ("GetGatherBands", "RT64_GetGatherBands", C.c_int, [_P, C.POINTER(C.c_int), C.c_int]),
     ("BalanceGatherBands", "RT64_BalanceGatherBands", None, [C.POINTER(C.c_uint), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
 ]

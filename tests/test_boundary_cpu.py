@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(built):
     h = C.CDLL(built, mode=C.RTLD_LOCAL)
     header = open(os.path.join(ROOT, "include", "rt64.h")).read()
     declared = sorted(set(re.findall(r"X\(\w+,\s*(RT64_\w+),", header)))
-    assert len(declared) == 33 + 23, declared          # the reference's 33 + the additive exports (12 headless / readback / stats + 11 multi-GPU gather)
+    assert len(declared) == 33 + 27, declared          # the reference's 33 + the additive exports (13 headless / readback / stats + 14 multi-GPU gather)
     assert sorted(rt64.exported_symbols()) == declared
     for name in declared:
         assert hasattr(h, name), name
@@ -87,3 +87,58 @@ int main(void) {
     r = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
     assert r.returncode == 0, r.stdout
     assert "device ok" in r.stdout or "no device" in r.stdout, r.stdout
+
+
+def _oracle_tree_depth(bvh):
+    """Inner nodes on the longest root-to-leaf path of an oracle LBVH (what lbvh.hip leaves in BlasHeader::depth)."""
+    nodes, n = bvh["nodes"], bvh["count"]
+    if n <= 1:
+        return 1
+    depth, todo = 0, [(0, 1)]
+    while todo:
+        i, d = todo.pop()
+        depth = max(depth, d)
+        for c in (int(nodes["left"][i]), int(nodes["right"][i])):
+            if not (c & 0x80000000):
+                todo.append((c, d + 1))
+    return depth
+
+
+def test_host_side_tree_depth_equals_the_depth_of_the_oracle_lbvh(built, sample_data):
+    """RT64_SetMesh sizes the traversal stacks from a depth it computes on the host (no wait for the device build).  RT64_MeshTreeDepth is
+    that computation as a pure function: it has to be the depth of the tree the builders make -- the oracle's LBVH, which the device
+    builder reproduces bit for bit (tests/test_gpu_parity.py) -- on the sample meshes, random soups, duplicates and degenerate inputs."""
+    import numpy as np
+    from sm64rt_legacy_renderer_amd import rt64
+    from oracle import oracle_py
+    lib = rt64.Library(built)
+    L = oracle_py.lib()
+    rng = np.random.default_rng(11)
+
+    def check(verts, idx, stride=None):
+        v = np.ascontiguousarray(verts); i = np.ascontiguousarray(idx, dtype=np.uint32)
+        stride = stride or v.dtype.itemsize * (v.shape[1] if v.ndim == 2 else 1)
+        m = L.oracle_mesh_create(1)
+        try:
+            L.oracle_mesh_set(m, v.ctypes.data, len(v), stride, i.ctypes.data, len(i))
+            want = _oracle_tree_depth(oracle_py.bvh_to_numpy(L.oracle_mesh_bvh(m)))
+        finally:
+            L.oracle_mesh_destroy(m)
+        got = lib.MeshTreeDepth(v.ctypes.data, len(v), stride, i.ctypes.data, len(i))
+        assert got == want, (got, want, len(i) // 3)
+        return got
+
+    for m in sample_data.meshes:
+        if m.flags & rt64.MESH_RAYTRACE_ENABLED:
+            check(m.vertices, m.indices, m.vertices.dtype.itemsize)
+    for n in (1, 2, 3, 17, 320, 1500, 4096):
+        p = rng.normal(size=(3 * n, 3)).astype(np.float32) * np.float32(5.0)
+        check(p, np.arange(3 * n), 12)
+    p = np.tile(rng.normal(size=(3, 3)).astype(np.float32), (64, 1))            # 64 copies of one triangle: equal codes, the leaf number decides
+    assert check(p, np.arange(192), 12) >= 6
+    p = np.zeros((300, 3), dtype=np.float32)                                      # every triangle degenerate at the origin (extent 0 on all axes)
+    check(p, np.arange(300), 12)
+    p = rng.normal(size=(600, 3)).astype(np.float32); p[:, 1] = 0.0              # flat soup: one axis without extent
+    check(p, rng.integers(0, 600, size=900), 12)
+    big = rng.normal(size=(3 * 4097, 3)).astype(np.float32)                       # above the single-workgroup builder: "deep" without looking
+    assert lib.MeshTreeDepth(big.ctypes.data, len(big), 12, np.arange(3 * 4097, dtype=np.uint32).ctypes.data, 3 * 4097) == 255

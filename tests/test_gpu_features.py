@@ -447,3 +447,131 @@ def test_interleaved_strip_partition_reassembles_the_whole_frame(rt64_lib, sampl
         assert np.array_equal(tiles.assemble(packed, H, W, ranks), whole)
     finally:
         s.close()
+
+
+def _mutation_sequences():
+    """Scene changes a host can make between a lean frame and the next frame (name -> function(scene, data, lib) applied after frame 1)."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+
+    def add_instance_and_gi(s, data, lib):
+        h = lib.CreateInstance(s.scene)
+        s.instances.append(h)
+        inst = copy.copy(data.instances[1]); inst.material = sample_scene.copy_material(inst.material); inst.name = "sphere2"
+        t = np.eye(4, dtype=np.float32); t[3, 0] = 3.5; t[3, 2] = -2.0
+        inst.transform = inst.previous_transform = t
+        s.set_instance(len(s.instances) - 1, inst)
+        s.set_view_description(gi_samples=1, denoiser=True)
+
+    def rebuild_mesh_and_translucent(s, data, lib):
+        v = data.meshes[0].vertices.copy(); v["position"][:, 0] += np.float32(1.25); v["position"][:, 1] *= np.float32(0.8)
+        s.set_mesh(s.meshes[0], v, data.meshes[0].indices)                  # not UPDATABLE: a rebuild with another topology
+        inst = copy.copy(data.instances[1]); inst.material = sample_scene.copy_material(inst.material)
+        inst.material.solidAlphaMultiplier = 0.6                              # the sphere leaves rule O1: k-buffer frame
+        data.instances[1] = inst
+
+    def remove_instance_and_reflection(s, data, lib):
+        lib.DestroyInstance(s.instances[3]); s.instances[3] = None          # the floor goes
+        inst = copy.copy(data.instances[1]); inst.material = sample_scene.copy_material(inst.material)
+        inst.material.reflectionFactor = 0.4
+        data.instances[1] = inst
+
+    def swap_texture(s, data, lib):
+        t = data.textures[4]                                                   # tiles_dif: destroyed and replaced by its negative
+        lib.DestroyTexture(s.textures[4])
+        d = rt64.TEXTURE_DESC(); buf = np.ascontiguousarray(255 - t.data); buf[..., 3] = 255
+        d.bytes = buf.ctypes.data; d.byteCount = buf.nbytes; d.format = t.format; d.width, d.height, d.rowPitch = t.width, t.height, t.width * 4
+        s.textures[4] = lib.CreateTexture(s.device, d)
+        for k, inst in enumerate(data.instances):
+            if s.instances[k] is not None and inst.diffuse == 4:
+                s.set_instance(k, inst)
+        s.set_view_description(gi_samples=1, denoiser=True)
+    return dict(add_instance_and_gi=add_instance_and_gi, rebuild_mesh_and_translucent=rebuild_mesh_and_translucent,
+                remove_instance_and_reflection=remove_instance_and_reflection, swap_texture=swap_texture)
+
+
+@pytest.mark.parametrize("change", sorted(_mutation_sequences()))
+def test_scene_change_after_a_lean_frame_keeps_that_frame_intact(rt64_lib, sample_data, change):
+    """A lean frame stores its back buffer only; its other images are re-traced on demand from the frame's meshes, textures, tables, TLAS and
+    LDS cache image (View::materialise).  When the host then changes the scene -- adds or removes an instance, rebuilds a mesh, replaces a
+    texture -- and the next frame is not lean, the library must produce the lean frame's images BEFORE the new contents overwrite what they
+    are made from (round-2 ADVICE, high).  Same call sequence with lean_frames = 0 (every frame stores its whole G-buffer): every image of
+    the frame after the change -- history-dependent ones included -- and of the frame before it (read after the change) is the same bytes."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    images = [rt64.IMAGE_FINAL_RGBA8, rt64.IMAGE_OUTPUT_RGBA32F, rt64.IMAGE_PRIMARY_HIT, rt64.IMAGE_INSTANCE_ID, rt64.IMAGE_DIFFUSE, rt64.IMAGE_DIRECT_LIGHT_RAW,
+              rt64.IMAGE_INDIRECT_LIGHT_RAW, rt64.IMAGE_INDIRECT_LIGHT_FILTERED, rt64.IMAGE_SHADING_POSITION, rt64.IMAGE_SHADING_NORMAL, rt64.IMAGE_DEPTH,
+              rt64.IMAGE_FLOW, rt64.IMAGE_REFLECTION, rt64.IMAGE_TRANSPARENT, rt64.IMAGE_FIRST_INSTANCE_ID]
+    got = {}
+    for lean in (1, 0):
+        data = _variant(sample_data, lambda d: None)
+        s = sample_scene.Rt64Scene(rt64_lib, data, 333, 187, hip_device=0)
+        try:
+            s.option("lean_frames", lean)
+            s.draw(); s.draw()
+            assert s.stats().leanFrame == lean
+            _mutation_sequences()[change](s, data, rt64_lib)
+            before = [s.readback(i) for i in (rt64.IMAGE_INSTANCE_ID, rt64.IMAGE_PRIMARY_HIT, rt64.IMAGE_SHADING_NORMAL, rt64.IMAGE_DIFFUSE)]      # frame 1, read after the change
+            # Rt64Scene.draw re-sends the sphere's descriptor like the sample host (main.cpp:129): from `data`, which the change updated
+            s._desc_cache.clear()
+            s.draw(); s.draw()
+            assert s.stats().leanFrame == 0
+            got[lean] = before + [s.readback(i) for i in images]
+        finally:
+            s.instances = [h for h in s.instances if h is not None]
+            s.close()
+    for k, (a, b) in enumerate(zip(got[1], got[0])):
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8)), (change, k)
+
+
+def test_frames_after_a_scene_change_hold_off_lean_rendering_then_return_to_it(rt64_lib, sample_data):
+    """A host that changes its scene every frame would pay for a materialise per frame; after a change that had to materialise a lean frame the
+    next RT64_LEAN_HOLDOFF_FRAMES frames store their G-buffer themselves, then lean frames resume.  Back buffers are the same bytes either way."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    data = _variant(sample_data, lambda d: None)
+    s = sample_scene.Rt64Scene(rt64_lib, data, 320, 180, hip_device=0)
+    try:
+        s.draw(); s.draw()
+        ref = s.readback(rt64.IMAGE_FINAL_RGBA8).copy()
+        assert s.stats().leanFrame == 1
+        s.set_mesh(s.meshes[0], data.meshes[0].vertices, data.meshes[0].indices)       # same arrays: a change as far as the library can tell
+        lean = []
+        for f in range(8):
+            s.draw()
+            lean.append(int(s.stats().leanFrame))
+            assert np.array_equal(s.readback(rt64.IMAGE_FINAL_RGBA8), ref), f
+        assert lean[0] == 0 and lean[-1] == 1 and sorted(lean) == lean, lean
+    finally:
+        s.close()
+
+
+def test_host_side_tree_depth_is_the_depth_the_device_builder_reports(rt64_lib, sample_data):
+    """RT64_ACCEL_HOST_DEPTH (computed at RT64_SetMesh, no wait) against BlasHeader::depth written by the device builder, for the sample
+    meshes, a random soup, duplicates, and a refit that keeps the topology."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    s = sample_scene.Rt64Scene(rt64_lib, sample_data, 64, 64, hip_device=0)
+    rng = np.random.default_rng(3)
+    try:
+        def depths(mesh):
+            hdr = np.zeros(8, dtype=np.uint32); host = np.zeros(1, dtype=np.uint32)
+            assert rt64_lib.ReadbackMeshAccel(mesh, rt64.ACCEL_HEADER, hdr.ctypes.data, hdr.nbytes) == 32
+            assert rt64_lib.ReadbackMeshAccel(mesh, rt64.ACCEL_HOST_DEPTH, host.ctypes.data, 4) == 4
+            return int(hdr[7]), int(host[0])
+        for k, m in enumerate(sample_data.meshes):
+            if m.flags & rt64.MESH_RAYTRACE_ENABLED:
+                dev, host = depths(s.meshes[k])
+                assert dev == host and 1 <= dev < 64, (m.name, dev, host)
+        h = rt64_lib.CreateMesh(s.device, rt64.MESH_RAYTRACE_ENABLED | rt64.MESH_RAYTRACE_UPDATABLE)
+        s.meshes.append(h)
+        for n in (1, 2, 77, 1024, 4096):
+            p = np.zeros(3 * n, dtype=sample_scene.VERTEX_DTYPE)
+            p["position"][:, :3] = rng.normal(size=(3 * n, 3)).astype(np.float32); p["position"][:, 3] = 1.0
+            if n == 77:
+                p["position"][3:] = p["position"][np.arange(3 * n - 3) % 3]        # 77 copies of one triangle
+            s.set_mesh(h, p, np.arange(3 * n, dtype=np.uint32))
+            dev, host = depths(h)
+            assert dev == host, (n, dev, host)
+            q = p.copy(); q["position"][:, :3] = rng.normal(size=(3 * n, 3)).astype(np.float32)
+            s.set_mesh(h, q, np.arange(3 * n, dtype=np.uint32))                    # same shape on an UPDATABLE mesh: refit, topology (and depth) kept
+            dev2, host2 = depths(h)
+            assert dev2 == dev and host2 == host, (n, dev2, host2)
+    finally:
+        s.close()

@@ -64,6 +64,38 @@ def test_library_layout_exports_agree_with_the_python_partition():
                     assert lib.GatherRowOwner(h, n, bands, y, C.byref(p)) == owner[y] and p.value == packed_row[y], (h, n, bands, y)
 
 
+def test_layout_exports_for_cost_balanced_bands_take_the_boundaries():
+    """bands = 2: the boundaries come from a frame, so the (height, count, bands) forms refuse it (-1) and the *Of forms answer from
+    starts[] -- the table RT64_GetGatherBands / RT64_BalanceGatherBands produce.  Pure host functions, no GPU."""
+    import ctypes as C
+    from sm64rt_legacy_renderer_amd import rt64
+    lib = rt64.Library()
+    p = C.c_int()
+    assert lib.GatherRowOwner(1080, 4, 2, 10, C.byref(p)) == -1 and lib.GatherOwnedRows(1080, 4, 2, 0) == -1 and lib.GatherSlotRows(1080, 4, 2) == -1
+    rng = np.random.default_rng(5)
+    for h, w, n in ((270, 480, 3), (1080, 1920, 8), (64, 64, 4), (2160, 3840, 8)):
+        hits = np.zeros(h, dtype=np.uint32)
+        hits[h // 2:] = rng.integers(w // 2, w, size=h - h // 2)            # sky above, geometry below
+        starts = (C.c_int * (n + 1))()
+        lib.BalanceGatherBands(hits.ctypes.data_as(C.POINTER(C.c_uint)), w, h, n, starts)
+        st = list(starts)
+        assert st[0] == 0 and st[n] == h and all(b > a for a, b in zip(st, st[1:]))
+        cost = (w + 6.0 * hits.astype(np.float64))
+        per = [cost[a:b].sum() for a, b in zip(st, st[1:])]
+        assert max(per) <= 1.35 * cost.sum() / n or max(b - a for a, b in zip(st, st[1:])) <= 16       # balanced unless the 16-row minimum binds
+        if h >= 32 * n:
+            assert st != [min(r * ((h + n - 1) // n), h) for r in range(n + 1)]                          # ... and not the equal-height cut
+        assert lib.GatherSlotRowsOf(h, n, starts) == max(b - a for a, b in zip(st, st[1:]))
+        for r in range(n):
+            assert lib.GatherOwnedRowsOf(h, n, starts, r) == st[r + 1] - st[r]
+        for y in range(h):
+            r = lib.GatherRowOwnerOf(h, n, starts, y, C.byref(p))
+            assert st[r] <= y < st[r + 1] and p.value == y - st[r], (h, n, y, r)
+        assert lib.GatherRowOwnerOf(h, n, starts, h, C.byref(p)) == -1
+        bad = (C.c_int * (n + 1))(*([0] + [h] * n)); bad[n] = h - 1
+        assert lib.GatherRowOwnerOf(h, n, bad, 0, C.byref(p)) == -1                                      # starts[count] must be the height
+
+
 def _worker(rank, world, init_file, h, w, out_file):
     import torch
     import torch.distributed as dist
