@@ -58,6 +58,8 @@ def parse_args():
     ap.add_argument("--subdiv", type=int, default=0, help="stress variant: sphere subdivision levels")
     ap.add_argument("--floor-grid", type=int, default=1, help="stress variant: floor tessellation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the full-size comparison with the oracle after the timed loop (profiling runs)")
+    ap.add_argument("--parity-frames", type=int, default=0, help="frames of the GI configurations rendered on a fresh scene + oracle pair for the parity object (0: 2 for C3 / C4 / C5)")
     ap.add_argument("--always-rebuild", action="store_true", help="upload the frame tables and rebuild the TLAS every frame (the reference's behaviour)")
     ap.add_argument("--prewarm", type=int, default=100, help="untimed frames before the W warm-up steps (GPU clock ramp; the line reports them)")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE", help="RT64_SetDeviceOption(key, value) before the run (A/B measurements; the line records them under config.options)")
@@ -230,6 +232,7 @@ def main():
         if n != my_bytes:
             raise RuntimeError("RT64_CopyDeviceImage returned %d, expected %d: %s" % (n, my_bytes, lib.last_error()))
 
+    exit_code = [0]
     frame_no = [0]
     step_no = [0]
     packed = [None]              # None: not probed yet; True: frames write the gather slot themselves (RT64_SetDeviceGatherTarget); False: RT64_CopyDeviceImage after each frame
@@ -431,8 +434,15 @@ def main():
                          "tris_per_primary_ray": round(counts["trisPrimary"] / max(counts["primary"], 1), 3),
                          "nodes_per_shadow_ray": round(counts["nodesDirect"] / max(counts["shadow"], 1), 3),
                          "tris_per_shadow_ray": round(counts["trisDirect"] / max(counts["shadow"], 1), 3)})
+        stress = bool(args.subdiv or args.floor_grid > 1)
+        if args.config == "C2" and not stress and not (args.gi_samples or args.denoiser) and (W, H) == (1920, 1080):
+            metric = "Mrays/s (primary+shadow), sample scene 1080p 1spp"                      # BASELINE.json's metric, on the config it is quoted on
+        else:
+            metric = "Mrays/s (primary+shadow%s%s), %s %dx%d, 1 primary sample per pixel%s" % (
+                "+GI bounce" if args.gi_samples else "", "+reflection" if counts["reflection"] else "", "stress variant of the sample scene" if stress else "sample scene", W, H,
+                (", %d GI sample%s per pixel (1 bounce each)%s" % (args.gi_samples, "s" if args.gi_samples > 1 else "", " + SVGF" if args.denoiser else "")) if args.gi_samples else "")
         result = {
-            "metric": "Mrays/s (primary+shadow), sample scene 1080p 1spp", "value": round(value, 2), "unit": "Mrays/s",
+            "metric": metric, "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: src/sample scene, primary+shadow rays + shading + compose, %dx%d 1spp%s" % (
@@ -442,6 +452,8 @@ def main():
                 "partition": ("DIAGNOSIS: rank 0's share of a %d-way partition only, no gather" % PR) if PR > 1 else ("%s x%d + RCCL gather of RGBA8" % (("cost-balanced contiguous bands %s with denoiser halo" % (list(band_starts) if native else "")) if use_bands else "interleaved 16-row strips", N)) if N > 1 else "single GPU"},
             "roofline": roofline,
         }
+        if args.config in sample_scene.BENCH_DEVIATIONS:
+            result["config"]["deviation"] = sample_scene.BENCH_DEVIATIONS[args.config]
         result["prewarm_frames"] = args.prewarm
         if args.option:
             result["config"]["options"] = list(args.option)      # non-default library options: an A/B line, not the headline
@@ -457,8 +469,13 @@ def main():
         if rebuild is not None:
             result["always_rebuild"] = rebuild
         result["frame_tables"] = "rebuilt every frame (always_rebuild)" if args.always_rebuild else "cached while the host re-sends identical descriptors (steady state of the sample host, main.cpp:97-134); `always_rebuild` holds the figure with the cache off"
+        oracle_frame = None
         if N == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(data, W, H, args.cpu_baseline_height)
+            result["cpu_baseline"], oracle_frame = cpu_baseline(data, W, H, args.cpu_baseline_height, keep_frame=(args.config == "C2" and not args.gi_samples))
+        if N == 1 and not G and PR <= 1 and not args.no_parity:
+            # Outside the timed region: the measured configuration at its full size against the oracle (BASELINE.json gate: RMSE <= 1e-3 on the
+            # composed RGBA32F image; hit records are bit-exact).  A line whose frame is wrong is not a measurement: exit non-zero.
+            result["parity"] = parity_object(lib, scene, data, args, W, H, local_rank, oracle_frame)
         if not G:
             fetch(local)
             frame = local[:H * W * 4]
@@ -466,6 +483,9 @@ def main():
         else:
             result["frame_checksum"] = gathered_checksum
         os.write(json_fd, (json.dumps(result) + "\n").encode())
+        if result.get("parity") and not result["parity"]["pass"]:
+            print("bench.py: PARITY FAILED against the oracle at %dx%d: %s" % (W, H, json.dumps(result["parity"])), file=sys.stderr)
+            exit_code[0] = 3
 
     if gatherer:
         gatherer.close()                 # torch's current stream goes back to the default one before the renderer's stream is destroyed
@@ -475,6 +495,8 @@ def main():
     if G:
         dist.barrier()
         dist.destroy_process_group()
+    if exit_code[0]:
+        raise SystemExit(exit_code[0])
 
 
 VALU_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: fp32 vector peak = 1024 SIMD-32s x 32 lanes x 2 flop x 2.4 GHz, i.e. ONE wave64 instruction per SIMD every 2 cycles
@@ -599,7 +621,7 @@ def host_threads():
     return max(1, n)
 
 
-def cpu_baseline(data, W, H, rows):
+def cpu_baseline(data, W, H, rows, keep_frame=False):
     """The scalar C oracle (kind "port": same LBVH, same traversal, same shading math) on the host cores."""
     from oracle import oracle_py
     threads = host_threads()            # every host core this process may use (SURVEY 8d: omp_get_max_threads())
@@ -608,8 +630,12 @@ def cpu_baseline(data, W, H, rows):
         tile = (0, rows) if rows and rows < H else None
         # bounded sample: whole frames of the same workload until about 10 s of CPU work have been timed
         frames, secs, rays, build, t0 = 0, 0.0, 0, 0.0, time.perf_counter()
+        kept = None
         while secs < 10.0 and frames < 400:
-            c = ora.render(W, H, threads=threads, tile=tile)["counters"]
+            r = ora.render(W, H, threads=threads, tile=tile)
+            if keep_frame and kept is None and tile is None:
+                kept = {k: r[k] for k in ("output", "final", "primaryHit")}      # the frame the GPU's measured frame is compared with (parity_object)
+            c = r["counters"]
             rays += c["primaryRays"] + c["shadowRays"] + c["indirectRays"]
             secs += c["secondsRender"]; build += c["secondsBuild"]; frames += 1
         dt = time.perf_counter() - t0
@@ -621,9 +647,65 @@ def cpu_baseline(data, W, H, rows):
         return {"value": round(rays / secs / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
                 "sample": "%d frames of the same C2 workload at %dx%d (%d rows), %d rays, %.2f s render + %.3f s BVH build; %d OpenMP threads on %s (%d logical CPUs)" % (
                     frames, W, H, (tile[1] if tile else H), rays, secs, build, threads, cpu, os.cpu_count() or 0),
-                "ms_per_frame": round(dt * 1e3 / frames, 1)}
+                "ms_per_frame": round(dt * 1e3 / frames, 1)}, kept
     finally:
         ora.close()
+
+
+def compare_frames(got_out, got_final, got_hit, ref, W, H, what):
+    import numpy as np
+    d_out = got_out[..., :3].astype(np.float64) - ref["output"][..., :3].astype(np.float64)
+    d_fin = got_final[..., :3].astype(np.float64) / 255.0 - ref["final"][..., :3].astype(np.float64) / 255.0
+    p = {"size": [W, H], "what": what,
+         "rmse_output": float(np.sqrt(np.mean(d_out ** 2))), "rmse_final": float(np.sqrt(np.mean(d_fin ** 2))),
+         "max_rgba8_diff": int(np.abs(got_final.astype(np.int32) - ref["final"].astype(np.int32)).max()),
+         "hit_mismatches": int((got_hit != ref["primaryHit"]).any(axis=-1).sum()),
+         "gate": {"rmse_output": 1e-3, "rmse_final": 1e-3, "hit_mismatches": 0}}
+    p["pass"] = bool(p["rmse_output"] <= 1e-3 and p["rmse_final"] <= 1e-3 and p["hit_mismatches"] == 0)
+    p["rmse_output"] = float("%.4g" % p["rmse_output"]); p["rmse_final"] = float("%.4g" % p["rmse_final"])
+    return p
+
+
+def parity_object(lib, scene, data, args, W, H, hip_device, oracle_frame):
+    """The measured configuration at its BASELINE size against the oracle (test infrastructure used as the checker, outside the timed region).
+    C2 is a static frame: the images of the scene that was just timed are compared with the frame the cpu_baseline leg rendered.  The GI
+    configurations depend on the frame number (blue-noise slice, history): a fresh scene + oracle pair renders the first F frames of the
+    same call sequence (C4: with its per-frame SetMesh) and the F-th frames are compared."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    from oracle import oracle_py
+    threads = host_threads()
+    if not (args.gi_samples or args.denoiser):
+        if oracle_frame is None:
+            ora = oracle_py.OracleScene(data)
+            try:
+                r = ora.render(W, H, threads=threads)
+                oracle_frame = {k: r[k] for k in ("output", "final", "primaryHit")}
+            finally:
+                ora.close()
+        got = [scene.readback(i) for i in (rt64.IMAGE_OUTPUT_RGBA32F, rt64.IMAGE_FINAL_RGBA8, rt64.IMAGE_PRIMARY_HIT)]
+        return compare_frames(got[0], got[1], got[2], oracle_frame, W, H, "the measured frame (static scene) vs the oracle's frame of the cpu_baseline leg")
+    F = args.parity_frames or 2
+    import copy
+    d2 = copy.copy(data)
+    d2.meshes = [copy.copy(m) for m in data.meshes]
+    anim = sample_scene.c4_animation(d2) if args.config == "C4" else None       # (the material edits of C5 are already in `data`)
+    s2 = sample_scene.Rt64Scene(lib, d2, W, H, hip_device=hip_device)
+    ora = oracle_py.OracleScene(d2)
+    try:
+        s2.set_view_description(gi_samples=args.gi_samples, denoiser=args.denoiser)
+        for kv in args.option:
+            k, _, v = kv.partition("=")
+            s2.option(k, float(v))
+        for f in range(F):
+            if anim is not None:
+                v = anim[(f + 1) % len(anim)]
+                s2.set_mesh(s2.meshes[0], v, d2.meshes[0].indices); ora.set_mesh(ora.meshes[0], v, d2.meshes[0].indices)
+            s2.draw()
+            ref = ora.render(W, H, threads=threads, giSamples=args.gi_samples, denoiserEnabled=int(args.denoiser), denoiserMode=1)
+        got = [s2.readback(i) for i in (rt64.IMAGE_OUTPUT_RGBA32F, rt64.IMAGE_FINAL_RGBA8, rt64.IMAGE_PRIMARY_HIT)]
+        return compare_frames(got[0], got[1], got[2], ref, W, H, "frame %d of a fresh scene + oracle pair running this configuration's call sequence" % F)
+    finally:
+        s2.close(); ora.close()
 
 
 if __name__ == "__main__":

@@ -169,9 +169,9 @@ class OracleScene:
         L.oracle_scene_set_bluenoise(self.scene, bn.ctypes.data)
         self.textures = []
         for t in data.textures:
-            buf = np.ascontiguousarray(t.data)
+            buf, pitch = t.upload_buffer() if hasattr(t, "upload_buffer") else (np.ascontiguousarray(t.data), t.width * 4)
             if t.format == 1:
-                h = L.oracle_texture_create_rgba8(buf.ctypes.data, t.width, t.height, t.width * 4)
+                h = L.oracle_texture_create_rgba8(buf.ctypes.data, t.width, t.height, pitch)
             else:
                 h = L.oracle_texture_create_dds(buf.ctypes.data, buf.nbytes)
             assert h, t.name

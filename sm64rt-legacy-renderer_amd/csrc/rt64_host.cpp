@@ -537,6 +537,11 @@ void Mesh::set(const void *vertexArray, int vcount, int vstride, const unsigned 
     if (vertices.ptr) device->beforeSceneMutation();       // a kept lean frame may still read this mesh's arrays (a first upload changes nothing a frame has seen)
     // rt64_mesh.cpp:30-39,76-82: a change of counts/stride discards the BLAS even if updatable.
     const bool sameShape = vertices.ptr && vertexCount == vcount && vertexStride == vstride && indexCount == icount;
+    // A build that is still only recorded has to run on the arrays it was recorded for when this call is going to REFIT its tree (the
+    // reference's command list holds the build, then the update, in that order): launch it now, before the new arrays are queued behind it.
+    // (Two refits, or anything followed by a full build, merge into the last one: only the latest positions matter there.)
+    if (buildPending && !pendingRefit && (flags & RT64_MESH_RAYTRACE_ENABLED) && (flags & RT64_MESH_RAYTRACE_UPDATABLE) && sameShape && blasCount == (uint32_t)icount / 3)
+        device->flushMeshBuilds();
     const size_t vbytes = (size_t)vcount * vstride, ibytes = (size_t)icount * 4;
     hostVertices.assign(static_cast<const uint8_t *>(vertexArray), static_cast<const uint8_t *>(vertexArray) + vbytes);
     vertices.reserve(vbytes); indices.reserve((size_t)icount);

@@ -36,6 +36,15 @@ class TextureData:
     data: np.ndarray                 # RGBA8: [h, w, 4] uint8 ; DDS: raw file bytes (uint8 1-D)
     width: int = -1
     height: int = -1
+    row_pitch: int = 0               # RGBA8 only: bytes between rows as handed to RT64_CreateTexture (0 = 4 * width, tightly packed)
+
+    def upload_buffer(self):
+        """(bytes, rowPitch) as the host passes them: `data` itself, or -- with a row_pitch -- rows padded with bytes that must never be sampled."""
+        if self.format != rt64.TEXTURE_FORMAT_RGBA8 or self.row_pitch in (0, self.width * 4):
+            return np.ascontiguousarray(self.data), self.width * 4
+        buf = np.full((self.height, self.row_pitch), 0xAB, dtype=np.uint8)
+        buf[:, :self.width * 4] = np.ascontiguousarray(self.data).reshape(self.height, self.width * 4)
+        return buf, self.row_pitch
 
 
 @dataclass
@@ -270,6 +279,15 @@ BENCH_CONFIGS = {
 }
 
 
+# How these definitions read BASELINE.json's wording where the reference has no such knob (bench.py prints it as config.deviation).
+BENCH_DEVIATIONS = {
+    "C4": "BASELINE.json words C4 '2-bounce GI, 2 spp'; as run: giSamples = 2 (two GI rays per pixel), ONE bounce per GI ray, ONE primary sample per pixel. "
+          "The reference has neither a bounce-depth nor a primary-spp knob (IndirectRayGen.hlsl:58-131 traces one bounce per sample; RT64_VIEW_DESC, rt64.h:172-182).",
+    "C5": "BASELINE.json words C5 '4 spp full path trace'; as run: giSamples = 4 (four GI rays per pixel, one bounce each), ONE primary sample per pixel, reflective floor "
+          "(reflectionFactor 0.3, two reflection bounces), SVGF. No primary multi-sampling, no multi-bounce paths: the reference has no such knobs.",
+}
+
+
 def c4_animation(data: "SceneData", frames=16):
     """C4: the sphere mesh becomes UPDATABLE and is displaced every frame, p += 0.1 n sin(frame 0.1 + p.y) (build-defined, seedless).
     Returns the vertex arrays of `frames` consecutive frames; the caller hands one to RT64_SetMesh per step (host copy + refit)."""
@@ -313,10 +331,10 @@ class Rt64Scene:
         self.textures = []
         for t in data.textures:
             d = rt64.TEXTURE_DESC()
-            buf = np.ascontiguousarray(t.data)
+            buf, pitch = t.upload_buffer()
             d.bytes = buf.ctypes.data; d.byteCount = buf.nbytes; d.format = t.format
             if t.format == rt64.TEXTURE_FORMAT_RGBA8:
-                d.width, d.height, d.rowPitch = t.width, t.height, t.width * 4
+                d.width, d.height, d.rowPitch = t.width, t.height, pitch
             else:
                 d.width = d.height = d.rowPitch = -1
             h = lib.CreateTexture(self.device, d)

@@ -89,6 +89,28 @@ def test_c4_refit_every_frame_with_two_gi_samples_and_svgf(rt64_lib, sample_data
     assert np.abs(got["INDIRECT_LIGHT_RAW"][..., 3][hit] - hist[hit]).max() < 1.01
 
 
+@pytest.mark.parametrize("config,width,height,frames", [("C2", 1920, 1080, 1), ("C3", 1920, 1080, 2), ("C4", 1280, 720, 2), ("C5", 1920, 1080, 2)])
+def test_baseline_size_frames_against_the_oracle(rt64_lib, sample_data, config, width, height, frames):
+    """BASELINE.json's configurations at their own size (C2, C3: 1920 x 1080) or half of it per axis (C4: 1280 x 720 of 2560 x 1440, C5:
+    1920 x 1080 of 3840 x 2160 -- the oracle's time), as bench.py sets them up: hit records bit-exact, composed image within the BASELINE gate
+    (RMSE <= 1e-3), back buffer within one RGBA8 step almost everywhere.  These sizes run the code the small frames of the other tests do
+    not: 8 160 workgroups of the one-kernel frame, the 2 048-workgroup persistent grids with several tiles each, full-size SVGF."""
+    got, ref, st = _bench_pair(rt64_lib, sample_data, config, frames=frames, width=width, height=height)
+    assert got["PRIMARY_HIT"].shape == (height, width, 4)
+    assert np.array_equal(got["PRIMARY_HIT"], ref["primaryHit"])
+    assert _rmse(got["OUTPUT_RGBA32F"][..., :3], ref["output"][..., :3]) <= 1e-3
+    assert _rmse(got["FINAL_RGBA8"][..., :3] / 255.0, ref["final"][..., :3] / 255.0) <= 1e-3
+    d = np.abs(got["FINAL_RGBA8"].astype(np.int32) - ref["final"].astype(np.int32))
+    assert (d > 1).mean() < (1e-5 if config == "C2" else 2e-3), (d.max(), (d > 1).mean())
+    assert np.abs(got["DIFFUSE"] - ref["diffuse"]).max() <= 1.0 / 255.0 + 1e-6
+    c = ref["counters"]
+    assert st[0].primaryRays == c["primaryRays"] == width * height
+    assert st[0].nodesPrimary == c["nodesVisitedPrimary"] and st[0].trianglesPrimary == c["trianglesTestedPrimary"]
+    if config != "C2":
+        assert _rmse(got["INDIRECT_LIGHT_FILTERED"][..., :3], ref["filteredIndirect"][..., :3]) <= 2e-3
+        assert st[0].indirectRays == c["indirectRays"] > 0
+
+
 @pytest.mark.parametrize("bands", [None, [(0, 64), (64, 121), (121, H)]])
 def test_c5_four_gi_samples_reflective_floor_svgf(rt64_lib, sample_data, bands):
     """C5 as `bench.py --config C5` sets it: 4 GI samples, floor reflectionFactor 0.3 (two reflection bounces), SVGF -- once whole, once
