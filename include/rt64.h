@@ -394,6 +394,9 @@ typedef struct {
     X(GetDeviceStats, RT64_GetDeviceStats, int, (RT64_DEVICE *device, RT64_FRAME_STATS *stats)) \
     /* Named numeric knobs ("count_traversal", "profile_passes", "sync_present", ...). Returns 0 when the key is unknown. */ \
     X(SetDeviceOption, RT64_SetDeviceOption, int, (RT64_DEVICE *device, const char *key, double value)) \
+    /* Profiling aid (RT64_SetDeviceOption("tile_timing", 1)): two 16-byte records per wave of the last one-kernel frame, in workgroup order: at its \
+       start { chip-wide 100 MHz clock, shader clock (low 32 bits each), HW_ID, 1 }, at its end { clock, shader clock, 0, 1 }; zeros for waves that did not run. */ \
+    X(ReadbackTileTiming, RT64_ReadbackTileTiming, size_t, (RT64_DEVICE *device, void *dst, size_t dstBytes)) \
     /* hipStream_t the device submits on, as void*. */ \
     X(GetDeviceStream, RT64_GetDeviceStream, void *, (RT64_DEVICE *device)) \
     /* Debug readback of acceleration structures (RT64_ACCEL_*): the mesh's BLAS / the view's TLAS of the last frame. \

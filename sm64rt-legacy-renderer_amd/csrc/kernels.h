@@ -40,6 +40,7 @@ hipError_t bc7_decode_launch(const uint8_t *blocks, uint8_t *rgba, uint32_t widt
 #define RT_STACK_LDS 24               // traversal stack entries per lane in LDS of the kernels without the scene cache; deeper levels go to the HBM spill slab
 #define RT_STACK_LDS_CACHED 16        // traversal stack entries (LDS only, no spill path) of the kernels that hold the LDS scene cache: a power of two
 #define RT_GRID_BLOCKS 2048           // persistent grid of every ray kernel (8 workgroups of 256 per CU)
+#define RT_TIMING_WAVES ((8192u + 8u) * 4u)   // waves the tile-timing buffer has records for (profiling aid)
 #define RT_MAX_FRAME_GROUPS 8192u     // largest grid of the one-workgroup-per-tile kernels (bigger frames give every workgroup a few tiles)
 size_t rt_stack_spill_bytes(int width, int rows);        // bytes FrameParams::traversalStack needs for a frame of that size
 
@@ -56,7 +57,8 @@ hipError_t launch_gaussian(const uint16_t *in, uint16_t *out, int width, int hei
 hipError_t launch_compose_post(const FrameParams &P, const ViewImages &I, int cur, bool lean, bool writeFinal, hipStream_t s);
 // A lean frame in one launch: primary visibility + resolve + direct light + compose (passes.hip, lean_frame_kernel).
 // maxGroups: cap of the grid (RT_MAX_FRAME_GROUPS; device option max_frame_groups lowers it so that small frames exercise the several-tiles-per-workgroup walk)
-hipError_t launch_lean_frame(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, int cur, bool full, int ownedY0, int ownedY1, unsigned maxGroups, hipStream_t s);
+// perWave: frames without the LDS scene cache run one wave (an 8 x 8 wave-tile) per workgroup instead of one 16 x 16 tile
+hipError_t launch_lean_frame(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, int cur, bool full, int ownedY0, int ownedY1, unsigned maxGroups, bool perWave, hipStream_t s);
 hipError_t launch_post_process(const FrameParams &P, const ViewImages &I, hipStream_t s);      // PostProcessPS as its own pass (resolution scale / motion blur)
 // passes_simple.hip: the same launchers over kernels compiled without non-power-of-two texture addressing and without the shadow any-hit
 // program; the launchers above route to them when FrameParams::simpleKernels is set
@@ -65,7 +67,7 @@ hipError_t launch_direct_simple(const FrameParams &P, const ViewImages &I, int c
 hipError_t launch_indirect_simple(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, int walk, hipStream_t s);
 hipError_t launch_refraction_simple(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s);
 hipError_t launch_reflection_simple(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s);
-hipError_t launch_lean_frame_simple(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, int cur, bool full, int ownedY0, int ownedY1, unsigned maxGroups, hipStream_t s);
+hipError_t launch_lean_frame_simple(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, int cur, bool full, int ownedY0, int ownedY1, unsigned maxGroups, bool perWave, hipStream_t s);
 hipError_t launch_clear_final(const FrameParams &P, const ViewImages &I, hipStream_t s);
 
 // ---- raster.hip ----------------------------------------------------------------------------------------------------

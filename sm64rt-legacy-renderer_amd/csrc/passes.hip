@@ -67,12 +67,20 @@ template <int SHAPE = TILE_SQUARE> DEV Pixel tile_pixel(PRef P, uint32_t tile) {
 
 DEV bool row_owned(PRef P, int y) { return (((y - P.tileY0) / 16) % P.stripCount) == P.stripRank; }
 
-DEV TraceStack make_stack(PRef P, uint32_t *ldsStack) {
+// wordsPerLane: uint32 words of the stack array per lane (RT_STACK_LDS, or RT_STACK_LDS_CACHED / 2 for the int16 stacks of the cached kernels)
+DEV TraceStack make_stack(PRef P, uint32_t *ldsStack, uint32_t wordsPerLane = RT_STACK_LDS) {
     TraceStack s;
-    s.lds = (LdsU32Ptr)(ldsStack + threadIdx.x);
-    s.spill = (GlobalU32Ptr)(P.traversalStack + ((size_t)blockIdx.x * RT_BLOCK + threadIdx.x) * RT_STACK_SPILL);
-    s.cache = nullptr; s.ldsEntries = RT_STACK_LDS; s.lds16 = nullptr;
+    uint32_t *block = ldsStack + (threadIdx.x >> 6) * wordsPerLane * RT_LANES;       // this wave's [entry][lane] block
+    s.lds = (LdsU32Ptr)(block + (threadIdx.x & 63u));
+    s.lds16 = (LdsI16Ptr)block + (threadIdx.x & 63u);
+    s.spill = (GlobalU32Ptr)(P.traversalStack + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * RT_STACK_SPILL);
+    s.cache = nullptr; s.ldsEntries = RT_STACK_LDS;
     return s;
+}
+// this lane's columns of the light-candidate arrays, [wave][slots][lane] (floats, then bytes)
+DEV void light_columns(ShadeEnv &env, float *intensities, uint8_t *indices, uint32_t slots) {
+    const uint32_t at = (threadIdx.x >> 6) * slots * RT_LANES + (threadIdx.x & 63u);
+    env.lightIntensity = intensities + at; env.lightIndex = indices + at;
 }
 
 // LDS scene cache, filled once per workgroup (all threads call it; ends with a barrier).  Layout in 16-byte words:
@@ -218,10 +226,11 @@ DEV bool surface_record(PRef P, IRef I, size_t pixel, uint32_t hit, const Surfac
 template <bool KLIST, bool CACHED = false>
 __global__ __launch_bounds__(RT_BLOCK, KLIST ? 2 : TRACE_WAVES) void primary_trace_kernel(FrameParams Pv, ViewImages Iv, int32_t *hitInstance) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
-    __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED / 2 : RT_STACK_LDS) * RT_BLOCK];
+    constexpr uint32_t STACK_WORDS = CACHED ? RT_STACK_LDS_CACHED / 2 : RT_STACK_LDS;
+    __shared__ uint32_t ldsStack[STACK_WORDS * RT_BLOCK];
     extern __shared__ u32x4_lds dynLds[];
     if (CACHED) fill_scene_cache(P, dynLds);
-    ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
+    ShadeEnv env; env.stk = make_stack(P, ldsStack, STACK_WORDS); env.cnt = TraceCounts(); env.shadowRays = 0;
     env.lightIntensity = nullptr; env.lightIndex = nullptr;              // pure visibility: no light is picked in this kernel
     if (CACHED) env.stk.use_cache(dynLds);
     uint32_t rays = 0;
@@ -420,11 +429,12 @@ DEV void store_primary(PRef P, IRef I, size_t i, int cur, f3 rayDirection, const
 template <bool TRANSPARENT_LIGHT, bool KLIST, bool FULL>
 __global__ __launch_bounds__(RT_BLOCK, SHADE_WAVES) void primary_shade_kernel(FrameParams Pv, ViewImages Iv, const int32_t *hitInstance, int cur) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
-    __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
+    constexpr uint32_t STACK_WORDS = RT_STACK_LDS;
+    __shared__ uint32_t ldsStack[STACK_WORDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
-    ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
-    env.lightIntensity = ldsLightIntensity + threadIdx.x; env.lightIndex = ldsLightIndex + threadIdx.x;
+    ShadeEnv env; env.stk = make_stack(P, ldsStack, STACK_WORDS); env.cnt = TraceCounts(); env.shadowRays = 0;
+    light_columns(env, ldsLightIntensity, ldsLightIndex, RT64_MAX_LIGHTS + 1);
     const uint32_t tiles = tile_count<SHADE_TILE>(P);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         PRef P = *kernel_params_here(); IRef I = *kernel_images_here();      // this trip's view of the frame constants and the image table (read where used, never carried across trips)
@@ -503,8 +513,7 @@ DEV void cached_env(PRef P, ShadeEnv &env, u32x4_lds *dynLds) {
     fill_scene_cache(P, dynLds);
     env.stk.use_cache(dynLds);
     float *li = reinterpret_cast<float *>(dynLds + P.cacheWords);
-    env.lightIntensity = li + threadIdx.x;
-    env.lightIndex = reinterpret_cast<uint8_t *>(li + light_slots(P) * RT_BLOCK) + threadIdx.x;
+    light_columns(env, li, reinterpret_cast<uint8_t *>(li + light_slots(P) * blockDim.x), light_slots(P));
 }
 
 // DirectRayGen.hlsl:47-58 for one lit pixel: sampled lights + self light + eye light (before the temporal accumulation).
@@ -524,12 +533,13 @@ DEV f3 direct_light_pixel(PRef P, ShadeEnv &env, uint32_t px, uint32_t py, f3 ra
 template <bool FULL, bool CACHED = false>
 __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void direct_kernel(FrameParams Pv, ViewImages Iv, int cur) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
-    __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED / 2 : RT_STACK_LDS) * RT_BLOCK];
+    constexpr uint32_t STACK_WORDS = CACHED ? RT_STACK_LDS_CACHED / 2 : RT_STACK_LDS;
+    __shared__ uint32_t ldsStack[STACK_WORDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     extern __shared__ u32x4_lds dynLds[];
-    ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
-    env.lightIntensity = ldsLightIntensity + threadIdx.x; env.lightIndex = ldsLightIndex + threadIdx.x;
+    ShadeEnv env; env.stk = make_stack(P, ldsStack, STACK_WORDS); env.cnt = TraceCounts(); env.shadowRays = 0;
+    light_columns(env, ldsLightIntensity, ldsLightIndex, RT64_MAX_LIGHTS + 1);
     if (CACHED) cached_env(P, env, dynLds);
     const uint32_t tiles = tile_count<DIRECT_TILE>(P);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
@@ -576,27 +586,49 @@ __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void direct_kernel(FramePar
 // refraction, fog, motion blur downstream): it writes the reference's whole G-buffer like primary_shade_kernel<.., FULL> and
 // DirectRayGen's two images like direct_kernel<true>, and leaves Compose to its own pass.  ownedY0 / ownedY1: the rows DirectRayGen
 // covers (the frame parameters may include a denoiser halo above and below them, which only the G-buffer part renders).
-template <bool CACHED, bool FULL, int WAVES>
 #ifndef LEAN_WAVES
 #define LEAN_WAVES 3          // waves per SIMD of the one-kernel frame: 3 (168 VGPRs) measured 12 % faster than 2 (193 VGPRs, no spills); 4 (128 VGPRs, 62 spilled dwords in the simple build) measured 30 % slower
 #endif
-__global__ __launch_bounds__(RT_BLOCK, WAVES) void lean_frame_kernel(FrameParams Pv, ViewImages Iv, int32_t *hitInstance, int cur, int ownedY0, int ownedY1) {
+// BLOCK = 256: one 16 x 16 tile per workgroup trip, a wave owns an 8 x 8 quadrant (scenes with the LDS scene cache: its fill is shared by four waves).
+// BLOCK = 64 : the per-wave form for scenes that walk from HBM / L2 -- one 8 x 8 wave-tile per workgroup trip.  Nothing is shared between the waves of
+//              such a frame, and with one wave per workgroup every wave's registers AND its LDS are free the moment it ends: a tile whose four quadrants
+//              cost very differently (the silhouette of a dense mesh) no longer holds three finished waves' resources until its slowest wave is done,
+//              and the dispatcher balances 4 x as many, 4 x smaller jobs.  Wave-tile -> workgroup map (wave_tile_of): the four quadrants of a tile go to
+//              workgroups 8 apart -- the same XCD under round-robin placement, so a tile's rays still share one L2.
+DEV bool wave_tile_of(uint32_t seq, uint32_t tiles, uint32_t &tileSeq, uint32_t &quadrant) {
+    const uint32_t xcd = seq & 7u, j = seq >> 3;
+    quadrant = j & 3u; tileSeq = (j >> 2) * 8u + xcd;
+    return tileSeq < tiles;
+}
+template <bool CACHED, bool FULL, int WAVES, int BLOCK = RT_BLOCK>
+__global__ __launch_bounds__(BLOCK, WAVES) void lean_frame_kernel(FrameParams Pv, ViewImages Iv, int32_t *hitInstance, int cur, int ownedY0, int ownedY1) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
-    __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED / 2 : RT_STACK_LDS) * RT_BLOCK];
-    __shared__ float ldsLightIntensity[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
-    __shared__ uint8_t ldsLightIndex[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
+    constexpr uint32_t STACK_WORDS = CACHED ? RT_STACK_LDS_CACHED / 2 : RT_STACK_LDS;
+    __shared__ uint32_t ldsStack[STACK_WORDS * BLOCK];
+    // dynamic LDS: [scene cache (CACHED)][light candidates: intensities, indices -- sized by the frame's light count]
     extern __shared__ u32x4_lds dynLds[];
-    ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
-    env.lightIntensity = ldsLightIntensity + threadIdx.x; env.lightIndex = ldsLightIndex + threadIdx.x;
+    ShadeEnv env; env.stk = make_stack(P, ldsStack, STACK_WORDS); env.cnt = TraceCounts(); env.shadowRays = 0;
     if (CACHED) cached_env(P, env, dynLds);
+    else { float *li = reinterpret_cast<float *>(dynLds); light_columns(env, li, reinterpret_cast<uint8_t *>(li + light_slots(P) * BLOCK), light_slots(P)); }
     uint32_t rays = 0;
-    TraceCounts primaryCnt; primaryCnt.nodes = primaryCnt.tris = 0;
+    TraceCounts primaryCnt = TraceCounts();
     const uint32_t tiles = tile_count(P);
-    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const uint32_t trips = BLOCK == RT_BLOCK ? tiles : ((tiles + 7u) / 8u) * 32u;
+    if (P.tileTiming && (threadIdx.x & 63u) == 0u) {      // profiling aid (device option tile_timing): two records per wave, written where they are taken so that nothing stays live across the frame
+        uint32_t hwId; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwId));
+        P.tileTiming[2 * ((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6))] = make_uint4((uint32_t)__builtin_amdgcn_s_memrealtime(), (uint32_t)__builtin_amdgcn_s_memtime(), hwId, 1u);
+    }
+    for (uint32_t trip = blockIdx.x; trip < trips; trip += gridDim.x) {
         PRef P = *kernel_params_here(); IRef I = *kernel_images_here();      // this tile's view of the frame constants and the image table: read where used, never carried across tiles
         // tiles are walked from the bottom of the frame up: the expensive ones (geometry) start first and the cheap ones (sky, at the
         // top of a typical frame) fill the tail of the launch
-        Pixel p = tile_pixel(P, tiles - 1u - tile);
+        Pixel p;
+        if (BLOCK == RT_BLOCK) p = tile_pixel(P, tiles - 1u - trip);
+        else {
+            uint32_t tileSeq, quadrant;
+            if (!wave_tile_of(trip, tiles, tileSeq, quadrant)) continue;
+            p = tile_pixel_at(P, tiles - 1u - tileSeq, quadrant, threadIdx.x & 63u);
+        }
         if (!p.valid) continue;
         const uint32_t px = p.x, py = p.y;
         const size_t i = (size_t)py * (size_t)P.width + px;
@@ -653,8 +685,22 @@ __global__ __launch_bounds__(RT_BLOCK, WAVES) void lean_frame_kernel(FrameParams
             }
         }
     }
+    if (P.tileTiming) {       // end record: clock, then the most node + triangle visits any lane of the wave made and the wave's total (<< 8 | 1: the valid mark)
+        uint32_t worst = env.cnt.nodes + env.cnt.tris, total = worst;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { worst = max(worst, (uint32_t)__shfl_xor((int)worst, d, 64)); total += (uint32_t)__shfl_xor((int)total, d, 64); }
+        if ((threadIdx.x & 63u) == 0u)
+            P.tileTiming[2 * ((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) + 1] = make_uint4((uint32_t)__builtin_amdgcn_s_memrealtime(), (uint32_t)__builtin_amdgcn_s_memtime(), worst, (total << 8) | 1u);
+#ifdef RT_PROFILE_TRIPS
+        uint32_t tn = env.cnt.tripsNode, tl = env.cnt.tripsLeaf, sm = env.cnt.spills, ss = env.cnt.spills;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { tn = max(tn, (uint32_t)__shfl_xor((int)tn, d, 64)); tl = max(tl, (uint32_t)__shfl_xor((int)tl, d, 64)); sm = max(sm, (uint32_t)__shfl_xor((int)sm, d, 64)); ss += (uint32_t)__shfl_xor((int)ss, d, 64); }
+        if ((threadIdx.x & 63u) == 0u)
+            P.tileTiming[(size_t)RT_TIMING_WAVES * 2 + (size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)] = make_uint4(tn, tl, sm, ss);
+#endif
+    }
     // counters: the primary rays' visits under PASS_PRIMARY_TRACE, the shadow rays' under PASS_DIRECT (same split as the separate kernels)
-    TraceCounts directCnt; directCnt.nodes = env.cnt.nodes - primaryCnt.nodes; directCnt.tris = env.cnt.tris - primaryCnt.tris;
+    TraceCounts directCnt = TraceCounts(); directCnt.nodes = env.cnt.nodes - primaryCnt.nodes; directCnt.tris = env.cnt.tris - primaryCnt.tris;
     flush_counts(P, primaryCnt, PASS_PRIMARY_TRACE);
     env.cnt = directCnt;
     flush_env(P, env, PASS_DIRECT, CTR_PRIMARY, rays);
@@ -665,11 +711,12 @@ __global__ __launch_bounds__(RT_BLOCK, WAVES) void lean_frame_kernel(FrameParams
 template <bool KLIST>
 __global__ __launch_bounds__(RT_BLOCK, 3) void indirect_kernel(FrameParams Pv, ViewImages Iv, int cur, int writeFiltered) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
-    __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
+    constexpr uint32_t STACK_WORDS = RT_STACK_LDS;
+    __shared__ uint32_t ldsStack[STACK_WORDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
-    ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
-    env.lightIntensity = ldsLightIntensity + threadIdx.x; env.lightIndex = ldsLightIndex + threadIdx.x;
+    ShadeEnv env; env.stk = make_stack(P, ldsStack, STACK_WORDS); env.cnt = TraceCounts(); env.shadowRays = 0;
+    light_columns(env, ldsLightIntensity, ldsLightIndex, RT64_MAX_LIGHTS + 1);
     uint32_t rays = 0;
     const f3 ambientBase = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]);
     const f3 ambient = ambientBase + mk3(P.ambientNoGIColor[0], P.ambientNoGIColor[1], P.ambientNoGIColor[2]);
@@ -785,14 +832,15 @@ DEV f3 bounce_sky_term(PRef P, f3 rayDirection);
 template <bool CACHED>
 __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kernel(FrameParams Pv, ViewImages Iv) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
-    __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED / 2 : RT_STACK_LDS) * RT_BLOCK];
+    constexpr uint32_t STACK_WORDS = CACHED ? RT_STACK_LDS_CACHED / 2 : RT_STACK_LDS;
+    __shared__ uint32_t ldsStack[STACK_WORDS * RT_BLOCK];
     __shared__ uint32_t ldsCount[2];
     extern __shared__ u32x4_lds dynLds[];
     if (threadIdx.x < 2) ldsCount[threadIdx.x] = 0;
     if (CACHED) fill_scene_cache(P, dynLds);
     __syncthreads();
     const uint32_t segment = bounce_segment_size(P); const size_t missBase = bounce_miss_base(P, segment);
-    ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
+    ShadeEnv env; env.stk = make_stack(P, ldsStack, STACK_WORDS); env.cnt = TraceCounts(); env.shadowRays = 0;
     env.lightIntensity = nullptr; env.lightIndex = nullptr;
     if (CACHED) env.stk.use_cache(dynLds);
     uint32_t rays = 0;
@@ -849,12 +897,13 @@ __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kern
 #define BOUNCE_MIN_LIVE 40
 __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_refill_kernel(FrameParams Pv, ViewImages Iv) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
-    __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
+    constexpr uint32_t STACK_WORDS = RT_STACK_LDS;
+    __shared__ uint32_t ldsStack[STACK_WORDS * RT_BLOCK];
     __shared__ uint32_t ldsCount[2];
     if (threadIdx.x < 2) ldsCount[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t segment = bounce_segment_size(P); const size_t missBase = bounce_miss_base(P, segment);
-    ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
+    ShadeEnv env; env.stk = make_stack(P, ldsStack, STACK_WORDS); env.cnt = TraceCounts(); env.shadowRays = 0;
     env.lightIntensity = nullptr; env.lightIndex = nullptr;
     uint32_t rays = 0;
     const size_t stride = (size_t)P.width * (size_t)P.height;
@@ -929,12 +978,13 @@ DEV f3 bounce_sky_term(PRef P, f3 rayDirection) {
 template <bool CACHED>
 __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void bounce_hit_kernel(FrameParams Pv, ViewImages Iv) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
-    __shared__ uint32_t ldsStack[(CACHED ? RT_STACK_LDS_CACHED / 2 : RT_STACK_LDS) * RT_BLOCK];
+    constexpr uint32_t STACK_WORDS = CACHED ? RT_STACK_LDS_CACHED / 2 : RT_STACK_LDS;
+    __shared__ uint32_t ldsStack[STACK_WORDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     extern __shared__ u32x4_lds dynLds[];
-    ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
-    env.lightIntensity = ldsLightIntensity + threadIdx.x; env.lightIndex = ldsLightIndex + threadIdx.x;
+    ShadeEnv env; env.stk = make_stack(P, ldsStack, STACK_WORDS); env.cnt = TraceCounts(); env.shadowRays = 0;
+    light_columns(env, ldsLightIntensity, ldsLightIndex, RT64_MAX_LIGHTS + 1);
     if (CACHED) cached_env(P, env, dynLds);
     const f3 ambientBase = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]);
     const f3 ambient = ambientBase + mk3(P.ambientNoGIColor[0], P.ambientNoGIColor[1], P.ambientNoGIColor[2]);
@@ -1038,11 +1088,12 @@ DEV f3 hlsl_refract(f3 i, f3 n, float eta) {
 template <bool KLIST>
 __global__ __launch_bounds__(RT_BLOCK) void refraction_kernel(FrameParams Pv, ViewImages Iv) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
-    __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
+    constexpr uint32_t STACK_WORDS = RT_STACK_LDS;
+    __shared__ uint32_t ldsStack[STACK_WORDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
-    ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
-    env.lightIntensity = ldsLightIntensity + threadIdx.x; env.lightIndex = ldsLightIndex + threadIdx.x;
+    ShadeEnv env; env.stk = make_stack(P, ldsStack, STACK_WORDS); env.cnt = TraceCounts(); env.shadowRays = 0;
+    light_columns(env, ldsLightIntensity, ldsLightIndex, RT64_MAX_LIGHTS + 1);
     uint32_t rays = 0;
     const f3 ambient = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]) + mk3(P.ambientNoGIColor[0], P.ambientNoGIColor[1], P.ambientNoGIColor[2]);
     const uint32_t tiles = tile_count(P);
@@ -1103,11 +1154,12 @@ __global__ __launch_bounds__(RT_BLOCK) void refraction_kernel(FrameParams Pv, Vi
 template <bool KLIST>
 __global__ __launch_bounds__(RT_BLOCK) void reflection_kernel(FrameParams Pv, ViewImages Iv) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
-    __shared__ uint32_t ldsStack[RT_STACK_LDS * RT_BLOCK];
+    constexpr uint32_t STACK_WORDS = RT_STACK_LDS;
+    __shared__ uint32_t ldsStack[STACK_WORDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
-    ShadeEnv env; env.stk = make_stack(P, ldsStack); env.cnt.nodes = env.cnt.tris = 0; env.shadowRays = 0;
-    env.lightIntensity = ldsLightIntensity + threadIdx.x; env.lightIndex = ldsLightIndex + threadIdx.x;
+    ShadeEnv env; env.stk = make_stack(P, ldsStack, STACK_WORDS); env.cnt = TraceCounts(); env.shadowRays = 0;
+    light_columns(env, ldsLightIntensity, ldsLightIndex, RT64_MAX_LIGHTS + 1);
     uint32_t rays = 0;
     const f3 ambient = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]) + mk3(P.ambientNoGIColor[0], P.ambientNoGIColor[1], P.ambientNoGIColor[2]);
     const uint32_t tiles = tile_count(P);
@@ -1347,7 +1399,8 @@ __global__ __launch_bounds__(256) void clear_final_kernel(FrameParams Pv, ViewIm
 size_t rt_stack_spill_bytes(int width, int rows) {
     const size_t tiles = (size_t)((width + 15) / 16) * (size_t)((rows + 15) / 16);
     size_t blocks = tiles > (size_t)RT_GRID_BLOCKS ? tiles : (size_t)RT_GRID_BLOCKS;
-    if (blocks > RT_MAX_FRAME_GROUPS) blocks = RT_MAX_FRAME_GROUPS;       // no launch has more workgroups than that (launch_lean_frame, sparse_grid)
+    if (blocks > RT_MAX_FRAME_GROUPS) blocks = RT_MAX_FRAME_GROUPS;
+    blocks += 8;          // the per-wave frame rounds its grid up to whole groups of 8 tiles (32 one-wave workgroups)       // no launch has more workgroups than that (launch_lean_frame, sparse_grid)
     return blocks * RT_BLOCK * RT_STACK_SPILL * sizeof(uint32_t);
 }
 #endif
@@ -1401,21 +1454,36 @@ hipError_t RT_LAUNCHER(launch_direct)(const FrameParams &P, const ViewImages &I,
 // CU), which together with the bottom-up tile order (geometry first) is a longest-job-first schedule; a resident round of
 // persistent workgroups with a static round-robin walk measured 8 % slower on the full frame (181 against 165 us) and keeps every
 // register file full until the launch ends, so nothing on another stream (the RCCL gather) can run beside it.
-hipError_t RT_LAUNCHER(launch_lean_frame)(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, int cur, bool full, int ownedY0, int ownedY1, unsigned maxGroups, hipStream_t s) {
-    RT_ROUTE_SIMPLE(launch_lean_frame_simple(P, I, hitInstance, cur, full, ownedY0, ownedY1, maxGroups, s));
+#ifndef PERWAVE_WAVES
+#define PERWAVE_WAVES 3        // waves per SIMD of the per-wave (64-thread workgroup) form
+#endif
+hipError_t RT_LAUNCHER(launch_lean_frame)(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, int cur, bool full, int ownedY0, int ownedY1, unsigned maxGroups, bool perWave, hipStream_t s) {
+    RT_ROUTE_SIMPLE(launch_lean_frame_simple(P, I, hitInstance, cur, full, ownedY0, ownedY1, maxGroups, perWave, s));
     const unsigned strips = (unsigned)(P.tileY1 - P.tileY0 + 15) / 16, owned = strips > (unsigned)P.stripRank ? (strips - (unsigned)P.stripRank + (unsigned)P.stripCount - 1) / (unsigned)P.stripCount : 0u;
     const unsigned tiles = (unsigned)((P.width + 15) / 16) * owned;
     // ... up to 8192 workgroups; bigger frames give every workgroup ceil(tiles / 8192) tiles (round-robin, same bottom-up order), which
     // amortises the scene-cache fill again (1440p: 2 tiles per workgroup, 4K: 4)
     if (maxGroups < 1u || maxGroups > RT_MAX_FRAME_GROUPS) maxGroups = RT_MAX_FRAME_GROUPS;
-    const unsigned perGroup = (tiles + maxGroups - 1u) / maxGroups, grid = tiles < 1u ? 1u : (tiles + perGroup - 1u) / perGroup;
-    const size_t lds = P.cacheWords ? cached_lds_bytes(P, true) : 0;
+    const size_t lds = cached_lds_bytes(P, true);       // the scene cache (when the frame has one) + the light-candidate columns of this frame's light count
     if (P.cacheWords) {
+        const unsigned perGroup = (tiles + maxGroups - 1u) / maxGroups, grid = tiles < 1u ? 1u : (tiles + perGroup - 1u) / perGroup;
         if (full) hipLaunchKernelGGL((lean_frame_kernel<true, true, LEAN_WAVES>), dim3(grid), dim3(RT_BLOCK), lds, s, P, I, hitInstance, cur, ownedY0, ownedY1);
         else hipLaunchKernelGGL((lean_frame_kernel<true, false, LEAN_WAVES>), dim3(grid), dim3(RT_BLOCK), lds, s, P, I, hitInstance, cur, ownedY0, ownedY1);
     }
-    else if (full) hipLaunchKernelGGL((lean_frame_kernel<false, true, LEAN_WAVES>), dim3(grid), dim3(RT_BLOCK), 0, s, P, I, hitInstance, cur, ownedY0, ownedY1);
-    else hipLaunchKernelGGL((lean_frame_kernel<false, false, LEAN_WAVES>), dim3(grid), dim3(RT_BLOCK), 0, s, P, I, hitInstance, cur, ownedY0, ownedY1);
+    else if (perWave) {
+        // one wave per workgroup: trips = 32 per 8 tiles (wave_tile_of), up to 4 x maxGroups workgroups, a multiple of 32 so that every trip of a workgroup stays on its XCD's tiles
+        const unsigned trips = ((tiles + 7u) / 8u) * 32u, cap = maxGroups * 4u, perGroup = (trips + cap - 1u) / cap;
+        unsigned grid = trips < 1u ? 32u : (trips + perGroup - 1u) / perGroup;
+        grid = (grid + 31u) / 32u * 32u;
+        const size_t ldsWave = cached_lds_bytes(P, true) / (RT_BLOCK / 64) + 16;
+        if (full) hipLaunchKernelGGL((lean_frame_kernel<false, true, PERWAVE_WAVES, 64>), dim3(grid), dim3(64), ldsWave, s, P, I, hitInstance, cur, ownedY0, ownedY1);
+        else hipLaunchKernelGGL((lean_frame_kernel<false, false, PERWAVE_WAVES, 64>), dim3(grid), dim3(64), ldsWave, s, P, I, hitInstance, cur, ownedY0, ownedY1);
+    }
+    else {
+        const unsigned perGroup = (tiles + maxGroups - 1u) / maxGroups, grid = tiles < 1u ? 1u : (tiles + perGroup - 1u) / perGroup;
+        if (full) hipLaunchKernelGGL((lean_frame_kernel<false, true, LEAN_WAVES>), dim3(grid), dim3(RT_BLOCK), lds, s, P, I, hitInstance, cur, ownedY0, ownedY1);
+        else hipLaunchKernelGGL((lean_frame_kernel<false, false, LEAN_WAVES>), dim3(grid), dim3(RT_BLOCK), lds, s, P, I, hitInstance, cur, ownedY0, ownedY1);
+    }
     return hipGetLastError();
 }
 hipError_t RT_LAUNCHER(launch_indirect)(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, int walk, hipStream_t s) {

@@ -136,6 +136,7 @@ struct FrameParams {
     const RT64_LIGHT *lights;
     const uint8_t *blueNoise;            // 512x512 RGBA8
     uint32_t *traversalStack;            // overflow stack, per resident lane
+    uint4 *tileTiming;                   // profiling aid (device option tile_timing), nullptr = off: two records per wave of the one-kernel frame: at its start { 100 MHz chip-wide clock, shader clock, HW_ID, 1 } and at its end { clock, shader clock, 0, 1 }
     unsigned long long *counters;        // [0] nodes [1] triangles [2] primary rays [3] shadow rays [4] indirect [5] reflection [6] refraction
 };
 

@@ -144,6 +144,8 @@ struct Options {
     bool simpleKernels = true;    // frames whose textures are all power-of-two sized and whose instances are all shadow-opaque run the kernels of passes_simple.hip
     bool ldsCache = true;         // small scenes: BVH nodes + instance records cached in LDS by the ray kernels (0: always walk from HBM/L2)
     bool spinPresent = true;      // RT64_DrawDevice waits for the frame by polling the stream (0: blocking hipStreamSynchronize)
+    int perWaveFrame = -1;        // one-kernel frame of scenes without the LDS scene cache as one-wave workgroups (8 x 8 wave-tiles): 1 on, 0 off (16 x 16 tiles, four waves), -1 auto (on)
+    bool tileTiming = false;      // profiling aid: the one-kernel frame records when each of its waves started and ended (RT64_ReadbackTileTiming)
     int bounceRefill = -1;        // bounce-ray traversal with wave-ballot refill: 1 on, 0 off, -1 auto (on when the scene has >= 64 Ki triangles)
     int denoiserMode = 1;          // 0 = reference 5x Gaussian, 1 = SVGF
     int maxReflections = 2;        // rt64_view.cpp:60 (inspector-only knob in the reference)
@@ -164,6 +166,7 @@ struct Device {
     DevArray<uint32_t> spillStack;
     void *gatherTarget = nullptr; size_t gatherTargetBytes = 0;          // RT64_SetDeviceGatherTarget
     DevArray<unsigned long long> counters;
+    DevArray<uint4> tileTiming; unsigned tileTimingWaves = 0;        // option tile_timing: records of the last one-kernel frame
     DevArray<uint8_t> blueNoise;
     uint8_t *pinned[2] = { nullptr, nullptr }; size_t pinnedBytes[2] = { 0, 0 };
     enum { EV_BEGIN, EV_BUILD, EV_PRIMARY_TRACE, EV_PRIMARY, EV_DIRECT, EV_INDIRECT, EV_REFL, EV_DENOISE, EV_END, EV_COUNT };
@@ -559,7 +562,7 @@ void Mesh::set(const void *vertexArray, int vcount, int vstride, const unsigned 
         // A refit keeps the topology of the tree that exists (or is about to exist, if its build is still pending).
         pendingRefit = buildPending ? (pendingRefit && refit) : refit;
         if (!pendingRefit) depth = host_blas_depth(static_cast<const uint8_t *>(vertexArray), (size_t)vstride, indexArray, n);
-        nodes.reserve(std::max<size_t>(n - 1, 1)); tris.reserve(n); header.reserve(1);
+        nodes.reserve(std::max<size_t>(n - 1, 1)); tris.reserve((size_t)n + 1); header.reserve(1);      // + 1: the stepwise walk reads a 48-byte triangle as 64 bytes (trace.h)
         sortedIndex.reserve(n); morton.reserve(n); leafParent.reserve(n);
         if (n > LBVH_SMALL_MAX) buildScratch.reserve(lbvh_large_scratch_bytes(n));
         blasCount = n;
@@ -1168,6 +1171,8 @@ void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64
     P.instances = dInstances.ptr; P.tlasNodes = tlasNodesAt; P.tlasIndex = tlasIndexAt; P.textures = dTextures.ptr; P.lights = dLights.ptr;
     if (needSpillSlab) dev->spillStack.reserve(rt_stack_spill_bytes(imgW, imgH) / sizeof(uint32_t));      // grows with the render size (no-op otherwise); never allocated for shallow scenes
     P.blueNoise = dev->blueNoise.ptr; P.traversalStack = dev->spillStack.ptr; P.counters = dev->counters.ptr;
+    P.tileTiming = nullptr;
+    if (dev->opt.tileTiming) { dev->tileTiming.reserve((size_t)RT_TIMING_WAVES * 3); P.tileTiming = dev->tileTiming.ptr; }      // two records per wave + one more in diagnostic builds
 }
 
 void View::render() {                          // View::render, rt64_view.cpp:1180-1670
@@ -1232,6 +1237,7 @@ void View::render() {                          // View::render, rt64_view.cpp:11
             X.tileY0 = std::max(0, P.tileY0 - halo); X.tileY1 = std::min(imgH, P.tileY1 + halo);
         }
         const bool lean = leanNow;
+        const bool perWave = dev->opt.perWaveFrame != 0;          // (only frames without the LDS scene cache take that form: launch_lean_frame)
         // A lean frame is pixel-local end to end: one kernel carries every pixel from the primary ray to the back buffer
         // (device option fused_lean = 0 keeps the three separate kernels; same back buffer bit for bit).
         const bool fused = lean && dev->opt.fusedLean;
@@ -1254,13 +1260,15 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         }
         if (fused) {
             // nullptr: the frame stores its back buffer only (hit records and the direct-light image come back through materialise); option lean_records = 1 keeps them
-            L(launch_lean_frame(P, img, dev->opt.leanRecords ? hitInstance.ptr : nullptr, cur, false, 0, imgH, dev->opt.maxFrameGroups, s));
+            if (P.tileTiming) { HIP_CHECK(hipMemsetAsync(dev->tileTiming.ptr, 0, dev->tileTiming.bytes(), s)); }
+            L(launch_lean_frame(P, img, dev->opt.leanRecords ? hitInstance.ptr : nullptr, cur, false, 0, imgH, dev->opt.maxFrameGroups, perWave, s));
             fusedStoreless = !dev->opt.leanRecords;
             mark(Device::EV_PRIMARY_TRACE); mark(Device::EV_PRIMARY); mark(Device::EV_DIRECT);
         }
         else if (fusedFull) {
             if (P.stripCount > 1 && (X.tileY0 != P.tileY0 || X.tileY1 != P.tileY1)) throw std::runtime_error("RT64_DrawDevice: interleaved strips with a denoiser halo.");
-            L(launch_lean_frame(X, img, hitInstance.ptr, cur, true, P.tileY0, P.tileY1, dev->opt.maxFrameGroups, s));
+            if (X.tileTiming) { HIP_CHECK(hipMemsetAsync(dev->tileTiming.ptr, 0, dev->tileTiming.bytes(), s)); }
+            L(launch_lean_frame(X, img, hitInstance.ptr, cur, true, P.tileY0, P.tileY1, dev->opt.maxFrameGroups, perWave, s));
             mark(Device::EV_PRIMARY_TRACE); mark(Device::EV_PRIMARY); mark(Device::EV_DIRECT);
         }
         else {
@@ -1327,7 +1335,8 @@ void View::materialise() {
         FrameParams Q = lastParams;
         Q.rasterFg = nullptr; Q.rasterFgTris = nullptr; Q.rasterFgCount = 0; Q.finalPacked = nullptr;
         Q.countTraversal = 0;        // the frame's rays were counted when the frame ran
-        HIP_CHECK(launch_lean_frame(Q, img, hitInstance.ptr, lastCur, true, Q.tileY0, Q.tileY1, dev->opt.maxFrameGroups, dev->stream));
+        Q.tileTiming = nullptr;
+        HIP_CHECK(launch_lean_frame(Q, img, hitInstance.ptr, lastCur, true, Q.tileY0, Q.tileY1, dev->opt.maxFrameGroups, dev->opt.perWaveFrame != 0, dev->stream));
         HIP_CHECK(launch_indirect_constant(lastParams, img, lastCur, dev->stream));
     }
     else {
@@ -1626,6 +1635,8 @@ RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, doubl
     else if (k == "sync_present") d->opt.syncPresent = value != 0.0;
     else if (k == "denoiser_mode") d->opt.denoiserMode = (int)value;
     else if (k == "bounce_refill") d->opt.bounceRefill = (int)value;
+    else if (k == "per_wave_frame") d->opt.perWaveFrame = (int)value;
+    else if (k == "tile_timing") d->opt.tileTiming = value != 0.0;
     else if (k == "spin_present") d->opt.spinPresent = value != 0.0;
     else if (k == "lds_cache") d->opt.ldsCache = value != 0.0;
     else if (k == "lean_records") d->opt.leanRecords = value != 0.0;
@@ -1640,6 +1651,19 @@ RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, doubl
     else if (k == "max_frame_groups") d->opt.maxFrameGroups = value >= 1.0 && value <= (double)RT_MAX_FRAME_GROUPS ? (unsigned)value : RT_MAX_FRAME_GROUPS;
     else return 0;
     return 1;
+}
+// Profiling aid (option tile_timing = 1): two 16-byte records per wave of the last one-kernel frame, in workgroup order -- at the wave's start { chip-wide 100 MHz
+// clock, shader clock (low 32 bits each), HW_ID, 1 } and at its end { clock, shader clock, 0, 1 }.  Waves that did not run leave zeros.  Returns bytes written.
+RT64_EXPORT size_t RT64_ReadbackTileTiming(RT64_DEVICE *device, void *dst, size_t dstBytes) {
+    RT64_TRY
+    Device *d = reinterpret_cast<Device *>(device);
+    if (!d || !dst || !d->tileTiming.ptr) throw std::runtime_error("RT64_ReadbackTileTiming: set the device option tile_timing and draw a frame first.");
+    d->use();
+    const size_t bytes = std::min(dstBytes, d->tileTiming.bytes());
+    HIP_CHECK(hipMemcpyAsync(dst, d->tileTiming.ptr, bytes, hipMemcpyDeviceToHost, d->stream));
+    HIP_CHECK(hipStreamSynchronize(d->stream));
+    return bytes;
+    RT64_CATCH(0)
 }
 RT64_EXPORT void *RT64_GetDeviceStream(RT64_DEVICE *device) { Device *d = reinterpret_cast<Device *>(device); return d ? d->stream : nullptr; }
 

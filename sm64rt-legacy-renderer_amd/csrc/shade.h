@@ -553,8 +553,8 @@ struct ShadeEnv {                // per-lane traversal resources handed down to 
     TraceStack stk;
     TraceCounts cnt;
     uint32_t shadowRays;
-    float *lightIntensity;       // LDS, [RT64_MAX_LIGHTS + 1][RT_BLOCK] (&array[threadIdx.x]): candidate intensities of ComputeLightsRandom
-    uint8_t *lightIndex;         // LDS, [RT64_MAX_LIGHTS + 1][RT_BLOCK]
+    float *lightIntensity;       // LDS, [wave][slots][RT_LANES] (this lane's column): candidate intensities of ComputeLightsRandom
+    uint8_t *lightIndex;         // LDS, [wave][slots][RT_LANES]
 };
 
 template <bool CACHED = false>
@@ -651,7 +651,7 @@ DEV f3 compute_lights_random(PRef P, ShadeEnv &env, uint32_t px, uint32_t py, f3
         const RT64_LIGHT Ll = load_const(P.lights + l);           // uniform index: scalar loads
         if (m.lightGroupMaskBits & Ll.groupBits) {
             float li = light_intensity_simple(Ll, position, normal, m.ignoreNormalFactor);
-            if (li > RT_EPSILON) { sInt[sCount * RT_BLOCK] = li; sIdx[sCount * RT_BLOCK] = (uint8_t)l; total += li; sCount++; }
+            if (li > RT_EPSILON) { sInt[sCount * RT_LANES] = li; sIdx[sCount * RT_LANES] = (uint8_t)l; total += li; sCount++; }
         }
     }
     if (sCount == 1 && maxLightCount >= 1)       // one candidate: it is chosen whatever the random number is, with probability 1 (randomRange / cInt = total / total)
@@ -662,10 +662,10 @@ DEV f3 compute_lights_random(PRef P, ShadeEnv &env, uint32_t px, uint32_t py, f3
     for (uint32_t s = 0; s < lCount; s++) {
         float r = blue_noise(P, px, py, P.frameCount + s).x * randomRange;
         uint32_t chosen = 0; float rInt = sInt[0];
-        while (chosen < sCount - 1 && r >= rInt) { chosen++; rInt += sInt[chosen * RT_BLOCK]; }
-        float cInt = sInt[chosen * RT_BLOCK]; uint32_t cIdx = sIdx[chosen * RT_BLOCK];
+        while (chosen < sCount - 1 && r >= rInt) { chosen++; rInt += sInt[chosen * RT_LANES]; }
+        float cInt = sInt[chosen * RT_LANES]; uint32_t cIdx = sIdx[chosen * RT_LANES];
         float invProbability = useProbability ? s_div(randomRange, cInt) : 1.0f;
-        sInt[chosen * RT_BLOCK] = 0.0f; randomRange -= cInt;
+        sInt[chosen * RT_LANES] = 0.0f; randomRange -= cInt;
         result = result + compute_light<CACHED>(P, env, px, py, cIdx, rayDirection, m, position, normal, specular, checkShadows) * invProbability;
     }
     return result;

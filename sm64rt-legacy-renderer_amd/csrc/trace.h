@@ -12,7 +12,7 @@
 //   R4 Moller-Trumbore with the g_dot3 / g_cross3 fma chains; u,v >= 0, u+v <= 1, tmin < t < tmax
 //   R5 the hit handler may lower tmax or end the walk
 //
-// Stack: RT_STACK_LDS entries per lane in LDS, laid out [entry][thread] so a wave's push/pop is one conflict-free
+// Stack: RT_STACK_LDS entries per lane in LDS, laid out [wave][entry][lane] so a wave's push/pop is one conflict-free
 // ds_write_b32/ds_read_b32; deeper entries spill to a per-resident-lane slab in HBM (never touched on the sample scene:
 // LBVH depth <= 30 + log2(n) per level).
 #pragma once
@@ -35,7 +35,9 @@ DEV IPtr kernel_images_here() { uint32_t z; asm volatile("s_mov_b32 %0, 0" : "=s
 DEV PPtr kernel_params() { return (PPtr)__builtin_amdgcn_kernarg_segment_ptr(); }
 // Same, through an offset the compiler cannot see through (always 0): loads that depend on it stay inside the loop iteration that made it.
 DEV PPtr kernel_params_here() { uint32_t z; asm volatile("s_mov_b32 %0, 0" : "=s"(z)); return (PPtr)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + z); }
-#define RT_BLOCK 256                 // threads per workgroup of every ray kernel
+#define RT_BLOCK 256                 // threads per workgroup of the ray kernels (the per-wave form of the one-kernel frame runs 64)
+#define RT_LANES 64                  // lanes of a wave: the per-lane LDS columns (node stack, light candidates) are laid out [wave][entry][lane], so a
+                                     // wave's push / pop is one conflict-free ds access and the layout does not depend on the workgroup size
 #ifndef RT_STACK_LDS
 #define RT_STACK_LDS 24                 // (kernels.h defines it for the host too)
 #endif
@@ -102,30 +104,37 @@ typedef int16_t __attribute__((address_space(3))) *LdsI16Ptr;
 // the stack of the cached kernels holds int16 entries: ds_write_b16 truncates, ds_read_i16 sign-extends -- half the LDS of a uint32 stack.
 #define RT_CACHE_INDEX_MASK 0x7FFFu
 struct TraceStack {
-    LdsU32Ptr lds;        // &ldsStack[threadIdx.x], stride RT_BLOCK
-    LdsI16Ptr lds16;      // the same array as int16 entries (cached kernels): &((int16 *)ldsStack)[threadIdx.x], stride RT_BLOCK
+    LdsU32Ptr lds;        // this lane's column in its wave's block of the stack array, stride RT_LANES
+    LdsI16Ptr lds16;      // the same block as int16 entries (cached kernels), stride RT_LANES
     GlobalU32Ptr spill;   // per-lane slab of RT_STACK_SPILL entries
     const u32x4_lds *cache;   // LDS scene cache (see fill_scene_cache), nullptr when the scene does not fit
     int ldsEntries;       // entries of this lane's stack that live in LDS (RT_STACK_LDS or RT_STACK_LDS_CACHED)
-    DEV void use_cache(const u32x4_lds *c) {
-        cache = c; ldsEntries = RT_STACK_LDS_CACHED;
-        lds16 = (LdsI16Ptr)(lds - threadIdx.x) + threadIdx.x;
-    }
+    DEV void use_cache(const u32x4_lds *c) { cache = c; ldsEntries = RT_STACK_LDS_CACHED; }
     template <bool LDS_ONLY = false> DEV void push(int &sp, uint32_t v) const {
-        if (LDS_ONLY) { lds16[(sp & (RT_STACK_LDS_CACHED - 1)) * RT_BLOCK] = (int16_t)v; sp++; return; }      // depth checked by the host (the mask only keeps a wrong depth inside the array)
-        if (sp < ldsEntries) lds[sp * RT_BLOCK] = v;
+        if (LDS_ONLY) { lds16[(sp & (RT_STACK_LDS_CACHED - 1)) * RT_LANES] = (int16_t)v; sp++; return; }      // depth checked by the host (the mask only keeps a wrong depth inside the array)
+        if (sp < ldsEntries) lds[sp * RT_LANES] = v;
         else if (sp < ldsEntries + RT_STACK_SPILL) spill[sp - ldsEntries] = v;
         else return;      // deeper than any tree this builder produces for n < 2^20 leaves, m < 2^13 instances
         sp++;
     }
     template <bool LDS_ONLY = false> DEV uint32_t pop(int &sp) const {
         sp--;
-        if (LDS_ONLY) return (uint32_t)(int32_t)lds16[(sp & (RT_STACK_LDS_CACHED - 1)) * RT_BLOCK];
-        return sp < ldsEntries ? lds[sp * RT_BLOCK] : spill[sp - ldsEntries];
+        if (LDS_ONLY) return (uint32_t)(int32_t)lds16[(sp & (RT_STACK_LDS_CACHED - 1)) * RT_LANES];
+        return sp < ldsEntries ? lds[sp * RT_LANES] : spill[sp - ldsEntries];
     }
 };
 
+#ifdef RT_PROFILE_TRIPS       // diagnostic build (never shipped): how many trips of the node loop / leaf step a WAVE made, counted in SGPRs whatever the exec mask is
+struct TraceCounts { uint32_t nodes, tris, tripsNode, tripsLeaf, spills; };
+#define RT_TRIP_DECL(name) __shared__ uint32_t name##Lds[16]; if ((threadIdx.x & 63u) == 0u) name##Lds[threadIdx.x >> 6] = 0u; uint32_t name = 0
+#define RT_TRIP(name) do { if ((int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(1)) - 1) name##Lds[threadIdx.x >> 6]++; } while (0)
+#define RT_TRIP_END(name) name = name##Lds[threadIdx.x >> 6]
+#else
 struct TraceCounts { uint32_t nodes, tris; };
+#define RT_TRIP_DECL(name)
+#define RT_TRIP(name)
+#define RT_TRIP_END(name)
+#endif
 
 // Pointers that were loaded from memory are "generic" to the compiler (flat_load + both wait counters).  Every BVH array
 // lives in HBM, so fetch through address space 1: global_load_dwordx4, vmcnt only.
@@ -168,10 +177,105 @@ DEV GpuNode load_node_lds(const u32x4_lds *q) {
 }
 
 
+// ---- the one-step-per-trip walk (scenes that walk from HBM / L2) ---------------------------------------------------------------------------------
+// The "while-while" loop of trace_ray below makes a wave's lanes take turns by kind of step: the node loop runs until EVERY live lane holds a leaf,
+// then all leaves are processed.  That is the right shape while the vector ALU is what a wave waits for (the LDS-cached walk of small scenes).  A
+// walk that fetches every node from HBM waits for memory instead, one dependent round trip of ~1 300 cycles per step, and there the turns cost
+// dearly: a lane that reaches its leaf early idles through the other lanes' node steps, so a wave makes 2-3 x as many trips as its busiest lane has
+// steps (measured on the 5.4 M-triangle stress scene, tools/tile_timing.py: 846 node trips + 48 leaf trips against 327 visits of the busiest lane in
+// the waves that set the frame time).  Here every live lane takes exactly ONE step per trip, whatever its kind: the lane's record -- a 64-byte node,
+// or a 48-byte triangle read as 64 bytes (the triangle arrays carry 16 bytes of padding behind the last record) -- is fetched by the same four
+// 16-byte loads from a per-lane address, so node lanes and triangle lanes wait for memory together, and the two kinds of arithmetic follow under
+// their exec masks (~130 vector instructions against the round trip).  A wave then makes as many trips as its busiest lane has steps.  The order
+// of operations of each individual ray is that of trace_ray (R3), so hits, visit counts and every bit of the results are unchanged.
+// (Measured and not kept: touching the record of every pushed entry with a one-dword load, so that its pop would find the line in L2.  Loads
+// return in order, so the next trip's record -- often an L2 hit -- then waits behind the prefetch's HBM miss: the stress frame went from 0.667
+// to 0.743 ms, gpurun_out/r03_tt_stress_pf2.txt.)
+union NodeOrTri { u32x4 w[4]; GpuNode n; GpuTri t; };
+template <class OnHit>
+DEV void trace_ray_stepwise(PRef P, const float o[3], const float d[3], float tmin, float tmax, bool cullBackFaces,
+                            const TraceStack &stk, OnHit &&onHit, TraceCounts &cnt) {
+    RaySpace W, R;
+    make_ray_space(o, d, W);
+    R = W;
+    const GpuNode *nodes = P.tlasNodes;
+    const GpuTri *tris = nullptr;
+    int sp = 0, blasBase = -1;
+    uint32_t inst = 0, instFlags = 0;
+    float instDepthBias = 0.0f;
+    bool cull = false;
+    uint32_t cur = 0;
+    bool alive = true;
+    RT_TRIP_DECL(tripsNode); RT_TRIP_DECL(tripsLeaf);
+    auto popNext = [&]() -> bool {
+        if (blasBase >= 0 && sp == blasBase) { blasBase = -1; R = W; nodes = P.tlasNodes; }      // BLAS exhausted: resume the TLAS walk in world space
+        if (sp == 0) return false;
+        cur = stk.pop(sp);
+        return true;
+    };
+    while (alive) {
+        RT_TRIP(tripsNode);
+        const bool isNode = !(cur & RT64_LEAF_BIT), isTri = !isNode && cur != RT64_NO_CHILD && blasBase >= 0;
+        NodeOrTri rec;
+        if (isNode || isTri) {       // one fetch for both kinds of lane
+            const uintptr_t at = isNode ? reinterpret_cast<uintptr_t>(nodes + cur) : reinterpret_cast<uintptr_t>(tris + (cur & 0x7FFFFFFFu));
+            GlobalU4 q = reinterpret_cast<GlobalU4>(at);
+            rec.w[0] = q[0]; rec.w[1] = q[1]; rec.w[2] = q[2]; rec.w[3] = q[3];
+        }
+        if (isNode) {
+            cnt.nodes++;
+            float tl, tr;
+            const bool hl = box_hit(R, rec.n.lmin, rec.n.lmax, tmin, tmax, tl);
+            const bool hr = box_hit(R, rec.n.rmin, rec.n.rmax, tmin, tmax, tr);
+            const bool both = hl && hr, rightFirst = tr < tl;
+            const uint32_t nearChild = both ? (rightFirst ? rec.n.right : rec.n.left) : (hl ? rec.n.left : rec.n.right);
+            if (both) stk.push(sp, rightFirst ? rec.n.left : rec.n.right);
+            if (hl || hr) cur = nearChild;
+            else alive = popNext();
+        }
+        else if (isTri) {
+            cnt.tris++;
+            float t, u, v;
+            if (tri_hit(R, rec.t, cull, tmin, tmax, t, u, v) && onHit(t, u, v, inst, rec.t.prim, tmax, instFlags, instDepthBias)) alive = false;
+            else alive = popNext();
+        }
+        else if (cur != RT64_NO_CHILD) {
+            // TLAS leaf: enter the instance (G8)
+            inst = load_global(P.tlasIndex + (cur & 0x7FFFFFFFu));
+            const GpuInstance *in = P.instances + inst;
+            const float *M = in->worldToObject;
+            float oo[3], dd[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float m0 = load_global(M + c), m1 = load_global(M + 4 + c), m2 = load_global(M + 8 + c), m3 = load_global(M + 12 + c);
+                oo[c] = fmaf(W.o[2], m2, fmaf(W.o[1], m1, fmaf(W.o[0], m0, m3)));
+                dd[c] = fmaf(W.d[2], m2, fmaf(W.d[1], m1, W.d[0] * m0));
+            }
+            nodes = load_global(&in->nodes); tris = load_global(&in->tris);
+            const uint32_t flags = load_global(&in->flags); instDepthBias = load_global(&in->material.depthBias);
+            make_ray_space(oo, dd, R);
+            instFlags = flags;
+            cull = cullBackFaces && !(flags & GPU_INST_CULL_DISABLE);
+            blasBase = sp;
+            cur = 0;
+        }
+        else alive = popNext();
+    }
+#ifdef RT_PROFILE_TRIPS
+    RT_TRIP_END(tripsNode); RT_TRIP_END(tripsLeaf);
+    cnt.tripsNode += tripsNode; cnt.tripsLeaf += tripsLeaf;
+#endif
+}
+
+#ifndef RT_STEPWISE_WALK
+#define RT_STEPWISE_WALK 1       // 0: scenes without the LDS scene cache keep the while-while loop too (A/B builds)
+#endif
+
 template <bool CACHED = false, class OnHit>
 DEV void trace_ray(PRef P, const float o[3], const float d[3], float tmin, float tmax, bool cullBackFaces,
                    const TraceStack &stk, OnHit &&onHit, TraceCounts &cnt) {
     if (P.instanceCount == 0) return;
+    if (!CACHED && RT_STEPWISE_WALK) { trace_ray_stepwise(P, o, d, tmin, tmax, cullBackFaces, stk, onHit, cnt); return; }
     RaySpace W, R;
     make_ray_space(o, d, W);
     R = W;
@@ -186,17 +290,22 @@ DEV void trace_ray(PRef P, const float o[3], const float d[3], float tmin, float
     bool cull = false;
     uint32_t cur = 0;
     bool alive = true;
+    RT_TRIP_DECL(tripsNode); RT_TRIP_DECL(tripsLeaf);
     auto popNext = [&]() -> bool {
         if (blasBase >= 0 && sp == blasBase) {          // BLAS exhausted: resume the TLAS walk in world space
             blasBase = -1; R = W; nodes = P.tlasNodes; nodeOff = tlasOff;
         }
         if (sp == 0) return false;
+#ifdef RT_PROFILE_TRIPS
+        if (!CACHED && sp > stk.ldsEntries) cnt.spills++;
+#endif
         cur = stk.template pop<CACHED>(sp);
         return true;
     };
     while (alive) {
         // ---- inner nodes ----
         while (alive && !(cur & RT64_LEAF_BIT)) {
+            RT_TRIP(tripsNode);
             const GpuNode nd = CACHED ? load_node_lds(stk.cache + nodeOff + 4u * cur) : load_node(nodes + cur);
             cnt.nodes++;
             float tl, tr;
@@ -211,6 +320,7 @@ DEV void trace_ray(PRef P, const float o[3], const float d[3], float tmin, float
             else alive = popNext();
         }
         if (!alive) break;
+        RT_TRIP(tripsLeaf);
         // ---- leaf ----
         if (cur != RT64_NO_CHILD) {
             if (blasBase < 0) {
@@ -256,10 +366,15 @@ DEV void trace_ray(PRef P, const float o[3], const float d[3], float tmin, float
             cnt.tris++;
             float t, u, v;
             if (tri_hit(R, tri, cull, tmin, tmax, t, u, v))
-                if (onHit(t, u, v, inst, tri.prim, tmax, instFlags, instDepthBias)) return;
+                if (onHit(t, u, v, inst, tri.prim, tmax, instFlags, instDepthBias)) alive = false;
+            if (!alive) break;
         }
         alive = popNext();
     }
+#ifdef RT_PROFILE_TRIPS
+    RT_TRIP_END(tripsNode); RT_TRIP_END(tripsLeaf);
+    cnt.tripsNode += tripsNode; cnt.tripsLeaf += tripsLeaf;
+#endif
 }
 
 // RayWalk: the same walk as trace_ray (same operations per ray, kept textually parallel) with its state in a struct so that it

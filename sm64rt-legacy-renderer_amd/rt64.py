@@ -189,6 +189,7 @@ EXT_API = [
     ("CopyDeviceImage", "RT64_CopyDeviceImage", C.c_size_t, [_P, C.c_int, _P, C.c_size_t]),
     ("GetDeviceStats", "RT64_GetDeviceStats", C.c_int, [_P, C.POINTER(FRAME_STATS)]),
     ("SetDeviceOption", "RT64_SetDeviceOption", C.c_int, [_P, C.c_char_p, C.c_double]),
+    ("ReadbackTileTiming", "RT64_ReadbackTileTiming", C.c_size_t, [_P, _P, C.c_size_t]),
     ("GetDeviceStream", "RT64_GetDeviceStream", _P, [_P]),
     ("SetDeviceGatherTarget", "RT64_SetDeviceGatherTarget", None, [_P, _P, C.c_size_t]),
     ("ReadbackMeshAccel", "RT64_ReadbackMeshAccel", C.c_size_t, [_P, C.c_int, _P, C.c_size_t]),
