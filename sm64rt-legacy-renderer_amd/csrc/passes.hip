@@ -30,6 +30,9 @@
 #define RT_LAUNCHER(name) name
 #define RT_ROUTE_SIMPLE(call) if (P.simpleKernels) return call
 #endif
+#ifndef RT_ABLATE
+#define RT_ABLATE 0              // diagnostic builds (never shipped, tools/exp/r03_bounce_ablate.sh): parts of bounce_trace_plain_kernel stubbed out to price them
+#endif
 
 namespace {
 
@@ -861,13 +864,23 @@ __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kern
             const f3 rayDirection = cos_hemisphere_blue_noise(P, px, py, P.frameCount + smp * blueNoiseMult, shadingNormal);
             RayDiff rd; rd.dOdx = rd.dOdy = rd.dDdx = rd.dDdy = mk3s(0.0f);
             SurfaceHit best;
+#if RT_ABLATE >= 2
+            best.hit = false;                  // 2, 4: no walk
+#else
             trace_surface<false, CACHED>(P, env, I, i, rayOrigin, rayDirection, rd, px, py, best);
+#endif
             rays++;
             const size_t id = (size_t)(smp - 1) * stride + i;
             if (!best.hit) {
                 // a ray that leaves the scene is finished here: its radiance is the sky term (what bounce_miss_kernel computes from a record and a
-                // list entry -- one 16-byte store instead of a 32-byte record, a list append, and a kernel that reads both back)
+                // list entry -- one 16-byte store instead of a 32-byte record, a list append, and a kernel that reads both back).  (Round 3 measured the
+                // third place for it: the direction and a mark in the result slot, the sky lookup in bounce_resolve_kernel.  C5: this kernel 1.334 -> 1.254 ms,
+                // the resolve 0.098 -> 0.266 ms -- worse; the lookup costs 0.08 ms here.)
+#if RT_ABLATE == 1 || RT_ABLATE == 2
+                const f3 resIndirect = ambientBase + rayDirection * (P.giSkyStrength * 1.0f);       // 1, 2: no sky lookup
+#else
                 const f3 resIndirect = ambientBase + bounce_sky_term(P, rayDirection) * (P.giSkyStrength * 1.0f);
+#endif
                 I.bounceResults[id] = make_float4(resIndirect.x, resIndirect.y, resIndirect.z, 0.0f);
                 continue;
             }
@@ -881,6 +894,144 @@ __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kern
         }
     }
     __syncthreads();
+    if (threadIdx.x < 2) I.bounceCounts[2 * blockIdx.x + threadIdx.x] = ldsCount[threadIdx.x];
+    flush_env(P, env, PASS_INDIRECT, CTR_INDIRECT, rays);
+}
+
+// ---- the bounce walk in two phases (small scenes, several samples per pixel) ---------------------------------------------------------------------
+// Bounce rays differ in LENGTH: on a scene of a few instances many of them miss every instance box and end after one or two TLAS nodes, the ones that
+// enter an instance go on for ten to twenty steps, and the pixels of a tile that show the sky have no ray at all -- a wave of the plain walk keeps
+// those lanes idle until its longest ray is done (26 % VALU lane utilisation, C5).  Here a workgroup takes up to four (tile, sample) items -- 256
+// rays each -- through
+//   phase 1: ray generation + the TLAS part of the walk only, every lane busy.  A ray that reaches no TLAS leaf has finished exactly as trace_ray
+//            would finish it (same nodes, same tests, same count): it takes its sky term and is done.  A ray that reaches a leaf is a SURVIVOR: its
+//            direction goes to its record, its (item, pixel slot) to a list in LDS (wave ballot + one LDS atomic per wave), nothing is counted;
+//   phase 2: the lanes of the workgroup take the survivors densely from the list and walk each one in full, from the root (trace_surface: the walk
+//            the plain kernel makes, counted here), then record the hit or take the sky term.
+// Per ray the operations and their order are those of the plain kernel, so hits, records and visit counters are bit-identical
+// (tests/test_gpu_features.py::test_bounce_walk_in_two_phases_matches_the_plain_walk); the survivors' TLAS steps run twice.
+// Measured (MI355X, ms of the three bounce kernels, plain -> two phases at 4096 workgroups and 5 waves per SIMD): C5 (4 samples) 1.81 -> 1.58,
+// C4 (2 samples) 0.529 -> 0.471, C3 (1 sample) 0.233 -> 0.247: the host takes this form for frames with two or more samples per pixel.
+#define SPLIT_ITEMS 4u
+#define SPLIT_WAVES 5          // waves per SIMD (96 VGPRs, 13 dwords spilled outside the walk): 3 % faster than 4 on C4 / C5
+template <bool CACHED>
+DEV bool tlas_reaches_a_leaf(PRef P, const f3 &o, const f3 &d, const TraceStack &stk, uint32_t &nodesVisited) {
+    nodesVisited = 0;
+    if (P.instanceCount == 0) return false;
+    const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
+    RaySpace W;
+    make_ray_space(oo, dd, W);
+    const uint32_t tlasOff = 4u * P.cacheInstances;
+    int sp = 0;
+    uint32_t cur = 0;
+    for (;;) {
+        while (!(cur & RT64_LEAF_BIT)) {
+            const GpuNode nd = CACHED ? load_node_lds(stk.cache + tlasOff + 4u * cur) : load_node(P.tlasNodes + cur);
+            nodesVisited++;
+            float tl, tr;
+            const bool hl = box_hit(W, nd.lmin, nd.lmax, RT_RAY_MIN_DISTANCE, RT_RAY_MAX_DISTANCE, tl);
+            const bool hr = box_hit(W, nd.rmin, nd.rmax, RT_RAY_MIN_DISTANCE, RT_RAY_MAX_DISTANCE, tr);
+            const bool both = hl && hr, rightFirst = tr < tl;
+            const uint32_t nearChild = both ? (rightFirst ? nd.right : nd.left) : (hl ? nd.left : nd.right);
+            if (both) stk.template push<CACHED>(sp, rightFirst ? nd.left : nd.right);
+            if (hl || hr) cur = nearChild;
+            else { if (sp == 0) return false; cur = stk.template pop<CACHED>(sp); }
+        }
+        if (cur != RT64_NO_CHILD) return true;
+        if (sp == 0) return false;
+        cur = stk.template pop<CACHED>(sp);
+    }
+}
+
+template <bool CACHED>
+__global__ __launch_bounds__(RT_BLOCK, CACHED ? SPLIT_WAVES : TRACE_WAVES) void bounce_trace_split_kernel(FrameParams Pv, ViewImages Iv) {
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
+    constexpr uint32_t STACK_WORDS = CACHED ? RT_STACK_LDS_CACHED / 2 : RT_STACK_LDS;
+    __shared__ uint32_t ldsStack[STACK_WORDS * RT_BLOCK];
+    __shared__ uint32_t ldsCount[2];
+    __shared__ uint32_t ldsSurvivors;
+    __shared__ uint16_t ldsList[SPLIT_ITEMS * RT_BLOCK];
+    extern __shared__ u32x4_lds dynLds[];
+    if (threadIdx.x < 2) ldsCount[threadIdx.x] = 0;
+    if (threadIdx.x == 2) ldsSurvivors = 0;
+    if (CACHED) fill_scene_cache(P, dynLds);
+    __syncthreads();
+    const uint32_t segment = bounce_segment_size(P); const size_t missBase = bounce_miss_base(P, segment);
+    ShadeEnv env; env.stk = make_stack(P, ldsStack, STACK_WORDS); env.cnt = TraceCounts(); env.shadowRays = 0;
+    env.lightIntensity = nullptr; env.lightIndex = nullptr;
+    if (CACHED) env.stk.use_cache(dynLds);
+    uint32_t rays = 0;
+    const size_t stride = (size_t)P.width * (size_t)P.height;
+    const uint32_t tiles = tile_count(P), S = P.giSamples, blueNoiseMult = 64u / S;
+    const uint32_t myTiles = blockIdx.x < tiles ? (tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u, items = myTiles * S;
+    // item w of this workgroup: tile blockIdx.x + (w / S) * gridDim.x, sample S - (w % S) (the plain kernel's order)
+    for (uint32_t w0 = 0; w0 < items; w0 += SPLIT_ITEMS) {
+        PRef P = *kernel_params_here(); IRef I = *kernel_images_here();      // this round's view of the frame constants and the image table
+        const f3 ambientBase = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]);
+        // ---- phase 1 ----
+        for (uint32_t k = 0; k < SPLIT_ITEMS && w0 + k < items; k++) {
+            const uint32_t w = w0 + k, tile = blockIdx.x + (w / S) * gridDim.x, smp = S - (w % S);
+            const Pixel p = tile_pixel(P, tile);
+            bool survivor = false;
+            if (p.valid) {
+                const size_t i = (size_t)p.y * (size_t)P.width + p.x;
+                if (I.instanceId[i] >= 0) {
+                    const float4 pos4 = reinterpret_cast<const float4 *>(I.shadingPosition)[i];
+                    const f3 rayOrigin = mk3(pos4.x, pos4.y, pos4.z), shadingNormal = xyz(load_rgba16f(I.shadingNormal, i));
+                    const f3 rayDirection = cos_hemisphere_blue_noise(P, p.x, p.y, P.frameCount + smp * blueNoiseMult, shadingNormal);
+                    uint32_t visited;
+                    survivor = tlas_reaches_a_leaf<CACHED>(P, rayOrigin, rayDirection, env.stk, visited);
+                    const size_t id = (size_t)(smp - 1) * stride + i;
+                    if (survivor) {
+                        uint4 b; b.x = __float_as_uint(rayDirection.x); b.y = __float_as_uint(rayDirection.y); b.z = __float_as_uint(rayDirection.z); b.w = 0xFFFFFFFFu;
+                        I.bounceRecords[id * 2 + 1] = b;
+                    }
+                    else {
+                        env.cnt.nodes += visited; rays++;
+                        const f3 resIndirect = ambientBase + bounce_sky_term(P, rayDirection) * (P.giSkyStrength * 1.0f);
+                        I.bounceResults[id] = make_float4(resIndirect.x, resIndirect.y, resIndirect.z, 0.0f);
+                    }
+                }
+            }
+            const unsigned long long sm = __ballot(survivor);
+            if (sm) {
+                const uint32_t lane = threadIdx.x & 63u;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&ldsSurvivors, (uint32_t)__popcll(sm));
+                base = (uint32_t)__shfl((int)base, 0, 64);
+                if (survivor) ldsList[base + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull))] = (uint16_t)((k << 8) | threadIdx.x);
+            }
+        }
+        __syncthreads();
+        // ---- phase 2 ----
+        const uint32_t n = ldsSurvivors;
+        for (uint32_t e = threadIdx.x; e < n; e += RT_BLOCK) {
+            const uint32_t entry = ldsList[e], w = w0 + (entry >> 8), slot = entry & 255u;
+            const uint32_t tile = blockIdx.x + (w / S) * gridDim.x, smp = S - (w % S);
+            const Pixel p = tile_pixel_at(P, tile, slot >> 6, slot & 63u);
+            const size_t i = (size_t)p.y * (size_t)P.width + p.x, id = (size_t)(smp - 1) * stride + i;
+            const float4 pos4 = reinterpret_cast<const float4 *>(I.shadingPosition)[i];
+            const uint4 b = I.bounceRecords[id * 2 + 1];
+            const f3 rayOrigin = mk3(pos4.x, pos4.y, pos4.z), rayDirection = mk3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
+            RayDiff rd; rd.dOdx = rd.dOdy = rd.dDdx = rd.dDdy = mk3s(0.0f);
+            SurfaceHit best;
+            trace_surface<false, CACHED>(P, env, I, i, rayOrigin, rayDirection, rd, p.x, p.y, best);
+            rays++;
+            if (!best.hit) {
+                const f3 resIndirect = ambientBase + bounce_sky_term(P, rayDirection) * (P.giSkyStrength * 1.0f);
+                I.bounceResults[id] = make_float4(resIndirect.x, resIndirect.y, resIndirect.z, 0.0f);
+                continue;
+            }
+            uint4 a;
+            a.x = __float_as_uint(best.t); a.y = __float_as_uint(best.u); a.z = __float_as_uint(best.v); a.w = best.prim;
+            uint4 *rec = I.bounceRecords + id * 2;
+            rec[0] = a; rec[1] = make_uint4(b.x, b.y, b.z, best.instance);
+            bounce_append(I, ldsCount, segment, missBase, true, (uint32_t)id);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) ldsSurvivors = 0;
+        __syncthreads();
+    }
     if (threadIdx.x < 2) I.bounceCounts[2 * blockIdx.x + threadIdx.x] = ldsCount[threadIdx.x];
     flush_env(P, env, PASS_INDIRECT, CTR_INDIRECT, rays);
 }
@@ -1486,19 +1637,29 @@ hipError_t RT_LAUNCHER(launch_lean_frame)(const FrameParams &P, const ViewImages
     }
     return hipGetLastError();
 }
-hipError_t RT_LAUNCHER(launch_indirect)(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, int walk, hipStream_t s) {
-    RT_ROUTE_SIMPLE(launch_indirect_simple(P, I, cur, writeFiltered, klist, walk, s));
+hipError_t RT_LAUNCHER(launch_indirect)(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, int walk, unsigned groups, hipStream_t s) {
+    RT_ROUTE_SIMPLE(launch_indirect_simple(P, I, cur, writeFiltered, klist, walk, groups, s));
     if (klist) LAUNCH_RAY(indirect_kernel<true>, P, I, cur, writeFiltered ? 1 : 0);
     if (P.giSamples == 0 || !I.bounceRecords) LAUNCH_RAY(indirect_kernel<false>, P, I, cur, writeFiltered ? 1 : 0);
-    if (walk == BOUNCE_WALK_REFILL) hipLaunchKernelGGL(bounce_trace_refill_kernel, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
-    else if (P.cacheWords) hipLaunchKernelGGL(bounce_trace_plain_kernel<true>, dim3(rt_grid(P)), dim3(RT_BLOCK), cached_lds_bytes(P, false), s, P, I);
-    else hipLaunchKernelGGL(bounce_trace_plain_kernel<false>, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
+    // grid of the bounce kernels: `groups` workgroups (0 = the persistent grid of the other ray kernels), never more than there are tiles
+    unsigned grid = rt_grid(P);
+    if (groups) {
+        const unsigned all = (unsigned)(P.tileY1 - P.tileY0 + 15) / 16, strips = all > (unsigned)P.stripRank ? (all - (unsigned)P.stripRank + (unsigned)P.stripCount - 1) / (unsigned)P.stripCount : 0u;
+        const unsigned tiles = (unsigned)((P.width + 15) / 16) * strips;
+        grid = groups < RT_MAX_FRAME_GROUPS ? groups : RT_MAX_FRAME_GROUPS;
+        if (grid > tiles) grid = tiles < 1u ? 1u : tiles;
+    }
+    if (walk == BOUNCE_WALK_REFILL) hipLaunchKernelGGL(bounce_trace_refill_kernel, dim3(grid), dim3(RT_BLOCK), 0, s, P, I);
+    else if (walk == BOUNCE_WALK_SPLIT && P.cacheWords) hipLaunchKernelGGL(bounce_trace_split_kernel<true>, dim3(grid), dim3(RT_BLOCK), cached_lds_bytes(P, false), s, P, I);
+    else if (walk == BOUNCE_WALK_SPLIT) hipLaunchKernelGGL(bounce_trace_split_kernel<false>, dim3(grid), dim3(RT_BLOCK), 0, s, P, I);
+    else if (P.cacheWords) hipLaunchKernelGGL(bounce_trace_plain_kernel<true>, dim3(grid), dim3(RT_BLOCK), cached_lds_bytes(P, false), s, P, I);
+    else hipLaunchKernelGGL(bounce_trace_plain_kernel<false>, dim3(grid), dim3(RT_BLOCK), 0, s, P, I);
     // same grid for the three kernels: workgroup b shades the segments workgroup b of bounce_trace filled (lengths stay on the device)
-    if (P.cacheWords) hipLaunchKernelGGL(bounce_hit_kernel<true>, dim3(rt_grid(P)), dim3(RT_BLOCK), cached_lds_bytes(P, true), s, P, I);
-    else hipLaunchKernelGGL(bounce_hit_kernel<false>, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
-    if (walk == BOUNCE_WALK_REFILL) hipLaunchKernelGGL(bounce_miss_kernel, dim3(rt_grid(P)), dim3(RT_BLOCK), 0, s, P, I);      // the plain walk finishes its misses itself
-    dim3 grid((unsigned)(P.width + 31) / 32, (unsigned)(P.tileY1 - P.tileY0 + 7) / 8);
-    hipLaunchKernelGGL(bounce_resolve_kernel, grid, dim3(256), 0, s, P, I, cur, writeFiltered ? 1 : 0);
+    if (P.cacheWords) hipLaunchKernelGGL(bounce_hit_kernel<true>, dim3(grid), dim3(RT_BLOCK), cached_lds_bytes(P, true), s, P, I);
+    else hipLaunchKernelGGL(bounce_hit_kernel<false>, dim3(grid), dim3(RT_BLOCK), 0, s, P, I);
+    if (walk == BOUNCE_WALK_REFILL) hipLaunchKernelGGL(bounce_miss_kernel, dim3(grid), dim3(RT_BLOCK), 0, s, P, I);      // the other walks finish their misses themselves
+    dim3 rgrid((unsigned)(P.width + 31) / 32, (unsigned)(P.tileY1 - P.tileY0 + 7) / 8);
+    hipLaunchKernelGGL(bounce_resolve_kernel, rgrid, dim3(256), 0, s, P, I, cur, writeFiltered ? 1 : 0);
     return hipGetLastError();
 }
 #ifndef RT_ASSUME_SIMPLE

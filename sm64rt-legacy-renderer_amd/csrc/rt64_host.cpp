@@ -146,6 +146,8 @@ struct Options {
     bool spinPresent = true;      // RT64_DrawDevice waits for the frame by polling the stream (0: blocking hipStreamSynchronize)
     int perWaveFrame = -1;        // one-kernel frame of scenes without the LDS scene cache as one-wave workgroups (8 x 8 wave-tiles): 1 on, 0 off (16 x 16 tiles, four waves), -1 auto (on)
     bool tileTiming = false;      // profiling aid: the one-kernel frame records when each of its waves started and ended (RT64_ReadbackTileTiming)
+    int bounceGroups = -1;        // grid of the bounce kernels: -1 auto (4096 with the two-phase walk, else the persistent grid), 0 the persistent grid of RT_GRID_BLOCKS workgroups, n
+    int bounceSplit = -1;         // two-phase bounce walk (TLAS part first, survivors compacted through LDS): 1 on, 0 off, -1 auto (scenes with the LDS scene cache, two or more GI samples per pixel)
     int bounceRefill = -1;        // bounce-ray traversal with wave-ballot refill: 1 on, 0 off, -1 auto (on when the scene has >= 64 Ki triangles)
     int denoiserMode = 1;          // 0 = reference 5x Gaussian, 1 = SVGF
     int maxReflections = 2;        // rt64_view.cpp:60 (inspector-only knob in the reference)
@@ -383,7 +385,7 @@ Device::Device(int w, int h, int dev) {
         fclose(f);
         if (got != bn.size()) throw std::runtime_error("Blue-noise table " + path + " is truncated.");
     }
-    else fprintf(stderr, "rt64: blue-noise table %s not found; soft shadows / GI sampling use a constant sequence.\n", path.c_str());
+    else throw std::runtime_error("Blue-noise table " + path + " not found (the library looks in <its directory>/../assets; RT64_ASSETS_DIR overrides): soft shadows and GI sampling need it.");
     HIP_CHECK(hipMemcpy(blueNoise.ptr, bn.data(), bn.size(), hipMemcpyHostToDevice));
     HIP_CHECK(hipStreamSynchronize(stream));
 }
@@ -1219,8 +1221,8 @@ void View::render() {                          // View::render, rt64_view.cpp:11
             void *l = nullptr, *c = nullptr, *r = nullptr;
             // per-workgroup list segments: ceil(tiles / grid) tiles of 256 pixels each -> at most n + grid * 256 entries per list and sample
             const size_t tilesAll = (size_t)((imgW + 15) / 16) * (size_t)((imgH + 15) / 16);
-            HIP_CHECK(hipMalloc(&l, (size_t)giSamples * (tilesAll + RT_GRID_BLOCKS) * 256 * 2 * sizeof(uint32_t))); allocations.push_back(l);
-            HIP_CHECK(hipMalloc(&c, (size_t)RT_GRID_BLOCKS * 2 * sizeof(uint32_t))); allocations.push_back(c);
+            HIP_CHECK(hipMalloc(&l, (size_t)giSamples * (tilesAll + RT_MAX_FRAME_GROUPS) * 256 * 2 * sizeof(uint32_t))); allocations.push_back(l);
+            HIP_CHECK(hipMalloc(&c, (size_t)RT_MAX_FRAME_GROUPS * 2 * sizeof(uint32_t))); allocations.push_back(c);
             HIP_CHECK(hipMalloc(&r, (size_t)giSamples * n * sizeof(float4))); allocations.push_back(r);
             img.bounceLists = static_cast<uint32_t *>(l); img.bounceCounts = static_cast<uint32_t *>(c); img.bounceResults = static_cast<float4 *>(r);
         }
@@ -1286,8 +1288,10 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         else {
             bool refill = dev->opt.bounceRefill == 1;
             if (dev->opt.bounceRefill < 0) { size_t tri = 0; for (auto &ri : rtInstances) tri += ri.instance->mesh->blasCount; refill = tri >= 65536; }
-            const int walk = refill ? BOUNCE_WALK_REFILL : BOUNCE_WALK_PLAIN;
-            L(launch_indirect(X, img, cur, !denoiseGI, klist, walk, s));
+            const bool split = dev->opt.bounceSplit == 1 || (dev->opt.bounceSplit < 0 && X.cacheWords != 0 && giSamples >= 2);
+            const int walk = refill ? BOUNCE_WALK_REFILL : (split ? BOUNCE_WALK_SPLIT : BOUNCE_WALK_PLAIN);
+            const unsigned groups = dev->opt.bounceGroups >= 0 ? (unsigned)dev->opt.bounceGroups : (walk == BOUNCE_WALK_SPLIT ? 4096u : 0u);
+            L(launch_indirect(X, img, cur, !denoiseGI, klist, walk, groups, s));
         }
         mark(Device::EV_INDIRECT);
         // Refraction / reflection touch only pixels whose primary hit has a refraction / reflection factor (alpha > EPSILON).
@@ -1635,6 +1639,8 @@ RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, doubl
     else if (k == "sync_present") d->opt.syncPresent = value != 0.0;
     else if (k == "denoiser_mode") d->opt.denoiserMode = (int)value;
     else if (k == "bounce_refill") d->opt.bounceRefill = (int)value;
+    else if (k == "bounce_split") d->opt.bounceSplit = (int)value;
+    else if (k == "bounce_groups") d->opt.bounceGroups = value >= 0.0 && value <= (double)RT_MAX_FRAME_GROUPS ? (int)value : -1;
     else if (k == "per_wave_frame") d->opt.perWaveFrame = (int)value;
     else if (k == "tile_timing") d->opt.tileTiming = value != 0.0;
     else if (k == "spin_present") d->opt.spinPresent = value != 0.0;

@@ -17,7 +17,7 @@
 // The a-trous kernel can register-block ATROUS_ROWS output rows spaced by the step per lane (8 x 5 fetched taps serve 4 outputs: 10
 // taps per pixel instead of 25).  Measured at 1080p (five iterations + guide + variance): 4 rows 0.240 ms (133 VGPRs, 3 waves/SIMD),
 // 2 rows 0.223 ms, 1 row 0.210 ms (68 VGPRs, 7 waves/SIMD): the pass is latency-bound and occupancy beats tap reuse, so 1 it is.
-// Sky pixels (56 % of the sample frame) copy through.
+// Sky pixels (56 % of the sample frame) are written to both ping-pong images by the variance kernel and skipped by the iterations.
 // Round 2 measured the other way to reuse taps as well: steps 1 and 2 with the workgroup's (64 + 4S) x (8 + 4S) input pixels staged in LDS
 // (1.6 / 2.3 global loads per output instead of 50, same values into the same arithmetic).  Slower again -- C3 SVGF 0.240 against 0.210 ms,
 // C5 0.800 against 0.751 (profiles/r02_experiments/atrous_lds_tiled*, the patch is there too): the staging barrier and 5 instead of 8
@@ -37,40 +37,6 @@ DEV float grad_z(const float *depth, int x, int y, int w, int h) {
     return fmaxf(fabsf(zx - z), fabsf(zy - z));
 }
 
-__global__ __launch_bounds__(256) void svgf_variance_kernel(const uint16_t *color, const float *moments, const int32_t *instanceId, const uint16_t *normal,
-                                                            const float *depth, uint16_t *out, int w, int h, int y0, int y1) {
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = y0 + blockIdx.y * 8 + (threadIdx.x >> 5);
-    if (x >= w || y >= y1) return;
-    const size_t i = (size_t)y * w + x;
-    const f4 c = load_rgba16f(color, i);
-    float var = 0.0f;
-    if (instanceId[i] >= 0) {
-        if (c.w >= 4.0f) { const float m1 = moments[2 * i], m2 = moments[2 * i + 1]; var = fmaxf(0.0f, m2 - m1 * m1); }
-        else {
-            const f3 np = xyz(load_rgba16f(normal, i));
-            const float zp = depth[i], gz = grad_z(depth, x, y, w, h);
-            float sw = 0.0f, s1 = 0.0f, s2 = 0.0f;
-            for (int dy = -3; dy <= 3; dy++)
-                for (int dx = -3; dx <= 3; dx++) {
-                    const int qx = x + dx, qy = y + dy;
-                    if (qx < 0 || qy < 0 || qx >= w || qy >= h) continue;
-                    const size_t j = (size_t)qy * w + qx;
-                    if (instanceId[j] < 0) continue;
-                    const f3 nq = xyz(load_rgba16f(normal, j));
-                    const float dist = sqrtf((float)(dx * dx + dy * dy));
-                    const float wz = expf(-fabsf(zp - depth[j]) / (1.0f * gz * dist + 1e-8f));
-                    const float wn = powf(fmaxf(0.0f, dot3(np, nq)), 128.0f);
-                    const float wt = wz * wn;
-                    const f4 cq = load_rgba16f(color, j);
-                    const float l = lum3(cq.x, cq.y, cq.z);
-                    sw += wt; s1 += wt * l; s2 += wt * l * l;
-                }
-            if (sw > 0.0f) { const float m1 = s1 / sw, m2 = s2 / sw; var = fmaxf(0.0f, m2 - m1 * m1) * (4.0f / fmaxf(c.w, 1.0f)); }
-        }
-    }
-    store_rgba16f(out, i, c.x, c.y, c.z, var);
-}
-
 struct GuideRec { f3 n; float z, gz; bool valid; };
 DEV GuideRec unpack_guide(uint4 g) {
     GuideRec r;
@@ -86,7 +52,81 @@ DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 DEV float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 #define LOG2E 1.44269504088896f
 
-// guide record of every pixel (svgf_variance_kernel fills it for the frame)
+// Variance of every pixel.  Pixels with four frames of history take it from the luminance moments (28 B of traffic per pixel).  Younger pixels --
+// disocclusions, and every pixel of a mesh that deforms, whose history restarts each frame (C4) -- take the 7 x 7 bilateral estimate: a workgroup with
+// such a pixel stages the (32 + 6) x (8 + 6) neighbourhood of its outputs in LDS once, as 16-byte records (normal 3 x f16 + valid flag, depth,
+// luminance: the guide record with the luminance in the place of the depth gradient), and the 49 taps of a pixel are ds_read_b128s.  Per tap the
+// two edge stops are one v_exp_f32 like in the a-trous kernel:  w = exp2(128 log2(max(0, n.n')) - log2e |dz| / (gz dist + 1e-8)),  the ten distinct
+// values of log2e / (gz dist + 1e-8) computed once per pixel.  (Round 2: four scattered loads, expf, powf and sqrtf per tap: 196 us at 1440p on C4.)
+#define VAR_TILE_W (32 + 6)
+#define VAR_TILE_H (8 + 6)
+__global__ __launch_bounds__(256) void svgf_variance_kernel(const uint2 *__restrict__ color, const float2 *__restrict__ moments, const int32_t *__restrict__ instanceId,
+                                                            const uint4 *__restrict__ guide, uint2 *__restrict__ out, uint2 *__restrict__ outSky, int w, int h, int y0, int y1) {
+    __shared__ uint4 tile[VAR_TILE_W * VAR_TILE_H];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int x = blockIdx.x * 32 + tx, y = y0 + blockIdx.y * 8 + ty;
+    const bool inside = x < w && y < y1;
+    const size_t i = inside ? (size_t)y * w + x : 0;
+    uint2 cbits = make_uint2(0u, 0u);
+    float history = 0.0f, var = 0.0f;
+    bool spatial = false, valid = false;
+    if (inside) {
+        cbits = color[i];
+        history = f16_bits_to_f32((uint16_t)(cbits.y >> 16));
+        valid = instanceId[i] >= 0;
+        if (valid) {
+            if (history >= 4.0f) { const float2 m = moments[i]; var = fmaxf(0.0f, m.y - m.x * m.x); }
+            else spatial = true;
+        }
+    }
+    if (__syncthreads_or(spatial ? 1 : 0)) {         // workgroup-uniform
+        const int bx = blockIdx.x * 32 - 3, by = y0 + blockIdx.y * 8 - 3;
+        for (int t = threadIdx.x; t < VAR_TILE_W * VAR_TILE_H; t += 256) {
+            const int qx = bx + t % VAR_TILE_W, qy = by + t / VAR_TILE_W;
+            uint4 rec = make_uint4(0u, 0u, 0u, 0u);                       // outside the frame: not valid
+            if (qx >= 0 && qx < w && qy >= 0 && qy < h) {
+                const size_t j = (size_t)qy * w + qx;
+                const uint4 g = guide[j];
+                const f4 cq = unpack_rgba16f(color[j]);
+                rec = make_uint4(g.x, g.y, g.z, __float_as_uint(lum3(cq.x, cq.y, cq.z)));
+            }
+            tile[t] = rec;
+        }
+        __syncthreads();
+        if (spatial) {
+            const uint4 *centre = tile + (ty + 3) * VAR_TILE_W + tx + 3;
+            const GuideRec p = unpack_guide(*centre);                      // (.gz holds the luminance here; the gradient comes from the guide image)
+            const float gz = __uint_as_float(guide[i].w);
+            float sw = 0.0f, s1 = 0.0f, s2 = 0.0f;
+            // rows rolled, the seven taps of a row unrolled: log2e / (gz |(ax, ay)| + 1e-8) for ax = 0..3 is made per row (fully unrolled the 49 taps
+            // hoist their LDS reads and the ten constants into 118 VGPRs -- 4 waves per SIMD for a kernel that streams on most of the frame)
+#pragma unroll 1
+            for (int dy = -3; dy <= 3; dy++) {
+                const float fy2 = (float)(dy * dy);
+                float kz[4];
+#pragma unroll
+                for (int ax = 0; ax <= 3; ax++) kz[ax] = LOG2E * s_rcp(gz * s_sqrt((float)(ax * ax) + fy2) + 1e-8f);
+                const uint4 *row = centre + dy * VAR_TILE_W;
+#pragma unroll
+                for (int dx = -3; dx <= 3; dx++) {
+                    const GuideRec q = unpack_guide(row[dx]);
+                    const float e = 128.0f * fast_log2(fmaxf(0.0f, dot3(p.n, q.n))) - fabsf(p.z - q.z) * kz[dx < 0 ? -dx : dx];
+                    const float wt = q.valid ? fast_exp2(e) : 0.0f;
+                    const float l = q.gz;
+                    sw += wt; s1 += wt * l; s2 += wt * l * l;
+                }
+            }
+            if (sw > 0.0f) { const float inv = s_rcp(sw), m1 = s1 * inv, m2 = s2 * inv; var = fmaxf(0.0f, m2 - m1 * m1) * (4.0f * s_rcp(fmaxf(history, 1.0f))); }
+        }
+    }
+    if (inside) {
+        const uint2 v = make_uint2(cbits.x, (cbits.y & 0xFFFFu) | ((uint32_t)f32_to_f16_bits(var) << 16));
+        out[i] = v;
+        if (!valid) outSky[i] = v;        // pixels without a surface pass through the filter unchanged: written to the other ping-pong image here, skipped by every a-trous iteration
+    }
+}
+
+// guide record of every pixel (runs before svgf_variance_kernel, which reads it too)
 __global__ __launch_bounds__(256) void svgf_guide_kernel(const int32_t *instanceId, const uint16_t *normal, const float *depth, uint4 *guide, int w, int h, int y0, int y1) {
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = y0 + blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= w || y >= y1) return;
@@ -116,9 +156,9 @@ __global__ __launch_bounds__(256, 6) void svgf_atrous_kernel(const uint2 *__rest
         c[j] = mk4(0.0f, 0.0f, 0.0f, 0.0f); np[j] = mk3s(0.0f); zp[j] = lp[j] = kl[j] = gzc[j] = 0.0f;
         if (y >= y1) continue;
         const size_t i = (size_t)y * w + x;
-        c[j] = unpack_rgba16f(in[i]);
         const GuideRec g = unpack_guide(guide[i]);
-        if (!g.valid) { out[i] = in[i]; continue; }
+        if (!g.valid) continue;               // sky: svgf_variance_kernel wrote the pixel to both ping-pong images, nothing to filter or to copy
+        c[j] = unpack_rgba16f(in[i]);
         live[j] = true; any = true;
         // 3x3 Gaussian of the variance drives the luminance edge stop
         const float G[3] = { 0.25f, 0.5f, 0.25f };
@@ -215,7 +255,8 @@ hipError_t launch_svgf(const ViewImages &I, int cur, int width, int height, int 
     const int rows = y1 - y0;
     dim3 grid((unsigned)(width + 31) / 32, (unsigned)(rows + 7) / 8);
     hipLaunchKernelGGL(svgf_guide_kernel, grid, dim3(256), 0, s, I.instanceId, I.normal[cur], I.depth[cur], I.svgfGuide, width, height, y0, y1);
-    hipLaunchKernelGGL(svgf_variance_kernel, grid, dim3(256), 0, s, I.indirectLight[cur], I.moments[cur], I.instanceId, I.normal[cur], I.depth[cur], I.filteredIndirect[0], width, height, y0, y1);
+    hipLaunchKernelGGL(svgf_variance_kernel, grid, dim3(256), 0, s, reinterpret_cast<const uint2 *>(I.indirectLight[cur]), reinterpret_cast<const float2 *>(I.moments[cur]), I.instanceId, I.svgfGuide,
+                       reinterpret_cast<uint2 *>(I.filteredIndirect[0]), reinterpret_cast<uint2 *>(I.filteredIndirect[1]), width, height, y0, y1);
     for (int k = 0; k < 5; k++) {
         const int step = 1 << k;
         const unsigned laneRows = (unsigned)((rows + ATROUS_ROWS * step - 1) / (ATROUS_ROWS * step)) * (unsigned)step;     // lanes per column

@@ -575,3 +575,24 @@ def test_host_side_tree_depth_is_the_depth_the_device_builder_reports(rt64_lib, 
             assert dev2 == dev and host2 == host, (n, dev2, host2)
     finally:
         s.close()
+
+
+@pytest.mark.parametrize("gi_samples,groups", [(1, 0), (4, 0), (2, 7), (8, 3)])
+def test_bounce_walk_in_two_phases_matches_the_plain_walk(rt64_lib, sample_data, gi_samples, groups):
+    """Device option bounce_split: the bounce rays take the TLAS part of their walk first, the ones that reach an instance are compacted through LDS
+    and walked in full by dense waves (passes.hip bounce_trace_split_kernel).  Per ray the operations are those of the plain walk: the GI buffers, the
+    composed image and the traversal counters are identical -- with one, several and more than four samples per pixel (rounds of four (tile, sample)
+    items), a frame size that leaves partial tiles (320 x 180) and grids that give a workgroup several tiles."""
+    runs = []
+    for split in (0, 1):
+        opts = {"bounce_split": split, "bounce_refill": 0, "denoiser_mode": 1}
+        if groups:
+            opts["bounce_groups"] = groups
+        got, _, st = _render_pair(rt64_lib, sample_data, frames=3, view_desc=dict(gi_samples=gi_samples, denoiser=True), options=opts,
+                                  images=("INDIRECT_LIGHT_RAW", "INDIRECT_LIGHT_FILTERED", "OUTPUT_RGBA32F", "FINAL_RGBA8"))
+        runs.append((got, st))
+    (a, sa), (b, sb) = runs
+    assert sa.indirectRays == sb.indirectRays > 0 and sa.shadowRays == sb.shadowRays
+    assert (sa.nodesVisited, sa.trianglesTested) == (sb.nodesVisited, sb.trianglesTested)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
