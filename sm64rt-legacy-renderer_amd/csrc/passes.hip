@@ -1302,36 +1302,28 @@ __global__ __launch_bounds__(RT_BLOCK) void refraction_kernel(FrameParams Pv, Vi
     flush_env(P, env, PASS_REFRACTION, CTR_REFRACTION, rays);
 }
 
-// CACHED (opaque frames of scenes that fit the LDS scene cache): the mirror rays and their shadow rays walk from LDS like the other ray passes.  Most
-// tiles of a frame have no mirror pixel, so a workgroup fills its cache only when it meets its first tile with work (a workgroup-wide vote per tile).
-template <bool KLIST, bool CACHED = false>
+template <bool KLIST>
 __global__ __launch_bounds__(RT_BLOCK) void reflection_kernel(FrameParams Pv, ViewImages Iv) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
-    constexpr uint32_t STACK_WORDS = CACHED ? RT_STACK_LDS_CACHED / 2 : RT_STACK_LDS;
+    constexpr uint32_t STACK_WORDS = RT_STACK_LDS;
     __shared__ uint32_t ldsStack[STACK_WORDS * RT_BLOCK];
-    __shared__ float ldsLightIntensity[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
-    __shared__ uint8_t ldsLightIndex[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
-    extern __shared__ u32x4_lds dynLds[];
+    __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
+    __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     ShadeEnv env; env.stk = make_stack(P, ldsStack, STACK_WORDS); env.cnt = TraceCounts(); env.shadowRays = 0;
     light_columns(env, ldsLightIntensity, ldsLightIndex, RT64_MAX_LIGHTS + 1);
-    bool cacheReady = false;
     uint32_t rays = 0;
     const f3 ambient = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]) + mk3(P.ambientNoGIColor[0], P.ambientNoGIColor[1], P.ambientNoGIColor[2]);
     const uint32_t tiles = tile_count(P);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         PRef P = *kernel_params_here(); IRef I = *kernel_images_here();      // this trip's view of the frame constants and the image table (read where used, never carried across trips)
         Pixel p = tile_pixel(P, tile);
+        if (!p.valid) continue;
         const uint32_t px = p.x, py = p.y;
-        const size_t i = p.valid ? (size_t)py * (size_t)P.width + px : 0;
-        const int instanceId = p.valid ? I.instanceId[i] : -1;
-        f4 refl = p.valid ? load_rgba16f(I.reflection, i) : mk4(0, 0, 0, 0);
+        const size_t i = (size_t)py * (size_t)P.width + px;
+        const int instanceId = I.instanceId[i];
+        f4 refl = load_rgba16f(I.reflection, i);
         const float reflectionAlpha = refl.w;
-        const bool work = p.valid && !(instanceId < 0 || reflectionAlpha <= RT_EPSILON);
-        if (CACHED) {
-            if (!__syncthreads_or(work ? 1 : 0)) continue;                   // (workgroup-uniform)
-            if (!cacheReady) { cached_env(P, env, dynLds); cacheReady = true; }
-        }
-        if (!work) continue;
+        if (instanceId < 0 || reflectionAlpha <= RT_EPSILON) continue;
         const float4 pos4 = reinterpret_cast<const float4 *>(I.shadingPosition)[i];
         f3 shadingPosition = mk3(pos4.x, pos4.y, pos4.z), viewDirection = xyz(load_rgba16f(I.viewDirection, i)), shadingNormal = xyz(load_rgba16f(I.shadingNormal, i));
         f3 rayDirection = reflect3(viewDirection, shadingNormal);
@@ -1339,7 +1331,7 @@ __global__ __launch_bounds__(RT_BLOCK) void reflection_kernel(FrameParams Pv, Vi
         const f3 bgColor = sky_over_background_envmap(P, rayDirection);
         RayDiff rd; rd.dOdx = rd.dOdy = rd.dDdx = rd.dDdy = mk3s(0.0f);
         SurfaceHit best;
-        const uint32_t nhits = trace_surface<KLIST, CACHED>(P, env, I, i, shadingPosition, rayDirection, rd, px, py, best);
+        const uint32_t nhits = trace_surface<KLIST>(P, env, I, i, shadingPosition, rayDirection, rd, px, py, best);
         rays++;
         const RT64_MATERIAL &pm = P.instances[instanceId].material;
         f3 resPosition = mk3s(0.0f), resNormal = mk3s(0.0f), resSpecular = mk3s(0.0f), resTransparent = mk3s(0.0f); f4 resColor = mk4(0, 0, 0, 1); int resInstanceId = -1;
@@ -1372,7 +1364,7 @@ __global__ __launch_bounds__(RT_BLOCK) void reflection_kernel(FrameParams Pv, Vi
         }
         f3 rgb = xyz(resColor);
         if (resInstanceId >= 0) {
-            f3 directLight = compute_lights_random<CACHED>(P, env, px, py, rayDirection, (uint32_t)resInstanceId, resPosition, resNormal, resSpecular, 1, false) + ld_v3(P.instances[resInstanceId].material.selfLight);
+            f3 directLight = compute_lights_random(P, env, px, py, rayDirection, (uint32_t)resInstanceId, resPosition, resNormal, resSpecular, 1, false) + ld_v3(P.instances[resInstanceId].material.selfLight);
             rgb = rgb * (ambient + directLight);
             reinterpret_cast<float4 *>(I.shadingPosition)[i] = make_float4(resPosition.x, resPosition.y, resPosition.z, 0.0f);
             store_rgba16f(I.viewDirection, i, rayDirection.x, rayDirection.y, rayDirection.z, 0.0f);
@@ -1695,7 +1687,6 @@ hipError_t RT_LAUNCHER(launch_refraction)(const FrameParams &P, const ViewImages
 hipError_t RT_LAUNCHER(launch_reflection)(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s) {
     RT_ROUTE_SIMPLE(launch_reflection_simple(P, I, klist, s));
     if (klist) hipLaunchKernelGGL(reflection_kernel<true>, dim3(sparse_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
-    else if (P.cacheWords) hipLaunchKernelGGL((reflection_kernel<false, true>), dim3(sparse_grid(P)), dim3(RT_BLOCK), cached_lds_bytes(P, true), s, P, I);
     else hipLaunchKernelGGL(reflection_kernel<false>, dim3(sparse_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
     return hipGetLastError();
 }
