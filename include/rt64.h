@@ -435,10 +435,30 @@ typedef struct {
        derive the same boundaries.  RT64_GetGatherBands reads the boundaries of a gather (starts[0..count]); RT64_BalanceGatherBands is the cut \
        itself as a pure function of per-row hit counts. */ \
     X(GetGatherBands, RT64_GetGatherBands, int, (RT64_GATHER *gather, int *starts, int capacity)) \
-    X(BalanceGatherBands, RT64_BalanceGatherBands, void, (const unsigned int *hitCounts, int width, int height, int count, int *starts))
+    X(BalanceGatherBands, RT64_BalanceGatherBands, void, (const unsigned int *hitCounts, int width, int height, int count, int *starts)) \
+    /* ---- halo EXCHANGE for band partitions of frames with GI + the SVGF denoiser.  The filter result of a row depends on the filter INPUT (noisy GI + \
+       variance, guide record: 24 bytes per pixel) of RT64_HALO_ROWS rows above and below.  By default a band re-renders those rows (primary visibility, \
+       G-buffer, GI bounce: the expensive passes); with the exchange a band makes the filter input of its own rows only and, in the middle of the frame, \
+       ships its edge rows to the neighbouring bands and receives theirs.  RT64_HaloPlan is the schedule as a pure function: the regions rank `rank` \
+       sends (send = 1: rows [y0, y1) of its own band, to `peer`) and receives (send = 0: rows of `peer`'s band it needs), for bands starts[0 .. count]; \
+       returns the number of regions (writes at most `capacity`; `host` / `bytes` are left 0).  Two transports: \
+         - RCCL (the device's gather, bands = 1 or 2): RT64_SetDeviceOption(device, "halo_exchange", 1) -- grouped ncclSend / ncclRecv between the \
+           devices' images on the gather's communication stream, the render stream waits for it; \
+         - the host's own (MPI, sockets, shared memory; the gloo rehearsal of tests/): RT64_SetDeviceHaloExchange(device, fn, user, starts, rank, count) \
+           -- in the middle of RT64_DrawDevice the library stages the outgoing rows in pinned host memory, calls fn(user, regions, n) -- every region \
+           with its `host` buffer of `bytes` = rows x width x 24: fn sends the send regions' bytes to their peers and fills the others from theirs -- \
+           and uploads what arrived.  fn = NULL turns it off.  Returns 0 on invalid arguments. \
+       Both leave the frame bit-identical to the single-device frame (tests/test_gpu_halo.py).  The temporal history of a band then covers its rows + \
+       RT64_SetDeviceOption(device, "halo_margin", rows) (default 4, the minimum): a host whose camera moves more than that per frame raises it. */ \
+    X(HaloPlan, RT64_HaloPlan, int, (int height, int count, const int *starts, int rank, int haloRows, RT64_HALO_REGION *regions, int capacity)) \
+    X(SetDeviceHaloExchange, RT64_SetDeviceHaloExchange, int, (RT64_DEVICE *device, RT64_HALO_EXCHANGE exchange, void *user, const int *starts, int rank, int count))
 
 typedef struct RT64_GATHER RT64_GATHER;
 #define RT64_GATHER_ID_BYTES 128       /* size of the rendezvous id (an ncclUniqueId) */
+#define RT64_HALO_ROWS 62              /* rows of filter input around a row that its SVGF result depends on: 2 x (1 + 2 + 4 + 8 + 16) */
+#define RT64_HALO_BYTES_PER_PIXEL 24   /* filter input of a pixel: RGBA16F colour + variance (8) and the guide record (16) */
+typedef struct { int peer; int send; int y0, y1; void *host; size_t bytes; } RT64_HALO_REGION;     /* rows [y0, y1) of the frame; host buffer = the rows' colour + variance, then their guide records */
+typedef void (*RT64_HALO_EXCHANGE)(void *user, const RT64_HALO_REGION *regions, int count);
 
 #define RT64_X(member, symbol, ret, args) typedef ret (*member##Ptr) args;
 RT64_EXT_API_LIST(RT64_X)

@@ -150,6 +150,8 @@ struct Options {
     int bounceSplit = -1;         // two-phase bounce walk (TLAS part first, survivors compacted through LDS): 1 on, 0 off, -1 auto (scenes with the LDS scene cache, two or more GI samples per pixel)
     int bounceRefill = -1;        // bounce-ray traversal with wave-ballot refill: 1 on, 0 off, -1 auto (on when the scene has >= 64 Ki triangles)
     int denoiserMode = 1;          // 0 = reference 5x Gaussian, 1 = SVGF
+    bool haloExchange = false;     // band partitions of GI + SVGF frames: ship the filter input of the halo rows between the devices of the gather (RCCL) instead of re-rendering them
+    int haloMargin = SVGF_INPUT_HALO_ROWS;   // with a halo exchange: rows of G-buffer + GI kept around the band (temporal history under camera motion); at least SVGF_INPUT_HALO_ROWS
     int maxReflections = 2;        // rt64_view.cpp:60 (inspector-only knob in the reference)
     unsigned maxFrameGroups = RT_MAX_FRAME_GROUPS;   // grid cap of the one-kernel frame (tests lower it: several tiles per workgroup on a small frame)
 };
@@ -167,6 +169,14 @@ struct Device {
     void finishStats();
     DevArray<uint32_t> spillStack;
     void *gatherTarget = nullptr; size_t gatherTargetBytes = 0;          // RT64_SetDeviceGatherTarget
+    // Halo exchange of the SVGF filter input between the bands of a partition (RT64_SetDeviceHaloExchange / option halo_exchange): transport and layout
+    struct HaloLink {
+        RT64_HALO_EXCHANGE fn = nullptr; void *user = nullptr; int rank = 0, count = 0; std::vector<int> starts;       // the host's transport
+        struct Gather *gather = nullptr;                                                                                 // RCCL: the device's gather (bands), set by RT64_CreateGather
+        hipEvent_t ready = nullptr, done = nullptr;
+        uint8_t *pinned = nullptr; size_t pinnedBytes = 0;
+    } halo;
+    bool haloActive() const;
     DevArray<unsigned long long> counters;
     DevArray<uint4> tileTiming; unsigned tileTimingWaves = 0;        // option tile_timing: records of the last one-kernel frame
     DevArray<uint8_t> blueNoise;
@@ -399,6 +409,9 @@ Device::~Device() {
     for (Scene *s : scenesCopy) delete s;                 // rt64_device.cpp:97-100
     for (auto &ev : events) if (ev) hipEventDestroy(ev);
     for (auto *p : pinned) if (p) hipHostFree(p);
+    if (halo.pinned) hipHostFree(halo.pinned);
+    if (halo.ready) hipEventDestroy(halo.ready);
+    if (halo.done) hipEventDestroy(halo.done);
     if (ring) hipHostFree(ring);
     if (stream) hipStreamDestroy(stream);
 }
@@ -1177,6 +1190,8 @@ void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64
     if (dev->opt.tileTiming) { dev->tileTiming.reserve((size_t)RT_TIMING_WAVES * 3); P.tileTiming = dev->tileTiming.ptr; }      // two records per wave + one more in diagnostic builds
 }
 
+static void halo_exchange(Device *dev, const ViewImages &img, int W, int H, hipStream_t s);     // (after Gather, below)
+
 void View::render() {                          // View::render, rt64_view.cpp:1180-1670
     Device *dev = scene->device;
     hipStream_t s = dev->stream;
@@ -1233,9 +1248,13 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         // refraction, compose) stay on the owned rows.  The halo rows are recomputed, not exchanged: no mid-frame collective.
         const bool denoiseGI = denoiserEnabled && giSamples > 0;
         FrameParams X = P;                                        // X: owned rows + halo
+        bool haloExchange = false;
         if (denoiseGI && !P.separatePost && (P.tileY0 > 0 || P.tileY1 < imgH || P.stripCount > 1)) {
             if (P.stripCount > 1) throw std::runtime_error("RT64_DrawDevice: a frame with GI + denoiser filters across rows; partition it into contiguous bands (RT64_SetDeviceTile), not interleaved strips.");
-            const int halo = dev->opt.denoiserMode == 1 ? SVGF_HALO_ROWS : GAUSSIAN_HALO_ROWS;
+            // ... or, with a halo exchange (SVGF only), the passes cover the band and the few rows the filter INPUT of the band needs (and the temporal
+            // history margin); the filter input of the 62 halo rows arrives from the neighbouring bands in the middle of the frame (halo_exchange below).
+            haloExchange = dev->opt.denoiserMode == 1 && dev->haloActive();
+            const int halo = haloExchange ? std::max(dev->opt.haloMargin, SVGF_INPUT_HALO_ROWS) : (dev->opt.denoiserMode == 1 ? SVGF_HALO_ROWS : GAUSSIAN_HALO_ROWS);
             X.tileY0 = std::max(0, P.tileY0 - halo); X.tileY1 = std::min(imgH, P.tileY1 + halo);
         }
         const bool lean = leanNow;
@@ -1298,7 +1317,13 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         if (anyRefraction) L(launch_refraction(P, img, klist, s));
         if (anyReflection) for (int r = 0; r < dev->opt.maxReflections; r++) L(launch_reflection(P, img, klist, s));
         mark(Device::EV_REFL);
-        if (denoiseGI && dev->opt.denoiserMode == 1) L(launch_svgf(img, cur, imgW, imgH, X.tileY0, X.tileY1, s));
+        if (denoiseGI && dev->opt.denoiserMode == 1 && haloExchange) {
+            // filter input (variance image + guide records) of the band's own rows; the guide records of 3 rows around them feed the variance estimate
+            L(launch_svgf_inputs(img, cur, imgW, imgH, std::max(0, P.tileY0 - 3), std::min(imgH, P.tileY1 + 3), P.tileY0, P.tileY1, s));
+            halo_exchange(dev, img, imgW, imgH, s);
+            L(launch_svgf_atrous(img, imgW, imgH, std::max(0, P.tileY0 - SVGF_ATROUS_HALO_ROWS), std::min(imgH, P.tileY1 + SVGF_ATROUS_HALO_ROWS), s));
+        }
+        else if (denoiseGI && dev->opt.denoiserMode == 1) L(launch_svgf(img, cur, imgW, imgH, X.tileY0, X.tileY1, s));
         else if (denoiseGI) {
             L(hipMemcpyAsync(img.filteredIndirect[0], img.indirectLight[cur], n * 8, hipMemcpyDeviceToDevice, s));
             for (int k = 0; k < 5; k++)            // rt64_view.cpp:1512-1530
@@ -1639,6 +1664,8 @@ RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, doubl
     else if (k == "sync_present") d->opt.syncPresent = value != 0.0;
     else if (k == "denoiser_mode") d->opt.denoiserMode = (int)value;
     else if (k == "bounce_refill") d->opt.bounceRefill = (int)value;
+    else if (k == "halo_exchange") d->opt.haloExchange = value != 0.0;
+    else if (k == "halo_margin") d->opt.haloMargin = std::max((int)value, SVGF_INPUT_HALO_ROWS);
     else if (k == "bounce_split") d->opt.bounceSplit = (int)value;
     else if (k == "bounce_groups") d->opt.bounceGroups = value >= 0.0 && value <= (double)RT_MAX_FRAME_GROUPS ? (int)value : -1;
     else if (k == "per_wave_frame") d->opt.perWaveFrame = (int)value;
@@ -1957,12 +1984,14 @@ Gather::Gather(Device *d, const ncclUniqueId &id, int rank_, int count_, int ban
     }
     HIP_CHECK(hipStreamSynchronize(dev->stream));
     RCCL_CHECK(rccl().CommInitRank(&comm, count, id, rank));
+    if (bands) dev->halo.gather = this;           // the bands can exchange their denoiser halos over this communicator (option halo_exchange)
     prepare(0);
 }
 Gather::~Gather() {
     hipSetDevice(dev->hipDevice);
     hipStreamSynchronize(dev->stream); if (commStream) hipStreamSynchronize(commStream);
     if (dev->gatherTarget == slots[0].local || dev->gatherTarget == slots[1].local) { dev->gatherTarget = nullptr; dev->gatherTargetBytes = 0; }
+    if (dev->halo.gather == this) dev->halo.gather = nullptr;
     if (comm) rccl().CommDestroy(comm);
     for (Slot &sl : slots) { if (sl.local) hipFree(sl.local); if (sl.bucket) hipFree(sl.bucket); if (sl.frame) hipFree(sl.frame); if (sl.produced) hipEventDestroy(sl.produced); if (sl.gathered) hipEventDestroy(sl.gathered); }
     if (commStream) hipStreamDestroy(commStream);
@@ -2006,6 +2035,108 @@ void Gather::wait(int slot, bool host) {
     Slot &sl = slots[slot];
     if (host) HIP_CHECK(hipEventSynchronize(sl.gathered));
     else HIP_CHECK(hipStreamWaitEvent(dev->stream, sl.gathered, 0));
+}
+
+// ---- halo exchange of the SVGF filter input ("renders its rows plus a halo ..., or exchanges halos") -------------------------------------
+// Schedule of rank `rank` for bands starts[0 .. count]: band q lies wholly above or below band r, so each pair of bands shares at most one interval
+// per direction.  Regions are listed by peer, the send before the receive.  Returns how many there are (writes at most `cap`).
+static int halo_plan(int H, int count, const int *starts, int rank, int halo, RT64_HALO_REGION *out, int cap) {
+    auto needs = [&](int r, int q, int &a, int &b) {           // rows of band q among the `halo` rows above / below band r
+        const int s0 = starts[r], e0 = starts[r + 1], qs = starts[q], qe = starts[q + 1];
+        if (e0 <= s0 || qe <= qs) return false;
+        a = std::max(std::max(0, s0 - halo), qs); b = std::min(s0, qe);
+        if (b > a) return true;
+        a = std::max(e0, qs); b = std::min(std::min(H, e0 + halo), qe);
+        return b > a;
+    };
+    int n = 0;
+    for (int q = 0; q < count; q++) {
+        if (q == rank) continue;
+        int a, b;
+        if (needs(q, rank, a, b)) { if (n < cap) { RT64_HALO_REGION &g = out[n]; g.peer = q; g.send = 1; g.y0 = a; g.y1 = b; g.host = nullptr; g.bytes = 0; } n++; }
+        if (needs(rank, q, a, b)) { if (n < cap) { RT64_HALO_REGION &g = out[n]; g.peer = q; g.send = 0; g.y0 = a; g.y1 = b; g.host = nullptr; g.bytes = 0; } n++; }
+    }
+    return n;
+}
+static bool halo_starts_valid(int H, int count, const int *starts) {
+    if (!starts || count < 1 || count > RT64_GATHER_MAX_RANKS || starts[0] != 0 || starts[count] != H) return false;
+    for (int r = 0; r < count; r++) if (starts[r + 1] < starts[r]) return false;
+    return true;
+}
+bool Device::haloActive() const {
+    if (halo.fn) return halo.count > 1;
+    return opt.haloExchange && halo.gather && halo.gather->count > 1 && halo.gather->bands != 0;
+}
+// In the middle of a frame, on the render stream `s`: the filter input of this band's rows is in filteredIndirect[0] / svgfGuide; after this call so is
+// the input of the RT64_HALO_ROWS rows above and below it (and the received colour rows are in the other ping-pong image too: the a-trous iterations
+// skip sky pixels, which the variance kernel writes to both images).
+static void halo_exchange(Device *dev, const ViewImages &img, int W, int H, hipStream_t s) {
+    Device::HaloLink &h = dev->halo;
+    int rank, count; std::vector<int> starts;
+    if (h.fn) { rank = h.rank; count = h.count; starts = h.starts; }
+    else {
+        Gather *g = h.gather; rank = g->rank; count = g->count; starts.resize((size_t)count + 1);
+        for (int r = 0; r <= count; r++) starts[(size_t)r] = g->bands == 2 ? g->layout.starts[r] : std::min(r * gather_band_rows(g->H, count), g->H);
+    }
+    if (!halo_starts_valid(H, count, starts.data()) || dev->tileY0 != starts[(size_t)rank] || dev->tileY1 != starts[(size_t)rank + 1])
+        throw std::runtime_error("RT64_DrawDevice: the halo exchange's band layout does not match the device's rows (RT64_SetDeviceTile / frame size changed after it was set up).");
+    RT64_HALO_REGION regs[2 * RT64_GATHER_MAX_RANKS];
+    const int n = halo_plan(H, count, starts.data(), rank, SVGF_ATROUS_HALO_ROWS, regs, 2 * RT64_GATHER_MAX_RANKS);
+    uint8_t *colour = reinterpret_cast<uint8_t *>(img.filteredIndirect[0]), *colourOther = reinterpret_cast<uint8_t *>(img.filteredIndirect[1]), *guide = reinterpret_cast<uint8_t *>(img.svgfGuide);
+    const size_t rowC = (size_t)W * 8, rowG = (size_t)W * 16;
+    if (h.fn) {
+        size_t total = 0;
+        for (int k = 0; k < n; k++) { regs[k].bytes = (size_t)(regs[k].y1 - regs[k].y0) * (rowC + rowG); total += regs[k].bytes; }
+        if (total > h.pinnedBytes) {
+            if (h.pinned) hipHostFree(h.pinned);
+            h.pinnedBytes = total; HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h.pinned), h.pinnedBytes, hipHostMallocDefault));
+        }
+        size_t at = 0;
+        for (int k = 0; k < n; k++) {
+            RT64_HALO_REGION &g = regs[k]; g.host = h.pinned + at; at += g.bytes;
+            if (!g.send) continue;
+            const size_t rows = (size_t)(g.y1 - g.y0);
+            HIP_CHECK(hipMemcpyAsync(g.host, colour + (size_t)g.y0 * rowC, rows * rowC, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipMemcpyAsync(static_cast<uint8_t *>(g.host) + rows * rowC, guide + (size_t)g.y0 * rowG, rows * rowG, hipMemcpyDeviceToHost, s));
+        }
+        HIP_CHECK(hipStreamSynchronize(s));
+        h.fn(h.user, regs, n);
+        for (int k = 0; k < n; k++) {
+            const RT64_HALO_REGION &g = regs[k];
+            if (g.send) continue;
+            const size_t rows = (size_t)(g.y1 - g.y0);
+            HIP_CHECK(hipMemcpyAsync(colour + (size_t)g.y0 * rowC, g.host, rows * rowC, hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipMemcpyAsync(guide + (size_t)g.y0 * rowG, static_cast<const uint8_t *>(g.host) + rows * rowC, rows * rowG, hipMemcpyHostToDevice, s));
+        }
+    }
+    else {
+        // RCCL: one group of point-to-point transfers between the images themselves (rows are contiguous), on the gather's communication stream --
+        // behind the previous frame's gather, in the same order on every rank -- and the render stream waits for the group.
+        Gather *g = h.gather; RcclApi &R = rccl();
+        if (!h.ready) { HIP_CHECK(hipEventCreateWithFlags(&h.ready, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&h.done, hipEventDisableTiming)); }
+        HIP_CHECK(hipEventRecord(h.ready, s));
+        HIP_CHECK(hipStreamWaitEvent(g->commStream, h.ready, 0));
+        RCCL_CHECK(R.GroupStart());
+        for (int k = 0; k < n; k++) {
+            const RT64_HALO_REGION &q = regs[k];
+            const size_t rows = (size_t)(q.y1 - q.y0);
+            if (q.send) {
+                RCCL_CHECK(R.Send(colour + (size_t)q.y0 * rowC, rows * rowC, ncclUint8, q.peer, g->comm, g->commStream));
+                RCCL_CHECK(R.Send(guide + (size_t)q.y0 * rowG, rows * rowG, ncclUint8, q.peer, g->comm, g->commStream));
+            }
+            else {
+                RCCL_CHECK(R.Recv(colour + (size_t)q.y0 * rowC, rows * rowC, ncclUint8, q.peer, g->comm, g->commStream));
+                RCCL_CHECK(R.Recv(guide + (size_t)q.y0 * rowG, rows * rowG, ncclUint8, q.peer, g->comm, g->commStream));
+            }
+        }
+        RCCL_CHECK(R.GroupEnd());
+        HIP_CHECK(hipEventRecord(h.done, g->commStream));
+        HIP_CHECK(hipStreamWaitEvent(s, h.done, 0));
+    }
+    for (int k = 0; k < n; k++) {
+        const RT64_HALO_REGION &g = regs[k];
+        if (!g.send) HIP_CHECK(hipMemcpyAsync(colourOther + (size_t)g.y0 * rowC, colour + (size_t)g.y0 * rowC, (size_t)(g.y1 - g.y0) * rowC, hipMemcpyDeviceToDevice, s));
+    }
 }
 
 }  // namespace rt64
@@ -2071,6 +2202,17 @@ RT64_EXPORT int RT64_GatherRowOwnerOf(int height, int count, const int *starts, 
 }
 RT64_EXPORT int RT64_GatherOwnedRowsOf(int height, int count, const int *starts, int rank) { GatherLayout L; return (!gather_layout_of(height, count, starts, L) || rank < 0 || rank >= count) ? -1 : gather_owned_rows(L, rank); }
 RT64_EXPORT int RT64_GatherSlotRowsOf(int height, int count, const int *starts) { GatherLayout L; return !gather_layout_of(height, count, starts, L) ? -1 : gather_max_owned_rows(L); }
+RT64_EXPORT int RT64_HaloPlan(int height, int count, const int *starts, int rank, int haloRows, RT64_HALO_REGION *regions, int capacity) {
+    if (!halo_starts_valid(height, count, starts) || rank < 0 || rank >= count || haloRows < 0 || (capacity > 0 && !regions)) return -1;
+    return halo_plan(height, count, starts, rank, haloRows, regions, capacity < 0 ? 0 : capacity);
+}
+RT64_EXPORT int RT64_SetDeviceHaloExchange(RT64_DEVICE *device, RT64_HALO_EXCHANGE exchange, void *user, const int *starts, int rank, int count) {
+    Device *d = reinterpret_cast<Device *>(device); if (!d) return 0;
+    if (!exchange) { d->halo.fn = nullptr; d->halo.user = nullptr; d->halo.count = 0; d->halo.starts.clear(); return 1; }
+    if (!halo_starts_valid(d->pendingHeight, count, starts) || rank < 0 || rank >= count) return 0;
+    d->halo.fn = exchange; d->halo.user = user; d->halo.rank = rank; d->halo.count = count; d->halo.starts.assign(starts, starts + count + 1);
+    return 1;
+}
 // The band boundaries of an existing gather (bands = 1 or 2): starts[0 .. count], rank r owns rows [starts[r], starts[r + 1]).  Returns count, 0 for interleaved strips.
 RT64_EXPORT int RT64_GetGatherBands(RT64_GATHER *gather, int *starts, int capacity) {
     Gather *g = reinterpret_cast<Gather *>(gather);

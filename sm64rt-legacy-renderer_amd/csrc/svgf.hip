@@ -247,16 +247,27 @@ __global__ __launch_bounds__(256, 6) void svgf_atrous_kernel(const uint2 *__rest
 
 }  // namespace
 
-// Rows [y0, y1) are filtered (an image-tile partition passes its rows + SVGF_HALO_ROWS on each side: the five iterations reach
-// 2 * (1 + 2 + 4 + 8 + 16) = 62 rows, the 7x7 variance estimate 3, the depth gradient 1).  Taps may fall outside [y0, y1) but
-// inside the frame: they only reach output rows that are themselves farther than the halo from the rows the device owns.
-hipError_t launch_svgf(const ViewImages &I, int cur, int width, int height, int y0, int y1, hipStream_t s) {
+// The denoiser in two halves.  launch_svgf_inputs: guide records of rows [gy0, gy1), variance (= the a-trous input image, both ping-pong images for sky
+// pixels) of rows [vy0, vy1); the 7 x 7 variance estimate reads guide records and colour 3 rows around its rows, the guide's depth gradient one row below.
+// launch_svgf_atrous: the five iterations over rows [y0, y1).  An image-tile partition passes its rows + the halo: the iterations reach
+// 2 * (1 + 2 + 4 + 8 + 16) = SVGF_ATROUS_HALO_ROWS rows.  Taps may fall outside [y0, y1) but inside the frame: they only reach output rows that are
+// themselves farther than the halo from the rows the device owns.  With halo RECOMPUTE (SVGF_HALO_ROWS = 62 + 3 + 1) both halves run on rows + halo;
+// with halo EXCHANGE (rt64_host.cpp) the inputs are made for the device's own rows only and the halo rows of both images arrive from the neighbours.
+hipError_t launch_svgf_inputs(const ViewImages &I, int cur, int width, int height, int gy0, int gy1, int vy0, int vy1, hipStream_t s) {
+    if (gy1 > gy0) {
+        dim3 grid((unsigned)(width + 31) / 32, (unsigned)(gy1 - gy0 + 7) / 8);
+        hipLaunchKernelGGL(svgf_guide_kernel, grid, dim3(256), 0, s, I.instanceId, I.normal[cur], I.depth[cur], I.svgfGuide, width, height, gy0, gy1);
+    }
+    if (vy1 > vy0) {
+        dim3 grid((unsigned)(width + 31) / 32, (unsigned)(vy1 - vy0 + 7) / 8);
+        hipLaunchKernelGGL(svgf_variance_kernel, grid, dim3(256), 0, s, reinterpret_cast<const uint2 *>(I.indirectLight[cur]), reinterpret_cast<const float2 *>(I.moments[cur]), I.instanceId, I.svgfGuide,
+                           reinterpret_cast<uint2 *>(I.filteredIndirect[0]), reinterpret_cast<uint2 *>(I.filteredIndirect[1]), width, height, vy0, vy1);
+    }
+    return hipGetLastError();
+}
+hipError_t launch_svgf_atrous(const ViewImages &I, int width, int height, int y0, int y1, hipStream_t s) {
     if (y1 <= y0) return hipSuccess;
     const int rows = y1 - y0;
-    dim3 grid((unsigned)(width + 31) / 32, (unsigned)(rows + 7) / 8);
-    hipLaunchKernelGGL(svgf_guide_kernel, grid, dim3(256), 0, s, I.instanceId, I.normal[cur], I.depth[cur], I.svgfGuide, width, height, y0, y1);
-    hipLaunchKernelGGL(svgf_variance_kernel, grid, dim3(256), 0, s, reinterpret_cast<const uint2 *>(I.indirectLight[cur]), reinterpret_cast<const float2 *>(I.moments[cur]), I.instanceId, I.svgfGuide,
-                       reinterpret_cast<uint2 *>(I.filteredIndirect[0]), reinterpret_cast<uint2 *>(I.filteredIndirect[1]), width, height, y0, y1);
     for (int k = 0; k < 5; k++) {
         const int step = 1 << k;
         const unsigned laneRows = (unsigned)((rows + ATROUS_ROWS * step - 1) / (ATROUS_ROWS * step)) * (unsigned)step;     // lanes per column
@@ -265,4 +276,9 @@ hipError_t launch_svgf(const ViewImages &I, int cur, int width, int height, int 
                            reinterpret_cast<uint2 *>(I.filteredIndirect[(k % 2) ^ 1]), I.svgfGuide, width, height, step, y0, y1);
     }
     return hipGetLastError();
+}
+hipError_t launch_svgf(const ViewImages &I, int cur, int width, int height, int y0, int y1, hipStream_t s) {
+    if (y1 <= y0) return hipSuccess;
+    hipError_t e = launch_svgf_inputs(I, cur, width, height, y0, y1, y0, y1, s);
+    return e != hipSuccess ? e : launch_svgf_atrous(I, width, height, y0, y1, s);
 }

@@ -209,7 +209,18 @@ EXT_API = [
     ("GatherSlotRowsOf", "RT64_GatherSlotRowsOf", C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
     ("GetGatherBands", "RT64_GetGatherBands", C.c_int, [_P, C.POINTER(C.c_int), C.c_int]),
     ("BalanceGatherBands", "RT64_BalanceGatherBands", None, [C.POINTER(C.c_uint), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    ("HaloPlan", "RT64_HaloPlan", C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, _P, C.c_int]),
+    ("SetDeviceHaloExchange", "RT64_SetDeviceHaloExchange", C.c_int, [_P, _P, _P, C.POINTER(C.c_int), C.c_int, C.c_int]),
 ]
+HALO_ROWS = 62
+HALO_BYTES_PER_PIXEL = 24
+
+
+class HALO_REGION(C.Structure):
+    _fields_ = [("peer", C.c_int), ("send", C.c_int), ("y0", C.c_int), ("y1", C.c_int), ("host", C.c_void_p), ("bytes", C.c_size_t)]
+
+
+HALO_EXCHANGE = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(HALO_REGION), C.c_int)
 GATHER_ID_BYTES = 128
 
 

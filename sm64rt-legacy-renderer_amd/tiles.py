@@ -217,3 +217,22 @@ class _Null:
 
     def __exit__(self, *a):
         return False
+
+
+def halo_exchange_gloo(regions, count):
+    """Transport of the SVGF halo exchange over torch.distributed (the body of a RT64_HALO_EXCHANGE callback: RT64_SetDeviceHaloExchange): every region's
+    host buffer is sent to / filled from its peer.  Non-blocking sends and receives, so the order of the regions cannot deadlock; two messages between
+    the same pair of ranks are matched in issue order, which the schedule keeps identical on both sides (RT64_HaloPlan lists regions by peer)."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    reqs, keep = [], []
+    for k in range(count):
+        g = regions[k]
+        if g.bytes == 0:
+            continue
+        t = torch.frombuffer((C.c_uint8 * g.bytes).from_address(g.host), dtype=torch.uint8)
+        keep.append(t)
+        reqs.append(dist.isend(t, g.peer) if g.send else dist.irecv(t, g.peer))
+    for r in reqs:
+        r.wait()

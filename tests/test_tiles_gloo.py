@@ -193,3 +193,90 @@ def test_cost_balanced_bands_are_balanced_deterministic_and_cover_the_frame():
     lib.BalanceGatherBands(zero.ctypes.data_as(C.POINTER(C.c_uint)), 64, 100, 8, starts)
     s = list(starts)
     assert s[0] == 0 and s[-1] == 100 and all(b > a for a, b in zip(s, s[1:]))
+
+
+def _halo_regions(lib, h, starts, rank, halo):
+    import ctypes as C
+    from sm64rt_legacy_renderer_amd import rt64
+    n = len(starts) - 1
+    arr = (C.c_int * (n + 1))(*starts)
+    regs = (rt64.HALO_REGION * (2 * n))()
+    got = lib.HaloPlan(h, n, arr, rank, halo, C.cast(regs, C.c_void_p), 2 * n)
+    assert 0 <= got <= 2 * n
+    assert lib.HaloPlan(h, n, arr, rank, halo, None, 0) == got                     # capacity 0: the count alone
+    return [(g.peer, g.send, g.y0, g.y1) for g in regs[:got]]
+
+
+def test_halo_plan_pairs_every_receive_with_a_send_and_covers_the_halo():
+    """RT64_HaloPlan (the schedule of the SVGF halo exchange, pure host function): what rank r expects from q is what q sends to r; a rank's receives
+    are exactly the rows within `halo` of its band that other bands own; its sends lie inside its own band.  Equal bands, cost-balanced (ragged) bands,
+    bands thinner than the halo (rows from several neighbours), empty bands, a world of one."""
+    from sm64rt_legacy_renderer_amd import rt64
+    lib = rt64.Library()
+    cases = [(180, [0, 90, 180], 62), (180, [0, 70, 131, 180], 62), (2160, [0, 300, 700, 1100, 1259, 1418, 1577, 1800, 2160], 62), (100, [0, 20, 40, 60, 80, 100], 62),
+             (64, [0, 16, 16, 40, 64], 5), (50, [0, 50], 62), (1080, [0, 540, 1080], 0)]
+    for h, starts, halo in cases:
+        n = len(starts) - 1
+        plans = [_halo_regions(lib, h, starts, r, halo) for r in range(n)]
+        for r, plan in enumerate(plans):
+            a, b = starts[r], starts[r + 1]
+            need = np.zeros(h, dtype=np.int32)
+            for peer, send, y0, y1 in plan:
+                assert peer != r and 0 <= y0 < y1 <= h
+                if send:
+                    assert a <= y0 and y1 <= b                                        # rows of my own band
+                    assert (r, 0, y0, y1) in plans[peer]                              # ... that the peer expects from me
+                else:
+                    assert starts[peer] <= y0 and y1 <= starts[peer + 1]              # rows of the peer's band
+                    assert (r, 1, y0, y1) in plans[peer]                              # ... that the peer sends me
+                    need[y0:y1] += 1
+            want = np.zeros(h, dtype=np.int32)
+            if b > a:
+                want[max(0, a - halo):a] = 1; want[b:min(h, b + halo)] = 1
+            assert np.array_equal(need, want), (h, starts, r)
+    import ctypes as C
+    bad = (C.c_int * 3)(0, 90, 179)
+    assert lib.HaloPlan(180, 2, bad, 0, 62, None, 0) == -1
+
+
+def _halo_worker(rank, world, init_file, h, w, starts, out_file):
+    """The schedule carried out over gloo: the callback a host hands to RT64_SetDeviceHaloExchange, here fed with synthetic rows."""
+    import ctypes as C
+    import torch.distributed as dist
+    from sm64rt_legacy_renderer_amd import rt64
+    dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
+    lib = rt64.Library()
+    arr = (C.c_int * (world + 1))(*starts)
+    regs = (rt64.HALO_REGION * (2 * world))()
+    n = lib.HaloPlan(h, world, arr, rank, rt64.HALO_ROWS, C.cast(regs, C.c_void_p), 2 * world)
+    row_bytes = w * rt64.HALO_BYTES_PER_PIXEL
+
+    def row_pattern(owner, y):                      # the bytes rank `owner` holds for row y
+        return ((np.arange(row_bytes, dtype=np.int64) * 7 + y * 13 + owner * 101) % 251).astype(np.uint8)
+    bufs = []
+    for k in range(n):
+        g = regs[k]
+        buf = np.zeros((g.y1 - g.y0) * row_bytes, dtype=np.uint8)
+        if g.send:
+            buf[:] = np.concatenate([row_pattern(rank, y) for y in range(g.y0, g.y1)])
+        g.host = buf.ctypes.data; g.bytes = buf.nbytes
+        bufs.append(buf)
+    tiles.halo_exchange_gloo(regs, n)
+    for k in range(n):
+        g = regs[k]
+        if not g.send:
+            assert np.array_equal(bufs[k], np.concatenate([row_pattern(g.peer, y) for y in range(g.y0, g.y1)])), (rank, g.peer, g.y0, g.y1)
+    dist.barrier()
+    if rank == 0:
+        open(out_file, "w").write("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,h,starts", [(2, 180, [0, 90, 180]), (3, 180, [0, 70, 131, 180])])
+def test_halo_exchange_schedule_over_gloo(world, h, starts):
+    pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as d:
+        init_file = os.path.join(d, "init"); out_file = os.path.join(d, "out")
+        mp.spawn(_halo_worker, args=(world, init_file, h, 40, starts, out_file), nprocs=world, join=True)
+        assert open(out_file).read() == "ok"
