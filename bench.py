@@ -64,6 +64,7 @@ def parse_args():
     ap.add_argument("--prewarm", type=int, default=100, help="untimed frames before the W warm-up steps (GPU clock ramp; the line reports them)")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE", help="RT64_SetDeviceOption(key, value) before the run (A/B measurements; the line records them under config.options)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU-staged rehearsal of the N>1 path")
+    ap.add_argument("--halo", default="exchange", choices=["exchange", "recompute"], help="N > 1, GI + denoiser bands: exchange the denoiser's halo rows between neighbouring bands (RCCL) or re-render them on every band")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a 1-GPU box: every rank renders on device 0")
     ap.add_argument("--force-gather", action="store_true", help="rehearsal: run the N > 1 code path (enqueued frames + pipelined RCCL gather) with a world of 1")
     ap.add_argument("--pretend-ranks", type=int, default=0, help="diagnosis on a 1-GPU box: render only rank 0's share of a P-way partition, frames enqueued, no gather; `value` is then NOT a throughput of the whole frame")
@@ -216,11 +217,17 @@ def main():
     gatherer = tiles.FrameGatherer(H, W, rank, N, comm_device, stream=ext_stream, bands=use_bands) if (G and not native) else None
     staging = torch.zeros(max(tiles.strips_per_rank(H, N) * 16, tiles.band_rows(H, N)) * W * 4, dtype=torch.uint8, device="cuda") if (G and not pipelined) else None
     local = torch.zeros(max(tiles.max_owned_rows(H, N), 1) * W * 4, dtype=torch.uint8, device="cuda")
+    halo_mode = None
     if native and use_bands:
         band_starts = (C.c_int * (N + 1))()
         if lib.GetGatherBands(gather, band_starts, N + 1) != N:
             raise SystemExit("RT64_GetGatherBands failed")
         my_rows = band_starts[rank + 1] - band_starts[rank]
+        # GI + SVGF bands: the filter input of the 62 halo rows travels between neighbouring bands over the gather's communicator (grouped
+        # ncclSend / ncclRecv in the middle of the frame) instead of being re-rendered by every band; --halo recompute keeps the re-rendering
+        halo_mode = args.halo
+        if args.halo == "exchange" and N > 1:
+            scene.option("halo_exchange", 1)
     elif native:
         my_rows = lib.GatherOwnedRows(H, N, 0, rank)
     my_bytes = (gatherer.owned_bytes() if gatherer else my_rows * W * 4) if G else H * W * 4
@@ -460,6 +467,7 @@ def main():
         if G:
             result["pipeline"] = {"frames": "enqueued (sync_present=0), 2 gather slots" if pipelined else "synchronous, CPU-staged gather (rehearsal)",
                                   "gather": "in-library (RT64_SubmitGather: grouped ncclSend / ncclRecv + reassembly kernel on the library's comm stream)" if native else "torch.distributed gather (tiles.FrameGatherer)",
+                              "denoiser_halo": (("exchanged between neighbouring bands (ncclSend / ncclRecv of 24 B per pixel, 62 rows per side)" if halo_mode == "exchange" else "re-rendered by every band (66 rows per side)") if halo_mode else "none (pixel-local frame)"),
                               "send_buffer": ("written by the frame kernel (RT64_SetDeviceGatherTarget)" if (packed[0] or (native and scene.stats().packedFinal)) else "packed after each frame (RT64_CopyDeviceImage layout)"),
                                   "host_ms_per_step": round(enqueue_ms, 5)}
         result["accel_build"] = {"first_frame_ms": round(first_frame_build_ms, 4), "triangles": int(st_full.triangleCount), "blas_node_bytes": int(st_full.blasNodeBytes),

@@ -53,7 +53,7 @@ def _render_bands(rt64_lib, sample_data, bands, frames, gi_samples, exchange, ma
         starts = (C.c_int * (n + 1))(*([b[0] for b in bands] + [H]))
         for r, (s, (a, b)) in enumerate(zip(parts, bands)):
             s.set_view_description(gi_samples=gi_samples, denoiser=True)
-            assert s.option("denoiser_mode", 1)
+            assert s.option("denoiser_mode", 1) and s.option("count_traversal", 1)
             s.set_tile(a, b)
             if exchange:
                 cb = box.callback(rt64, r); keep.append(cb)

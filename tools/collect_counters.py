@@ -20,11 +20,11 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-SHORT = [("lean_frame_kernel<true, true>", "full_frame"), ("lean_frame_kernel<false, true>", "full_frame"), ("lean_frame_kernel", "lean_frame"),
+SHORT = [("lean_frame_kernel<true, true,", "full_frame"), ("lean_frame_kernel<false, true,", "full_frame"), ("lean_frame_kernel", "lean_frame"),
          ("raster_draw_kernel", "raster_draw"), ("raster_setup_kernel", "raster_setup"), ("primary_trace_kernel", "primary_trace"),
          ("primary_shade_kernel", "primary_shade"), ("direct_kernel", "direct"), ("compose_post_kernel", "compose_post"), ("post_process_kernel", "post_process"),
          ("indirect_constant_kernel", "indirect_constant"), ("indirect_kernel", "indirect_klist"), ("bounce_trace_plain_kernel", "bounce_trace"),
-         ("bounce_trace_refill_kernel", "bounce_trace"), ("bounce_hit_kernel", "bounce_hit"), ("bounce_miss_kernel", "bounce_miss"),
+         ("bounce_trace_refill_kernel", "bounce_trace"), ("bounce_trace_split_kernel", "bounce_trace"), ("bounce_hit_kernel", "bounce_hit"), ("bounce_miss_kernel", "bounce_miss"),
          ("bounce_resolve_kernel", "bounce_resolve"), ("reflection_kernel", "reflection"), ("refraction_kernel", "refraction"),
          ("svgf_atrous_kernel", "svgf_atrous"), ("svgf_variance_kernel", "svgf_variance"), ("svgf_guide_kernel", "svgf_guide"), ("gaussian_kernel", "gaussian"),
          ("lbvh_small_batch_kernel", "lbvh_small_batch"), ("lbvh_small_kernel", "lbvh_small"), ("lg_", "lbvh_large"), ("taa_", "taa_upsample")]

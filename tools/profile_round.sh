@@ -7,7 +7,7 @@
 # tools/collect_counters.py then merges the four into profiles/kernel_counters.json (run it here AND commit the result: bench.py
 # refuses a file whose source hash differs from the kernels it runs).
 set -e
-TAG=${1:-r02}; WL=${2:-C2}; shift 2 || true
+TAG=${1:-r03}; WL=${2:-C2}; shift 2 || true
 REPO=$(pwd)
 OUT=$REPO/gpurun_out
 mkdir -p "$OUT"
