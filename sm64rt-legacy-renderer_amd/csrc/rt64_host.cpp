@@ -150,6 +150,7 @@ struct Options {
     int bounceSplit = -1;         // two-phase bounce walk (TLAS part first, survivors compacted through LDS): 1 on, 0 off, -1 auto (scenes with the LDS scene cache, two or more GI samples per pixel)
     int bounceRefill = -1;        // bounce-ray traversal with wave-ballot refill: 1 on, 0 off, -1 auto (on when the scene has >= 64 Ki triangles)
     int denoiserMode = 1;          // 0 = reference 5x Gaussian, 1 = SVGF
+    bool overlapReflection = true; // frames with reflection passes AND the SVGF denoiser: the reflection launches run on a second stream beside the a-trous iterations (they share no image)
     bool haloExchange = false;     // band partitions of GI + SVGF frames: ship the filter input of the halo rows between the devices of the gather (RCCL) instead of re-rendering them
     int haloMargin = SVGF_INPUT_HALO_ROWS;   // with a halo exchange: rows of G-buffer + GI kept around the band (temporal history under camera motion); at least SVGF_INPUT_HALO_ROWS
     int maxReflections = 2;        // rt64_view.cpp:60 (inspector-only knob in the reference)
@@ -169,6 +170,7 @@ struct Device {
     void finishStats();
     DevArray<uint32_t> spillStack;
     void *gatherTarget = nullptr; size_t gatherTargetBytes = 0;          // RT64_SetDeviceGatherTarget
+    hipStream_t auxStream = nullptr; hipEvent_t forkEvent = nullptr, joinEvent = nullptr;      // second stream of a frame whose reflection passes run beside its denoiser (created on first use)
     // Halo exchange of the SVGF filter input between the bands of a partition (RT64_SetDeviceHaloExchange / option halo_exchange): transport and layout
     struct HaloLink {
         RT64_HALO_EXCHANGE fn = nullptr; void *user = nullptr; int rank = 0, count = 0; std::vector<int> starts;       // the host's transport
@@ -409,6 +411,9 @@ Device::~Device() {
     for (Scene *s : scenesCopy) delete s;                 // rt64_device.cpp:97-100
     for (auto &ev : events) if (ev) hipEventDestroy(ev);
     for (auto *p : pinned) if (p) hipHostFree(p);
+    if (auxStream) { hipStreamSynchronize(auxStream); hipStreamDestroy(auxStream); }
+    if (forkEvent) hipEventDestroy(forkEvent);
+    if (joinEvent) hipEventDestroy(joinEvent);
     if (halo.pinned) hipHostFree(halo.pinned);
     if (halo.ready) hipEventDestroy(halo.ready);
     if (halo.done) hipEventDestroy(halo.done);
@@ -1315,9 +1320,33 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         mark(Device::EV_INDIRECT);
         // Refraction / reflection touch only pixels whose primary hit has a refraction / reflection factor (alpha > EPSILON).
         if (anyRefraction) L(launch_refraction(P, img, klist, s));
-        if (anyReflection) for (int r = 0; r < dev->opt.maxReflections; r++) L(launch_reflection(P, img, klist, s));
+        // The reflection passes read and rewrite the G-buffer (position, view direction, normal, instance id) and their own image; the a-trous iterations
+        // read and write the filter's ping-pong images and read the guide records: no image in common.  On frames that have both, the reflection launches
+        // therefore go to a second stream once the filter's INPUT is made (the variance kernel reads the instance ids the reflection pass rewrites), beside the
+        // five iterations, and the frame joins the two before Compose -- two latency-bound launches fill each other's idle issue slots (C5: DESIGN 8).
+        const bool reflectBeside = anyReflection && dev->opt.maxReflections > 0 && denoiseGI && dev->opt.denoiserMode == 1 && dev->opt.overlapReflection;
+        auto reflectOnAux = [&]() {
+            if (!dev->auxStream) {
+                HIP_CHECK(hipStreamCreateWithFlags(&dev->auxStream, hipStreamNonBlocking));
+                HIP_CHECK(hipEventCreateWithFlags(&dev->forkEvent, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&dev->joinEvent, hipEventDisableTiming));
+            }
+            HIP_CHECK(hipEventRecord(dev->forkEvent, s));
+            HIP_CHECK(hipStreamWaitEvent(dev->auxStream, dev->forkEvent, 0));
+            for (int r = 0; r < dev->opt.maxReflections; r++) L(launch_reflection(P, img, klist, dev->auxStream));
+            HIP_CHECK(hipEventRecord(dev->joinEvent, dev->auxStream));
+        };
+        if (anyReflection && !reflectBeside) for (int r = 0; r < dev->opt.maxReflections; r++) L(launch_reflection(P, img, klist, s));
         mark(Device::EV_REFL);
-        if (denoiseGI && dev->opt.denoiserMode == 1 && haloExchange) {
+        if (denoiseGI && dev->opt.denoiserMode == 1 && reflectBeside) {
+            const int ay0 = haloExchange ? std::max(0, P.tileY0 - SVGF_ATROUS_HALO_ROWS) : X.tileY0, ay1 = haloExchange ? std::min(imgH, P.tileY1 + SVGF_ATROUS_HALO_ROWS) : X.tileY1;
+            if (haloExchange) { L(launch_svgf_inputs(img, cur, imgW, imgH, std::max(0, P.tileY0 - 3), std::min(imgH, P.tileY1 + 3), P.tileY0, P.tileY1, s)); }
+            else L(launch_svgf_inputs(img, cur, imgW, imgH, X.tileY0, X.tileY1, X.tileY0, X.tileY1, s));
+            reflectOnAux();                                      // (before the exchange: the reflection pass also runs beside the wait for the neighbours' rows)
+            if (haloExchange) halo_exchange(dev, img, imgW, imgH, s);
+            L(launch_svgf_atrous(img, imgW, imgH, ay0, ay1, s));
+            HIP_CHECK(hipStreamWaitEvent(s, dev->joinEvent, 0));
+        }
+        else if (denoiseGI && dev->opt.denoiserMode == 1 && haloExchange) {
             // filter input (variance image + guide records) of the band's own rows; the guide records of 3 rows around them feed the variance estimate
             L(launch_svgf_inputs(img, cur, imgW, imgH, std::max(0, P.tileY0 - 3), std::min(imgH, P.tileY1 + 3), P.tileY0, P.tileY1, s));
             halo_exchange(dev, img, imgW, imgH, s);
@@ -1664,6 +1693,7 @@ RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, doubl
     else if (k == "sync_present") d->opt.syncPresent = value != 0.0;
     else if (k == "denoiser_mode") d->opt.denoiserMode = (int)value;
     else if (k == "bounce_refill") d->opt.bounceRefill = (int)value;
+    else if (k == "overlap_reflection") d->opt.overlapReflection = value != 0.0;
     else if (k == "halo_exchange") d->opt.haloExchange = value != 0.0;
     else if (k == "halo_margin") d->opt.haloMargin = std::max((int)value, SVGF_INPUT_HALO_ROWS);
     else if (k == "bounce_split") d->opt.bounceSplit = (int)value;
