@@ -41,6 +41,7 @@ hipError_t bc7_decode_launch(const uint8_t *blocks, uint8_t *rgba, uint32_t widt
 #define RT_STACK_LDS_CACHED 16        // traversal stack entries (LDS only, no spill path) of the kernels that hold the LDS scene cache: a power of two
 #define RT_GRID_BLOCKS 2048           // persistent grid of every ray kernel (8 workgroups of 256 per CU)
 #define RT_TIMING_WAVES ((8192u + 8u) * 4u)   // waves the tile-timing buffer has records for (profiling aid)
+#define RT_MAX_BOUNCE_GROUPS 65536u    // largest grid of the bounce kernels (one workgroup per 16 x 16 tile up to 4K and beyond; hit-list segments and counts are sized for it)
 #define RT_MAX_FRAME_GROUPS 8192u     // largest grid of the one-workgroup-per-tile kernels (bigger frames give every workgroup a few tiles)
 size_t rt_stack_spill_bytes(int width, int rows);        // bytes FrameParams::traversalStack needs for a frame of that size
 

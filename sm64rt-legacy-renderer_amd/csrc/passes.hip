@@ -808,6 +808,27 @@ __global__ __launch_bounds__(RT_BLOCK, 3) void indirect_kernel(FrameParams Pv, V
 // grid, workgroup b on the segments of workgroup b: lanes that shade a surface and trace a shadow ray are no longer interleaved with
 // lanes that only look up the sky (the one-kernel form ran at 30 % VALU lane utilisation).
 struct BounceSegments { uint32_t perBlock; };        // list entries reserved per workgroup and list
+// Tiles of the bounce walk's workgroups.  One workgroup per tile (frames of up to RT_MAX_BOUNCE_GROUPS tiles; bigger ones give workgroup b the tiles b,
+// b + grid, ...), walked from the bottom of the frame up like the one-kernel frame: the dispatcher hands the next tile to whichever CU has a free slot,
+// geometry (the bottom of a typical frame) first, sky last, and a workgroup whose tiles show no surface ends before it fills its scene cache
+// (bounce_any_surface).  (Round 3; until then a persistent grid walked tiles b, b + grid, ...: whenever the grid shares a large factor with the tiles of a
+// row, a workgroup's tiles line up in one column of the picture and the launch waits for the workgroups that drew the sphere -- C5 bounce kernels between
+// 1.50 and 1.95 ms for grids of 1920 ... 5120; consecutive blocks of tiles per workgroup are worse still: profiles/r03_experiments/r03_grid_sweep*.txt.)
+DEV uint32_t bounce_tiles_per_group(uint32_t tiles) { return (tiles + gridDim.x - 1) / gridDim.x; }
+DEV bool bounce_tile_of(uint32_t tiles, uint32_t per, uint32_t k, uint32_t &tile) {         // k-th tile of this workgroup
+    const uint32_t at = blockIdx.x + k * gridDim.x;
+    tile = tiles - 1u - at;
+    return k < per && at < tiles;
+}
+// Does any pixel of this workgroup's tiles show a surface (i.e. has a bounce ray)?  Workgroup-uniform; every thread calls it.
+DEV bool bounce_any_surface(PRef P, IRef I, uint32_t tiles, uint32_t per) {
+    bool any = false;
+    for (uint32_t k = 0, tile; bounce_tile_of(tiles, per, k, tile); k++) {
+        const Pixel p = tile_pixel(P, tile);
+        if (p.valid && I.instanceId[(size_t)p.y * (size_t)P.width + p.x] >= 0) any = true;
+    }
+    return __syncthreads_or(any ? 1 : 0) != 0;
+}
 DEV uint32_t bounce_segment_size(PRef P) {
     const uint32_t tiles = tile_count(P);
     return ((tiles + gridDim.x - 1) / gridDim.x) * RT_BLOCK * P.giSamples;
@@ -839,6 +860,8 @@ __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kern
     __shared__ uint32_t ldsStack[STACK_WORDS * RT_BLOCK];
     __shared__ uint32_t ldsCount[2];
     extern __shared__ u32x4_lds dynLds[];
+    const uint32_t tiles = tile_count(P), per = bounce_tiles_per_group(tiles);
+    if (!bounce_any_surface(P, I, tiles, per)) { if (threadIdx.x < 2) I.bounceCounts[2 * blockIdx.x + threadIdx.x] = 0; return; }      // nothing but sky: no ray, no cache fill
     if (threadIdx.x < 2) ldsCount[threadIdx.x] = 0;
     if (CACHED) fill_scene_cache(P, dynLds);
     __syncthreads();
@@ -848,8 +871,7 @@ __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kern
     if (CACHED) env.stk.use_cache(dynLds);
     uint32_t rays = 0;
     const size_t stride = (size_t)P.width * (size_t)P.height;
-    const uint32_t tiles = tile_count(P);
-    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    for (uint32_t k = 0, tile; bounce_tile_of(tiles, per, k, tile); k++) {
         PRef P = *kernel_params_here(); IRef I = *kernel_images_here();      // this trip's view of the frame constants and the image table (read where used, never carried across trips)
         Pixel p = tile_pixel(P, tile);
         if (!p.valid) continue;
@@ -910,8 +932,8 @@ __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kern
 //            the plain kernel makes, counted here), then record the hit or take the sky term.
 // Per ray the operations and their order are those of the plain kernel, so hits, records and visit counters are bit-identical
 // (tests/test_gpu_features.py::test_bounce_walk_in_two_phases_matches_the_plain_walk); the survivors' TLAS steps run twice.
-// Measured (MI355X, ms of the three bounce kernels, plain -> two phases at 4096 workgroups and 5 waves per SIMD): C5 (4 samples) 1.81 -> 1.58,
-// C4 (2 samples) 0.529 -> 0.471, C3 (1 sample) 0.233 -> 0.247: the host takes this form for frames with two or more samples per pixel.
+// Measured (MI355X, ms of the three bounce kernels, plain walk on a persistent grid of 2048 -> two phases, one workgroup per tile, 5 waves per SIMD): C5 (4 samples)
+// 1.81 -> 1.49, C4 (2 samples) 0.529 -> 0.487, C3 (1 sample) 0.233 -> 0.235: the host takes this form for frames with two or more samples per pixel.
 #define SPLIT_ITEMS 4u
 #define SPLIT_WAVES 5          // waves per SIMD (96 VGPRs, 13 dwords spilled outside the walk): 3 % faster than 4 on C4 / C5
 template <bool CACHED>
@@ -952,6 +974,8 @@ __global__ __launch_bounds__(RT_BLOCK, CACHED ? SPLIT_WAVES : TRACE_WAVES) void 
     __shared__ uint32_t ldsSurvivors;
     __shared__ uint16_t ldsList[SPLIT_ITEMS * RT_BLOCK];
     extern __shared__ u32x4_lds dynLds[];
+    const uint32_t tiles = tile_count(P), S = P.giSamples, blueNoiseMult = 64u / S, per = bounce_tiles_per_group(tiles);
+    if (!bounce_any_surface(P, I, tiles, per)) { if (threadIdx.x < 2) I.bounceCounts[2 * blockIdx.x + threadIdx.x] = 0; return; }      // nothing but sky: no ray, no cache fill
     if (threadIdx.x < 2) ldsCount[threadIdx.x] = 0;
     if (threadIdx.x == 2) ldsSurvivors = 0;
     if (CACHED) fill_scene_cache(P, dynLds);
@@ -962,15 +986,14 @@ __global__ __launch_bounds__(RT_BLOCK, CACHED ? SPLIT_WAVES : TRACE_WAVES) void 
     if (CACHED) env.stk.use_cache(dynLds);
     uint32_t rays = 0;
     const size_t stride = (size_t)P.width * (size_t)P.height;
-    const uint32_t tiles = tile_count(P), S = P.giSamples, blueNoiseMult = 64u / S;
     const uint32_t myTiles = blockIdx.x < tiles ? (tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u, items = myTiles * S;
-    // item w of this workgroup: tile blockIdx.x + (w / S) * gridDim.x, sample S - (w % S) (the plain kernel's order)
+    // item w of this workgroup: its (w / S)-th tile (bounce_tile_of), sample S - (w % S) (the plain kernel's order)
     for (uint32_t w0 = 0; w0 < items; w0 += SPLIT_ITEMS) {
         PRef P = *kernel_params_here(); IRef I = *kernel_images_here();      // this round's view of the frame constants and the image table
         const f3 ambientBase = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]);
         // ---- phase 1 ----
         for (uint32_t k = 0; k < SPLIT_ITEMS && w0 + k < items; k++) {
-            const uint32_t w = w0 + k, tile = blockIdx.x + (w / S) * gridDim.x, smp = S - (w % S);
+            const uint32_t w = w0 + k, tile = tiles - 1u - (blockIdx.x + (w / S) * gridDim.x), smp = S - (w % S);
             const Pixel p = tile_pixel(P, tile);
             bool survivor = false;
             if (p.valid) {
@@ -1007,7 +1030,7 @@ __global__ __launch_bounds__(RT_BLOCK, CACHED ? SPLIT_WAVES : TRACE_WAVES) void 
         const uint32_t n = ldsSurvivors;
         for (uint32_t e = threadIdx.x; e < n; e += RT_BLOCK) {
             const uint32_t entry = ldsList[e], w = w0 + (entry >> 8), slot = entry & 255u;
-            const uint32_t tile = blockIdx.x + (w / S) * gridDim.x, smp = S - (w % S);
+            const uint32_t tile = tiles - 1u - (blockIdx.x + (w / S) * gridDim.x), smp = S - (w % S);
             const Pixel p = tile_pixel_at(P, tile, slot >> 6, slot & 63u);
             const size_t i = (size_t)p.y * (size_t)P.width + p.x, id = (size_t)(smp - 1) * stride + i;
             const float4 pos4 = reinterpret_cast<const float4 *>(I.shadingPosition)[i];
@@ -1134,13 +1157,15 @@ __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void bounce_hit_kernel(Fram
     __shared__ float ldsLightIntensity[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     __shared__ uint8_t ldsLightIndex[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
     extern __shared__ u32x4_lds dynLds[];
+    const uint32_t n = I.bounceCounts[2 * blockIdx.x];      // the segment bounce_trace's workgroup blockIdx.x filled
+    if (n == 0) return;                                     // (workgroup-uniform) no hit listed: nothing to shade, no cache fill
     ShadeEnv env; env.stk = make_stack(P, ldsStack, STACK_WORDS); env.cnt = TraceCounts(); env.shadowRays = 0;
     light_columns(env, ldsLightIntensity, ldsLightIndex, RT64_MAX_LIGHTS + 1);
     if (CACHED) cached_env(P, env, dynLds);
     const f3 ambientBase = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]);
     const f3 ambient = ambientBase + mk3(P.ambientNoGIColor[0], P.ambientNoGIColor[1], P.ambientNoGIColor[2]);
     const uint32_t stride = (uint32_t)P.width * (uint32_t)P.height;
-    const uint32_t segment = bounce_segment_size(P), n = I.bounceCounts[2 * blockIdx.x];      // the segment bounce_trace's workgroup blockIdx.x filled
+    const uint32_t segment = bounce_segment_size(P);
     for (uint32_t e = threadIdx.x; e < n; e += RT_BLOCK) {
         PRef P = *kernel_params_here(); IRef I = *kernel_images_here();      // this trip's view of the frame constants and the image table (read where used, never carried across trips)
         const uint32_t id = I.bounceLists[(size_t)blockIdx.x * segment + e], i = id % stride;
@@ -1641,13 +1666,13 @@ hipError_t RT_LAUNCHER(launch_indirect)(const FrameParams &P, const ViewImages &
     RT_ROUTE_SIMPLE(launch_indirect_simple(P, I, cur, writeFiltered, klist, walk, groups, s));
     if (klist) LAUNCH_RAY(indirect_kernel<true>, P, I, cur, writeFiltered ? 1 : 0);
     if (P.giSamples == 0 || !I.bounceRecords) LAUNCH_RAY(indirect_kernel<false>, P, I, cur, writeFiltered ? 1 : 0);
-    // grid of the bounce kernels: `groups` workgroups (0 = the persistent grid of the other ray kernels), never more than there are tiles
+    // grid of the bounce kernels: one workgroup per tile up to `groups` workgroups (0 = RT_MAX_BOUNCE_GROUPS), then tiles b, b + grid, ... (bounce_tile_of)
     unsigned grid = rt_grid(P);
-    if (groups) {
+    {
         const unsigned all = (unsigned)(P.tileY1 - P.tileY0 + 15) / 16, strips = all > (unsigned)P.stripRank ? (all - (unsigned)P.stripRank + (unsigned)P.stripCount - 1) / (unsigned)P.stripCount : 0u;
-        const unsigned tiles = (unsigned)((P.width + 15) / 16) * strips;
-        grid = groups < RT_MAX_FRAME_GROUPS ? groups : RT_MAX_FRAME_GROUPS;
-        if (grid > tiles) grid = tiles < 1u ? 1u : tiles;
+        const unsigned tiles = (unsigned)((P.width + 15) / 16) * strips, most = P.cacheWords ? RT_MAX_BOUNCE_GROUPS : RT_MAX_FRAME_GROUPS /* the HBM spill slab of the traversal stacks is sized for that many workgroups */, cap = groups && groups < most ? groups : most;
+        const unsigned per = tiles > cap ? (tiles + cap - 1) / cap : 1u;
+        if (walk != BOUNCE_WALK_REFILL) grid = tiles < 1u ? 1u : (tiles + per - 1) / per;
     }
     if (walk == BOUNCE_WALK_REFILL) hipLaunchKernelGGL(bounce_trace_refill_kernel, dim3(grid), dim3(RT_BLOCK), 0, s, P, I);
     else if (walk == BOUNCE_WALK_SPLIT && P.cacheWords) hipLaunchKernelGGL(bounce_trace_split_kernel<true>, dim3(grid), dim3(RT_BLOCK), cached_lds_bytes(P, false), s, P, I);

@@ -146,7 +146,7 @@ struct Options {
     bool spinPresent = true;      // RT64_DrawDevice waits for the frame by polling the stream (0: blocking hipStreamSynchronize)
     int perWaveFrame = -1;        // one-kernel frame of scenes without the LDS scene cache as one-wave workgroups (8 x 8 wave-tiles): 1 on, 0 off (16 x 16 tiles, four waves), -1 auto (on)
     bool tileTiming = false;      // profiling aid: the one-kernel frame records when each of its waves started and ended (RT64_ReadbackTileTiming)
-    int bounceGroups = -1;        // grid of the bounce kernels: -1 auto (4096 with the two-phase walk, else the persistent grid), 0 the persistent grid of RT_GRID_BLOCKS workgroups, n
+    int bounceGroups = -1;        // cap of the bounce kernels' grid: 0 one workgroup per tile (up to RT_MAX_BOUNCE_GROUPS), n at most n workgroups (tiles b, b + n, ...), -1 auto (per tile for the two-phase walk, 1024 for the plain walk)
     int bounceSplit = -1;         // two-phase bounce walk (TLAS part first, survivors compacted through LDS): 1 on, 0 off, -1 auto (scenes with the LDS scene cache, two or more GI samples per pixel)
     int bounceRefill = -1;        // bounce-ray traversal with wave-ballot refill: 1 on, 0 off, -1 auto (on when the scene has >= 64 Ki triangles)
     int denoiserMode = 1;          // 0 = reference 5x Gaussian, 1 = SVGF
@@ -1241,8 +1241,8 @@ void View::render() {                          // View::render, rt64_view.cpp:11
             void *l = nullptr, *c = nullptr, *r = nullptr;
             // per-workgroup list segments: ceil(tiles / grid) tiles of 256 pixels each -> at most n + grid * 256 entries per list and sample
             const size_t tilesAll = (size_t)((imgW + 15) / 16) * (size_t)((imgH + 15) / 16);
-            HIP_CHECK(hipMalloc(&l, (size_t)giSamples * (tilesAll + RT_MAX_FRAME_GROUPS) * 256 * 2 * sizeof(uint32_t))); allocations.push_back(l);
-            HIP_CHECK(hipMalloc(&c, (size_t)RT_MAX_FRAME_GROUPS * 2 * sizeof(uint32_t))); allocations.push_back(c);
+            HIP_CHECK(hipMalloc(&l, (size_t)giSamples * (tilesAll + std::min<size_t>(tilesAll, RT_MAX_BOUNCE_GROUPS)) * 256 * 2 * sizeof(uint32_t))); allocations.push_back(l);
+            HIP_CHECK(hipMalloc(&c, (size_t)RT_MAX_BOUNCE_GROUPS * 2 * sizeof(uint32_t))); allocations.push_back(c);
             HIP_CHECK(hipMalloc(&r, (size_t)giSamples * n * sizeof(float4))); allocations.push_back(r);
             img.bounceLists = static_cast<uint32_t *>(l); img.bounceCounts = static_cast<uint32_t *>(c); img.bounceResults = static_cast<float4 *>(r);
         }
@@ -1314,7 +1314,9 @@ void View::render() {                          // View::render, rt64_view.cpp:11
             if (dev->opt.bounceRefill < 0) { size_t tri = 0; for (auto &ri : rtInstances) tri += ri.instance->mesh->blasCount; refill = tri >= 65536; }
             const bool split = dev->opt.bounceSplit == 1 || (dev->opt.bounceSplit < 0 && X.cacheWords != 0 && giSamples >= 2);
             const int walk = refill ? BOUNCE_WALK_REFILL : (split ? BOUNCE_WALK_SPLIT : BOUNCE_WALK_PLAIN);
-            const unsigned groups = dev->opt.bounceGroups >= 0 ? (unsigned)dev->opt.bounceGroups : (walk == BOUNCE_WALK_SPLIT ? 4096u : 0u);
+            // grid: the two-phase walk takes one workgroup per tile (0); the plain walk of one-sample frames one resident round of persistent workgroups (4 per CU at its
+            // 118 VGPRs): a tile of 256 rays is too little work to pay for a scene-cache fill of its own (C3 bounce kernels 0.235 -> 0.198 ms against 0.220 per tile)
+            const unsigned groups = dev->opt.bounceGroups >= 0 ? (unsigned)dev->opt.bounceGroups : (walk == BOUNCE_WALK_PLAIN ? 1024u : 0u);
             L(launch_indirect(X, img, cur, !denoiseGI, klist, walk, groups, s));
         }
         mark(Device::EV_INDIRECT);
@@ -1697,7 +1699,7 @@ RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, doubl
     else if (k == "halo_exchange") d->opt.haloExchange = value != 0.0;
     else if (k == "halo_margin") d->opt.haloMargin = std::max((int)value, SVGF_INPUT_HALO_ROWS);
     else if (k == "bounce_split") d->opt.bounceSplit = (int)value;
-    else if (k == "bounce_groups") d->opt.bounceGroups = value >= 0.0 && value <= (double)RT_MAX_FRAME_GROUPS ? (int)value : -1;
+    else if (k == "bounce_groups") d->opt.bounceGroups = value >= 0.0 && value <= (double)RT_MAX_BOUNCE_GROUPS ? (int)value : -1;
     else if (k == "per_wave_frame") d->opt.perWaveFrame = (int)value;
     else if (k == "tile_timing") d->opt.tileTiming = value != 0.0;
     else if (k == "spin_present") d->opt.spinPresent = value != 0.0;

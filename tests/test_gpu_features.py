@@ -582,15 +582,20 @@ def test_bounce_walk_in_two_phases_matches_the_plain_walk(rt64_lib, sample_data,
     """Device option bounce_split: the bounce rays take the TLAS part of their walk first, the ones that reach an instance are compacted through LDS
     and walked in full by dense waves (passes.hip bounce_trace_split_kernel).  Per ray the operations are those of the plain walk: the GI buffers, the
     composed image and the traversal counters are identical -- with one, several and more than four samples per pixel (rounds of four (tile, sample)
-    items), a frame size that leaves partial tiles (320 x 180) and grids that give a workgroup several tiles."""
+    items), a frame size that leaves partial tiles (320 x 180) and grids that give a workgroup several tiles.  (GPU against GPU: the oracle is not run.)"""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
     runs = []
     for split in (0, 1):
-        opts = {"bounce_split": split, "bounce_refill": 0, "denoiser_mode": 1}
-        if groups:
-            opts["bounce_groups"] = groups
-        got, _, st = _render_pair(rt64_lib, sample_data, frames=3, view_desc=dict(gi_samples=gi_samples, denoiser=True), options=opts,
-                                  images=("INDIRECT_LIGHT_RAW", "INDIRECT_LIGHT_FILTERED", "OUTPUT_RGBA32F", "FINAL_RGBA8"))
-        runs.append((got, st))
+        s = sample_scene.Rt64Scene(rt64_lib, sample_data, W, H, hip_device=0)
+        try:
+            s.set_view_description(gi_samples=gi_samples, denoiser=True)
+            for k, v in (("bounce_split", split), ("bounce_refill", 0), ("denoiser_mode", 1), ("count_traversal", 1)) + ((("bounce_groups", groups),) if groups else ()):
+                assert s.option(k, v)
+            for _ in range(3):
+                s.draw()
+            runs.append(({im: s.readback(im) for im in (rt64.IMAGE_INDIRECT_LIGHT_RAW, rt64.IMAGE_INDIRECT_LIGHT_FILTERED, rt64.IMAGE_OUTPUT_RGBA32F, rt64.IMAGE_FINAL_RGBA8)}, s.stats()))
+        finally:
+            s.close()
     (a, sa), (b, sb) = runs
     assert sa.indirectRays == sb.indirectRays > 0 and sa.shadowRays == sb.shadowRays
     assert (sa.nodesVisited, sa.trianglesTested) == (sb.nodesVisited, sb.trianglesTested)
