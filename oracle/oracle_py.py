@@ -58,7 +58,7 @@ class OFrameParams(C.Structure):
                 ("denoiserEnabled", C.c_int), ("denoiserMode", C.c_int),
                 ("motionBlurStrength", C.c_float), ("motionBlurSamples", C.c_uint), ("maxReflections", C.c_int),
                 ("bruteForce", C.c_int), ("cullBehindOpaque", C.c_int), ("threads", C.c_int), ("resolutionScale", C.c_float),
-                ("upscaler", C.c_int), ("upscalerMode", C.c_int)]
+                ("upscaler", C.c_int), ("upscalerMode", C.c_int), ("giBounces", C.c_int), ("primarySpp", C.c_int)]
 
 
 _FP = C.POINTER(C.c_float)
@@ -187,7 +187,7 @@ class OracleScene:
             d = self._desc(inst)
             L.oracle_scene_add_instance(self.scene, C.byref(d))
         self.params = dict(diSamples=0, giSamples=0, maxLights=12, denoiserEnabled=0, denoiserMode=0,
-                           motionBlurStrength=0.0, motionBlurSamples=32, maxReflections=2, upscaler=0, upscalerMode=0)
+                           motionBlurStrength=0.0, motionBlurSamples=32, maxReflections=2, upscaler=0, upscalerMode=0, giBounces=1, primarySpp=1)
 
     def set_mesh(self, handle, vertices, indices):
         v = np.ascontiguousarray(vertices); i = np.ascontiguousarray(indices, dtype=np.uint32)

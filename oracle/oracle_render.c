@@ -189,7 +189,8 @@ static int instance_is_shadow_opaque(const OInst *in) {
     return lo >= 0.0f && in->desc.material.shadowAlphaMultiplier * lo >= 0.999f;
 }
 
-static void update_view(OScene *s, const OFrameParams *p) {
+/* `still`: a later sub-frame of a primarySpp frame (rule P2): nothing has moved since the sub-frame before it */
+static void update_view(OScene *s, const OFrameParams *p, int still) {
     free(s->rt); s->rt = (OInst *)calloc((size_t)(s->instanceCount > 0 ? s->instanceCount : 1), sizeof(OInst)); s->rtCount = 0;
     for (int i = 0; i < s->instanceCount; i++) {
         const OInstanceDesc *d = &s->instances[i];
@@ -197,7 +198,7 @@ static void update_view(OScene *s, const OFrameParams *p) {
         OInst *in = &s->rt[s->rtCount++];
         in->desc = *d; in->sceneIndex = i;
         ocombiner_decode(d->shaderId, &in->cc);
-        in->objectToWorld = d->transform; in->objectToWorldPrevious = d->previousTransform;
+        in->objectToWorld = d->transform; in->objectToWorldPrevious = still ? d->transform : d->previousTransform;
         om4 upper = d->transform;                                   /* ref:rt64_view.cpp:358-368 */
         upper.m[0][3] = upper.m[1][3] = upper.m[2][3] = 0.0f; upper.m[3][0] = upper.m[3][1] = upper.m[3][2] = 0.0f; upper.m[3][3] = 1.0f;
         om4 inv; omatrix_inverse_d(&upper, &inv);
@@ -260,7 +261,7 @@ static void update_global_params(OScene *s, const OFrameParams *p, int screenW, 
     c->viewportW = (float)screenW; c->viewportH = (float)screenH;
     c->width = p->width; c->height = p->height; c->screenW = screenW; c->screenH = screenH;     /* resolution.xy = render size, .zw = screen size (ref:rt64_view.cpp:145-148) */
     c->pixelJitter.x = c->pixelJitter.y = 0.0f;                     /* jitter only with an upscaler, ref:rt64_view.cpp:1273-1281 */
-    c->frameCount = s->frameCount; c->diSamples = p->diSamples; c->giSamples = p->giSamples; c->maxLights = p->maxLights;
+    c->frameCount = s->frameCount; c->diSamples = p->diSamples; c->giSamples = p->giSamples; c->maxLights = p->maxLights; c->giBounces = p->giBounces;
     c->diReproject = 0;                                             /* DI_REPROJECTION_SUPPORT undefined, ref:rt64_view.cpp:1012-1016 */
     c->giReproject = (s->haveHistory && p->denoiserEnabled && p->giSamples > 0) ? 1 : 0;   /* :1017 */
     c->binaryLockMask = 1;                                          /* rtUpscaleMode != FSR, :1018 */
@@ -510,6 +511,55 @@ typedef struct { of3 position, normal, specular, transparent; of4 color; int ins
 
 /* ---- IndirectRayGen ------------------------------------------------------------------------------------------------- */
 
+/* Radiance one GI ray brings back (IndirectRayGen.hlsl:58-131): front-to-back resolve of its hit list, one light sample at the resolved surface, the sky behind what
+ * is left.  `more` = bounces still allowed behind this one.  The reference has more == 0: what a surface receives besides its direct light is the constant
+ * ambient term.  Extension giBounces = 2 (rt64_oracle.h):
+ *   B1  a ray that resolves to a surface sends ONE further ray from the resolved position (depth bias included, like every bounce origin), cosine-weighted about
+ *       the resolved normal (RGBA16 SNORM hit-record normal), direction from blue-noise slice noiseFrame + noiseStep (noiseStep = half the distance between the
+ *       slices of two GI samples, 1 when they are adjacent) at the PIXEL's coordinates;
+ *   B2  the radiance that ray returns (this function, more - 1) stands where `ambient` stands in the reference's line 118: (ambient + directLight) becomes
+ *       (incoming + directLight); everything else -- giDiffuseStrength, the ambientBase start value, the sky term -- is per ray, unchanged;
+ *   B3  the further ray counts as an indirect ray, its node / triangle visits with the indirect pass's. */
+static of3 gi_ray_radiance(OShadeCtx *c, of3 rayOrigin, of3 rayDirection, uint32_t px, uint32_t py, uint32_t noiseFrame, uint32_t noiseStep, int more) {
+    const of3 ambient = v3add(c->desc.ambientBaseColor, c->desc.ambientNoGIColor);
+    ORayDiff rd; memset(&rd, 0, sizeof(rd));
+    SurfacePayload pl;
+    trace_surface(c, rayOrigin, rayDirection, rd, px, py, &pl, &c->nodesOther, &c->trisOther);
+    c->indirectRays++;
+    of3 bgColor = oshade_sample_background_envmap(c, rayDirection);
+    of4 sky = oshade_sample_sky_plane(c, rayDirection);
+    bgColor = v3lerp(bgColor, v3(sky.x, sky.y, sky.z), sky.w);
+    of3 resPosition = v3s(0.0f), resNormal = v3s(0.0f), resSpecular = v3s(0.0f); of4 resColor = { 0, 0, 0, 1 }; int resInstanceId = -1;
+    for (uint32_t hit = 0; hit < pl.nhits; hit++) {
+        const OHitRecord *r = hit_slot(&pl, hit);
+        of4 hitColor = rec_color(r);
+        float alphaContrib = resColor.w * hitColor.w;
+        if (alphaContrib >= O_EPSILON) {
+            uint32_t id = r->instanceId; const OMaterial *m = &c->rt[id].desc.material;
+            resPosition = v3add(rayOrigin, v3scale(rayDirection, r->dist + m->depthBias));
+            resNormal = rec_normal(r); resSpecular = v3mul(m->specularColor, rec_specular(r));
+            resColor.x += hitColor.x * alphaContrib; resColor.y += hitColor.y * alphaContrib; resColor.z += hitColor.z * alphaContrib;
+            resColor.w *= (1.0f - hitColor.w);
+            resInstanceId = (int)id;
+        }
+        if (resColor.w <= O_EPSILON) break;
+    }
+    of3 resIndirect = c->desc.ambientBaseColor;
+    if (resInstanceId >= 0) {
+        of3 directLight = v3add(oshade_lights_random(c, px, py, rayDirection, (uint32_t)resInstanceId, resPosition, resNormal, resSpecular, 1, 1),
+                                c->rt[resInstanceId].desc.material.selfLight);
+        of3 incoming = ambient;
+        if (more > 0) {                                                                                  /* B1, B2 */
+            of3 nextDirection = oshade_cos_hemisphere_blue_noise(c, px, py, noiseFrame + noiseStep, resNormal);
+            incoming = gi_ray_radiance(c, resPosition, nextDirection, px, py, noiseFrame + noiseStep, noiseStep, more - 1);
+        }
+        of3 indirectLight = v3scale(v3mul(v3scale(v3(resColor.x, resColor.y, resColor.z), 1.0f - resColor.w), v3add(incoming, directLight)), c->desc.giDiffuseStrength);
+        resIndirect = v3add(resIndirect, indirectLight);
+    }
+    resIndirect = v3add(resIndirect, v3scale(bgColor, c->desc.giSkyStrength * resColor.w));
+    return resIndirect;
+}
+
 static void pass_indirect(OScene *s, OShadeCtx *c, uint32_t px, uint32_t py, int cur) {
     size_t i = (size_t)py * (size_t)c->width + px;
     int instanceId = s->instanceId[i];
@@ -533,37 +583,9 @@ static void pass_indirect(OScene *s, OShadeCtx *c, uint32_t px, uint32_t py, int
     }
     uint32_t maxSamples = c->giSamples; const uint32_t blueNoiseMult = 64u / c->giSamples;
     while (maxSamples > 0) {
-        of3 rayDirection = oshade_cos_hemisphere_blue_noise(c, px, py, c->frameCount + maxSamples * blueNoiseMult, shadingNormal);
-        ORayDiff rd; memset(&rd, 0, sizeof(rd));
-        SurfacePayload pl;
-        trace_surface(c, rayOrigin, rayDirection, rd, px, py, &pl, &c->nodesOther, &c->trisOther);
-        c->indirectRays++;
-        of3 bgColor = oshade_sample_background_envmap(c, rayDirection);
-        of4 sky = oshade_sample_sky_plane(c, rayDirection);
-        bgColor = v3lerp(bgColor, v3(sky.x, sky.y, sky.z), sky.w);
-        of3 resPosition = v3s(0.0f), resNormal = v3s(0.0f), resSpecular = v3s(0.0f); of4 resColor = { 0, 0, 0, 1 }; int resInstanceId = -1;
-        for (uint32_t hit = 0; hit < pl.nhits; hit++) {
-            const OHitRecord *r = hit_slot(&pl, hit);
-            of4 hitColor = rec_color(r);
-            float alphaContrib = resColor.w * hitColor.w;
-            if (alphaContrib >= O_EPSILON) {
-                uint32_t id = r->instanceId; const OMaterial *m = &c->rt[id].desc.material;
-                resPosition = v3add(rayOrigin, v3scale(rayDirection, r->dist + m->depthBias));
-                resNormal = rec_normal(r); resSpecular = v3mul(m->specularColor, rec_specular(r));
-                resColor.x += hitColor.x * alphaContrib; resColor.y += hitColor.y * alphaContrib; resColor.z += hitColor.z * alphaContrib;
-                resColor.w *= (1.0f - hitColor.w);
-                resInstanceId = (int)id;
-            }
-            if (resColor.w <= O_EPSILON) break;
-        }
-        of3 resIndirect = c->desc.ambientBaseColor;
-        if (resInstanceId >= 0) {
-            of3 directLight = v3add(oshade_lights_random(c, px, py, rayDirection, (uint32_t)resInstanceId, resPosition, resNormal, resSpecular, 1, 1),
-                                    c->rt[resInstanceId].desc.material.selfLight);
-            of3 indirectLight = v3scale(v3mul(v3scale(v3(resColor.x, resColor.y, resColor.z), 1.0f - resColor.w), v3add(ambient, directLight)), c->desc.giDiffuseStrength);
-            resIndirect = v3add(resIndirect, indirectLight);
-        }
-        resIndirect = v3add(resIndirect, v3scale(bgColor, c->desc.giSkyStrength * resColor.w));
+        const uint32_t noiseFrame = c->frameCount + maxSamples * blueNoiseMult;
+        of3 rayDirection = oshade_cos_hemisphere_blue_noise(c, px, py, noiseFrame, shadingNormal);
+        of3 resIndirect = gi_ray_radiance(c, rayOrigin, rayDirection, px, py, noiseFrame, blueNoiseMult > 1u ? blueNoiseMult / 2u : 1u, c->giBounces >= 2 ? 1 : 0);
         historyLength = fminf(historyLength + 1.0f, 64.0f);
         newIndirect = v3lerp(newIndirect, resIndirect, 1.0f / historyLength);
         { float l = 0.2126f * resIndirect.x + 0.7152f * resIndirect.y + 0.0722f * resIndirect.z; sumL += l; sumL2 += l * l; }
@@ -890,7 +912,19 @@ int oracle_render(OScene *s, const OFrameParams *pIn, OFrameResult *out) {
     double t0 = now_s();
     alloc_images(s, p->width, p->height);
     if (s->finalW != screenW || s->finalH != screenH) { free(s->finalRGBA8); s->finalRGBA8 = (uint8_t *)calloc((size_t)screenW * (size_t)screenH * 4, 1); s->finalW = screenW; s->finalH = screenH; }
-    update_view(s, p);
+    /* Extension primarySpp = N (rt64_oracle.h): the frame as N complete sub-frames.
+     *   P1  sub-frame k = 0 .. N - 1 runs every pass of a frame up to ComposePS; frameCount, the ping-pong index and the temporal history advance after each, as if
+     *       the host had drawn N frames without moving anything;
+     *   P2  its primary rays (and the screen-space sky / background lookups) are jittered by (Halton(k + 1, 2) - 0.5, Halton(k + 1, 3) - 0.5); for k >= 1 every
+     *       instance's previous transform is its transform and the previous camera is the camera;
+     *   P3  rtOutput = (((out_0 + out_1) + ...) + out_{N-1}) * (1.0f / N) in fp32, per channel; the back buffer is PostProcessPS of that image; the other images a
+     *       reader sees afterwards are those of the last sub-frame; ray and visit counters are sums over the sub-frames;
+     *   P4  not combined with an upscaler, a resolution scale, motion blur or a viewport rectangle (oracle_render returns 0). */
+    const int spp = pIn->primarySpp > 1 ? pIn->primarySpp : 1;
+    if (spp > 1 && (separatePost || upscale)) return 0;
+    float *sppSum = spp > 1 ? (float *)malloc((size_t)local.width * (size_t)local.height * 4 * sizeof(float)) : NULL;
+    OShadeCtx sums; memset(&sums, 0, sizeof(sums));
+    update_view(s, p, 0);
     OShadeCtx ctx;
     update_global_params(s, p, screenW, screenH, &ctx);
     if (upscale) {                  /* jitter only with an upscaler (ref:rt64_view.cpp:1273-1281); FSR takes a continuous lock mask (:1018) */
@@ -927,6 +961,20 @@ int oracle_render(OScene *s, const OFrameParams *pIn, OFrameResult *out) {
     int cur = s->rtSwap;
     size_t n = (size_t)p->width * (size_t)p->height;
     if (s->rtCount > 0) {
+      for (int sub = 0; sub < spp; sub++) {
+        if (sub > 0) {                                  /* P1: the sub-frame before this one is over; P2: nothing moved */
+            s->rtSwap ^= 1; s->haveHistory = 1; s->frameCount++;
+            cur = s->rtSwap;
+            const OTexture *bg = ctx.background;
+            reduce_ctx(&sums, &ctx);
+            update_view(s, p, 1);
+            update_global_params(s, p, screenW, screenH, &ctx);
+            ctx.viewportW = rtVp[2]; ctx.viewportH = rtVp[3]; ctx.background = bg;
+        }
+        if (spp > 1) {
+            ctx.pixelJitter.x = oracle_halton(sub + 1, 2) - 0.5f; ctx.pixelJitter.y = oracle_halton(sub + 1, 3) - 0.5f;
+            ctx.separatePost = 1;                       /* ComposePS writes rtOutput only; the back buffer comes from the mean (P3) */
+        }
         run_pass(s, &ctx, p, cur, 0);
         run_pass(s, &ctx, p, cur, 1);
         run_pass(s, &ctx, p, cur, 2);
@@ -943,6 +991,21 @@ int oracle_render(OScene *s, const OFrameParams *pIn, OFrameResult *out) {
         }
         else osvgf_filter(s, p, cur);
         run_pass(s, &ctx, p, cur, 5);
+        if (spp > 1) {                                  /* P3 */
+            for (int y = p->tileY0; y < p->tileY1; y++)
+                for (size_t q = (size_t)y * p->width * 4; q < (size_t)(y + 1) * p->width * 4; q++) sppSum[q] = sub == 0 ? s->outputRGBA32F[q] : sppSum[q] + s->outputRGBA32F[q];
+        }
+      }
+      if (spp > 1) {
+            const float inv = 1.0f / (float)spp;
+            for (int y = p->tileY0; y < p->tileY1; y++)
+                for (size_t q = (size_t)y * p->width; q < (size_t)(y + 1) * p->width; q++) {
+                    float *o = s->outputRGBA32F + 4 * q;
+                    for (int k = 0; k < 4; k++) o[k] = sppSum[4 * q + k] * inv;
+                    uint8_t *f = s->finalRGBA8 + 4 * q;
+                    f[0] = to_unorm8(o[0]); f[1] = to_unorm8(o[1]); f[2] = to_unorm8(o[2]); f[3] = 255;
+                }
+      }
         if (rtRect) {       /* the ray-traced picture covers only its rectangle: cleared buffer + background instances show around it (ref:rt64_view.cpp:1292-1296) */
             const size_t ns = (size_t)screenW * (size_t)screenH;
             memset(s->finalRGBA8, 0, ns * 4);
@@ -968,7 +1031,7 @@ int oracle_render(OScene *s, const OFrameParams *pIn, OFrameResult *out) {
     }
     /* Foreground instances over the finished frame (ref:rt64_view.cpp:1657-1661). */
     oraster_draw(s, fgList, fgCount, s->finalRGBA8, screenW, screenH, separatePost ? 0 : pIn->tileY0, separatePost ? screenH : pIn->tileY1, 1);
-    free(bgList); free(fgList);
+    free(bgList); free(fgList); free(sppSum);
     double t2 = now_s();
     if (out) {
         memset(out, 0, sizeof(*out));
@@ -983,6 +1046,7 @@ int oracle_render(OScene *s, const OFrameParams *pIn, OFrameResult *out) {
         out->reflection = s->reflection; out->refraction = s->refraction; out->transparent = s->transparent;
         out->viewDirection = s->viewDirection; out->normal = s->normal[cur]; out->flow = s->flow; out->reactiveMask = s->reactiveMask;
         out->lockMask = s->lockMask; out->depth = s->depth[cur]; out->primaryHit = s->primaryHit;
+        reduce_ctx(&ctx, &sums);                        /* (all zero without primarySpp) */
         out->primaryRays = ctx.primaryRays; out->shadowRays = ctx.shadowRays; out->indirectRays = ctx.indirectRays;
         out->reflectionRays = ctx.reflectionRays; out->refractionRays = ctx.refractionRays;
         out->nodesVisitedPrimary = ctx.nodesPrimary; out->trianglesTestedPrimary = ctx.trisPrimary;

@@ -22,6 +22,7 @@ typedef struct {
     int separatePost;                      /* PostProcessPS runs as its own pass (resolution scale / motion blur) */
     of2 pixelJitter;
     uint32_t frameCount, diSamples, giSamples, maxLights;
+    int giBounces;                         /* extension: 2 = a second bounce (oracle_render.c, rules B1-B3); otherwise the reference's one */
     int giReproject, diReproject, binaryLockMask;
     float maxDepthBias;
     int bruteForce, cullBehindOpaque;

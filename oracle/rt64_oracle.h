@@ -130,6 +130,13 @@ typedef struct {
     /* RT64_VIEW_DESC.upscaler / upscalerMode (RT64_UPSCALER_*, RT64_UPSCALER_MODE_*): AUTO / FSR select the built-in temporal upscaler
      * (oracle_upscale.c): the render size comes from the quality mode, primary rays are jittered, PostProcessPS reads the upscaled image. */
     int upscaler, upscalerMode;
+    /* Extensions beyond the reference (which has one bounce per GI ray, ref:IndirectRayGen.hlsl:58-131, and one primary sample per pixel,
+     * ref:rt64.h:172-182); both mirror device options of the HIP library ("Path-tracing extensions"):
+     *   giBounces  0 / 1 = the reference's single bounce; 2 = a bounce ray that hits a surface sends a second cosine-weighted ray from there (rule B1-B3
+     *              at pass_indirect) and the radiance that ray finds stands where the constant ambient term stands at the first hit;
+     *   primarySpp 0 / 1 = off; N = the frame is N complete sub-frames (primary + direct + GI + filter + Compose each) whose primary rays are jittered by
+     *              Halton(k + 1; 2, 3) - 0.5, k = 0 .. N - 1, and the composed RGBA32F outputs are averaged before PostProcess (rule P1-P4 at oracle_render). */
+    int giBounces, primarySpp;
 } OFrameParams;
 
 /* Output images of one frame, full-frame row-major arrays owned by the scene (valid until next render). */

@@ -71,6 +71,7 @@ hipError_t launch_refraction_simple(const FrameParams &P, const ViewImages &I, b
 hipError_t launch_reflection_simple(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s);
 hipError_t launch_lean_frame_simple(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, int cur, bool full, int ownedY0, int ownedY1, unsigned maxGroups, bool perWave, hipStream_t s);
 hipError_t launch_clear_final(const FrameParams &P, const ViewImages &I, hipStream_t s);
+hipError_t launch_spp_accumulate(const FrameParams &P, const ViewImages &I, float *sum, int sub, int count, hipStream_t s);
 
 // ---- raster.hip ----------------------------------------------------------------------------------------------------
 size_t raster_tri_bytes(uint32_t triTotal);       // setup records of a draw list

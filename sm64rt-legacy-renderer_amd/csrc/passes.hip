@@ -711,7 +711,44 @@ __global__ __launch_bounds__(BLOCK, WAVES) void lean_frame_kernel(FrameParams Pv
 
 // ---- bounce-ray resolve shared by Indirect / Refraction / Reflection ------------------------------------------------------
 
-template <bool KLIST>
+// ---- second bounce of a GI ray (extension gi_bounces = 2; rules B1-B3 at gi_ray_radiance, oracle/oracle_render.c) -----------------------------------------
+// The radiance ONE further ray brings back from the surface a GI ray resolved to: direction cosine-weighted about the resolved normal from blue-noise slice
+// `noiseFrame` at the pixel's coordinates, the same resolve / light sample / sky term as the first bounce (IndirectRayGen.hlsl:58-131) with the constant
+// ambient term as the light its surface receives besides its direct light.  Walked and shaded by the calling lane; its visits go to the caller's counters.
+template <bool KLIST, bool CACHED>
+DEV f3 second_bounce_radiance(PRef P, ShadeEnv &env, IRef I, size_t i, uint32_t px, uint32_t py, f3 rayOrigin, f3 normal, uint32_t noiseFrame, f3 ambientBase, f3 ambient) {
+    const f3 rayDirection = cos_hemisphere_blue_noise(P, px, py, noiseFrame, normal);
+    RayDiff rd; rd.dOdx = rd.dOdy = rd.dDdx = rd.dDdy = mk3s(0.0f);
+    SurfaceHit best;
+    const uint32_t nhits = trace_surface<KLIST, CACHED>(P, env, I, i, rayOrigin, rayDirection, rd, px, py, best);
+    f3 resPosition = mk3s(0.0f), resNormal = mk3s(0.0f), resSpecular = mk3s(0.0f); f4 resColor = mk4(0, 0, 0, 1); int resInstanceId = -1;
+    for (uint32_t hit = 0; hit < nhits; hit++) {
+        HitRecord r;
+        if (!surface_record<KLIST>(P, I, i, hit, best, rayDirection, rd, px, py, r)) continue;
+        f4 hitColor = r.color;
+        float alphaContrib = resColor.w * hitColor.w;
+        if (alphaContrib >= RT_EPSILON) {
+            const RT64_MATERIAL &m = P.instances[r.instanceId].material;
+            resPosition = rayOrigin + rayDirection * (r.dist + m.depthBias);
+            resNormal = r.normal; resSpecular = ld_v3(m.specularColor) * r.specular;
+            resColor.x += hitColor.x * alphaContrib; resColor.y += hitColor.y * alphaContrib; resColor.z += hitColor.z * alphaContrib;
+            resColor.w *= (1.0f - hitColor.w);
+            resInstanceId = (int)r.instanceId;
+        }
+        if (resColor.w <= RT_EPSILON) break;
+    }
+    f3 resIndirect = ambientBase;
+    if (resInstanceId >= 0) {
+        f3 directLight = compute_lights_random<CACHED>(P, env, px, py, rayDirection, (uint32_t)resInstanceId, resPosition, resNormal, resSpecular, 1, true) + ld_v3(P.instances[resInstanceId].material.selfLight);
+        f3 indirectLight = ((xyz(resColor) * (1.0f - resColor.w)) * (ambient + directLight)) * P.giDiffuseStrength;
+        resIndirect = resIndirect + indirectLight;
+    }
+    if (resColor.w != 0.0f) resIndirect = resIndirect + sky_over_background_envmap(P, rayDirection) * (P.giSkyStrength * resColor.w);
+    else resIndirect = resIndirect + mk3s(0.0f) * (P.giSkyStrength * resColor.w);
+    return resIndirect;
+}
+
+template <bool KLIST, bool SECOND = false>      // SECOND: extension gi_bounces = 2 (its own instantiation: the reference's one-bounce kernels stay as they were)
 __global__ __launch_bounds__(RT_BLOCK, 3) void indirect_kernel(FrameParams Pv, ViewImages Iv, int cur, int writeFiltered) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
     constexpr uint32_t STACK_WORDS = RT_STACK_LDS;
@@ -774,7 +811,12 @@ __global__ __launch_bounds__(RT_BLOCK, 3) void indirect_kernel(FrameParams Pv, V
             f3 resIndirect = ambientBase;
             if (resInstanceId >= 0) {
                 f3 directLight = compute_lights_random(P, env, px, py, rayDirection, (uint32_t)resInstanceId, resPosition, resNormal, resSpecular, 1, true) + ld_v3(P.instances[resInstanceId].material.selfLight);
-                f3 indirectLight = ((xyz(resColor) * (1.0f - resColor.w)) * (ambient + directLight)) * P.giDiffuseStrength;
+                f3 incoming = ambient;
+                if (SECOND) {                   // extension, rules B1-B3 (oracle/oracle_render.c: gi_ray_radiance)
+                    incoming = second_bounce_radiance<KLIST, false>(P, env, I, i, px, py, resPosition, resNormal, P.frameCount + maxSamples * blueNoiseMult + (blueNoiseMult > 1u ? blueNoiseMult / 2u : 1u), ambientBase, ambient);
+                    rays++;
+                }
+                f3 indirectLight = ((xyz(resColor) * (1.0f - resColor.w)) * (incoming + directLight)) * P.giDiffuseStrength;
                 resIndirect = resIndirect + indirectLight;
             }
             resIndirect = resIndirect + bgColor * (P.giSkyStrength * resColor.w);
@@ -1149,7 +1191,7 @@ DEV f3 bounce_sky_term(PRef P, f3 rayDirection) {
     return sky_over_background_envmap(P, rayDirection);
 }
 
-template <bool CACHED>
+template <bool CACHED, bool SECOND = false>    // SECOND: extension gi_bounces = 2 (its own instantiation: the reference's one-bounce kernel stays as it was)
 __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void bounce_hit_kernel(FrameParams Pv, ViewImages Iv) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
     constexpr uint32_t STACK_WORDS = CACHED ? RT_STACK_LDS_CACHED / 2 : RT_STACK_LDS;
@@ -1166,6 +1208,7 @@ __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void bounce_hit_kernel(Fram
     const f3 ambient = ambientBase + mk3(P.ambientNoGIColor[0], P.ambientNoGIColor[1], P.ambientNoGIColor[2]);
     const uint32_t stride = (uint32_t)P.width * (uint32_t)P.height;
     const uint32_t segment = bounce_segment_size(P);
+    uint32_t rays = 0;                                      // second-bounce rays (gi_bounces = 2)
     for (uint32_t e = threadIdx.x; e < n; e += RT_BLOCK) {
         PRef P = *kernel_params_here(); IRef I = *kernel_images_here();      // this trip's view of the frame constants and the image table (read where used, never carried across trips)
         const uint32_t id = I.bounceLists[(size_t)blockIdx.x * segment + e], i = id % stride;
@@ -1192,14 +1235,20 @@ __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void bounce_hit_kernel(Fram
         f3 resIndirect = ambientBase;
         if (resInstanceId >= 0) {
             f3 directLight = compute_lights_random<CACHED>(P, env, px, py, rayDirection, (uint32_t)resInstanceId, resPosition, resNormal, resSpecular, 1, true) + ld_v3(P.instances[resInstanceId].material.selfLight);
-            f3 indirectLight = ((xyz(resColor) * (1.0f - resColor.w)) * (ambient + directLight)) * P.giDiffuseStrength;
+            f3 incoming = ambient;
+            if (SECOND) {                       // extension, rules B1-B3 (oracle/oracle_render.c: gi_ray_radiance): the second bounce of this GI ray, walked and shaded by the lane that shades the first hit
+                const uint32_t blueNoiseMult = 64u / P.giSamples, noiseStep = blueNoiseMult > 1u ? blueNoiseMult / 2u : 1u;
+                incoming = second_bounce_radiance<false, CACHED>(P, env, I, i, px, py, resPosition, resNormal, P.frameCount + (id / stride + 1u) * blueNoiseMult + noiseStep, ambientBase, ambient);
+                rays++;
+            }
+            f3 indirectLight = ((xyz(resColor) * (1.0f - resColor.w)) * (incoming + directLight)) * P.giDiffuseStrength;
             resIndirect = resIndirect + indirectLight;
         }
         if (resColor.w != 0.0f) resIndirect = resIndirect + bounce_sky_term(P, rayDirection) * (P.giSkyStrength * resColor.w);
         else resIndirect = resIndirect + mk3s(0.0f) * (P.giSkyStrength * resColor.w);
         I.bounceResults[id] = make_float4(resIndirect.x, resIndirect.y, resIndirect.z, 0.0f);
     }
-    flush_env(P, env, PASS_INDIRECT, CTR_INDIRECT, 0);
+    flush_env(P, env, PASS_INDIRECT, CTR_INDIRECT, rays);
 }
 
 __global__ __launch_bounds__(RT_BLOCK) void bounce_miss_kernel(FrameParams Pv, ViewImages Iv) {
@@ -1482,6 +1531,22 @@ __global__ __launch_bounds__(256) void compose_post_kernel(FrameParams Pv, ViewI
     if (!P.separatePost && writeFinal) store_rgba8(I.final, i, result.x, result.y, result.z, 1.0f);   // PostProcessPS passthrough (motionBlurStrength == 0, render size == screen size)
 }
 
+// Extension primary_spp (rule P3, oracle/oracle_render.c): rtOutput of sub-frame `sub` added to the running sum of the frame's sub-frames, in order; the last
+// sub-frame turns the sum into the mean (one multiplication by 1.0f / count), stores it as rtOutput and its PostProcessPS passthrough as the back buffer.
+__global__ __launch_bounds__(256) void spp_accumulate_kernel(FrameParams Pv, ViewImages Iv, float4 *sum, int sub, int count) {
+    PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = P.tileY0 + blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= P.width || y >= P.tileY1 || !row_owned(P, y)) return;
+    const size_t i = (size_t)y * (size_t)P.width + x;
+    float4 v = reinterpret_cast<const float4 *>(I.output)[i];
+    if (sub > 0) { const float4 a = sum[i]; v.x = a.x + v.x; v.y = a.y + v.y; v.z = a.z + v.z; v.w = a.w + v.w; }
+    if (sub + 1 < count) { sum[i] = v; return; }
+    const float inv = 1.0f / (float)count;
+    v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
+    reinterpret_cast<float4 *>(I.output)[i] = v;
+    store_rgba8(I.final, i, v.x, v.y, v.z, 1.0f);
+}
+
 // PostProcessPS.hlsl:13-36 as its own pass: the screen-size back buffer resampled from the render-size output with the static
 // sampler of rt64_device.cpp:958-973 (MIN_MAG_MIP_LINEAR, WRAP), plus the motion-blur gather along gFlow.  Only launched when
 // the render size differs from the screen size (RT64_VIEW_DESC.resolutionScale) or motionBlurStrength > 0.
@@ -1664,7 +1729,10 @@ hipError_t RT_LAUNCHER(launch_lean_frame)(const FrameParams &P, const ViewImages
 }
 hipError_t RT_LAUNCHER(launch_indirect)(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, int walk, unsigned groups, hipStream_t s) {
     RT_ROUTE_SIMPLE(launch_indirect_simple(P, I, cur, writeFiltered, klist, walk, groups, s));
+    const bool second = P.giBounces >= 2u;
+    if (klist && second) LAUNCH_RAY((indirect_kernel<true, true>), P, I, cur, writeFiltered ? 1 : 0);
     if (klist) LAUNCH_RAY(indirect_kernel<true>, P, I, cur, writeFiltered ? 1 : 0);
+    if ((P.giSamples == 0 || !I.bounceRecords) && second) LAUNCH_RAY((indirect_kernel<false, true>), P, I, cur, writeFiltered ? 1 : 0);
     if (P.giSamples == 0 || !I.bounceRecords) LAUNCH_RAY(indirect_kernel<false>, P, I, cur, writeFiltered ? 1 : 0);
     // grid of the bounce kernels: one workgroup per tile up to `groups` workgroups (0 = RT_MAX_BOUNCE_GROUPS), then tiles b, b + grid, ... (bounce_tile_of)
     unsigned grid = rt_grid(P);
@@ -1680,7 +1748,9 @@ hipError_t RT_LAUNCHER(launch_indirect)(const FrameParams &P, const ViewImages &
     else if (P.cacheWords) hipLaunchKernelGGL(bounce_trace_plain_kernel<true>, dim3(grid), dim3(RT_BLOCK), cached_lds_bytes(P, false), s, P, I);
     else hipLaunchKernelGGL(bounce_trace_plain_kernel<false>, dim3(grid), dim3(RT_BLOCK), 0, s, P, I);
     // same grid for the three kernels: workgroup b shades the segments workgroup b of bounce_trace filled (lengths stay on the device)
-    if (P.cacheWords) hipLaunchKernelGGL(bounce_hit_kernel<true>, dim3(grid), dim3(RT_BLOCK), cached_lds_bytes(P, true), s, P, I);
+    if (P.cacheWords && second) hipLaunchKernelGGL((bounce_hit_kernel<true, true>), dim3(grid), dim3(RT_BLOCK), cached_lds_bytes(P, true), s, P, I);
+    else if (second) hipLaunchKernelGGL((bounce_hit_kernel<false, true>), dim3(grid), dim3(RT_BLOCK), 0, s, P, I);
+    else if (P.cacheWords) hipLaunchKernelGGL(bounce_hit_kernel<true>, dim3(grid), dim3(RT_BLOCK), cached_lds_bytes(P, true), s, P, I);
     else hipLaunchKernelGGL(bounce_hit_kernel<false>, dim3(grid), dim3(RT_BLOCK), 0, s, P, I);
     if (walk == BOUNCE_WALK_REFILL) hipLaunchKernelGGL(bounce_miss_kernel, dim3(grid), dim3(RT_BLOCK), 0, s, P, I);      // the other walks finish their misses themselves
     dim3 rgrid((unsigned)(P.width + 31) / 32, (unsigned)(P.tileY1 - P.tileY0 + 7) / 8);
@@ -1726,6 +1796,11 @@ hipError_t launch_compose_post(const FrameParams &P, const ViewImages &I, int cu
     dim3 grid((unsigned)(P.width + 31) / 32, (unsigned)(P.tileY1 - P.tileY0 + 7) / 8);
     if (lean) hipLaunchKernelGGL(compose_post_kernel<true>, grid, dim3(256), 0, s, P, I, cur, writeFinal ? 1 : 0);
     else hipLaunchKernelGGL(compose_post_kernel<false>, grid, dim3(256), 0, s, P, I, cur, writeFinal ? 1 : 0);
+    return hipGetLastError();
+}
+hipError_t launch_spp_accumulate(const FrameParams &P, const ViewImages &I, float *sum, int sub, int count, hipStream_t s) {
+    dim3 grid((unsigned)(P.width + 31) / 32, (unsigned)(P.tileY1 - P.tileY0 + 7) / 8);
+    hipLaunchKernelGGL(spp_accumulate_kernel, grid, dim3(256), 0, s, P, I, reinterpret_cast<float4 *>(sum), sub, count);
     return hipGetLastError();
 }
 hipError_t launch_post_process(const FrameParams &P, const ViewImages &I, hipStream_t s) {

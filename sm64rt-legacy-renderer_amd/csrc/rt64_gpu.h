@@ -129,6 +129,7 @@ struct FrameParams {
     // accesses, and a bilinear footprint then touches 1.56 cache lines on average instead of 2.1 (nullptr: not a power-of-two texture)
     const uint32_t *skyTiled; uint32_t skyTiledLog2W, skyTiledLog2H;
     uint32_t lightCount, instanceCount, countTraversal;
+    uint32_t giBounces;                  // extension (device option gi_bounces): 2 = a GI ray that resolves to a surface sends a second ray from there (rules B1-B3, oracle/oracle_render.c); otherwise the reference's one bounce
     const GpuInstance *instances;
     const GpuNode *tlasNodes;
     const uint32_t *tlasIndex;           // TLAS leaf slot -> instance

@@ -154,6 +154,9 @@ struct Options {
     bool haloExchange = false;     // band partitions of GI + SVGF frames: ship the filter input of the halo rows between the devices of the gather (RCCL) instead of re-rendering them
     int haloMargin = SVGF_INPUT_HALO_ROWS;   // with a halo exchange: rows of G-buffer + GI kept around the band (temporal history under camera motion); at least SVGF_INPUT_HALO_ROWS
     int maxReflections = 2;        // rt64_view.cpp:60 (inspector-only knob in the reference)
+    // Path-tracing extensions beyond the reference (one bounce per GI ray, IndirectRayGen.hlsl:58-131; one primary sample per pixel, rt64.h:172-182); DESIGN.md 4:
+    int giBounces = 1;             // 2: a GI ray that resolves to a surface sends a second cosine-weighted ray from there; what it finds stands where the constant ambient term stands at the first hit
+    int primarySpp = 1;            // N: RT64_DrawDevice renders N jittered sub-frames (every pass up to Compose each) and presents the mean of their composed outputs
     unsigned maxFrameGroups = RT_MAX_FRAME_GROUPS;   // grid cap of the one-kernel frame (tests lower it: several tiles per workgroup on a small frame)
 };
 
@@ -347,6 +350,8 @@ struct View {
     bool fusedStoreless = false;              // ... and that kernel stored the back buffer only (no hit records, no direct-light image)
     bool fusedFrame = false;                  // ... and ran as lean_frame_kernel: rtOutput was not written either (unless PostProcess ran separately)
     FrameParams lastParams; int lastCur = 0;
+    // extension primary_spp (rules P1-P4, oracle/oracle_render.c): the frame as `subFrames` complete sub-frames; Device::draw drives them
+    int subFrame = 0, subFrames = 1; DevArray<float> sppSum;
 
     explicit View(Scene *s);
     ~View();
@@ -988,7 +993,7 @@ void View::update() {                          // View::update, rt64_view.cpp:10
         GpuInstance &g = hInst[i];
         memset(&g, 0, sizeof(g));
         memcpy(g.objectToWorld, inst->transform.m, 64);
-        memcpy(g.objectToWorldPrevious, inst->previousTransform.m, 64);
+        memcpy(g.objectToWorldPrevious, subFrame > 0 ? inst->transform.m : inst->previousTransform.m, 64);      // (P2: nothing moves between the sub-frames of a primary_spp frame)
         Mat4 upper = inst->transform;           // rt64_view.cpp:358-368
         upper.m[3] = upper.m[7] = upper.m[11] = 0.0f; upper.m[12] = upper.m[13] = upper.m[14] = 0.0f; upper.m[15] = 1.0f;
         Mat4 nrm = mat_transpose(mat_inverse(upper));
@@ -1136,6 +1141,7 @@ void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64
     // jitter only with an upscaler (:1273-1281): HaltonJitter(frameCount, phases), rt64_common.h:359-361
     pixelJitter[0] = pixelJitter[1] = 0.0f;
     if (upscaleActive) { const int fi = (int)(frameCount % (uint32_t)jitterPhases) + 1; pixelJitter[0] = halton_sequence(fi, 2) - 0.5f; pixelJitter[1] = halton_sequence(fi, 3) - 0.5f; }
+    if (subFrames > 1) { pixelJitter[0] = halton_sequence(subFrame + 1, 2) - 0.5f; pixelJitter[1] = halton_sequence(subFrame + 1, 3) - 0.5f; }      // P2
     P.pixelJitter[0] = pixelJitter[0]; P.pixelJitter[1] = pixelJitter[1];
     P.motionBlurStrength = motionBlurStrength; P.motionBlurSamples = motionBlurSamples;
     P.skyPlaneTexIndex = skyPlane ? 0 : -1;
@@ -1152,7 +1158,7 @@ void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64
         P.skyTiled = skyTiled.ptr; P.skyTiledLog2W = skyTiledLog2[0]; P.skyTiledLog2H = skyTiledLog2[1];
     }
     P.randomSeed = frameCount; P.frameCount = frameCount;
-    P.diSamples = diSamples; P.giSamples = giSamples; P.maxLights = maxLights;
+    P.diSamples = diSamples; P.giSamples = giSamples; P.maxLights = maxLights; P.giBounces = (uint32_t)dev->opt.giBounces;
     P.diReproject = 0;                                        // DI_REPROJECTION_SUPPORT undefined (:1012-1016)
     P.giReproject = (!skipReprojection && denoiserEnabled && giSamples > 0) ? 1u : 0u;
     P.binaryLockMask = upscaleActive ? 0u : 1u;               // rtUpscaleMode != FSR (:1018): the built-in stage stands where FSR does and takes the continuous mask
@@ -1217,8 +1223,9 @@ void View::render() {                          // View::render, rt64_view.cpp:11
     // Lean frame: nothing downstream reads the view direction, the reflection / refraction / transparent accumulators, motion
     // vectors, upscaler masks, history guides or a GI buffer.  A full frame after lean ones reads the previous frame's guides and
     // history (temporal reprojection), so what that lean frame skipped is produced first, while its hit records still exist.
-    const bool leanNow = !rtInstances.empty() && dev->opt.leanFrames && !upscaleActive && !anyNonOpaque && !anyReflection && !anyRefraction && !anyFog && giSamples == 0 && motionBlurStrength <= 0.0f && dev->leanHoldoff == 0;
+    const bool leanNow = !rtInstances.empty() && dev->opt.leanFrames && !upscaleActive && !anyNonOpaque && !anyReflection && !anyRefraction && !anyFog && giSamples == 0 && motionBlurStrength <= 0.0f && dev->leanHoldoff == 0 && subFrames == 1;
     if (leanFrame && !leanNow) materialise();
+    if (subFrames > 1 && (upscaleActive || rtRect || separatePost())) throw std::runtime_error("RT64_DrawDevice: primary_spp > 1 is not combined with an upscaler, a resolution scale, motion blur or a viewport rectangle.");
     FrameParams P;
     fillParams(P);
     const int cur = rtSwap ? 1 : 0;
@@ -1361,7 +1368,11 @@ void View::render() {                          // View::render, rt64_view.cpp:11
                 L(launch_gaussian(img.filteredIndirect[k % 2], img.filteredIndirect[(k % 2) ^ 1], imgW, imgH, X.tileY0, X.tileY1, s));
         }
         mark(Device::EV_DENOISE);
-        if (!lean) L(launch_compose_post(P, img, cur, false, true, s));       // a lean frame is composed by direct_kernel<false> itself
+        if (!lean) L(launch_compose_post(P, img, cur, false, subFrames == 1, s));       // a lean frame is composed by direct_kernel<false> itself
+        if (subFrames > 1) {        // P3: rtOutput of the sub-frames summed in order; the last one turns the sum into the mean and PostProcessPS of it into the back buffer
+            sppSum.reserve(n * 4);
+            L(launch_spp_accumulate(P, img, sppSum.ptr, subFrame, subFrames, s));
+        }
         if (rtRect) {            // the ray-traced picture covers only its rectangle: cleared buffer + background instances show around it (rt64_view.cpp:1292-1296)
             L(launch_clear_final(P, img, s));
             drawRasterList(rasterBgScreen, img.final);
@@ -1380,7 +1391,7 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         L(launch_clear_final(P, img, s));
         drawRasterList(rasterBgScreen, img.final);           // nothing ray traced covers the background instances (rt64_view.cpp:1292-1296)
     }
-    if (!fgFolded) drawRasterList(rasterFgScreen, img.final);   // foreground instances over the finished frame (rt64_view.cpp:1657-1661)
+    if (!fgFolded && subFrame == subFrames - 1) drawRasterList(rasterFgScreen, img.final);   // foreground instances over the finished frame (rt64_view.cpp:1657-1661)
     // End of frame (rt64_view.cpp:1663-1667)
     rtSwap = !rtSwap; skipReprojection = false; frameCount++;
 }
@@ -1426,7 +1437,14 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
     flushMeshBuilds();
     for (Scene *sc : scenes) for (View *v : sc->views) v->update();
     auto tu1 = std::chrono::steady_clock::now();
-    for (Scene *sc : scenes) for (View *v : sc->views) v->render();
+    for (Scene *sc : scenes) for (View *v : sc->views) {
+        // extension primary_spp = N: N complete sub-frames -- every pass up to Compose, history and frame count advancing after each -- with jittered primary rays;
+        // the mean of their composed outputs is the frame (rules P1-P4 at oracle_render, oracle/oracle_render.c)
+        v->subFrames = std::max(1, opt.primarySpp); v->subFrame = 0;
+        v->render();
+        for (int sub = 1; sub < v->subFrames; sub++) { v->subFrame = sub; v->update(); v->render(); }
+        v->subFrame = 0;
+    }
     if (leanHoldoff) leanHoldoff--;
     auto tu2 = std::chrono::steady_clock::now();
     hostUpdateUs += std::chrono::duration<double, std::micro>(tu1 - tu0).count(); hostRenderUs += std::chrono::duration<double, std::micro>(tu2 - tu1).count(); hostFrames++;
@@ -1713,6 +1731,8 @@ RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, doubl
     else if (k == "lean_frames") d->opt.leanFrames = value != 0.0;                // 0: always write every image of the reference's G-buffer
     else if (k == "always_rebuild") d->opt.alwaysRebuild = value != 0.0;          // upload tables + rebuild the TLAS every frame like the reference
     else if (k == "max_reflections") d->opt.maxReflections = std::max(0, (int)value);
+    else if (k == "gi_bounces") { if (value != 1.0 && value != 2.0) return 0; d->opt.giBounces = (int)value; }
+    else if (k == "primary_spp") { if (!(value >= 1.0 && value <= 64.0)) return 0; d->opt.primarySpp = (int)value; }
     else if (k == "max_frame_groups") d->opt.maxFrameGroups = value >= 1.0 && value <= (double)RT_MAX_FRAME_GROUPS ? (unsigned)value : RT_MAX_FRAME_GROUPS;
     else return 0;
     return 1;

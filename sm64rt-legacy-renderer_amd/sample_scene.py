@@ -276,11 +276,19 @@ BENCH_CONFIGS = {
     "C3": dict(width=1920, height=1080, gi_samples=1, denoiser=True),
     "C4": dict(width=2560, height=1440, gi_samples=2, denoiser=True),      # + per-frame SetMesh refit of the UPDATABLE sphere
     "C5": dict(width=3840, height=2160, gi_samples=4, denoiser=True),      # + reflective floor
+    # BASELINE.json's C4 / C5 as WORDED ("2-bounce GI 1440p 2spp", "4K 4spp full path trace"), through the library's path-tracing extensions
+    # (device options primary_spp / gi_bounces; rules P1-P4 and B1-B3 in oracle/oracle_render.c): every primary sample carries one GI ray of two bounces.
+    "C4-literal": dict(width=2560, height=1440, gi_samples=1, denoiser=True, primary_spp=2, gi_bounces=2),      # + per-frame refit, like C4
+    "C5-literal": dict(width=3840, height=2160, gi_samples=1, denoiser=True, primary_spp=4, gi_bounces=2),      # + reflective floor, like C5
 }
 
 
 # How these definitions read BASELINE.json's wording where the reference has no such knob (bench.py prints it as config.deviation).
 BENCH_DEVIATIONS = {
+    "C4-literal": "BASELINE.json's C4 as worded: 2 primary samples per pixel (device option primary_spp = 2: two jittered sub-frames, composed outputs averaged), each with one GI ray of "
+                  "TWO bounces (gi_bounces = 2), SVGF per sub-frame, per-frame refit. Both knobs are extensions of this library (the reference has neither); the oracle implements the same rules.",
+    "C5-literal": "BASELINE.json's C5 as worded: 4 primary samples per pixel (primary_spp = 4), each a full path -- primary, shadow, one GI ray of two bounces (gi_bounces = 2), "
+                  "reflection bounces on the floor -- SVGF per sub-frame. Both knobs are extensions of this library (the reference has neither); the oracle implements the same rules.",
     "C4": "BASELINE.json words C4 '2-bounce GI, 2 spp'; as run: giSamples = 2 (two GI rays per pixel), ONE bounce per GI ray, ONE primary sample per pixel. "
           "The reference has neither a bounce-depth nor a primary-spp knob (IndirectRayGen.hlsl:58-131 traces one bounce per sample; RT64_VIEW_DESC, rt64.h:172-182).",
     "C5": "BASELINE.json words C5 '4 spp full path trace'; as run: giSamples = 4 (four GI rays per pixel, one bounce each), ONE primary sample per pixel, reflective floor "
@@ -304,9 +312,9 @@ def c4_animation(data: "SceneData", frames=16):
 
 def apply_bench_config(data: "SceneData", config: str):
     """Scene-side part of a config: C4 -> list of animated vertex arrays (else None); C5 -> floor reflectionFactor 0.3."""
-    if config == "C4":
+    if config in ("C4", "C4-literal"):
         return c4_animation(data)
-    if config == "C5":
+    if config in ("C5", "C5-literal"):
         for inst in data.instances:
             if inst.name == "floor":
                 inst.material.reflectionFactor = 0.3

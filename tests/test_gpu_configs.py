@@ -48,7 +48,8 @@ def _bench_pair(rt64_lib, sample_data, config, frames, width=W, height=H, bands=
             if band:
                 s.set_tile(*band)
             s.option("count_traversal", 1)
-        kw = dict(giSamples=cfg["gi_samples"], denoiserEnabled=int(cfg["denoiser"]), denoiserMode=1)
+            assert s.option("primary_spp", cfg.get("primary_spp", 1)) and s.option("gi_bounces", cfg.get("gi_bounces", 1))
+        kw = dict(giSamples=cfg["gi_samples"], denoiserEnabled=int(cfg["denoiser"]), denoiserMode=1, primarySpp=cfg.get("primary_spp", 1), giBounces=cfg.get("gi_bounces", 1))
         for f in range(frames):
             if anim is not None:          # bench.py step(): frame_no += 1; SetMesh(anim[frame_no % len])
                 v = anim[(f + 1) % len(anim)]
@@ -58,7 +59,7 @@ def _bench_pair(rt64_lib, sample_data, config, frames, width=W, height=H, bands=
             for s in parts:
                 s.draw()
             ref = o.render(width, height, **kw)
-        names = ("OUTPUT_RGBA32F", "FINAL_RGBA8", "PRIMARY_HIT", "INDIRECT_LIGHT_RAW", "INDIRECT_LIGHT_FILTERED", "REFLECTION", "DIFFUSE")
+        names = ("OUTPUT_RGBA32F", "FINAL_RGBA8", "PRIMARY_HIT", "INDIRECT_LIGHT_RAW", "INDIRECT_LIGHT_FILTERED", "REFLECTION", "DIFFUSE", "INSTANCE_ID")
         got = {k: np.concatenate([s.readback(getattr(rt64, "IMAGE_" + k)) for s in parts], axis=0) for k in names}
         return got, ref, [s.stats() for s in parts]
     finally:
@@ -124,6 +125,103 @@ def test_c5_four_gi_samples_reflective_floor_svgf(rt64_lib, sample_data, bands):
         assert st[0].reflectionRays == c["reflectionRays"] > 0 and st[0].indirectRays == c["indirectRays"] > 0
     else:                                          # pixel-local passes stay on the owned rows: their rays add up to the whole frame's
         assert sum(s.reflectionRays for s in st) == c["reflectionRays"] > 0
+
+
+@pytest.mark.parametrize("config,frames", [("C4-literal", 3), ("C5-literal", 2)])
+def test_c4_c5_as_baseline_words_them_primary_spp_and_two_bounces(rt64_lib, sample_data, config, frames):
+    """BASELINE.json words C4 "2-bounce GI 1440p 2spp" and C5 "4K 4spp full path trace".  The reference has neither knob; the library carries both as
+    extensions (device options primary_spp / gi_bounces) and the oracle implements the same rules (P1-P4, B1-B3 in oracle/oracle_render.c): N jittered
+    sub-frames -- every pass up to Compose, history advancing after each -- averaged before PostProcess, and a second cosine-weighted bounce whose
+    radiance stands where the constant ambient term stands at the first hit.  Hit records of the last sub-frame bit-exact, the averaged image within the
+    BASELINE gate, rays counted over all sub-frames."""
+    from sm64rt_legacy_renderer_amd import sample_scene
+    cfg = sample_scene.BENCH_CONFIGS[config]
+    got, ref, st = _bench_pair(rt64_lib, sample_data, config, frames=frames)
+    _check_gi_frame(got, ref)
+    c = ref["counters"]
+    assert st[0].primaryRays == c["primaryRays"] == cfg["primary_spp"] * W * H
+    assert st[0].indirectRays == c["indirectRays"]
+    hit = int((ref["instanceId"] >= 0).sum())
+    assert c["indirectRays"] > cfg["primary_spp"] * hit * 1.02          # first-bounce rays of every sub-frame + the second bounces of those that hit a surface
+    if config == "C5-literal":
+        assert np.abs(got["REFLECTION"] - ref["reflection"]).max() < 8e-3 and st[0].reflectionRays == c["reflectionRays"] > 0
+
+
+def test_second_bounce_on_the_wavefront_and_the_k_buffer_paths(rt64_lib, sample_data):
+    """gi_bounces = 2 against the oracle and against itself switched off: more indirect rays (one more per GI ray that resolved to a surface), a raw GI image
+    that moved, both on the wavefront GI kernels of an opaque frame (bounce_hit_kernel<.., true>) and on the one-kernel k-buffer form a translucent
+    instance forces (indirect_kernel<true, true>); values other than 1 and 2 are refused."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    from oracle import oracle_py
+    out = {}
+    for name, translucent in (("opaque", False), ("klist", True)):
+        def mod(d, translucent=translucent):
+            if translucent:
+                d.instances[0].material.solidAlphaMultiplier = 0.6          # not provably opaque any more: k-buffer kernels (indirect_kernel<true>)
+        data = _variant(sample_data, mod)
+        for bounces in (1, 2):
+            s = sample_scene.Rt64Scene(rt64_lib, data, W, H, hip_device=0)
+            o = oracle_py.OracleScene(data)
+            try:
+                s.set_view_description(gi_samples=2, denoiser=False)
+                assert s.option("gi_bounces", bounces) and s.option("count_traversal", 1)
+                for _ in range(2):
+                    s.draw()
+                    ref = o.render(W, H, giSamples=2, giBounces=bounces)
+                got = {k: s.readback(getattr(rt64, "IMAGE_" + k)) for k in ("OUTPUT_RGBA32F", "PRIMARY_HIT", "INDIRECT_LIGHT_RAW")}
+                st = s.stats()
+            finally:
+                s.close(); o.close()
+            assert np.array_equal(got["PRIMARY_HIT"], ref["primaryHit"])
+            assert _rmse(got["INDIRECT_LIGHT_RAW"][..., :3], ref["indirectLight"][..., :3]) <= 2e-3, (name, bounces)
+            assert _rmse(got["OUTPUT_RGBA32F"][..., :3], ref["output"][..., :3]) <= 1e-3
+            assert st.indirectRays == ref["counters"]["indirectRays"]
+            out[name, bounces] = (ref, st)
+        one, two = out[name, 1], out[name, 2]
+        assert two[1].indirectRays > one[1].indirectRays
+        assert np.abs(two[0]["indirectLight"][..., :3] - one[0]["indirectLight"][..., :3]).mean() > 1e-4
+    s = sample_scene.Rt64Scene(rt64_lib, _variant(sample_data), W, H, hip_device=0)
+    try:
+        assert not s.option("gi_bounces", 3) and not s.option("gi_bounces", 0) and not s.option("primary_spp", 0)
+    finally:
+        s.close()
+
+
+def test_primary_spp_on_a_frame_without_gi(rt64_lib, sample_data):
+    """primary_spp = 4 on the plain sample frame (no GI: otherwise a lean one-kernel frame): four jittered full frames averaged.  Parity with the oracle, rays
+    counted four times, silhouette pixels take values the one-sample frame does not have, the HUD is drawn once over the mean, and a frame after the
+    option is switched off is the plain frame again (byte for byte)."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    from oracle import oracle_py
+    data = _variant(sample_data)
+    s = sample_scene.Rt64Scene(rt64_lib, data, W, H, hip_device=0)
+    o = oracle_py.OracleScene(data)
+    try:
+        assert s.option("count_traversal", 1)
+        s.draw()
+        plain = {k: s.readback(getattr(rt64, "IMAGE_" + k)) for k in ("OUTPUT_RGBA32F", "FINAL_RGBA8")}
+        ref1 = o.render(W, H)
+        assert s.option("primary_spp", 4)
+        for _ in range(2):
+            s.draw()
+            ref = o.render(W, H, primarySpp=4)
+        got = {k: s.readback(getattr(rt64, "IMAGE_" + k)) for k in ("OUTPUT_RGBA32F", "FINAL_RGBA8", "PRIMARY_HIT")}
+        st = s.stats()
+        assert st.primaryRays == ref["counters"]["primaryRays"] == 4 * W * H and st.shadowRays == ref["counters"]["shadowRays"]
+        assert st.nodesPrimary == ref["counters"]["nodesVisitedPrimary"] and st.trianglesPrimary == ref["counters"]["trianglesTestedPrimary"]
+        assert np.array_equal(got["PRIMARY_HIT"], ref["primaryHit"])                # the last sub-frame's records
+        assert _rmse(got["OUTPUT_RGBA32F"][..., :3], ref["output"][..., :3]) <= 1e-4
+        assert np.abs(got["FINAL_RGBA8"].astype(np.int32) - ref["final"].astype(np.int32)).max() <= 1
+        moved = np.abs(ref["output"][..., :3] - ref1["output"][..., :3]).max(axis=-1) > 0.02
+        assert 0.002 < moved.mean() < 0.2                                           # edges and texture detail, not the whole picture
+        assert np.abs(got["OUTPUT_RGBA32F"][..., :3] - plain["OUTPUT_RGBA32F"][..., :3]).max(axis=-1)[moved].min() > 0.01
+        assert s.option("primary_spp", 1)
+        s.draw()
+        again = {k: s.readback(getattr(rt64, "IMAGE_" + k)) for k in ("OUTPUT_RGBA32F", "FINAL_RGBA8")}
+        for k in plain:
+            assert np.array_equal(plain[k].view(np.uint8), again[k].view(np.uint8)), k
+    finally:
+        s.close(); o.close()
 
 
 @pytest.mark.parametrize("config", ["C2", "C3"])
