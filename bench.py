@@ -50,7 +50,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5"],
+    ap.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5", "C4-literal", "C5-literal"],
                     help="BASELINE.json configs: C2 primary+shadow 1080p (the metric's config, default) | C3 +1 GI sample +SVGF 1080p | "
                          "C4 1440p, 2 GI samples, SVGF, per-frame SetMesh refit of the UPDATABLE sphere | C5 4K, 4 GI samples, SVGF, reflective floor")
     ap.add_argument("--gi-samples", type=int, default=0, help="C3: 1 (with --denoiser)")
@@ -138,6 +138,8 @@ def main():
     if args.config != "C2":
         c = sample_scene.BENCH_CONFIGS[args.config]
         args.width, args.height, args.gi_samples, args.denoiser = c["width"], c["height"], c["gi_samples"], c["denoiser"]
+    # BASELINE.json's C4 / C5 as worded run through the library's path-tracing extensions (device options; sample_scene.BENCH_CONFIGS)
+    ext = {k: sample_scene.BENCH_CONFIGS.get(args.config, {}).get(k, 1) for k in ("primary_spp", "gi_bounces")}
     W, H = args.width, args.height
     COUNTER_WORKLOAD[0] = ("stress_%d_%d" % (args.subdiv, args.floor_grid)) if (args.subdiv or args.floor_grid > 1) else args.config
     lib = rt64.Library()
@@ -157,6 +159,9 @@ def main():
     # rank renders redundantly (denoiser halo) never inflate the throughput.
     if args.gi_samples or args.denoiser:
         scene.set_view_description(gi_samples=args.gi_samples, denoiser=args.denoiser)
+    for k, v in ext.items():
+        if v != 1 and not scene.option(k, v):
+            raise SystemExit("bench.py: librt64.so refused option %s = %s" % (k, v))
     scene.option("count_traversal", 1)
     scene.draw()
     st_full = scene.stats()
@@ -445,22 +450,24 @@ def main():
         if args.config == "C2" and not stress and not (args.gi_samples or args.denoiser) and (W, H) == (1920, 1080):
             metric = "Mrays/s (primary+shadow), sample scene 1080p 1spp"                      # BASELINE.json's metric, on the config it is quoted on
         else:
-            metric = "Mrays/s (primary+shadow%s%s), %s %dx%d, 1 primary sample per pixel%s" % (
+            metric = "Mrays/s (primary+shadow%s%s), %s %dx%d, %d primary sample%s per pixel%s" % (
                 "+GI bounce" if args.gi_samples else "", "+reflection" if counts["reflection"] else "", "stress variant of the sample scene" if stress else "sample scene", W, H,
-                (", %d GI sample%s per pixel (1 bounce each)%s" % (args.gi_samples, "s" if args.gi_samples > 1 else "", " + SVGF" if args.denoiser else "")) if args.gi_samples else "")
+                ext["primary_spp"], "" if ext["primary_spp"] == 1 else "s",
+                (", %d GI sample%s per %s (%d bounce%s each)%s" % (args.gi_samples, "s" if args.gi_samples > 1 else "", "pixel" if ext["primary_spp"] == 1 else "primary sample", ext["gi_bounces"],
+                                                                 "" if ext["gi_bounces"] == 1 else "s", " + SVGF" if args.denoiser else "")) if args.gi_samples else "")
         result = {
             "metric": metric, "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: src/sample scene, primary+shadow rays + shading + compose, %dx%d 1spp%s" % (
-                args.config, W, H, "" if not (args.gi_samples or args.subdiv or args.floor_grid > 1) else " [gi=%d denoiser=%d subdiv=%d floor_grid=%d]" % (
+            "config": {"workload": "%s: src/sample scene, primary+shadow rays + shading + compose, %dx%d %dspp%s" % (
+                args.config, W, H, ext["primary_spp"], "" if not (args.gi_samples or args.subdiv or args.floor_grid > 1) else " [gi=%d denoiser=%d subdiv=%d floor_grid=%d]" % (
                     args.gi_samples, int(args.denoiser), args.subdiv, args.floor_grid)),
                 "rays_per_frame": int(rays_total), "width": W, "height": H,
                 "partition": ("DIAGNOSIS: rank 0's share of a %d-way partition only, no gather" % PR) if PR > 1 else ("%s x%d + RCCL gather of RGBA8" % (("cost-balanced contiguous bands %s with denoiser halo" % (list(band_starts) if native else "")) if use_bands else "interleaved 16-row strips", N)) if N > 1 else "single GPU"},
             "roofline": roofline,
         }
-        if args.config in sample_scene.BENCH_DEVIATIONS:
-            result["config"]["deviation"] = sample_scene.BENCH_DEVIATIONS[args.config]
+        if args.config in sample_scene.BENCH_DEVIATIONS:       # how the configuration reads BASELINE.json's wording ("deviation"), or which extensions run it as worded
+            result["config"]["extensions" if args.config.endswith("-literal") else "deviation"] = sample_scene.BENCH_DEVIATIONS[args.config]
         result["prewarm_frames"] = args.prewarm
         if args.option:
             result["config"]["options"] = list(args.option)      # non-default library options: an A/B line, not the headline
@@ -696,11 +703,14 @@ def parity_object(lib, scene, data, args, W, H, hip_device, oracle_frame):
     import copy
     d2 = copy.copy(data)
     d2.meshes = [copy.copy(m) for m in data.meshes]
-    anim = sample_scene.c4_animation(d2) if args.config == "C4" else None       # (the material edits of C5 are already in `data`)
+    anim = sample_scene.c4_animation(d2) if args.config in ("C4", "C4-literal") else None       # (the material edits of C5 are already in `data`)
+    ext = {k: sample_scene.BENCH_CONFIGS.get(args.config, {}).get(k, 1) for k in ("primary_spp", "gi_bounces")}
     s2 = sample_scene.Rt64Scene(lib, d2, W, H, hip_device=hip_device)
     ora = oracle_py.OracleScene(d2)
     try:
         s2.set_view_description(gi_samples=args.gi_samples, denoiser=args.denoiser)
+        for k, v in ext.items():
+            s2.option(k, v)
         for kv in args.option:
             k, _, v = kv.partition("=")
             s2.option(k, float(v))
@@ -709,7 +719,7 @@ def parity_object(lib, scene, data, args, W, H, hip_device, oracle_frame):
                 v = anim[(f + 1) % len(anim)]
                 s2.set_mesh(s2.meshes[0], v, d2.meshes[0].indices); ora.set_mesh(ora.meshes[0], v, d2.meshes[0].indices)
             s2.draw()
-            ref = ora.render(W, H, threads=threads, giSamples=args.gi_samples, denoiserEnabled=int(args.denoiser), denoiserMode=1)
+            ref = ora.render(W, H, threads=threads, giSamples=args.gi_samples, denoiserEnabled=int(args.denoiser), denoiserMode=1, primarySpp=ext["primary_spp"], giBounces=ext["gi_bounces"])
         got = [s2.readback(i) for i in (rt64.IMAGE_OUTPUT_RGBA32F, rt64.IMAGE_FINAL_RGBA8, rt64.IMAGE_PRIMARY_HIT)]
         return compare_frames(got[0], got[1], got[2], ref, W, H, "frame %d of a fresh scene + oracle pair running this configuration's call sequence" % F)
     finally:

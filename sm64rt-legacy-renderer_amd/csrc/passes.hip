@@ -1266,12 +1266,23 @@ __global__ __launch_bounds__(RT_BLOCK) void bounce_miss_kernel(FrameParams Pv, V
     }
 }
 
-__global__ __launch_bounds__(256) void bounce_resolve_kernel(FrameParams Pv, ViewImages Iv, int cur, int writeFiltered) {
+__global__ __launch_bounds__(256) void bounce_resolve_kernel(FrameParams Pv, ViewImages Iv, int cur, int writeFiltered, int writeGuide) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = P.tileY0 + blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= P.width || y >= P.tileY1 || !row_owned(P, y)) return;
     const uint32_t px = (uint32_t)x, py = (uint32_t)y;
     const size_t i = (size_t)py * (size_t)P.width + px, stride = (size_t)P.width * (size_t)P.height;
+    if (writeGuide) {
+        // the SVGF guide record of the pixel (svgf.hip: svgf_guide_kernel, the same bytes): this kernel already has the pixel's id, normal and depth in flight, so the
+        // denoiser's first launch -- a pass over the same three images -- is folded into it on frames whose GI runs as the wavefront chain (C5: 44 us + a launch gap)
+        const uint2 n = reinterpret_cast<const uint2 *>(I.normal[cur])[i];
+        const float *depth = I.depth[cur];
+        const float z = depth[i], zx = depth[(size_t)y * P.width + (x + 1 < P.width ? x + 1 : x)], zy = depth[(size_t)(y + 1 < P.height ? y + 1 : y) * P.width + x];
+        uint4 g;
+        g.x = n.x; g.y = (n.y & 0xFFFFu) | (I.instanceId[i] >= 0 ? 0x10000u : 0u);
+        g.z = __float_as_uint(z); g.w = __float_as_uint(fmaxf(fabsf(zx - z), fabsf(zy - z)));
+        I.svgfGuide[i] = g;
+    }
     if (I.instanceId[i] < 0) {
         const float ax = P.ambientBaseColor[0] + P.ambientNoGIColor[0], ay = P.ambientBaseColor[1] + P.ambientNoGIColor[1], az = P.ambientBaseColor[2] + P.ambientNoGIColor[2];
         store_rgba16f(I.indirectLight[cur], i, ax, ay, az, 0.0f);
@@ -1727,8 +1738,8 @@ hipError_t RT_LAUNCHER(launch_lean_frame)(const FrameParams &P, const ViewImages
     }
     return hipGetLastError();
 }
-hipError_t RT_LAUNCHER(launch_indirect)(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, int walk, unsigned groups, hipStream_t s) {
-    RT_ROUTE_SIMPLE(launch_indirect_simple(P, I, cur, writeFiltered, klist, walk, groups, s));
+hipError_t RT_LAUNCHER(launch_indirect)(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, int walk, unsigned groups, bool writeGuide, hipStream_t s) {
+    RT_ROUTE_SIMPLE(launch_indirect_simple(P, I, cur, writeFiltered, klist, walk, groups, writeGuide, s));
     const bool second = P.giBounces >= 2u;
     if (klist && second) LAUNCH_RAY((indirect_kernel<true, true>), P, I, cur, writeFiltered ? 1 : 0);
     if (klist) LAUNCH_RAY(indirect_kernel<true>, P, I, cur, writeFiltered ? 1 : 0);
@@ -1754,7 +1765,7 @@ hipError_t RT_LAUNCHER(launch_indirect)(const FrameParams &P, const ViewImages &
     else hipLaunchKernelGGL(bounce_hit_kernel<false>, dim3(grid), dim3(RT_BLOCK), 0, s, P, I);
     if (walk == BOUNCE_WALK_REFILL) hipLaunchKernelGGL(bounce_miss_kernel, dim3(grid), dim3(RT_BLOCK), 0, s, P, I);      // the other walks finish their misses themselves
     dim3 rgrid((unsigned)(P.width + 31) / 32, (unsigned)(P.tileY1 - P.tileY0 + 7) / 8);
-    hipLaunchKernelGGL(bounce_resolve_kernel, rgrid, dim3(256), 0, s, P, I, cur, writeFiltered ? 1 : 0);
+    hipLaunchKernelGGL(bounce_resolve_kernel, rgrid, dim3(256), 0, s, P, I, cur, writeFiltered ? 1 : 0, writeGuide ? 1 : 0);
     return hipGetLastError();
 }
 #ifndef RT_ASSUME_SIMPLE

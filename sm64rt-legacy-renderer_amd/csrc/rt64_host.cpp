@@ -150,6 +150,8 @@ struct Options {
     int bounceSplit = -1;         // two-phase bounce walk (TLAS part first, survivors compacted through LDS): 1 on, 0 off, -1 auto (scenes with the LDS scene cache, two or more GI samples per pixel)
     int bounceRefill = -1;        // bounce-ray traversal with wave-ballot refill: 1 on, 0 off, -1 auto (on when the scene has >= 64 Ki triangles)
     int denoiserMode = 1;          // 0 = reference 5x Gaussian, 1 = SVGF
+    bool foldCompose = true;       // frames with the SVGF denoiser: ComposePS inside the last a-trous iteration (0: compose_post_kernel, its own launch)
+    bool foldGuide = true;         // frames with the wavefront GI chain + SVGF: bounce_resolve_kernel writes the filter's guide records (0: svgf_guide_kernel, its own launch)
     bool overlapReflection = true; // frames with reflection passes AND the SVGF denoiser: the reflection launches run on a second stream beside the a-trous iterations (they share no image)
     bool haloExchange = false;     // band partitions of GI + SVGF frames: ship the filter input of the halo rows between the devices of the gather (RCCL) instead of re-rendering them
     int haloMargin = SVGF_INPUT_HALO_ROWS;   // with a halo exchange: rows of G-buffer + GI kept around the band (temporal history under camera motion); at least SVGF_INPUT_HALO_ROWS
@@ -1259,6 +1261,7 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         // GI bounce -- also cover a halo above and below the device's rows.  Pixel-local passes (direct light, reflection,
         // refraction, compose) stay on the owned rows.  The halo rows are recomputed, not exchanged: no mid-frame collective.
         const bool denoiseGI = denoiserEnabled && giSamples > 0;
+        bool guideByResolve = false;
         FrameParams X = P;                                        // X: owned rows + halo
         bool haloExchange = false;
         if (denoiseGI && !P.separatePost && (P.tileY0 > 0 || P.tileY1 < imgH || P.stripCount > 1)) {
@@ -1324,7 +1327,9 @@ void View::render() {                          // View::render, rt64_view.cpp:11
             // grid: the two-phase walk takes one workgroup per tile (0); the plain walk of one-sample frames one resident round of persistent workgroups (4 per CU at its
             // 118 VGPRs): a tile of 256 rays is too little work to pay for a scene-cache fill of its own (C3 bounce kernels 0.235 -> 0.198 ms against 0.220 per tile)
             const unsigned groups = dev->opt.bounceGroups >= 0 ? (unsigned)dev->opt.bounceGroups : (walk == BOUNCE_WALK_PLAIN ? 1024u : 0u);
-            L(launch_indirect(X, img, cur, !denoiseGI, klist, walk, groups, s));
+            // frames whose GI runs as the wavefront chain: its last kernel (the per-pixel resolve) writes the SVGF guide records of its rows as well
+            guideByResolve = denoiseGI && dev->opt.denoiserMode == 1 && !klist && img.bounceRecords != nullptr && dev->opt.foldGuide;
+            L(launch_indirect(X, img, cur, !denoiseGI, klist, walk, groups, guideByResolve, s));
         }
         mark(Device::EV_INDIRECT);
         // Refraction / reflection touch only pixels whose primary hit has a refraction / reflection factor (alpha > EPSILON).
@@ -1334,6 +1339,9 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         // therefore go to a second stream once the filter's INPUT is made (the variance kernel reads the instance ids the reflection pass rewrites), beside the
         // five iterations, and the frame joins the two before Compose -- two latency-bound launches fill each other's idle issue slots (C5: DESIGN 8).
         const bool reflectBeside = anyReflection && dev->opt.maxReflections > 0 && denoiseGI && dev->opt.denoiserMode == 1 && dev->opt.overlapReflection;
+        // Frames with the SVGF denoiser: ComposePS runs inside the last a-trous iteration (svgf.hip), on the filtered value that iteration has just rounded
+        SvgfComposeFold foldArgs = { img.diffuse, img.filteredDirect[1], img.reflection, img.refraction, img.transparent, img.output, img.final, P.tileY0, P.tileY1, (!P.separatePost && subFrames == 1) ? 1 : 0 };
+        const SvgfComposeFold *composeFold = (denoiseGI && dev->opt.denoiserMode == 1 && !lean && dev->opt.foldCompose && P.stripCount == 1) ? &foldArgs : nullptr;
         auto reflectOnAux = [&]() {
             if (!dev->auxStream) {
                 HIP_CHECK(hipStreamCreateWithFlags(&dev->auxStream, hipStreamNonBlocking));
@@ -1348,27 +1356,29 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         mark(Device::EV_REFL);
         if (denoiseGI && dev->opt.denoiserMode == 1 && reflectBeside) {
             const int ay0 = haloExchange ? std::max(0, P.tileY0 - SVGF_ATROUS_HALO_ROWS) : X.tileY0, ay1 = haloExchange ? std::min(imgH, P.tileY1 + SVGF_ATROUS_HALO_ROWS) : X.tileY1;
-            if (haloExchange) { L(launch_svgf_inputs(img, cur, imgW, imgH, std::max(0, P.tileY0 - 3), std::min(imgH, P.tileY1 + 3), P.tileY0, P.tileY1, s)); }
-            else L(launch_svgf_inputs(img, cur, imgW, imgH, X.tileY0, X.tileY1, X.tileY0, X.tileY1, s));
+            if (haloExchange) { L(launch_svgf_inputs(img, cur, imgW, imgH, std::max(0, P.tileY0 - 3), guideByResolve ? 0 : std::min(imgH, P.tileY1 + 3), P.tileY0, P.tileY1, s)); }
+            else L(launch_svgf_inputs(img, cur, imgW, imgH, X.tileY0, guideByResolve ? 0 : X.tileY1, X.tileY0, X.tileY1, s));
             reflectOnAux();                                      // (before the exchange: the reflection pass also runs beside the wait for the neighbours' rows)
             if (haloExchange) halo_exchange(dev, img, imgW, imgH, s);
-            L(launch_svgf_atrous(img, imgW, imgH, ay0, ay1, s));
+            // (the folded Compose reads the reflection image: the join comes before the last iteration instead of behind it)
+            L(launch_svgf_atrous(img, imgW, imgH, ay0, ay1, 0, composeFold ? 4 : 5, nullptr, s));
             HIP_CHECK(hipStreamWaitEvent(s, dev->joinEvent, 0));
+            if (composeFold) L(launch_svgf_atrous(img, imgW, imgH, ay0, ay1, 4, 5, composeFold, s));
         }
         else if (denoiseGI && dev->opt.denoiserMode == 1 && haloExchange) {
             // filter input (variance image + guide records) of the band's own rows; the guide records of 3 rows around them feed the variance estimate
-            L(launch_svgf_inputs(img, cur, imgW, imgH, std::max(0, P.tileY0 - 3), std::min(imgH, P.tileY1 + 3), P.tileY0, P.tileY1, s));
+            L(launch_svgf_inputs(img, cur, imgW, imgH, std::max(0, P.tileY0 - 3), guideByResolve ? 0 : std::min(imgH, P.tileY1 + 3), P.tileY0, P.tileY1, s));
             halo_exchange(dev, img, imgW, imgH, s);
-            L(launch_svgf_atrous(img, imgW, imgH, std::max(0, P.tileY0 - SVGF_ATROUS_HALO_ROWS), std::min(imgH, P.tileY1 + SVGF_ATROUS_HALO_ROWS), s));
+            L(launch_svgf_atrous(img, imgW, imgH, std::max(0, P.tileY0 - SVGF_ATROUS_HALO_ROWS), std::min(imgH, P.tileY1 + SVGF_ATROUS_HALO_ROWS), 0, 5, composeFold, s));
         }
-        else if (denoiseGI && dev->opt.denoiserMode == 1) L(launch_svgf(img, cur, imgW, imgH, X.tileY0, X.tileY1, s));
+        else if (denoiseGI && dev->opt.denoiserMode == 1) { L(launch_svgf_inputs(img, cur, imgW, imgH, X.tileY0, guideByResolve ? 0 : X.tileY1, X.tileY0, X.tileY1, s)); L(launch_svgf_atrous(img, imgW, imgH, X.tileY0, X.tileY1, 0, 5, composeFold, s)); }
         else if (denoiseGI) {
             L(hipMemcpyAsync(img.filteredIndirect[0], img.indirectLight[cur], n * 8, hipMemcpyDeviceToDevice, s));
             for (int k = 0; k < 5; k++)            // rt64_view.cpp:1512-1530
                 L(launch_gaussian(img.filteredIndirect[k % 2], img.filteredIndirect[(k % 2) ^ 1], imgW, imgH, X.tileY0, X.tileY1, s));
         }
         mark(Device::EV_DENOISE);
-        if (!lean) L(launch_compose_post(P, img, cur, false, subFrames == 1, s));       // a lean frame is composed by direct_kernel<false> itself
+        if (!lean && !composeFold) L(launch_compose_post(P, img, cur, false, subFrames == 1, s));       // a lean frame is composed by direct_kernel<false> itself
         if (subFrames > 1) {        // P3: rtOutput of the sub-frames summed in order; the last one turns the sum into the mean and PostProcessPS of it into the back buffer
             sppSum.reserve(n * 4);
             L(launch_spp_accumulate(P, img, sppSum.ptr, subFrame, subFrames, s));
@@ -1714,6 +1724,8 @@ RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, doubl
     else if (k == "denoiser_mode") d->opt.denoiserMode = (int)value;
     else if (k == "bounce_refill") d->opt.bounceRefill = (int)value;
     else if (k == "overlap_reflection") d->opt.overlapReflection = value != 0.0;
+    else if (k == "fold_guide") d->opt.foldGuide = value != 0.0;
+    else if (k == "fold_compose") d->opt.foldCompose = value != 0.0;
     else if (k == "halo_exchange") d->opt.haloExchange = value != 0.0;
     else if (k == "halo_margin") d->opt.haloMargin = std::max((int)value, SVGF_INPUT_HALO_ROWS);
     else if (k == "bounce_split") d->opt.bounceSplit = (int)value;

@@ -139,7 +139,30 @@ __global__ __launch_bounds__(256) void svgf_guide_kernel(const int32_t *instance
 }
 
 #define ATROUS_ROWS 1
-__global__ __launch_bounds__(256, 6) void svgf_atrous_kernel(const uint2 *__restrict__ in, uint2 *__restrict__ out, const uint4 *__restrict__ guide, int w, int h, int step, int y0, int y1) {
+// ComposePS of one pixel (ComposePS.hlsl:18-37 + the PostProcessPS passthrough; compose_post_kernel<false> of passes.hip, the same operations through the same
+// helpers -- none of them contracted, whatever this file's pragma says) with the filtered GI value the last a-trous iteration has just rounded to RGBA16F:
+// on frames with the SVGF denoiser the last iteration composes its pixel itself (one launch and one pass over the filtered image less per frame).
+DEV void compose_pixel(const SvgfComposeFold &f, size_t i, uint2 filtered) {
+#pragma clang fp contract(off)
+    const f4 d = load_rgba8(f.diffuse, i);
+    f3 result;
+    if (d.w > RT_EPSILON) {
+        const f3 diffuse = xyz(d);
+        const f3 direct = xyz(load_rgba16f(f.filteredDirect, i)), indirect = xyz(unpack_rgba16f(filtered));
+        result = diffuse * (direct + indirect);
+        result = lerp3(diffuse, result, d.w);
+        result = result + xyz(load_rgba16f(f.reflection, i));
+        result = result + xyz(load_rgba16f(f.refraction, i));
+        result = result + xyz(load_rgba16f(f.transparent, i));
+    }
+    else result = xyz(d);
+    reinterpret_cast<float4 *>(f.output)[i] = make_float4(result.x, result.y, result.z, 1.0f);
+    if (f.writeFinal) store_rgba8(f.final, i, result.x, result.y, result.z, 1.0f);
+}
+
+template <bool COMPOSE>
+__global__ __launch_bounds__(256, 6) void svgf_atrous_kernel(const uint2 *__restrict__ in, uint2 *__restrict__ out, const uint4 *__restrict__ guide, int w, int h, int step, int y0, int y1, SvgfComposeFold fold) {
+    static_assert(!COMPOSE || ATROUS_ROWS == 1, "the folded Compose takes one output pixel per lane");
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int t = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int yb = y0 + (t / step) * (ATROUS_ROWS * step) + (t % step);     // this lane filters rows yb + j*step, j = 0..3, inside [y0, y1)
@@ -177,7 +200,11 @@ __global__ __launch_bounds__(256, 6) void svgf_atrous_kernel(const uint2 *__rest
         np[j] = g.n; zp[j] = g.z; lp[j] = lum3(c[j].x, c[j].y, c[j].z);
         gzc[j] = g.gz;
     }
-    if (!any) return;
+    if (!any) {
+        // sky (or a row past the end): nothing to filter.  The folded Compose still owes the pixel: its GI value is what svgf_variance_kernel wrote to both images.
+        if (COMPOSE && yb >= fold.oy0 && yb < fold.oy1) compose_pixel(fold, (size_t)yb * w + x, in[(size_t)yb * w + x]);
+        return;
+    }
 
     // Tap rows are a rolled loop (8 rows, 5 taps = 10 loads each).  Which of the lane's 4 pixels a row serves (|ky| <= 2) is wave-uniform, so that test is a scalar
     // branch.  Out-of-frame / sky taps are fetched from a clamped address and get weight 0.
@@ -242,6 +269,7 @@ __global__ __launch_bounds__(256, 6) void svgf_atrous_kernel(const uint2 *__rest
         v.x = (uint32_t)f32_to_f16_bits(sr[j] * inv) | ((uint32_t)f32_to_f16_bits(sg[j] * inv) << 16);
         v.y = (uint32_t)f32_to_f16_bits(sb[j] * inv) | ((uint32_t)f32_to_f16_bits(sv[j] * inv * inv) << 16);
         out[(size_t)(yb + j * step) * w + x] = v;
+        if (COMPOSE && yb >= fold.oy0 && yb < fold.oy1) compose_pixel(fold, (size_t)yb * w + x, v);
     }
 }
 
@@ -265,20 +293,23 @@ hipError_t launch_svgf_inputs(const ViewImages &I, int cur, int width, int heigh
     }
     return hipGetLastError();
 }
-hipError_t launch_svgf_atrous(const ViewImages &I, int width, int height, int y0, int y1, hipStream_t s) {
+// Iterations [first, last) of the five; `fold` (may be nullptr) = Compose of the rows [oy0, oy1) inside iteration 4.
+hipError_t launch_svgf_atrous(const ViewImages &I, int width, int height, int y0, int y1, int first, int last, const SvgfComposeFold *fold, hipStream_t s) {
     if (y1 <= y0) return hipSuccess;
     const int rows = y1 - y0;
-    for (int k = 0; k < 5; k++) {
+    const SvgfComposeFold none = {};
+    for (int k = first; k < last; k++) {
         const int step = 1 << k;
         const unsigned laneRows = (unsigned)((rows + ATROUS_ROWS * step - 1) / (ATROUS_ROWS * step)) * (unsigned)step;     // lanes per column
         dim3 agrid((unsigned)(width + 63) / 64, (laneRows + 3) / 4);
-        hipLaunchKernelGGL(svgf_atrous_kernel, agrid, dim3(256), 0, s, reinterpret_cast<const uint2 *>(I.filteredIndirect[k % 2]),
-                           reinterpret_cast<uint2 *>(I.filteredIndirect[(k % 2) ^ 1]), I.svgfGuide, width, height, step, y0, y1);
+        const uint2 *in = reinterpret_cast<const uint2 *>(I.filteredIndirect[k % 2]); uint2 *out = reinterpret_cast<uint2 *>(I.filteredIndirect[(k % 2) ^ 1]);
+        if (k == 4 && fold) hipLaunchKernelGGL(svgf_atrous_kernel<true>, agrid, dim3(256), 0, s, in, out, I.svgfGuide, width, height, step, y0, y1, *fold);
+        else hipLaunchKernelGGL(svgf_atrous_kernel<false>, agrid, dim3(256), 0, s, in, out, I.svgfGuide, width, height, step, y0, y1, none);
     }
     return hipGetLastError();
 }
 hipError_t launch_svgf(const ViewImages &I, int cur, int width, int height, int y0, int y1, hipStream_t s) {
     if (y1 <= y0) return hipSuccess;
     hipError_t e = launch_svgf_inputs(I, cur, width, height, y0, y1, y0, y1, s);
-    return e != hipSuccess ? e : launch_svgf_atrous(I, width, height, y0, y1, s);
+    return e != hipSuccess ? e : launch_svgf_atrous(I, width, height, y0, y1, 0, 5, nullptr, s);
 }

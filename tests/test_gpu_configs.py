@@ -336,3 +336,24 @@ def test_simple_frame_kernels_equal_the_general_kernels(rt64_lib, sample_data, c
         assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), k
     assert (sa[0].primaryRays, sa[0].shadowRays, sa[0].indirectRays, sa[0].reflectionRays, sa[0].nodesVisited, sa[0].trianglesTested) == \
            (sb[0].primaryRays, sb[0].shadowRays, sb[0].indirectRays, sb[0].reflectionRays, sb[0].nodesVisited, sb[0].trianglesTested)
+
+
+@pytest.mark.parametrize("config,bands", [("C3", None), ("C4", None), ("C5", None), ("C5", [(0, 64), (64, 121), (121, H)])])
+def test_folded_guide_and_compose_equal_their_own_launches(rt64_lib, sample_data, config, bands):
+    """Frames with the wavefront GI chain + SVGF: bounce_resolve_kernel writes the filter's guide records (the same bytes as svgf_guide_kernel) and the last
+    a-trous iteration composes its pixels itself (the operations of compose_post_kernel on the value it has just rounded).  Device options fold_guide = 0 /
+    fold_compose = 0 bring the two launches back.  The guide fold changes no byte.  The Compose fold is another instantiation of the a-trous kernel, whose
+    arithmetic is compiled with fp-contract(fast) (tolerance-tested filter): the compiler may fuse a multiply-add differently in it, so a handful of filtered
+    values may differ by one RGBA16F step -- and nothing else."""
+    a, ref, sa = _bench_pair(rt64_lib, sample_data, config, frames=3, bands=bands)
+    g, _, _ = _bench_pair(rt64_lib, sample_data, config, frames=3, bands=bands, options={"fold_guide": 0})
+    for k in a:
+        assert np.array_equal(a[k].view(np.uint8), g[k].view(np.uint8)), k
+    b, _, sb = _bench_pair(rt64_lib, sample_data, config, frames=3, bands=bands, options={"fold_guide": 0, "fold_compose": 0})
+    for k in a:
+        if k in ("OUTPUT_RGBA32F", "FINAL_RGBA8", "INDIRECT_LIGHT_FILTERED"):
+            d = np.abs(a[k].astype(np.float64) - b[k].astype(np.float64))
+            assert (d > 0).any(axis=-1).mean() < 2e-3 and d.max() <= (1.0 if k == "FINAL_RGBA8" else 1.0 / 512.0), (k, d.max(), (d > 0).mean())
+        else:
+            assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), k
+    _check_gi_frame(a, ref)
