@@ -61,6 +61,8 @@ def parse_args():
     ap.add_argument("--no-parity", action="store_true", help="skip the full-size comparison with the oracle after the timed loop (profiling runs)")
     ap.add_argument("--parity-frames", type=int, default=0, help="frames of the GI configurations rendered on a fresh scene + oracle pair for the parity object (0: 2 for C3 / C4 / C5)")
     ap.add_argument("--always-rebuild", action="store_true", help="upload the frame tables and rebuild the TLAS every frame (the reference's behaviour)")
+    ap.add_argument("--pass-events-every", type=int, default=0, help="the library records its per-pass HIP events (the live kernel timings of `roofline`) on every n-th timed frame only: an event is a barrier packet "
+                    "(~5 us of stream time each, six per GI frame); 0 = auto: 1 for one-kernel frames (C2: two events, 0.4 us), 8 for frames of several passes")
     ap.add_argument("--prewarm", type=int, default=100, help="untimed frames before the W warm-up steps (GPU clock ramp; the line reports them)")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE", help="RT64_SetDeviceOption(key, value) before the run (A/B measurements; the line records them under config.options)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU-staged rehearsal of the N>1 path")
@@ -328,7 +330,9 @@ def main():
         acc["indirect"] += s.msIndirect; acc["compose"] += s.msComposePost; acc["build"] += s.msBuild; acc["total"] += s.msTotal
         acc["denoise"] += s.msDenoise; acc["reflect"] += s.msReflectRefract
     barrier()
-    scene.option("reset_accum", 1)   # the library sums the HIP-event timings of every frame from here on; read once after the loop
+    events_every = args.pass_events_every if args.pass_events_every > 0 else (1 if (fused and not args.gi_samples) else 8)
+    scene.option("profile_every", events_every)
+    scene.option("reset_accum", 1)   # the library sums the HIP-event timings of every sampled frame from here on; read once after the loop
     t0 = time.perf_counter()
     last_slot = None
     for _ in range(args.steps):
@@ -352,7 +356,8 @@ def main():
         gathered_checksum = int(gatherer.frame(last_slot).to(torch.int64).sum().item())
     if not G and PR <= 1:            # N = 1: every timed frame was measured live with HIP events inside the library
         s = scene.stats()
-        assert s.accumFrames == args.steps, (s.accumFrames, args.steps)
+        stat_frames = (args.steps + events_every - 1) // events_every
+        assert s.accumFrames == stat_frames, (s.accumFrames, stat_frames)
         acc.update(trace=s.accumMsPrimaryTrace, shade=s.accumMsPrimaryShade, direct=s.accumMsDirect, indirect=s.accumMsIndirect, compose=s.accumMsComposePost,
                    build=s.accumMsBuild, total=s.accumMsTotal, denoise=s.accumMsDenoise, reflect=s.accumMsReflectRefract)
     # The reference uploads its tables and rebuilds the TLAS every frame (rt64_view.cpp:451 updateOnly = false, :1150-1152); the timed
@@ -392,6 +397,7 @@ def main():
                     "what": "sync_present=0: RT64_DrawDevice enqueues, frames run back to back on the library's stream, one wait after the K-th (cached tables)"}
         scene.option("sync_present", 1)
         step(); barrier()
+    scene.option("profile_every", 1)
     if G or PR > 1:                  # per-kernel timings of this rank's strips from a few untimed frames (reading them synchronises)
         stat_frames = 10
         for _ in range(stat_frames):
@@ -469,6 +475,8 @@ def main():
         if args.config in sample_scene.BENCH_DEVIATIONS:       # how the configuration reads BASELINE.json's wording ("deviation"), or which extensions run it as worded
             result["config"]["extensions" if args.config.endswith("-literal") else "deviation"] = sample_scene.BENCH_DEVIATIONS[args.config]
         result["prewarm_frames"] = args.prewarm
+        result["pass_events"] = "HIP events around every pass of every timed frame" if events_every == 1 else (
+            "per-pass HIP events on every %dth timed frame (%d of %d frames sampled): each event is a barrier packet of ~5 us on the stream" % (events_every, stat_frames, args.steps))
         if args.option:
             result["config"]["options"] = list(args.option)      # non-default library options: an A/B line, not the headline
         if G:

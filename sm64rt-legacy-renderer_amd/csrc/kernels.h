@@ -93,7 +93,7 @@ hipError_t launch_svgf(const ViewImages &I, int cur, int width, int height, int 
 hipError_t launch_svgf_inputs(const ViewImages &I, int cur, int width, int height, int gy0, int gy1, int vy0, int vy1, hipStream_t s);
 // Compose folded into the last a-trous iteration (svgf.hip): what compose_post_kernel<false> reads and writes, for the rows [oy0, oy1) of the frame
 struct SvgfComposeFold { const uint8_t *diffuse; const uint16_t *filteredDirect, *reflection, *refraction, *transparent; float *output; uint8_t *final; int oy0, oy1, writeFinal; };
-hipError_t launch_svgf_atrous(const ViewImages &I, int width, int height, int y0, int y1, int first, int last, const SvgfComposeFold *fold, hipStream_t s);
+hipError_t launch_svgf_atrous(const ViewImages &I, int width, int height, int y0, int y1, int oy0, int oy1, int first, int last, const SvgfComposeFold *fold, hipStream_t s);
 
 // ---- upscale.hip ---------------------------------------------------------------------------------------------------
 // Temporal upscaler stage (Upscaler::upscale, rt64_view.cpp:1584-1618): rtOutput + flow + masks + depth (render size rw x rh, jitter jx / jy)

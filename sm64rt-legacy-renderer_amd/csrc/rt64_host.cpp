@@ -139,6 +139,7 @@ static GpuCombiner decode_combiner(uint32_t shaderId) {
 
 struct Options {
     bool countTraversal = false, profilePasses = true, syncPresent = true, alwaysRebuild = false, leanFrames = true, fusedLean = true, foldForeground = true;
+    int profileEvery = 1;         // with profile_passes: record the pass events on every n-th frame only (sampled timings; accumFrames counts the sampled frames)
     bool leanRecords = false;     // 1: the one-kernel lean frame also stores the hit records and the direct-light image (otherwise View::materialise re-traces them on demand)
     bool hostTlas = true;         // the TLAS of up to RT64_HOST_TLAS_MAX instances is built on the host and travels in the table upload (0: always the GPU builder)
     bool simpleKernels = true;    // frames whose textures are all power-of-two sized and whose instances are all shadow-opaque run the kernels of passes_simple.hip
@@ -171,6 +172,7 @@ struct Device {
     std::vector<Scene *> scenes;
     Options opt;
     RT64_FRAME_STATS stats = {}, accum = {}; bool statsPending = false, statsHaveView = false;
+    bool profNow = false, statsProfiled = false; unsigned profCounter = 0;       // this frame records its pass events (option profile_every)
     double hostUpdateUs = 0.0, hostRenderUs = 0.0, hostStageUs[16] = {}, hostEventUs = 0.0; unsigned long long hostFrames = 0;      // host-side cost of View::update / View::render (RT64_HOST_TIMING=1 prints them)
     void finishStats();
     DevArray<uint32_t> spillStack;
@@ -1208,7 +1210,7 @@ static void halo_exchange(Device *dev, const ViewImages &img, int W, int H, hipS
 void View::render() {                          // View::render, rt64_view.cpp:1180-1670
     Device *dev = scene->device;
     hipStream_t s = dev->stream;
-    const bool prof = dev->opt.profilePasses;
+    const bool prof = dev->profNow;
     static const bool hostTiming = getenv("RT64_HOST_TIMING") != nullptr;
     auto hostPrev = std::chrono::steady_clock::now();
     auto mark = [&](int ev) {
@@ -1361,17 +1363,17 @@ void View::render() {                          // View::render, rt64_view.cpp:11
             reflectOnAux();                                      // (before the exchange: the reflection pass also runs beside the wait for the neighbours' rows)
             if (haloExchange) halo_exchange(dev, img, imgW, imgH, s);
             // (the folded Compose reads the reflection image: the join comes before the last iteration instead of behind it)
-            L(launch_svgf_atrous(img, imgW, imgH, ay0, ay1, 0, composeFold ? 4 : 5, nullptr, s));
+            L(launch_svgf_atrous(img, imgW, imgH, ay0, ay1, P.tileY0, P.tileY1, 0, composeFold ? 4 : 5, nullptr, s));
             HIP_CHECK(hipStreamWaitEvent(s, dev->joinEvent, 0));
-            if (composeFold) L(launch_svgf_atrous(img, imgW, imgH, ay0, ay1, 4, 5, composeFold, s));
+            if (composeFold) L(launch_svgf_atrous(img, imgW, imgH, ay0, ay1, P.tileY0, P.tileY1, 4, 5, composeFold, s));
         }
         else if (denoiseGI && dev->opt.denoiserMode == 1 && haloExchange) {
             // filter input (variance image + guide records) of the band's own rows; the guide records of 3 rows around them feed the variance estimate
             L(launch_svgf_inputs(img, cur, imgW, imgH, std::max(0, P.tileY0 - 3), guideByResolve ? 0 : std::min(imgH, P.tileY1 + 3), P.tileY0, P.tileY1, s));
             halo_exchange(dev, img, imgW, imgH, s);
-            L(launch_svgf_atrous(img, imgW, imgH, std::max(0, P.tileY0 - SVGF_ATROUS_HALO_ROWS), std::min(imgH, P.tileY1 + SVGF_ATROUS_HALO_ROWS), 0, 5, composeFold, s));
+            L(launch_svgf_atrous(img, imgW, imgH, std::max(0, P.tileY0 - SVGF_ATROUS_HALO_ROWS), std::min(imgH, P.tileY1 + SVGF_ATROUS_HALO_ROWS), P.tileY0, P.tileY1, 0, 5, composeFold, s));
         }
-        else if (denoiseGI && dev->opt.denoiserMode == 1) { L(launch_svgf_inputs(img, cur, imgW, imgH, X.tileY0, guideByResolve ? 0 : X.tileY1, X.tileY0, X.tileY1, s)); L(launch_svgf_atrous(img, imgW, imgH, X.tileY0, X.tileY1, 0, 5, composeFold, s)); }
+        else if (denoiseGI && dev->opt.denoiserMode == 1) { L(launch_svgf_inputs(img, cur, imgW, imgH, X.tileY0, guideByResolve ? 0 : X.tileY1, X.tileY0, X.tileY1, s)); L(launch_svgf_atrous(img, imgW, imgH, X.tileY0, X.tileY1, P.tileY0, P.tileY1, 0, 5, composeFold, s)); }
         else if (denoiseGI) {
             L(hipMemcpyAsync(img.filteredIndirect[0], img.indirectLight[cur], n * 8, hipMemcpyDeviceToDevice, s));
             for (int k = 0; k < 5; k++)            // rt64_view.cpp:1512-1530
@@ -1442,7 +1444,9 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
     if (tileY1 > height) tileY1 = height;
     if (tileY0 >= tileY1) { tileY0 = 0; tileY1 = height; }
     if (opt.countTraversal) HIP_CHECK(hipMemsetAsync(counters.ptr, 0, counters.bytes(), stream));
-    if (opt.profilePasses) { HIP_CHECK(hipEventRecord(events[EV_BEGIN], stream)); eventAlias[EV_BEGIN] = EV_BEGIN; lastMark = EV_BEGIN; workSinceMark = false; }
+    // pass events on every profile_every-th frame only: each event is a barrier packet (~5 us of stream time; six of them are 5 % of a 0.6 ms GI frame)
+    profNow = opt.profilePasses && (opt.profileEvery <= 1 || profCounter++ % (unsigned)opt.profileEvery == 0);
+    if (profNow) { HIP_CHECK(hipEventRecord(events[EV_BEGIN], stream)); eventAlias[EV_BEGIN] = EV_BEGIN; lastMark = EV_BEGIN; workSinceMark = false; }
     auto tu0 = std::chrono::steady_clock::now();
     flushMeshBuilds();
     for (Scene *sc : scenes) for (View *v : sc->views) v->update();
@@ -1458,7 +1462,7 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
     if (leanHoldoff) leanHoldoff--;
     auto tu2 = std::chrono::steady_clock::now();
     hostUpdateUs += std::chrono::duration<double, std::micro>(tu1 - tu0).count(); hostRenderUs += std::chrono::duration<double, std::micro>(tu2 - tu1).count(); hostFrames++;
-    if (opt.profilePasses) {             // the end mark shares the last mark's event when nothing was launched after it (one barrier packet less per frame)
+    if (profNow) {             // the end mark shares the last mark's event when nothing was launched after it (one barrier packet less per frame)
         if (workSinceMark) { HIP_CHECK(hipEventRecord(events[EV_END], stream)); eventAlias[EV_END] = EV_END; }
         else eventAlias[EV_END] = eventAlias[lastMark];
     }
@@ -1491,7 +1495,7 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
         st.triangleCount = tri; st.blasNodeBytes = nodeBytes; st.blasTriangleBytes = triBytes;
         st.tlasNodeBytes = (unsigned)(std::max<size_t>(v->rtInstances.size() ? v->rtInstances.size() - 1 : 0, 1) * sizeof(GpuNode));
     }
-    stats = st; statsHaveView = haveView; statsPending = true;
+    stats = st; statsHaveView = haveView; statsPending = true; statsProfiled = profNow;
     if (opt.syncPresent) finishStats();
 }
 
@@ -1504,7 +1508,7 @@ void Device::finishStats() {
     // The timings and counters below belong to the LAST frame handed to RT64_DrawDevice (one event set, re-recorded by every frame):
     // wait for it whatever sync_present says now -- the option may have been switched since the frame was enqueued.
     HIP_CHECK(hipStreamSynchronize(stream));
-    if (opt.profilePasses && haveView) {
+    if (statsProfiled && haveView) {
         auto ms = [&](int a, int b) { float v = 0.0f; if (eventAlias[a] != eventAlias[b] && hipEventElapsedTime(&v, events[eventAlias[a]], events[eventAlias[b]]) != hipSuccess) { (void)hipGetLastError(); v = 0.0f; } return v; };
         st.msTotal = ms(EV_BEGIN, EV_END); st.msBuild = ms(EV_BEGIN, EV_BUILD); st.msPrimary = ms(EV_BUILD, EV_PRIMARY);
         st.msPrimaryTrace = ms(EV_BUILD, EV_PRIMARY_TRACE); st.msPrimaryShade = ms(EV_PRIMARY_TRACE, EV_PRIMARY);
@@ -1720,6 +1724,7 @@ RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, doubl
     std::string k = key;
     if (k == "count_traversal") d->opt.countTraversal = value != 0.0;
     else if (k == "profile_passes") d->opt.profilePasses = value != 0.0;
+    else if (k == "profile_every") { d->finishStats(); d->opt.profileEvery = std::max(1, (int)value); d->profCounter = 0; }       // pass timings (RT64_FRAME_STATS.ms*) from every n-th frame only; the other frames carry no event
     else if (k == "sync_present") d->opt.syncPresent = value != 0.0;
     else if (k == "denoiser_mode") d->opt.denoiserMode = (int)value;
     else if (k == "bounce_refill") d->opt.bounceRefill = (int)value;

@@ -293,23 +293,27 @@ hipError_t launch_svgf_inputs(const ViewImages &I, int cur, int width, int heigh
     }
     return hipGetLastError();
 }
-// Iterations [first, last) of the five; `fold` (may be nullptr) = Compose of the rows [oy0, oy1) inside iteration 4.
-hipError_t launch_svgf_atrous(const ViewImages &I, int width, int height, int y0, int y1, int first, int last, const SvgfComposeFold *fold, hipStream_t s) {
+// Iterations [first, last) of the five over rows [y0, y1); `fold` (may be nullptr) = Compose of the rows [oy0, oy1) inside iteration 4.
+// [oy0, oy1) = the rows whose RESULT is wanted (the device's own rows of an image-tile partition; the whole range otherwise): iteration k only has to cover
+// them + what the iterations after it still reach, 2 * (2^(k+1) + ... + 16) = 64 - 2^(k+2) rows on either side -- 60, 56, 48, 32, 0 -- instead of the full
+// halo five times (392 halo-row passes per band instead of 620).
+hipError_t launch_svgf_atrous(const ViewImages &I, int width, int height, int y0, int y1, int oy0, int oy1, int first, int last, const SvgfComposeFold *fold, hipStream_t s) {
     if (y1 <= y0) return hipSuccess;
-    const int rows = y1 - y0;
     const SvgfComposeFold none = {};
     for (int k = first; k < last; k++) {
-        const int step = 1 << k;
+        const int step = 1 << k, reach = 64 - (4 << k);
+        const int ky0 = y0 > oy0 - reach ? y0 : oy0 - reach, ky1 = y1 < oy1 + reach ? y1 : oy1 + reach, rows = ky1 - ky0;
+        if (rows <= 0) continue;
         const unsigned laneRows = (unsigned)((rows + ATROUS_ROWS * step - 1) / (ATROUS_ROWS * step)) * (unsigned)step;     // lanes per column
         dim3 agrid((unsigned)(width + 63) / 64, (laneRows + 3) / 4);
         const uint2 *in = reinterpret_cast<const uint2 *>(I.filteredIndirect[k % 2]); uint2 *out = reinterpret_cast<uint2 *>(I.filteredIndirect[(k % 2) ^ 1]);
-        if (k == 4 && fold) hipLaunchKernelGGL(svgf_atrous_kernel<true>, agrid, dim3(256), 0, s, in, out, I.svgfGuide, width, height, step, y0, y1, *fold);
-        else hipLaunchKernelGGL(svgf_atrous_kernel<false>, agrid, dim3(256), 0, s, in, out, I.svgfGuide, width, height, step, y0, y1, none);
+        if (k == 4 && fold) hipLaunchKernelGGL(svgf_atrous_kernel<true>, agrid, dim3(256), 0, s, in, out, I.svgfGuide, width, height, step, ky0, ky1, *fold);
+        else hipLaunchKernelGGL(svgf_atrous_kernel<false>, agrid, dim3(256), 0, s, in, out, I.svgfGuide, width, height, step, ky0, ky1, none);
     }
     return hipGetLastError();
 }
 hipError_t launch_svgf(const ViewImages &I, int cur, int width, int height, int y0, int y1, hipStream_t s) {
     if (y1 <= y0) return hipSuccess;
     hipError_t e = launch_svgf_inputs(I, cur, width, height, y0, y1, y0, y1, s);
-    return e != hipSuccess ? e : launch_svgf_atrous(I, width, height, y0, y1, 0, 5, nullptr, s);
+    return e != hipSuccess ? e : launch_svgf_atrous(I, width, height, y0, y1, y0, y1, 0, 5, nullptr, s);
 }
