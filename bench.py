@@ -66,6 +66,8 @@ def parse_args():
     ap.add_argument("--prewarm", type=int, default=100, help="untimed frames before the W warm-up steps (GPU clock ramp; the line reports them)")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE", help="RT64_SetDeviceOption(key, value) before the run (A/B measurements; the line records them under config.options)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU-staged rehearsal of the N>1 path")
+    ap.add_argument("--band-rebalance", type=int, default=2, help="N > 1, GI + denoiser bands: rounds of measured-cost feedback after the modelled cut (each rank times its band, one all-gather, "
+                    "RT64_RebalanceGatherBands + RT64_SetGatherBands on every rank); 0 keeps the modelled cut")
     ap.add_argument("--halo", default="exchange", choices=["exchange", "recompute"], help="N > 1, GI + denoiser bands: exchange the denoiser's halo rows between neighbouring bands (RCCL) or re-render them on every band")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a 1-GPU box: every rank renders on device 0")
     ap.add_argument("--force-gather", action="store_true", help="rehearsal: run the N > 1 code path (enqueued frames + pipelined RCCL gather) with a world of 1")
@@ -235,6 +237,30 @@ def main():
         halo_mode = args.halo
         if args.halo == "exchange" and N > 1:
             scene.option("halo_exchange", 1)
+        # The modelled cut does not know which rows are expensive (the band over the sphere costs 1.5 x a band over the floor: tools/band_costs.py).  Feedback: every
+        # rank times the GPU work of its own band -- frames drawn synchronously, nothing submitted, and with the exchange in dry-run mode so that no rank waits for a
+        # neighbour inside the frame --, the figures are shared, every rank computes the same new boundaries and hands them to its gather.
+        rebalance_log = []
+        for rnd in range(args.band_rebalance if N > 1 else 0):
+            if halo_mode == "exchange":
+                scene.option("halo_dry_run", 1)
+            for _ in range(10):
+                scene.draw()
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            for _ in range(30):
+                scene.draw()
+            mine = torch.tensor([(time.perf_counter() - tb) * 1e3 / 30], dtype=torch.float32, device=comm_device)
+            scene.option("halo_dry_run", 0)
+            every = [torch.zeros_like(mine) for _ in range(N)]
+            dist.all_gather(every, mine)
+            ms = (C.c_float * N)(*[float(t.item()) for t in every])
+            new_starts = (C.c_int * (N + 1))()
+            if not lib.RebalanceGatherBands(H, N, band_starts, ms, new_starts) or not lib.SetGatherBands(gather, new_starts):
+                raise SystemExit("band rebalancing failed: " + lib.last_error())
+            rebalance_log.append({"ms_per_rank": [round(float(v), 4) for v in ms], "starts": [int(v) for v in band_starts]})
+            band_starts = new_starts
+        my_rows = band_starts[rank + 1] - band_starts[rank]
     elif native:
         my_rows = lib.GatherOwnedRows(H, N, 0, rank)
     my_bytes = (gatherer.owned_bytes() if gatherer else my_rows * W * 4) if G else H * W * 4
@@ -474,6 +500,8 @@ def main():
         }
         if args.config in sample_scene.BENCH_DEVIATIONS:       # how the configuration reads BASELINE.json's wording ("deviation"), or which extensions run it as worded
             result["config"]["extensions" if args.config.endswith("-literal") else "deviation"] = sample_scene.BENCH_DEVIATIONS[args.config]
+        if N > 1 and native and use_bands and rebalance_log:
+            result["band_rebalance"] = rebalance_log
         result["prewarm_frames"] = args.prewarm
         result["pass_events"] = "HIP events around every pass of every timed frame" if events_every == 1 else (
             "per-pass HIP events on every %dth timed frame (%d of %d frames sampled): each event is a barrier packet of ~5 us on the stream" % (events_every, stat_frames, args.steps))

@@ -155,6 +155,7 @@ struct Options {
     bool foldGuide = true;         // frames with the wavefront GI chain + SVGF: bounce_resolve_kernel writes the filter's guide records (0: svgf_guide_kernel, its own launch)
     bool overlapReflection = true; // frames with reflection passes AND the SVGF denoiser: the reflection launches run on a second stream beside the a-trous iterations (they share no image)
     bool haloExchange = false;     // band partitions of GI + SVGF frames: ship the filter input of the halo rows between the devices of the gather (RCCL) instead of re-rendering them
+    bool haloDryRun = false;       // timing aid: an exchanging band runs its frame but moves no halo rows (what one rank's GPU work costs, measured on one device; results outside the band's interior are then wrong)
     int haloMargin = SVGF_INPUT_HALO_ROWS;   // with a halo exchange: rows of G-buffer + GI kept around the band (temporal history under camera motion); at least SVGF_INPUT_HALO_ROWS
     int maxReflections = 2;        // rt64_view.cpp:60 (inspector-only knob in the reference)
     // Path-tracing extensions beyond the reference (one bounce per GI ray, IndirectRayGen.hlsl:58-131; one primary sample per pixel, rt64.h:172-182); DESIGN.md 4:
@@ -1732,6 +1733,7 @@ RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, doubl
     else if (k == "fold_guide") d->opt.foldGuide = value != 0.0;
     else if (k == "fold_compose") d->opt.foldCompose = value != 0.0;
     else if (k == "halo_exchange") d->opt.haloExchange = value != 0.0;
+    else if (k == "halo_dry_run") d->opt.haloDryRun = value != 0.0;
     else if (k == "halo_margin") d->opt.haloMargin = std::max((int)value, SVGF_INPUT_HALO_ROWS);
     else if (k == "bounce_split") d->opt.bounceSplit = (int)value;
     else if (k == "bounce_groups") d->opt.bounceGroups = value >= 0.0 && value <= (double)RT_MAX_BOUNCE_GROUPS ? (int)value : -1;
@@ -2002,6 +2004,35 @@ static void gather_balanced_bands(const uint32_t *hitCounts, int width, int heig
     starts[count] = height;
 }
 
+// Feedback step of the band balance: given the bands a frame was cut into and what each rank's share cost (ms of GPU work per frame, measured), the bands of
+// about equal cost under the assumption that a band's cost is spread evenly over its rows.  A fixed point when all costs are equal; the caller iterates
+// (measure, rebalance) two or three times.  Moves are damped to 9/10 of the way and every band keeps RT64_BAND_MIN_ROWS rows.
+static void gather_rebalanced_bands(int height, int count, const int *starts, const float *ms, int *out) {
+    // what moves with the boundaries is the cost above the part every band pays whatever its height (launches, latency tails: about half of the cheapest
+    // band's time on the sample scene); 0.4 of the cheapest band is taken as that part
+    double fixed = (double)ms[0];
+    for (int r = 1; r < count; r++) fixed = std::min(fixed, (double)ms[r]);
+    fixed = 0.4 * std::max(fixed, 0.0);
+    std::vector<double> cum((size_t)count + 1, 0.0);
+    for (int r = 0; r < count; r++) cum[(size_t)r + 1] = cum[(size_t)r] + std::max((double)ms[r] - fixed, 1e-6);
+    const double total = cum[(size_t)count];
+    const int minRows = height >= count * RT64_BAND_MIN_ROWS ? RT64_BAND_MIN_ROWS : std::max(height / count, 1);
+    out[0] = 0;
+    for (int k = 1; k < count; k++) {
+        const double target = total * (double)k / (double)count;
+        int r = 0; while (r + 1 < count && cum[(size_t)r + 1] < target) r++;                  // the band the k-th cut falls into
+        const double rows = (double)(starts[r + 1] - starts[r]), inside = (target - cum[(size_t)r]) / (cum[(size_t)r + 1] - cum[(size_t)r]);
+        const double ideal = (double)starts[r] + rows * std::min(std::max(inside, 0.0), 1.0);
+        int y = (int)std::lround((double)starts[k] + 0.9 * (ideal - (double)starts[k]));
+        y = std::max(y, out[k - 1] + minRows);
+        y = std::min(y, height - (count - k) * minRows);
+        out[k] = std::max(y, out[k - 1]);
+    }
+    out[count] = height;
+}
+
+static bool halo_starts_valid(int H, int count, const int *starts);
+
 struct Gather {
     Device *dev; int rank, count, bands; int W, H; size_t slotBytes; GatherLayout layout;
     ncclComm_t comm = nullptr; hipStream_t commStream = nullptr;
@@ -2012,6 +2043,7 @@ struct Gather {
     void prepare(int slot);
     int submit();
     void wait(int slot, bool host);
+    void setBands(const int *starts);
 };
 
 Gather::Gather(Device *d, const ncclUniqueId &id, int rank_, int count_, int bands_) : dev(d), rank(rank_), count(count_), bands(bands_) {
@@ -2100,6 +2132,29 @@ int Gather::submit() {
     prepare(next);
     return slot;
 }
+// New boundaries for a gather of cost-balanced bands (RT64_SetGatherBands): every rank calls it with the same boundaries between the same two frames.
+void Gather::setBands(const int *starts) {
+    if (bands != 2) throw std::runtime_error("RT64_SetGatherBands: only a gather of cost-balanced bands (bands = 2) takes new boundaries.");
+    if (!halo_starts_valid(H, count, starts)) throw std::runtime_error("RT64_SetGatherBands: starts[0 .. count] must rise from 0 to the frame height.");
+    dev->use();
+    HIP_CHECK(hipStreamSynchronize(dev->stream)); HIP_CHECK(hipStreamSynchronize(commStream));        // nothing of the old layout is in flight
+    for (Slot &sl : slots) sl.pending = false;
+    for (int r = 0; r <= count; r++) layout.starts[r] = starts[r];
+    const size_t need = (size_t)gather_max_owned_rows(layout) * (size_t)W * 4;
+    if (need > slotBytes) {
+        for (Slot &sl : slots) {
+            if (dev->gatherTarget == sl.local) { dev->gatherTarget = nullptr; dev->gatherTargetBytes = 0; }
+            HIP_CHECK(hipFree(sl.local)); sl.local = nullptr;
+            HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&sl.local), need));
+            HIP_CHECK(hipMemsetAsync(sl.local, 0, need, dev->stream));
+            if (rank == 0) { HIP_CHECK(hipFree(sl.bucket)); sl.bucket = nullptr; HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&sl.bucket), need * (size_t)count)); }
+        }
+        slotBytes = need;
+        HIP_CHECK(hipStreamSynchronize(dev->stream));
+    }
+    dev->tileSet = true; dev->tileY0 = layout.starts[rank]; dev->tileY1 = layout.starts[rank + 1]; dev->stripRank = 0; dev->stripCount = 1;
+    prepare(next);
+}
 void Gather::wait(int slot, bool host) {
     Slot &sl = slots[slot];
     if (host) HIP_CHECK(hipEventSynchronize(sl.gathered));
@@ -2153,6 +2208,7 @@ static void halo_exchange(Device *dev, const ViewImages &img, int W, int H, hipS
     const int n = halo_plan(H, count, starts.data(), rank, SVGF_ATROUS_HALO_ROWS, regs, 2 * RT64_GATHER_MAX_RANKS);
     uint8_t *colour = reinterpret_cast<uint8_t *>(img.filteredIndirect[0]), *colourOther = reinterpret_cast<uint8_t *>(img.filteredIndirect[1]), *guide = reinterpret_cast<uint8_t *>(img.svgfGuide);
     const size_t rowC = (size_t)W * 8, rowG = (size_t)W * 16;
+    if (dev->opt.haloDryRun) return;         // timing aid (tools/band_costs.py): the frame of an exchanging band without the transfer itself -- the halo rows keep whatever they held
     if (h.fn) {
         size_t total = 0;
         for (int k = 0; k < n; k++) { regs[k].bytes = (size_t)(regs[k].y1 - regs[k].y0) * (rowC + rowG); total += regs[k].bytes; }
@@ -2290,6 +2346,14 @@ RT64_EXPORT int RT64_GetGatherBands(RT64_GATHER *gather, int *starts, int capaci
     return g->count;
 }
 // The same cut as a pure function: boundaries of `count` cost-balanced bands from per-row hit counts (what RT64_CreateGather(bands = 2) computes from its last frame).
+RT64_EXPORT int RT64_RebalanceGatherBands(int height, int count, const int *starts, const float *msPerRank, int *newStarts) {
+    if (!halo_starts_valid(height, count, starts) || !msPerRank || !newStarts) return 0;
+    gather_rebalanced_bands(height, count, starts, msPerRank, newStarts);
+    return 1;
+}
+RT64_EXPORT int RT64_SetGatherBands(RT64_GATHER *gather, const int *starts) {
+    RT64_TRY Gather *g = reinterpret_cast<Gather *>(gather); if (!g || !starts) return 0; g->setBands(starts); return 1; RT64_CATCH(0)
+}
 RT64_EXPORT void RT64_BalanceGatherBands(const unsigned int *hitCounts, int width, int height, int count, int *starts) {
     if (hitCounts && starts && width > 0 && height > 0 && count >= 1 && count <= RT64_GATHER_MAX_RANKS) gather_balanced_bands(hitCounts, width, height, count, starts);
 }

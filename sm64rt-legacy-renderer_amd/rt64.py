@@ -209,6 +209,8 @@ EXT_API = [
     ("GatherSlotRowsOf", "RT64_GatherSlotRowsOf", C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
     ("GetGatherBands", "RT64_GetGatherBands", C.c_int, [_P, C.POINTER(C.c_int), C.c_int]),
     ("BalanceGatherBands", "RT64_BalanceGatherBands", None, [C.POINTER(C.c_uint), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    ("RebalanceGatherBands", "RT64_RebalanceGatherBands", C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    ("SetGatherBands", "RT64_SetGatherBands", C.c_int, [_P, C.POINTER(C.c_int)]),
     ("HaloPlan", "RT64_HaloPlan", C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, _P, C.c_int]),
     ("SetDeviceHaloExchange", "RT64_SetDeviceHaloExchange", C.c_int, [_P, _P, _P, C.POINTER(C.c_int), C.c_int, C.c_int]),
 ]

@@ -47,6 +47,39 @@ def test_world_of_one_gather_returns_the_devices_frame(rt64_lib, sample_data, ba
         s.close()
 
 
+def test_set_gather_bands_on_a_world_of_one_and_the_dry_run_option(rt64_lib, sample_data):
+    """RT64_SetGatherBands on the one rank a test box has: a gather of cost-balanced bands takes new boundaries (here the only valid ones, [0, H]) and goes on
+    gathering the same frame; boundaries that do not span the frame and gathers of strips / equal bands are refused with an error; device option halo_dry_run is
+    accepted (the timing aid of tools/band_costs.py: it only has an effect on a band with an exchange set up)."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    W, H = 320, 180
+    s = sample_scene.Rt64Scene(rt64_lib, sample_data, W, H, hip_device=0)
+    try:
+        s.set_view_description(gi_samples=1, denoiser=True)
+        s.draw()                                             # cost-balanced bands are cut from a whole frame
+        uid = (C.c_uint8 * rt64.GATHER_ID_BYTES)()
+        assert rt64_lib.GetGatherUniqueId(uid, len(uid)) == 1
+        g = rt64_lib.CreateGather(s.device, uid, len(uid), 0, 1, 2)
+        assert g, rt64_lib.last_error()
+        s.draw(); rt64_lib.SubmitGather(g)
+        a = np.zeros((H, W, 4), dtype=np.uint8)
+        assert rt64_lib.ReadbackGather(g, -1, a.ctypes.data, a.nbytes, 0) == a.nbytes
+        assert rt64_lib.SetGatherBands(g, (C.c_int * 2)(0, H)) == 1, rt64_lib.last_error()
+        assert rt64_lib.SetGatherBands(g, (C.c_int * 2)(0, H - 1)) == 0 and "starts" in rt64_lib.last_error()
+        assert s.option("halo_dry_run", 1) and s.option("halo_dry_run", 0)
+        s.draw(); rt64_lib.SubmitGather(g)
+        b = np.zeros((H, W, 4), dtype=np.uint8)
+        assert rt64_lib.ReadbackGather(g, -1, b.ctypes.data, b.nbytes, 0) == b.nbytes
+        assert np.array_equal(b, s.readback(rt64.IMAGE_FINAL_RGBA8))
+        assert np.abs(a.astype(np.int32) - b.astype(np.int32)).mean() < 2.0          # consecutive frames of the same scene (GI noise only)
+        rt64_lib.DestroyGather(g)
+        g1 = rt64_lib.CreateGather(s.device, uid, len(uid), 0, 1, 1)
+        assert g1 and rt64_lib.SetGatherBands(g1, (C.c_int * 2)(0, H)) == 0 and "bands = 2" in rt64_lib.last_error()
+        rt64_lib.DestroyGather(g1)
+    finally:
+        s.close()
+
+
 def test_c_host_gathers_through_the_c_abi(rt64_lib):
     """tools/sample_host.c --ranks 1: fork-before-GPU launcher, id over a pipe, RT64_CreateGather + RT64_SubmitGather per frame from C; the
     gathered frame has the checksum of the frame the same host renders without a gather."""
