@@ -73,6 +73,7 @@ def test_set_gather_bands_on_a_world_of_one_and_the_dry_run_option(rt64_lib, sam
         assert np.array_equal(b, s.readback(rt64.IMAGE_FINAL_RGBA8))
         assert np.abs(a.astype(np.int32) - b.astype(np.int32)).mean() < 2.0          # consecutive frames of the same scene (GI noise only)
         rt64_lib.DestroyGather(g)
+        assert rt64_lib.GetGatherUniqueId(uid, len(uid)) == 1    # (an id makes one communicator)
         g1 = rt64_lib.CreateGather(s.device, uid, len(uid), 0, 1, 1)
         assert g1 and rt64_lib.SetGatherBands(g1, (C.c_int * 2)(0, H)) == 0 and "bands = 2" in rt64_lib.last_error()
         rt64_lib.DestroyGather(g1)
