@@ -621,6 +621,20 @@ __global__ __launch_bounds__(BLOCK, WAVES) void lean_frame_kernel(FrameParams Pv
         uint32_t hwId; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwId));
         P.tileTiming[2 * ((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6))] = make_uint4((uint32_t)__builtin_amdgcn_s_memrealtime(), (uint32_t)__builtin_amdgcn_s_memtime(), hwId, 1u);
     }
+    // (one-wave workgroups, device option tile_order) what a trip cost -- the most node + triangle visits any of its lanes made -- goes to its tile's entry for the next
+    // frame's order: lanes leave a trip at different places, so each notes its visits with an LDS max where it leaves (note_cost) and the wave, converged again at the
+    // top of the next trip and behind the loop, hands the trip's figure to the tile (flush_cost)
+    __shared__ uint32_t ldsTripCost;
+    uint32_t tileOfTrip = 0xFFFFFFFFu, visitsBefore = 0;
+    const bool costed = BLOCK != RT_BLOCK && P.tileCost != nullptr;
+    if (costed && threadIdx.x == 0) ldsTripCost = 0;
+    auto note_cost = [&]() { if (costed) atomicMax(&ldsTripCost, env.cnt.nodes + env.cnt.tris - visitsBefore); };
+    auto flush_cost = [&](PRef P) {
+        if (!costed || tileOfTrip == 0xFFFFFFFFu) return;
+        __syncthreads();             // (one wave: orders the lanes' LDS notes before lane 0 reads them)
+        if (threadIdx.x == 0) { atomicMax(&P.tileCost[tileOfTrip], ldsTripCost); ldsTripCost = 0; }
+        tileOfTrip = 0xFFFFFFFFu;
+    };
     for (uint32_t trip = blockIdx.x; trip < trips; trip += gridDim.x) {
         PRef P = *kernel_params_here(); IRef I = *kernel_images_here();      // this tile's view of the frame constants and the image table: read where used, never carried across tiles
         // tiles are walked from the bottom of the frame up: the expensive ones (geometry) start first and the cheap ones (sky, at the
@@ -628,9 +642,13 @@ __global__ __launch_bounds__(BLOCK, WAVES) void lean_frame_kernel(FrameParams Pv
         Pixel p;
         if (BLOCK == RT_BLOCK) p = tile_pixel(P, tiles - 1u - trip);
         else {
-            uint32_t tileSeq, quadrant;
-            if (!wave_tile_of(trip, tiles, tileSeq, quadrant)) continue;
-            p = tile_pixel_at(P, tiles - 1u - tileSeq, quadrant, threadIdx.x & 63u);
+            uint32_t tileSlot, quadrant;
+            flush_cost(P);
+            if (!wave_tile_of(trip, tiles, tileSlot, quadrant)) continue;
+            // longest-first (device option tile_order): slot -> tile through last frame's cost order; the four quadrants of a tile keep their XCD
+            tileOfTrip = P.tileOrder ? P.tileOrder[tileSlot] : tileSlot;
+            p = tile_pixel_at(P, tiles - 1u - tileOfTrip, quadrant, threadIdx.x & 63u);
+            visitsBefore = env.cnt.nodes + env.cnt.tris;
         }
         if (!p.valid) continue;
         const uint32_t px = p.x, py = p.y;
@@ -657,7 +675,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void lean_frame_kernel(FrameParams Pv
         resolve_primary<false, false, FULL>(P, I, env, px, py, i, o, rayDirection, ndc, h, nhits, R);
         if (FULL) {
             store_primary<true>(P, I, i, cur, rayDirection, R);
-            if ((int)py < ownedY0 || (int)py >= ownedY1) continue;          // halo row: G-buffer only
+            if ((int)py < ownedY0 || (int)py >= ownedY1) { note_cost(); continue; }          // halo row: G-buffer only
         }
         const f4 diffuse = mk4(q_unorm8(R.color.x), q_unorm8(R.color.y), q_unorm8(R.color.z), q_unorm8(R.color.w));     // rtDiffuse is RGBA8
         f3 direct = mk3s(1.0f); float historyLength = 0.0f;                                                            // DirectRayGen.hlsl:19
@@ -669,7 +687,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void lean_frame_kernel(FrameParams Pv
             direct = lerp3(mk3s(0.0f), resDirect, s_rcp(historyLength));
         }
         if (keepRecords) store_rgba16f(I.directLight[cur], i, direct.x, direct.y, direct.z, historyLength);
-        if (FULL) { store_rgba16f(I.filteredDirect[1], i, direct.x, direct.y, direct.z, historyLength); continue; }
+        if (FULL) { store_rgba16f(I.filteredDirect[1], i, direct.x, direct.y, direct.z, historyLength); note_cost(); continue; }
         const f3 result = compose_lean_value(P, diffuse, mk3(q_f16(direct.x), q_f16(direct.y), q_f16(direct.z)));
         if (P.separatePost) reinterpret_cast<float4 *>(I.output)[i] = make_float4(result.x, result.y, result.z, 1.0f);
         else {
@@ -687,7 +705,9 @@ __global__ __launch_bounds__(BLOCK, WAVES) void lean_frame_kernel(FrameParams Pv
                 P.finalPacked[(size_t)prow * (size_t)P.width + px] = bits;
             }
         }
+        note_cost();
     }
+    flush_cost(P);
     if (P.tileTiming) {       // end record: clock, then the most node + triangle visits any lane of the wave made and the wave's total (<< 8 | 1: the valid mark)
         uint32_t worst = env.cnt.nodes + env.cnt.tris, total = worst;
 #pragma unroll
@@ -945,7 +965,7 @@ __global__ __launch_bounds__(RT_BLOCK, TRACE_WAVES) void bounce_trace_plain_kern
 #else
                 const f3 resIndirect = ambientBase + bounce_sky_term(P, rayDirection) * (P.giSkyStrength * 1.0f);
 #endif
-                I.bounceResults[id] = make_float4(resIndirect.x, resIndirect.y, resIndirect.z, 0.0f);
+                I.bounceResults[id] = BounceRadiance{ resIndirect.x, resIndirect.y, resIndirect.z };
                 continue;
             }
             uint4 a, b;
@@ -1054,7 +1074,7 @@ __global__ __launch_bounds__(RT_BLOCK, CACHED ? SPLIT_WAVES : TRACE_WAVES) void 
                     else {
                         env.cnt.nodes += visited; rays++;
                         const f3 resIndirect = ambientBase + bounce_sky_term(P, rayDirection) * (P.giSkyStrength * 1.0f);
-                        I.bounceResults[id] = make_float4(resIndirect.x, resIndirect.y, resIndirect.z, 0.0f);
+                        I.bounceResults[id] = BounceRadiance{ resIndirect.x, resIndirect.y, resIndirect.z };
                     }
                 }
             }
@@ -1084,7 +1104,7 @@ __global__ __launch_bounds__(RT_BLOCK, CACHED ? SPLIT_WAVES : TRACE_WAVES) void 
             rays++;
             if (!best.hit) {
                 const f3 resIndirect = ambientBase + bounce_sky_term(P, rayDirection) * (P.giSkyStrength * 1.0f);
-                I.bounceResults[id] = make_float4(resIndirect.x, resIndirect.y, resIndirect.z, 0.0f);
+                I.bounceResults[id] = BounceRadiance{ resIndirect.x, resIndirect.y, resIndirect.z };
                 continue;
             }
             uint4 a;
@@ -1246,7 +1266,7 @@ __global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void bounce_hit_kernel(Fram
         }
         if (resColor.w != 0.0f) resIndirect = resIndirect + bounce_sky_term(P, rayDirection) * (P.giSkyStrength * resColor.w);
         else resIndirect = resIndirect + mk3s(0.0f) * (P.giSkyStrength * resColor.w);
-        I.bounceResults[id] = make_float4(resIndirect.x, resIndirect.y, resIndirect.z, 0.0f);
+        I.bounceResults[id] = BounceRadiance{ resIndirect.x, resIndirect.y, resIndirect.z };
     }
     flush_env(P, env, PASS_INDIRECT, CTR_INDIRECT, rays);
 }
@@ -1262,7 +1282,7 @@ __global__ __launch_bounds__(RT_BLOCK) void bounce_miss_kernel(FrameParams Pv, V
         const uint4 b = I.bounceRecords[(size_t)id * 2 + 1];
         const f3 rayDirection = mk3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
         const f3 resIndirect = ambientBase + bounce_sky_term(P, rayDirection) * (P.giSkyStrength * 1.0f);
-        I.bounceResults[id] = make_float4(resIndirect.x, resIndirect.y, resIndirect.z, 0.0f);
+        I.bounceResults[id] = BounceRadiance{ resIndirect.x, resIndirect.y, resIndirect.z };
     }
 }
 
@@ -1300,8 +1320,8 @@ __global__ __launch_bounds__(256) void bounce_resolve_kernel(FrameParams Pv, Vie
         newIndirect = xyz(prevAccum); historyLength = prevAccum.w * w;
     }
     for (uint32_t smp = P.giSamples; smp > 0; smp--) {
-        const float4 v = I.bounceResults[(size_t)(smp - 1) * stride + i];
-        const f3 resIndirect = mk3(v.x, v.y, v.z);
+        const BounceRadiance v = I.bounceResults[(size_t)(smp - 1) * stride + i];
+        const f3 resIndirect = mk3(v.r, v.g, v.b);
         historyLength = fminf(historyLength + 1.0f, 64.0f);
         newIndirect = lerp3(newIndirect, resIndirect, s_rcp(historyLength));
         { const float l = 0.2126f * resIndirect.x + 0.7152f * resIndirect.y + 0.0722f * resIndirect.z; sumL += l; sumL2 += l * l; }
@@ -1540,6 +1560,38 @@ __global__ __launch_bounds__(256) void compose_post_kernel(FrameParams Pv, ViewI
     else result = xyz(d);
     reinterpret_cast<float4 *>(I.output)[i] = make_float4(result.x, result.y, result.z, 1.0f);
     if (!P.separatePost && writeFinal) store_rgba8(I.final, i, result.x, result.y, result.z, 1.0f);   // PostProcessPS passthrough (motionBlurStrength == 0, render size == screen size)
+}
+
+// Longest-first order of the one-kernel frame's tiles (device option tile_order; scenes that walk from HBM): tiles sorted by the cost the frame just recorded, most
+// expensive first -- a counting sort over min(cost, 1023) in one workgroup (a 1080p frame has 8 160 tiles) -- and the costs cleared for the next frame.  Ties land in
+// whatever order the atomics resolve: any permutation renders the same picture.
+__global__ __launch_bounds__(1024) void tile_order_kernel(uint32_t *cost, uint32_t *order, uint32_t n) {
+    __shared__ uint32_t bucket[1024];
+    __shared__ uint32_t carry;
+    bucket[threadIdx.x] = 0;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) atomicAdd(&bucket[1023u - min(cost[i], 1023u)], 1u);
+    __syncthreads();
+    // exclusive scan of the 1024 counts: a wave scans its 64, then the 16 wave totals are added up by every thread
+    const uint32_t mine = bucket[threadIdx.x];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64); if ((threadIdx.x & 63u) >= (uint32_t)d) incl += up; }
+    __shared__ uint32_t waveTotal[16];
+    if ((threadIdx.x & 63u) == 63u) waveTotal[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) base += waveTotal[w];
+    bucket[threadIdx.x] = base + incl - mine;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+        const uint32_t b = 1023u - min(cost[i], 1023u);
+        order[atomicAdd(&bucket[b], 1u)] = i;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) cost[i] = 0;
+    (void)carry;
 }
 
 // Extension primary_spp (rule P3, oracle/oracle_render.c): rtOutput of sub-frame `sub` added to the running sum of the frame's sub-frames, in order; the last
@@ -1807,6 +1859,14 @@ hipError_t launch_compose_post(const FrameParams &P, const ViewImages &I, int cu
     dim3 grid((unsigned)(P.width + 31) / 32, (unsigned)(P.tileY1 - P.tileY0 + 7) / 8);
     if (lean) hipLaunchKernelGGL(compose_post_kernel<true>, grid, dim3(256), 0, s, P, I, cur, writeFinal ? 1 : 0);
     else hipLaunchKernelGGL(compose_post_kernel<false>, grid, dim3(256), 0, s, P, I, cur, writeFinal ? 1 : 0);
+    return hipGetLastError();
+}
+unsigned lean_frame_tiles(const FrameParams &P) {
+    const unsigned strips = (unsigned)(P.tileY1 - P.tileY0 + 15) / 16, owned = strips > (unsigned)P.stripRank ? (strips - (unsigned)P.stripRank + (unsigned)P.stripCount - 1) / (unsigned)P.stripCount : 0u;
+    return (unsigned)((P.width + 15) / 16) * owned;
+}
+hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, uint32_t tiles, hipStream_t s) {
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, cost, order, tiles);
     return hipGetLastError();
 }
 hipError_t launch_spp_accumulate(const FrameParams &P, const ViewImages &I, float *sum, int sub, int count, hipStream_t s) {

@@ -129,6 +129,9 @@ struct FrameParams {
     // accesses, and a bilinear footprint then touches 1.56 cache lines on average instead of 2.1 (nullptr: not a power-of-two texture)
     const uint32_t *skyTiled; uint32_t skyTiledLog2W, skyTiledLog2H;
     uint32_t lightCount, instanceCount, countTraversal;
+    // Longest-first order of the one-kernel frame's tiles on scenes that walk from HBM (one-wave workgroups): tileOrder[slot] = tile (bottom-up number) by last frame's
+    // cost, most expensive first (nullptr: slot = tile); tileCost[tile] = the most node + triangle visits any lane of the tile made this frame (atomicMax; nullptr: not recorded)
+    uint32_t *tileCost; const uint32_t *tileOrder;
     uint32_t giBounces;                  // extension (device option gi_bounces): 2 = a GI ray that resolves to a surface sends a second ray from there (rules B1-B3, oracle/oracle_render.c); otherwise the reference's one bounce
     const GpuInstance *instances;
     const GpuNode *tlasNodes;
@@ -140,6 +143,8 @@ struct FrameParams {
     uint4 *tileTiming;                   // profiling aid (device option tile_timing), nullptr = off: two records per wave of the one-kernel frame: at its start { 100 MHz chip-wide clock, shader clock, HW_ID, 1 } and at its end { clock, shader clock, 0, 1 }
     unsigned long long *counters;        // [0] nodes [1] triangles [2] primary rays [3] shadow rays [4] indirect [5] reflection [6] refraction
 };
+
+struct BounceRadiance { float r, g, b; };
 
 // G-buffer images of one view (device pointers), in the reference's formats.
 struct ViewImages {
@@ -160,7 +165,7 @@ struct ViewImages {
     float *moments[2];                   // SVGF: RG32F luminance moments
     uint4 *bounceRecords;                // IndirectRayGen wavefront: 2 x uint4 per (GI sample, pixel), sized for bounceSamples
     uint32_t *bounceLists, *bounceCounts; // ids of the traced rays compacted by outcome: [0, cap) hits, [cap, 2 cap) misses; counts[2]
-    float4 *bounceResults;               // radiance of every (GI sample, pixel)
+    BounceRadiance *bounceResults;       // radiance of every (GI sample, pixel), 12 bytes (round 3: was a float4 with an unused lane -- 4 x 16 B read by the resolve and written by the walk / hit kernels per pixel of C5)
     uint4 *svgfGuide;                    // SVGF: 16-B guide record per pixel (normal 3 x f16, valid, depth, depth gradient)
     // Per-pixel sorted hit list (k-buffer), [RT64_MAX_HIT_QUERIES + 1][pixels]; allocated only while some instance is not
     // provably opaque.  The reference keeps 17 x 34 B per pixel for every frame (rt64_view.cpp:237-241).

@@ -151,6 +151,7 @@ struct Options {
     int bounceSplit = -1;         // two-phase bounce walk (TLAS part first, survivors compacted through LDS): 1 on, 0 off, -1 auto (scenes with the LDS scene cache, two or more GI samples per pixel)
     int bounceRefill = -1;        // bounce-ray traversal with wave-ballot refill: 1 on, 0 off, -1 auto (on when the scene has >= 64 Ki triangles)
     int denoiserMode = 1;          // 0 = reference 5x Gaussian, 1 = SVGF
+    bool tileOrder = true;         // one-kernel frame of scenes without the LDS scene cache (one-wave workgroups): tiles start in the order of their cost in the frame before, most expensive first
     bool foldCompose = true;       // frames with the SVGF denoiser: ComposePS inside the last a-trous iteration (0: compose_post_kernel, its own launch)
     bool foldGuide = true;         // frames with the wavefront GI chain + SVGF: bounce_resolve_kernel writes the filter's guide records (0: svgf_guide_kernel, its own launch)
     bool overlapReflection = true; // frames with reflection passes AND the SVGF denoiser: the reflection launches run on a second stream beside the a-trous iterations (they share no image)
@@ -357,6 +358,8 @@ struct View {
     FrameParams lastParams; int lastCur = 0;
     // extension primary_spp (rules P1-P4, oracle/oracle_render.c): the frame as `subFrames` complete sub-frames; Device::draw drives them
     int subFrame = 0, subFrames = 1; DevArray<float> sppSum;
+    // longest-first tile order of the one-kernel frame on scenes that walk from HBM (device option tile_order): last frame's cost per tile and the order made from it
+    DevArray<uint32_t> tileCost, tileOrder; uint32_t tileOrderTiles = 0; bool tileOrderValid = false;
 
     explicit View(Scene *s);
     ~View();
@@ -1255,8 +1258,8 @@ void View::render() {                          // View::render, rt64_view.cpp:11
             const size_t tilesAll = (size_t)((imgW + 15) / 16) * (size_t)((imgH + 15) / 16);
             HIP_CHECK(hipMalloc(&l, (size_t)giSamples * (tilesAll + std::min<size_t>(tilesAll, RT_MAX_BOUNCE_GROUPS)) * 256 * 2 * sizeof(uint32_t))); allocations.push_back(l);
             HIP_CHECK(hipMalloc(&c, (size_t)RT_MAX_BOUNCE_GROUPS * 2 * sizeof(uint32_t))); allocations.push_back(c);
-            HIP_CHECK(hipMalloc(&r, (size_t)giSamples * n * sizeof(float4))); allocations.push_back(r);
-            img.bounceLists = static_cast<uint32_t *>(l); img.bounceCounts = static_cast<uint32_t *>(c); img.bounceResults = static_cast<float4 *>(r);
+            HIP_CHECK(hipMalloc(&r, (size_t)giSamples * n * sizeof(BounceRadiance))); allocations.push_back(r);
+            img.bounceLists = static_cast<uint32_t *>(l); img.bounceCounts = static_cast<uint32_t *>(c); img.bounceResults = static_cast<BounceRadiance *>(r);
         }
         const bool klist = anyNonOpaque;
         // Image-tile partition with a spatial filter downstream: the GI denoiser reads a neighbourhood of every row this device
@@ -1297,17 +1300,36 @@ void View::render() {                          // View::render, rt64_view.cpp:11
             P.finalPacked = static_cast<uint32_t *>(dev->gatherTarget);
             packedFinal = true;
         }
+        // Scenes that walk from HBM run the one-kernel frame as one-wave workgroups whose lengths differ by two orders of magnitude (a shadow ray that grazes a dense mesh
+        // walks hundreds of dependent fetches): the launch is as long as its longest wave plus the time that wave waited to start.  Each tile's cost (the most visits any
+        // of its lanes made) is recorded by the frame and the next frame starts its tiles most expensive first (tile_order_kernel; the scene changes little between frames).
+        auto orderTiles = [&](FrameParams &F) -> unsigned {
+            if (!(dev->opt.tileOrder && perWave && !F.cacheWords)) return 0u;
+            const unsigned tiles = lean_frame_tiles(F);
+            if (tiles == 0u) return 0u;
+            if (tileOrderTiles != tiles) {
+                tileCost.reserve(tiles); tileOrder.reserve(tiles);
+                HIP_CHECK(hipMemsetAsync(tileCost.ptr, 0, (size_t)tiles * 4, s));
+                tileOrderTiles = tiles; tileOrderValid = false;
+            }
+            F.tileCost = tileCost.ptr; F.tileOrder = tileOrderValid ? tileOrder.ptr : nullptr;
+            return tiles;
+        };
         if (fused) {
             // nullptr: the frame stores its back buffer only (hit records and the direct-light image come back through materialise); option lean_records = 1 keeps them
             if (P.tileTiming) { HIP_CHECK(hipMemsetAsync(dev->tileTiming.ptr, 0, dev->tileTiming.bytes(), s)); }
+            const unsigned ordered = orderTiles(P);
             L(launch_lean_frame(P, img, dev->opt.leanRecords ? hitInstance.ptr : nullptr, cur, false, 0, imgH, dev->opt.maxFrameGroups, perWave, s));
+            if (ordered) { L(launch_tile_order(tileCost.ptr, tileOrder.ptr, ordered, s)); tileOrderValid = true; }
             fusedStoreless = !dev->opt.leanRecords;
             mark(Device::EV_PRIMARY_TRACE); mark(Device::EV_PRIMARY); mark(Device::EV_DIRECT);
         }
         else if (fusedFull) {
             if (P.stripCount > 1 && (X.tileY0 != P.tileY0 || X.tileY1 != P.tileY1)) throw std::runtime_error("RT64_DrawDevice: interleaved strips with a denoiser halo.");
             if (X.tileTiming) { HIP_CHECK(hipMemsetAsync(dev->tileTiming.ptr, 0, dev->tileTiming.bytes(), s)); }
+            const unsigned ordered = orderTiles(X);
             L(launch_lean_frame(X, img, hitInstance.ptr, cur, true, P.tileY0, P.tileY1, dev->opt.maxFrameGroups, perWave, s));
+            if (ordered) { L(launch_tile_order(tileCost.ptr, tileOrder.ptr, ordered, s)); tileOrderValid = true; }
             mark(Device::EV_PRIMARY_TRACE); mark(Device::EV_PRIMARY); mark(Device::EV_DIRECT);
         }
         else {
@@ -1730,6 +1752,7 @@ RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, doubl
     else if (k == "denoiser_mode") d->opt.denoiserMode = (int)value;
     else if (k == "bounce_refill") d->opt.bounceRefill = (int)value;
     else if (k == "overlap_reflection") d->opt.overlapReflection = value != 0.0;
+    else if (k == "tile_order") d->opt.tileOrder = value != 0.0;
     else if (k == "fold_guide") d->opt.foldGuide = value != 0.0;
     else if (k == "fold_compose") d->opt.foldCompose = value != 0.0;
     else if (k == "halo_exchange") d->opt.haloExchange = value != 0.0;

@@ -601,3 +601,36 @@ def test_bounce_walk_in_two_phases_matches_the_plain_walk(rt64_lib, sample_data,
     assert (sa.nodesVisited, sa.trianglesTested) == (sb.nodesVisited, sb.trianglesTested)
     for k in a:
         assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("gi", [0, 1])
+def test_tiles_started_in_cost_order_render_the_same_frame(rt64_lib, sample_data, gi):
+    """Scenes that walk from HBM run the one-kernel frame as one-wave workgroups; device option tile_order (on by default) starts their tiles in the order of the cost
+    the frame before recorded, most expensive first (tile_order_kernel).  lds_cache = 0 puts the sample scene on that path: over four frames -- the first one in the
+    bottom-up order, the others in the recorded one -- every image and every counter equals the run with the option off, for the lean kernel (gi = 0) and the
+    G-buffer-writing one (gi = 1), with several trips per workgroup as well (max_frame_groups = 20)."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    W, H = 320, 180
+    names = ("OUTPUT_RGBA32F", "FINAL_RGBA8", "PRIMARY_HIT", "DIRECT_LIGHT_RAW", "SHADING_NORMAL")
+    out = {}
+    for groups in (0, 20):
+        for order in (1, 0):
+            s = sample_scene.Rt64Scene(rt64_lib, sample_data, W, H, hip_device=0)
+            try:
+                if gi:
+                    s.set_view_description(gi_samples=1, denoiser=True)
+                assert s.option("lds_cache", 0) and s.option("tile_order", order) and s.option("count_traversal", 1)
+                if groups:
+                    assert s.option("max_frame_groups", groups)
+                for _ in range(4):
+                    s.draw()
+                st = s.stats()
+                assert st.fusedFrame == (2 if gi else 1)
+                out[groups, order] = ({k: s.readback(getattr(rt64, "IMAGE_" + k)) for k in names},
+                                      (st.primaryRays, st.shadowRays, st.nodesVisited, st.trianglesTested, st.nodesPrimary, st.trianglesPrimary))
+            finally:
+                s.close()
+        a, b = out[groups, 1], out[groups, 0]
+        assert a[1] == b[1]
+        for k in names:
+            assert np.array_equal(a[0][k].view(np.uint8), b[0][k].view(np.uint8)), (groups, k)
