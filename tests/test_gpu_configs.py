@@ -127,8 +127,8 @@ def test_c5_four_gi_samples_reflective_floor_svgf(rt64_lib, sample_data, bands):
         assert sum(s.reflectionRays for s in st) == c["reflectionRays"] > 0
 
 
-@pytest.mark.parametrize("config,frames", [("C4-literal", 3), ("C5-literal", 2)])
-def test_c4_c5_as_baseline_words_them_primary_spp_and_two_bounces(rt64_lib, sample_data, config, frames):
+@pytest.mark.parametrize("config,frames,bands", [("C4-literal", 3, None), ("C5-literal", 2, None), ("C5-literal", 2, [(0, 64), (64, 121), (121, H)])])
+def test_c4_c5_as_baseline_words_them_primary_spp_and_two_bounces(rt64_lib, sample_data, config, frames, bands):
     """BASELINE.json words C4 "2-bounce GI 1440p 2spp" and C5 "4K 4spp full path trace".  The reference has neither knob; the library carries both as
     extensions (device options primary_spp / gi_bounces) and the oracle implements the same rules (P1-P4, B1-B3 in oracle/oracle_render.c): N jittered
     sub-frames -- every pass up to Compose, history advancing after each -- averaged before PostProcess, and a second cosine-weighted bounce whose
@@ -136,9 +136,12 @@ def test_c4_c5_as_baseline_words_them_primary_spp_and_two_bounces(rt64_lib, samp
     BASELINE gate, rays counted over all sub-frames."""
     from sm64rt_legacy_renderer_amd import sample_scene
     cfg = sample_scene.BENCH_CONFIGS[config]
-    got, ref, st = _bench_pair(rt64_lib, sample_data, config, frames=frames)
+    got, ref, st = _bench_pair(rt64_lib, sample_data, config, frames=frames, bands=bands)
     _check_gi_frame(got, ref)
     c = ref["counters"]
+    if bands:            # the multi-GPU partition (ragged bands + denoiser halo, every sub-frame): the bands put together are the oracle's frame; halo rows are traced again
+        assert sum(s.primaryRays for s in st) > c["primaryRays"] and sum(s.reflectionRays for s in st) == c["reflectionRays"] > 0
+        return
     assert st[0].primaryRays == c["primaryRays"] == cfg["primary_spp"] * W * H
     assert st[0].indirectRays == c["indirectRays"]
     hit = int((ref["instanceId"] >= 0).sum())
