@@ -94,7 +94,8 @@ hipError_t launch_svgf(const ViewImages &I, int cur, int width, int height, int 
 #define SVGF_INPUT_HALO_ROWS 4       // rows of G-buffer + GI around the rows whose a-trous input is made (3 variance taps + 1 depth gradient)
 hipError_t launch_svgf_inputs(const ViewImages &I, int cur, int width, int height, int gy0, int gy1, int vy0, int vy1, hipStream_t s);
 // Compose folded into the last a-trous iteration (svgf.hip): what compose_post_kernel<false> reads and writes, for the rows [oy0, oy1) of the frame
-struct SvgfComposeFold { const uint8_t *diffuse; const uint16_t *filteredDirect, *reflection, *refraction, *transparent; float *output; uint8_t *final; int oy0, oy1, writeFinal; };
+struct SvgfComposeFold { const uint8_t *diffuse; const uint16_t *filteredDirect, *reflection, *refraction, *transparent; float *output; uint8_t *final; int oy0, oy1, writeFinal;
+                         float *sppSum; int sppSub, sppCount; };      // extension primary_spp (rule P3): the composed value goes into the running sum of the frame's sub-frames; the last one stores the mean and the back buffer (sppCount <= 1: off)
 hipError_t launch_svgf_atrous(const ViewImages &I, int width, int height, int y0, int y1, int oy0, int oy1, int first, int last, const SvgfComposeFold *fold, hipStream_t s);
 
 // ---- upscale.hip ---------------------------------------------------------------------------------------------------

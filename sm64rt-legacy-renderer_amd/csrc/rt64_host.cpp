@@ -1365,7 +1365,9 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         // five iterations, and the frame joins the two before Compose -- two latency-bound launches fill each other's idle issue slots (C5: DESIGN 8).
         const bool reflectBeside = anyReflection && dev->opt.maxReflections > 0 && denoiseGI && dev->opt.denoiserMode == 1 && dev->opt.overlapReflection;
         // Frames with the SVGF denoiser: ComposePS runs inside the last a-trous iteration (svgf.hip), on the filtered value that iteration has just rounded
-        SvgfComposeFold foldArgs = { img.diffuse, img.filteredDirect[1], img.reflection, img.refraction, img.transparent, img.output, img.final, P.tileY0, P.tileY1, (!P.separatePost && subFrames == 1) ? 1 : 0 };
+        if (subFrames > 1) sppSum.reserve(n * 4);
+        SvgfComposeFold foldArgs = { img.diffuse, img.filteredDirect[1], img.reflection, img.refraction, img.transparent, img.output, img.final, P.tileY0, P.tileY1, (!P.separatePost && subFrames == 1) ? 1 : 0,
+                                     subFrames > 1 ? sppSum.ptr : nullptr, subFrame, subFrames };
         const SvgfComposeFold *composeFold = (denoiseGI && dev->opt.denoiserMode == 1 && !lean && dev->opt.foldCompose && P.stripCount == 1) ? &foldArgs : nullptr;
         auto reflectOnAux = [&]() {
             if (!dev->auxStream) {
@@ -1404,8 +1406,8 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         }
         mark(Device::EV_DENOISE);
         if (!lean && !composeFold) L(launch_compose_post(P, img, cur, false, subFrames == 1, s));       // a lean frame is composed by direct_kernel<false> itself
-        if (subFrames > 1) {        // P3: rtOutput of the sub-frames summed in order; the last one turns the sum into the mean and PostProcessPS of it into the back buffer
-            sppSum.reserve(n * 4);
+        if (subFrames > 1 && !composeFold) {        // P3: rtOutput of the sub-frames summed in order; the last one turns the sum into the mean and PostProcessPS of it into the back buffer
+            sppSum.reserve(n * 4);                   // (frames with the SVGF denoiser: the composing a-trous iteration does this too)
             L(launch_spp_accumulate(P, img, sppSum.ptr, subFrame, subFrames, s));
         }
         if (rtRect) {            // the ray-traced picture covers only its rectangle: cleared buffer + background instances show around it (rt64_view.cpp:1292-1296)

@@ -156,7 +156,22 @@ DEV void compose_pixel(const SvgfComposeFold &f, size_t i, uint2 filtered) {
         result = result + xyz(load_rgba16f(f.transparent, i));
     }
     else result = xyz(d);
-    reinterpret_cast<float4 *>(f.output)[i] = make_float4(result.x, result.y, result.z, 1.0f);
+    float4 v = make_float4(result.x, result.y, result.z, 1.0f);
+    if (f.sppCount > 1) {       // spp_accumulate_kernel of passes.hip, folded in as well (same additions in the same order, one multiplication by 1.0f / count at the end)
+        float4 *sum = reinterpret_cast<float4 *>(f.sppSum);
+        if (f.sppSub > 0) { const float4 a = sum[i]; v.x = a.x + v.x; v.y = a.y + v.y; v.z = a.z + v.z; v.w = a.w + v.w; }
+        if (f.sppSub + 1 < f.sppCount) {
+            sum[i] = v;
+            reinterpret_cast<float4 *>(f.output)[i] = make_float4(result.x, result.y, result.z, 1.0f);
+            return;
+        }
+        const float inv = 1.0f / (float)f.sppCount;
+        v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
+        reinterpret_cast<float4 *>(f.output)[i] = v;
+        store_rgba8(f.final, i, v.x, v.y, v.z, 1.0f);
+        return;
+    }
+    reinterpret_cast<float4 *>(f.output)[i] = v;
     if (f.writeFinal) store_rgba8(f.final, i, result.x, result.y, result.z, 1.0f);
 }
 
