@@ -439,8 +439,8 @@ typedef struct {
     /* Feedback on the measured cost: the modelled cut does not know which rows are expensive (a band over the sphere costs 1.5 x a band over the floor of the \
        sample scene).  Each rank measures the GPU time of its band, the host shares the figures (one all-gather of `count` floats), every rank computes the \
        same new boundaries with RT64_RebalanceGatherBands (pure function: equal cost above a fixed part (0.4 of the cheapest band) under an even spread inside each measured band, moves damped to 9/10, 16-row \
-       minimum; returns 0 on invalid boundaries) and hands them to its gather with RT64_SetGatherBands -- between the same two frames on every rank; the \
-       communicator stays, send buffers grow when a band does.  Two or three rounds level the bands (tools/band_costs.py --rebalance). */ \
+       minimum; returns 0 on invalid boundaries) and hands them to its gather with RT64_SetGatherBands -- a gather of bands = 1 or 2 (equal bands need no whole \
+       frame for the first cut), between the same two frames on every rank; the communicator stays, send buffers grow when a band does.  Two or three rounds level the bands (tools/band_costs.py --rebalance). */ \
     X(RebalanceGatherBands, RT64_RebalanceGatherBands, int, (int height, int count, const int *starts, const float *msPerRank, int *newStarts)) \
     X(SetGatherBands, RT64_SetGatherBands, int, (RT64_GATHER *gather, const int *starts)) \
     /* ---- halo EXCHANGE for band partitions of frames with GI + the SVGF denoiser.  The filter result of a row depends on the filter INPUT (noisy GI + \

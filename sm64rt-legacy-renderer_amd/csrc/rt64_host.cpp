@@ -2159,11 +2159,12 @@ int Gather::submit() {
 }
 // New boundaries for a gather of cost-balanced bands (RT64_SetGatherBands): every rank calls it with the same boundaries between the same two frames.
 void Gather::setBands(const int *starts) {
-    if (bands != 2) throw std::runtime_error("RT64_SetGatherBands: only a gather of cost-balanced bands (bands = 2) takes new boundaries.");
+    if (bands == 0) throw std::runtime_error("RT64_SetGatherBands: a gather of interleaved strips (bands = 0) has no boundaries; create it with bands = 1 or bands = 2.");
     if (!halo_starts_valid(H, count, starts)) throw std::runtime_error("RT64_SetGatherBands: starts[0 .. count] must rise from 0 to the frame height.");
     dev->use();
     HIP_CHECK(hipStreamSynchronize(dev->stream)); HIP_CHECK(hipStreamSynchronize(commStream));        // nothing of the old layout is in flight
     for (Slot &sl : slots) sl.pending = false;
+    bands = 2; layout.mode = 2;              // (a gather of equal bands becomes one of given boundaries: no whole frame has to be rendered for the first cut)
     for (int r = 0; r <= count; r++) layout.starts[r] = starts[r];
     const size_t need = (size_t)gather_max_owned_rows(layout) * (size_t)W * 4;
     if (need > slotBytes) {

@@ -49,7 +49,7 @@ def test_world_of_one_gather_returns_the_devices_frame(rt64_lib, sample_data, ba
 
 def test_set_gather_bands_on_a_world_of_one_and_the_dry_run_option(rt64_lib, sample_data):
     """RT64_SetGatherBands on the one rank a test box has: a gather of cost-balanced bands takes new boundaries (here the only valid ones, [0, H]) and goes on
-    gathering the same frame; boundaries that do not span the frame and gathers of strips / equal bands are refused with an error; device option halo_dry_run is
+    gathering the same frame; a gather of equal bands takes boundaries as well; boundaries that do not span the frame and gathers of interleaved strips are refused with an error; device option halo_dry_run is
     accepted (the timing aid of tools/band_costs.py: it only has an effect on a band with an exchange set up)."""
     from sm64rt_legacy_renderer_amd import rt64, sample_scene
     W, H = 320, 180
@@ -74,9 +74,15 @@ def test_set_gather_bands_on_a_world_of_one_and_the_dry_run_option(rt64_lib, sam
         assert np.abs(a.astype(np.int32) - b.astype(np.int32)).mean() < 2.0          # consecutive frames of the same scene (GI noise only)
         rt64_lib.DestroyGather(g)
         assert rt64_lib.GetGatherUniqueId(uid, len(uid)) == 1    # (an id makes one communicator)
-        g1 = rt64_lib.CreateGather(s.device, uid, len(uid), 0, 1, 1)
-        assert g1 and rt64_lib.SetGatherBands(g1, (C.c_int * 2)(0, H)) == 0 and "bands = 2" in rt64_lib.last_error()
+        g1 = rt64_lib.CreateGather(s.device, uid, len(uid), 0, 1, 1)          # equal bands take boundaries too (no whole frame needed for a first cut) ...
+        assert g1 and rt64_lib.SetGatherBands(g1, (C.c_int * 2)(0, H)) == 1, rt64_lib.last_error()
+        got = (C.c_int * 2)()
+        assert rt64_lib.GetGatherBands(g1, got, 2) == 1 and list(got) == [0, H]
         rt64_lib.DestroyGather(g1)
+        assert rt64_lib.GetGatherUniqueId(uid, len(uid)) == 1
+        g0 = rt64_lib.CreateGather(s.device, uid, len(uid), 0, 1, 0)          # ... interleaved strips do not
+        assert g0 and rt64_lib.SetGatherBands(g0, (C.c_int * 2)(0, H)) == 0 and "bands = 0" in rt64_lib.last_error()
+        rt64_lib.DestroyGather(g0)
     finally:
         s.close()
 
