@@ -54,7 +54,7 @@ enum { BOUNCE_WALK_PLAIN = 0, BOUNCE_WALK_REFILL = 1, BOUNCE_WALK_SPLIT = 2 };  
 hipError_t launch_indirect(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, int walk, unsigned groups, bool writeGuide, hipStream_t s);      // writeGuide: bounce_resolve_kernel also writes the SVGF guide records of its rows (wavefront chain only: !klist, bounce records allocated)
 hipError_t launch_indirect_constant(const FrameParams &P, const ViewImages &I, int cur, hipStream_t s);
 hipError_t launch_refraction(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s);
-hipError_t launch_reflection(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s);
+hipError_t launch_reflection(const FrameParams &P, const ViewImages &I, bool klist, int pass, bool last, int parity, hipStream_t s);      // pass / last / parity: see reflection_kernel (ViewImages::reflectFlags)
 hipError_t launch_gaussian(const uint16_t *in, uint16_t *out, int width, int height, int y0, int y1, hipStream_t s);
 hipError_t launch_compose_post(const FrameParams &P, const ViewImages &I, int cur, bool lean, bool writeFinal, hipStream_t s);
 // A lean frame in one launch: primary visibility + resolve + direct light + compose (passes.hip, lean_frame_kernel).
@@ -68,7 +68,7 @@ hipError_t launch_primary_shade_simple(const FrameParams &P, const ViewImages &I
 hipError_t launch_direct_simple(const FrameParams &P, const ViewImages &I, int cur, bool lean, hipStream_t s);
 hipError_t launch_indirect_simple(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, int walk, unsigned groups, bool writeGuide, hipStream_t s);
 hipError_t launch_refraction_simple(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s);
-hipError_t launch_reflection_simple(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s);
+hipError_t launch_reflection_simple(const FrameParams &P, const ViewImages &I, bool klist, int pass, bool last, int parity, hipStream_t s);
 hipError_t launch_lean_frame_simple(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, int cur, bool full, int ownedY0, int ownedY1, unsigned maxGroups, bool perWave, hipStream_t s);
 hipError_t launch_clear_final(const FrameParams &P, const ViewImages &I, hipStream_t s);
 unsigned lean_frame_tiles(const FrameParams &P);        // tiles of the one-kernel frame's launch (the device's rows, 16 x 16)

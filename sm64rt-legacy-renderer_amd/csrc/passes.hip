@@ -1407,9 +1407,15 @@ __global__ __launch_bounds__(RT_BLOCK) void refraction_kernel(FrameParams Pv, Vi
     flush_env(P, env, PASS_REFRACTION, CTR_REFRACTION, rays);
 }
 
+// pass = which of the frame's reflection passes this is, last = whether it is the last one, parity = the frame's ping-pong index.  A pass only has work where the
+// pass before it left a reflection alpha above EPSILON (a mirror seen in a mirror); that pass says so in I.reflectFlags[parity][pass], and a pass whose flag is
+// clear ends before it reads a pixel (the second pass of the sample scene's reflective floor: 32 us of a C5 frame).  The frame's last pass clears the other
+// parity's flags for the next frame.  A stale set flag only costs the scan it used to cost.
 template <bool KLIST>
-__global__ __launch_bounds__(RT_BLOCK) void reflection_kernel(FrameParams Pv, ViewImages Iv) {
+__global__ __launch_bounds__(RT_BLOCK) void reflection_kernel(FrameParams Pv, ViewImages Iv, int pass, int last, int parity) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
+    if (last && blockIdx.x == 0 && threadIdx.x < 4) I.reflectFlags[(parity ^ 1) * 4 + threadIdx.x] = 0;
+    if (pass > 0 && pass < 4 && I.reflectFlags[parity * 4 + pass] == 0u) return;          // (workgroup-uniform: written by the launch before this one; passes beyond the fourth always scan)
     constexpr uint32_t STACK_WORDS = RT_STACK_LDS;
     __shared__ uint32_t ldsStack[STACK_WORDS * RT_BLOCK];
     __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
@@ -1483,6 +1489,7 @@ __global__ __launch_bounds__(RT_BLOCK) void reflection_kernel(FrameParams Pv, Vi
         rgb = lerp3(rgb, ShadowColor, s_pow(fmaxf(-rayDirection.y, 0.0f) * shine, 3.0f));
         float k = reflectionAlpha * saturatef(1.0f - newReflectionAlpha);
         store_rgba16f(I.reflection, i, refl.x + rgb.x * k, refl.y + rgb.y * k, refl.z + rgb.z * k, saturatef(newReflectionAlpha));
+        if (pass < 3 && q_f16(saturatef(newReflectionAlpha)) > RT_EPSILON) I.reflectFlags[parity * 4 + pass + 1] = 1u;      // this pixel goes on to the next pass
     }
     flush_env(P, env, PASS_REFLECTION, CTR_REFLECTION, rays);
 }
@@ -1842,10 +1849,10 @@ hipError_t RT_LAUNCHER(launch_refraction)(const FrameParams &P, const ViewImages
     else hipLaunchKernelGGL(refraction_kernel<false>, dim3(sparse_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
     return hipGetLastError();
 }
-hipError_t RT_LAUNCHER(launch_reflection)(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s) {
-    RT_ROUTE_SIMPLE(launch_reflection_simple(P, I, klist, s));
-    if (klist) hipLaunchKernelGGL(reflection_kernel<true>, dim3(sparse_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
-    else hipLaunchKernelGGL(reflection_kernel<false>, dim3(sparse_grid(P)), dim3(RT_BLOCK), 0, s, P, I);
+hipError_t RT_LAUNCHER(launch_reflection)(const FrameParams &P, const ViewImages &I, bool klist, int pass, bool last, int parity, hipStream_t s) {
+    RT_ROUTE_SIMPLE(launch_reflection_simple(P, I, klist, pass, last, parity, s));
+    if (klist) hipLaunchKernelGGL(reflection_kernel<true>, dim3(sparse_grid(P)), dim3(RT_BLOCK), 0, s, P, I, pass, last ? 1 : 0, parity);
+    else hipLaunchKernelGGL(reflection_kernel<false>, dim3(sparse_grid(P)), dim3(RT_BLOCK), 0, s, P, I, pass, last ? 1 : 0, parity);
     return hipGetLastError();
 }
 

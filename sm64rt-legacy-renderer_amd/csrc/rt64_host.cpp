@@ -731,6 +731,7 @@ void View::createImages(int w, int h, int screenW, int screenH) {       // View:
         img.normal[i] = static_cast<uint16_t *>(alloc(n * 8)); img.depth[i] = static_cast<float *>(alloc(n * 4));
         img.moments[i] = static_cast<float *>(alloc(n * 16));
         if (i == 0) img.svgfGuide = static_cast<uint4 *>(alloc(n * 16));
+        if (i == 0) { img.reflectFlags = static_cast<uint32_t *>(alloc(64)); HIP_CHECK(hipMemset(img.reflectFlags, 0, 64)); }
     }
     img.reflection = static_cast<uint16_t *>(alloc(n * 8)); img.refraction = static_cast<uint16_t *>(alloc(n * 8)); img.transparent = static_cast<uint16_t *>(alloc(n * 8));
     img.flow = static_cast<uint16_t *>(alloc(n * 4));
@@ -1376,10 +1377,10 @@ void View::render() {                          // View::render, rt64_view.cpp:11
             }
             HIP_CHECK(hipEventRecord(dev->forkEvent, s));
             HIP_CHECK(hipStreamWaitEvent(dev->auxStream, dev->forkEvent, 0));
-            for (int r = 0; r < dev->opt.maxReflections; r++) L(launch_reflection(P, img, klist, dev->auxStream));
+            for (int r = 0; r < dev->opt.maxReflections; r++) L(launch_reflection(P, img, klist, r, r == dev->opt.maxReflections - 1, cur, dev->auxStream));
             HIP_CHECK(hipEventRecord(dev->joinEvent, dev->auxStream));
         };
-        if (anyReflection && !reflectBeside) for (int r = 0; r < dev->opt.maxReflections; r++) L(launch_reflection(P, img, klist, s));
+        if (anyReflection && !reflectBeside) for (int r = 0; r < dev->opt.maxReflections; r++) L(launch_reflection(P, img, klist, r, r == dev->opt.maxReflections - 1, cur, s));
         mark(Device::EV_REFL);
         if (denoiseGI && dev->opt.denoiserMode == 1 && reflectBeside) {
             const int ay0 = haloExchange ? std::max(0, P.tileY0 - SVGF_ATROUS_HALO_ROWS) : X.tileY0, ay1 = haloExchange ? std::min(imgH, P.tileY1 + SVGF_ATROUS_HALO_ROWS) : X.tileY1;
