@@ -130,3 +130,7 @@ DEV f4 load_rgba8(const uint8_t *img, size_t i) {
     uint32_t v = reinterpret_cast<const uint32_t *>(img)[i];
     return mk4(from_unorm8((uint8_t)(v & 0xFF)), from_unorm8((uint8_t)((v >> 8) & 0xFF)), from_unorm8((uint8_t)((v >> 16) & 0xFF)), from_unorm8((uint8_t)(v >> 24)));
 }
+
+// SVGF: variance of a pixel with enough history, from its luminance moments -- one definition for the two kernels that may compute it (svgf_variance_kernel and,
+// on frames whose GI runs as the wavefront chain, bounce_resolve_kernel), with the multiply-add spelled out so that both round alike whatever their files' contraction mode
+HD float svgf_moment_variance(float m1, float m2) { return fmaxf(0.0f, fmaf(-m1, m1, m2)); }

@@ -51,7 +51,7 @@ hipError_t launch_primary_shade(const FrameParams &P, const ViewImages &I, const
 hipError_t launch_direct(const FrameParams &P, const ViewImages &I, int cur, bool lean, hipStream_t s);
 enum { BOUNCE_WALK_PLAIN = 0, BOUNCE_WALK_REFILL = 1, BOUNCE_WALK_SPLIT = 2 };      // how bounce_trace hands rays to lanes (passes.hip)
 // walk: how bounce_trace hands rays to lanes; groups: grid of the bounce kernels (0 = the persistent grid)
-hipError_t launch_indirect(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, int walk, unsigned groups, bool writeGuide, hipStream_t s);      // writeGuide: bounce_resolve_kernel also writes the SVGF guide records of its rows (wavefront chain only: !klist, bounce records allocated)
+hipError_t launch_indirect(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, int walk, unsigned groups, int writeGuide, hipStream_t s);      // writeGuide: bounce_resolve_kernel also writes the SVGF guide records of its rows (wavefront chain only: !klist, bounce records allocated)
 hipError_t launch_indirect_constant(const FrameParams &P, const ViewImages &I, int cur, hipStream_t s);
 hipError_t launch_refraction(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s);
 hipError_t launch_reflection(const FrameParams &P, const ViewImages &I, bool klist, int pass, bool last, int parity, hipStream_t s);      // pass / last / parity: see reflection_kernel (ViewImages::reflectFlags)
@@ -66,7 +66,7 @@ hipError_t launch_post_process(const FrameParams &P, const ViewImages &I, hipStr
 // program; the launchers above route to them when FrameParams::simpleKernels is set
 hipError_t launch_primary_shade_simple(const FrameParams &P, const ViewImages &I, const int32_t *hitInstance, int cur, bool transparentLighting, bool lean, hipStream_t s);
 hipError_t launch_direct_simple(const FrameParams &P, const ViewImages &I, int cur, bool lean, hipStream_t s);
-hipError_t launch_indirect_simple(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, int walk, unsigned groups, bool writeGuide, hipStream_t s);
+hipError_t launch_indirect_simple(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, int walk, unsigned groups, int writeGuide, hipStream_t s);
 hipError_t launch_refraction_simple(const FrameParams &P, const ViewImages &I, bool klist, hipStream_t s);
 hipError_t launch_reflection_simple(const FrameParams &P, const ViewImages &I, bool klist, int pass, bool last, int parity, hipStream_t s);
 hipError_t launch_lean_frame_simple(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, int cur, bool full, int ownedY0, int ownedY1, unsigned maxGroups, bool perWave, hipStream_t s);
@@ -92,7 +92,7 @@ hipError_t launch_raster_draw(const GpuRasterInstance *instances, const void *tr
 hipError_t launch_svgf(const ViewImages &I, int cur, int width, int height, int y0, int y1, hipStream_t s);
 #define SVGF_ATROUS_HALO_ROWS 62     // rows of a-trous INPUT (variance image + guide records) the result of a row depends on: what a halo exchange ships
 #define SVGF_INPUT_HALO_ROWS 4       // rows of G-buffer + GI around the rows whose a-trous input is made (3 variance taps + 1 depth gradient)
-hipError_t launch_svgf_inputs(const ViewImages &I, int cur, int width, int height, int gy0, int gy1, int vy0, int vy1, hipStream_t s);
+hipError_t launch_svgf_inputs(const ViewImages &I, int cur, int width, int height, int gy0, int gy1, int vy0, int vy1, bool inputByResolve, hipStream_t s);      // inputByResolve: bounce_resolve_kernel wrote the filter input and marked the young pixels (ViewImages::svgfYoung)
 // Compose folded into the last a-trous iteration (svgf.hip): what compose_post_kernel<false> reads and writes, for the rows [oy0, oy1) of the frame
 struct SvgfComposeFold { const uint8_t *diffuse; const uint16_t *filteredDirect, *reflection, *refraction, *transparent; float *output; uint8_t *final; int oy0, oy1, writeFinal;
                          float *sppSum; int sppSub, sppCount; };      // extension primary_spp (rule P3): the composed value goes into the running sum of the frame's sub-frames; the last one stores the mean and the back buffer (sppCount <= 1: off)

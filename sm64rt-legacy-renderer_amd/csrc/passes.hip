@@ -1303,11 +1303,16 @@ __global__ __launch_bounds__(256) void bounce_resolve_kernel(FrameParams Pv, Vie
         g.z = __float_as_uint(z); g.w = __float_as_uint(fmaxf(fabsf(zx - z), fabsf(zy - z)));
         I.svgfGuide[i] = g;
     }
+    // writeGuide & 2: the filter's INPUT as well -- colour + variance in filteredIndirect[0], what svgf_variance_kernel writes for every pixel with four frames of
+    // history (variance from the luminance moments this kernel has just made) and for every pixel without a surface (both ping-pong images); pixels with a shorter
+    // history are marked in I.svgfYoung and svgf_variance_kernel then runs its 7 x 7 estimate only where a mark is set (C5, static scene: 40 -> 6 us)
+    const bool writeInput = (writeGuide & 2) != 0;
     if (I.instanceId[i] < 0) {
         const float ax = P.ambientBaseColor[0] + P.ambientNoGIColor[0], ay = P.ambientBaseColor[1] + P.ambientNoGIColor[1], az = P.ambientBaseColor[2] + P.ambientNoGIColor[2];
         store_rgba16f(I.indirectLight[cur], i, ax, ay, az, 0.0f);
         reinterpret_cast<float2 *>(I.moments[cur])[i] = make_float2(0.0f, 0.0f);
         if (writeFiltered) store_rgba16f(I.filteredIndirect[1], i, ax, ay, az, 0.0f);
+        if (writeInput) { store_rgba16f(I.filteredIndirect[0], i, ax, ay, az, 0.0f); store_rgba16f(I.filteredIndirect[1], i, ax, ay, az, 0.0f); }
         return;
     }
     const f3 shadingNormal = xyz(load_rgba16f(I.shadingNormal, i));
@@ -1329,7 +1334,13 @@ __global__ __launch_bounds__(256) void bounce_resolve_kernel(FrameParams Pv, Vie
     store_rgba16f(I.indirectLight[cur], i, newIndirect.x, newIndirect.y, newIndirect.z, historyLength);
     {
         const float nS = (float)P.giSamples, alphaM = fminf(nS / historyLength, 1.0f);
-        reinterpret_cast<float2 *>(I.moments[cur])[i] = make_float2(lerpf(prevM.x, sumL / nS, alphaM), lerpf(prevM.y, sumL2 / nS, alphaM));
+        const float2 m = make_float2(lerpf(prevM.x, sumL / nS, alphaM), lerpf(prevM.y, sumL2 / nS, alphaM));
+        reinterpret_cast<float2 *>(I.moments[cur])[i] = m;
+        if (writeInput) {
+            const bool young = q_f16(historyLength) < 4.0f;               // (the filter reads the history length back from the RGBA16F image)
+            store_rgba16f(I.filteredIndirect[0], i, newIndirect.x, newIndirect.y, newIndirect.z, young ? 0.0f : svgf_moment_variance(m.x, m.y));
+            if (young) I.svgfYoung[(size_t)y * (size_t)((P.width + 31) / 32) + (size_t)(x >> 5)] = 1u;
+        }
     }
     if (writeFiltered) store_rgba16f(I.filteredIndirect[1], i, newIndirect.x, newIndirect.y, newIndirect.z, historyLength);
 }
@@ -1797,7 +1808,7 @@ hipError_t RT_LAUNCHER(launch_lean_frame)(const FrameParams &P, const ViewImages
     }
     return hipGetLastError();
 }
-hipError_t RT_LAUNCHER(launch_indirect)(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, int walk, unsigned groups, bool writeGuide, hipStream_t s) {
+hipError_t RT_LAUNCHER(launch_indirect)(const FrameParams &P, const ViewImages &I, int cur, bool writeFiltered, bool klist, int walk, unsigned groups, int writeGuide, hipStream_t s) {
     RT_ROUTE_SIMPLE(launch_indirect_simple(P, I, cur, writeFiltered, klist, walk, groups, writeGuide, s));
     const bool second = P.giBounces >= 2u;
     if (klist && second) LAUNCH_RAY((indirect_kernel<true, true>), P, I, cur, writeFiltered ? 1 : 0);
@@ -1824,7 +1835,7 @@ hipError_t RT_LAUNCHER(launch_indirect)(const FrameParams &P, const ViewImages &
     else hipLaunchKernelGGL(bounce_hit_kernel<false>, dim3(grid), dim3(RT_BLOCK), 0, s, P, I);
     if (walk == BOUNCE_WALK_REFILL) hipLaunchKernelGGL(bounce_miss_kernel, dim3(grid), dim3(RT_BLOCK), 0, s, P, I);      // the other walks finish their misses themselves
     dim3 rgrid((unsigned)(P.width + 31) / 32, (unsigned)(P.tileY1 - P.tileY0 + 7) / 8);
-    hipLaunchKernelGGL(bounce_resolve_kernel, rgrid, dim3(256), 0, s, P, I, cur, writeFiltered ? 1 : 0, writeGuide ? 1 : 0);
+    hipLaunchKernelGGL(bounce_resolve_kernel, rgrid, dim3(256), 0, s, P, I, cur, writeFiltered ? 1 : 0, writeGuide);
     return hipGetLastError();
 }
 #ifndef RT_ASSUME_SIMPLE

@@ -167,6 +167,7 @@ struct ViewImages {
     uint32_t *bounceLists, *bounceCounts; // ids of the traced rays compacted by outcome: [0, cap) hits, [cap, 2 cap) misses; counts[2]
     BounceRadiance *bounceResults;       // radiance of every (GI sample, pixel), 12 bytes (round 3: was a float4 with an unused lane -- 4 x 16 B read by the resolve and written by the walk / hit kernels per pixel of C5)
     uint4 *svgfGuide;                    // SVGF: 16-B guide record per pixel (normal 3 x f16, valid, depth, depth gradient)
+    uint32_t *svgfYoung;                 // SVGF: [row][32-pixel segment] != 0: the segment has a pixel with fewer than 4 frames of history (set by bounce_resolve_kernel when it also writes the filter input, read and cleared by svgf_variance_kernel, which then only runs where one is set)
     uint32_t *reflectFlags;              // [2][4]: does any pixel go on to reflection pass p of the frame of this parity?  (set by pass p - 1, the other parity cleared by the frame's last pass; a later pass with nothing to do ends at once)
     // Per-pixel sorted hit list (k-buffer), [RT64_MAX_HIT_QUERIES + 1][pixels]; allocated only while some instance is not
     // provably opaque.  The reference keeps 17 x 34 B per pixel for every frame (rt64_view.cpp:237-241).

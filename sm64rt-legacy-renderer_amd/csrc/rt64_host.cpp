@@ -153,6 +153,7 @@ struct Options {
     int denoiserMode = 1;          // 0 = reference 5x Gaussian, 1 = SVGF
     bool tileOrder = true;         // one-kernel frame of scenes without the LDS scene cache (one-wave workgroups): tiles start in the order of their cost in the frame before, most expensive first
     bool foldCompose = true;       // frames with the SVGF denoiser: ComposePS inside the last a-trous iteration (0: compose_post_kernel, its own launch)
+    bool foldVariance = true;      // ... and the filter's input (variance from the moments) for every pixel with four frames of history; svgf_variance_kernel then only runs where a younger pixel is marked (0: it makes every pixel's input)
     bool foldGuide = true;         // frames with the wavefront GI chain + SVGF: bounce_resolve_kernel writes the filter's guide records (0: svgf_guide_kernel, its own launch)
     bool overlapReflection = true; // frames with reflection passes AND the SVGF denoiser: the reflection launches run on a second stream beside the a-trous iterations (they share no image)
     bool haloExchange = false;     // band partitions of GI + SVGF frames: ship the filter input of the halo rows between the devices of the gather (RCCL) instead of re-rendering them
@@ -731,6 +732,7 @@ void View::createImages(int w, int h, int screenW, int screenH) {       // View:
         img.normal[i] = static_cast<uint16_t *>(alloc(n * 8)); img.depth[i] = static_cast<float *>(alloc(n * 4));
         img.moments[i] = static_cast<float *>(alloc(n * 16));
         if (i == 0) img.svgfGuide = static_cast<uint4 *>(alloc(n * 16));
+        if (i == 0) { const size_t young = (size_t)((w + 31) / 32) * (size_t)h * 4; img.svgfYoung = static_cast<uint32_t *>(alloc(young)); HIP_CHECK(hipMemset(img.svgfYoung, 0, young)); }
         if (i == 0) { img.reflectFlags = static_cast<uint32_t *>(alloc(64)); HIP_CHECK(hipMemset(img.reflectFlags, 0, 64)); }
     }
     img.reflection = static_cast<uint16_t *>(alloc(n * 8)); img.refraction = static_cast<uint16_t *>(alloc(n * 8)); img.transparent = static_cast<uint16_t *>(alloc(n * 8));
@@ -1268,7 +1270,7 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         // GI bounce -- also cover a halo above and below the device's rows.  Pixel-local passes (direct light, reflection,
         // refraction, compose) stay on the owned rows.  The halo rows are recomputed, not exchanged: no mid-frame collective.
         const bool denoiseGI = denoiserEnabled && giSamples > 0;
-        bool guideByResolve = false;
+        bool guideByResolve = false, inputByResolve = false;
         FrameParams X = P;                                        // X: owned rows + halo
         bool haloExchange = false;
         if (denoiseGI && !P.separatePost && (P.tileY0 > 0 || P.tileY1 < imgH || P.stripCount > 1)) {
@@ -1355,7 +1357,8 @@ void View::render() {                          // View::render, rt64_view.cpp:11
             const unsigned groups = dev->opt.bounceGroups >= 0 ? (unsigned)dev->opt.bounceGroups : (walk == BOUNCE_WALK_PLAIN ? 1024u : 0u);
             // frames whose GI runs as the wavefront chain: its last kernel (the per-pixel resolve) writes the SVGF guide records of its rows as well
             guideByResolve = denoiseGI && dev->opt.denoiserMode == 1 && !klist && img.bounceRecords != nullptr && dev->opt.foldGuide;
-            L(launch_indirect(X, img, cur, !denoiseGI, klist, walk, groups, guideByResolve, s));
+            L(launch_indirect(X, img, cur, !denoiseGI, klist, walk, groups, guideByResolve ? (dev->opt.foldVariance ? 3 : 1) : 0, s));
+            inputByResolve = guideByResolve && dev->opt.foldVariance;
         }
         mark(Device::EV_INDIRECT);
         // Refraction / reflection touch only pixels whose primary hit has a refraction / reflection factor (alpha > EPSILON).
@@ -1384,8 +1387,8 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         mark(Device::EV_REFL);
         if (denoiseGI && dev->opt.denoiserMode == 1 && reflectBeside) {
             const int ay0 = haloExchange ? std::max(0, P.tileY0 - SVGF_ATROUS_HALO_ROWS) : X.tileY0, ay1 = haloExchange ? std::min(imgH, P.tileY1 + SVGF_ATROUS_HALO_ROWS) : X.tileY1;
-            if (haloExchange) { L(launch_svgf_inputs(img, cur, imgW, imgH, std::max(0, P.tileY0 - 3), guideByResolve ? 0 : std::min(imgH, P.tileY1 + 3), P.tileY0, P.tileY1, s)); }
-            else L(launch_svgf_inputs(img, cur, imgW, imgH, X.tileY0, guideByResolve ? 0 : X.tileY1, X.tileY0, X.tileY1, s));
+            if (haloExchange) { L(launch_svgf_inputs(img, cur, imgW, imgH, std::max(0, P.tileY0 - 3), guideByResolve ? 0 : std::min(imgH, P.tileY1 + 3), P.tileY0, P.tileY1, inputByResolve, s)); }
+            else L(launch_svgf_inputs(img, cur, imgW, imgH, X.tileY0, guideByResolve ? 0 : X.tileY1, X.tileY0, X.tileY1, inputByResolve, s));
             reflectOnAux();                                      // (before the exchange: the reflection pass also runs beside the wait for the neighbours' rows)
             if (haloExchange) halo_exchange(dev, img, imgW, imgH, s);
             // (the folded Compose reads the reflection image: the join comes before the last iteration instead of behind it)
@@ -1395,11 +1398,11 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         }
         else if (denoiseGI && dev->opt.denoiserMode == 1 && haloExchange) {
             // filter input (variance image + guide records) of the band's own rows; the guide records of 3 rows around them feed the variance estimate
-            L(launch_svgf_inputs(img, cur, imgW, imgH, std::max(0, P.tileY0 - 3), guideByResolve ? 0 : std::min(imgH, P.tileY1 + 3), P.tileY0, P.tileY1, s));
+            L(launch_svgf_inputs(img, cur, imgW, imgH, std::max(0, P.tileY0 - 3), guideByResolve ? 0 : std::min(imgH, P.tileY1 + 3), P.tileY0, P.tileY1, inputByResolve, s));
             halo_exchange(dev, img, imgW, imgH, s);
             L(launch_svgf_atrous(img, imgW, imgH, std::max(0, P.tileY0 - SVGF_ATROUS_HALO_ROWS), std::min(imgH, P.tileY1 + SVGF_ATROUS_HALO_ROWS), P.tileY0, P.tileY1, 0, 5, composeFold, s));
         }
-        else if (denoiseGI && dev->opt.denoiserMode == 1) { L(launch_svgf_inputs(img, cur, imgW, imgH, X.tileY0, guideByResolve ? 0 : X.tileY1, X.tileY0, X.tileY1, s)); L(launch_svgf_atrous(img, imgW, imgH, X.tileY0, X.tileY1, P.tileY0, P.tileY1, 0, 5, composeFold, s)); }
+        else if (denoiseGI && dev->opt.denoiserMode == 1) { L(launch_svgf_inputs(img, cur, imgW, imgH, X.tileY0, guideByResolve ? 0 : X.tileY1, X.tileY0, X.tileY1, inputByResolve, s)); L(launch_svgf_atrous(img, imgW, imgH, X.tileY0, X.tileY1, P.tileY0, P.tileY1, 0, 5, composeFold, s)); }
         else if (denoiseGI) {
             L(hipMemcpyAsync(img.filteredIndirect[0], img.indirectLight[cur], n * 8, hipMemcpyDeviceToDevice, s));
             for (int k = 0; k < 5; k++)            // rt64_view.cpp:1512-1530
@@ -1756,6 +1759,7 @@ RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, doubl
     else if (k == "bounce_refill") d->opt.bounceRefill = (int)value;
     else if (k == "overlap_reflection") d->opt.overlapReflection = value != 0.0;
     else if (k == "tile_order") d->opt.tileOrder = value != 0.0;
+    else if (k == "fold_variance") d->opt.foldVariance = value != 0.0;
     else if (k == "fold_guide") d->opt.foldGuide = value != 0.0;
     else if (k == "fold_compose") d->opt.foldCompose = value != 0.0;
     else if (k == "halo_exchange") d->opt.haloExchange = value != 0.0;

@@ -60,11 +60,22 @@ DEV float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 // values of log2e / (gz dist + 1e-8) computed once per pixel.  (Round 2: four scattered loads, expf, powf and sqrtf per tap: 196 us at 1440p on C4.)
 #define VAR_TILE_W (32 + 6)
 #define VAR_TILE_H (8 + 6)
+// young != nullptr: bounce_resolve_kernel has already written the filter input of every pixel but those with fewer than four frames of history, and marked the
+// 32-pixel row segments that hold such a pixel: a workgroup without a mark ends at once, the others estimate and store their young pixels only.
 __global__ __launch_bounds__(256) void svgf_variance_kernel(const uint2 *__restrict__ color, const float2 *__restrict__ moments, const int32_t *__restrict__ instanceId,
-                                                            const uint4 *__restrict__ guide, uint2 *__restrict__ out, uint2 *__restrict__ outSky, int w, int h, int y0, int y1) {
+                                                            const uint4 *__restrict__ guide, uint2 *__restrict__ out, uint2 *__restrict__ outSky, int w, int h, int y0, int y1, uint32_t *young) {
     __shared__ uint4 tile[VAR_TILE_W * VAR_TILE_H];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int x = blockIdx.x * 32 + tx, y = y0 + blockIdx.y * 8 + ty;
+    if (young) {
+        bool marked = false;
+        if (threadIdx.x < 8 && y0 + (int)blockIdx.y * 8 + (int)threadIdx.x < y1) {
+            uint32_t *f = young + (size_t)(y0 + blockIdx.y * 8 + threadIdx.x) * (size_t)((w + 31) / 32) + blockIdx.x;
+            marked = *f != 0u;
+            if (marked) *f = 0u;                  // (cleared for the next frame)
+        }
+        if (!__syncthreads_or(marked ? 1 : 0)) return;
+    }
     const bool inside = x < w && y < y1;
     const size_t i = inside ? (size_t)y * w + x : 0;
     uint2 cbits = make_uint2(0u, 0u);
@@ -75,7 +86,7 @@ __global__ __launch_bounds__(256) void svgf_variance_kernel(const uint2 *__restr
         history = f16_bits_to_f32((uint16_t)(cbits.y >> 16));
         valid = instanceId[i] >= 0;
         if (valid) {
-            if (history >= 4.0f) { const float2 m = moments[i]; var = fmaxf(0.0f, m.y - m.x * m.x); }
+            if (history >= 4.0f) { if (!young) { const float2 m = moments[i]; var = svgf_moment_variance(m.x, m.y); } }
             else spatial = true;
         }
     }
@@ -119,7 +130,7 @@ __global__ __launch_bounds__(256) void svgf_variance_kernel(const uint2 *__restr
             if (sw > 0.0f) { const float inv = s_rcp(sw), m1 = s1 * inv, m2 = s2 * inv; var = fmaxf(0.0f, m2 - m1 * m1) * (4.0f * s_rcp(fmaxf(history, 1.0f))); }
         }
     }
-    if (inside) {
+    if (inside && (!young || spatial)) {
         const uint2 v = make_uint2(cbits.x, (cbits.y & 0xFFFFu) | ((uint32_t)f32_to_f16_bits(var) << 16));
         out[i] = v;
         if (!valid) outSky[i] = v;        // pixels without a surface pass through the filter unchanged: written to the other ping-pong image here, skipped by every a-trous iteration
@@ -296,7 +307,7 @@ __global__ __launch_bounds__(256, 6) void svgf_atrous_kernel(const uint2 *__rest
 // 2 * (1 + 2 + 4 + 8 + 16) = SVGF_ATROUS_HALO_ROWS rows.  Taps may fall outside [y0, y1) but inside the frame: they only reach output rows that are
 // themselves farther than the halo from the rows the device owns.  With halo RECOMPUTE (SVGF_HALO_ROWS = 62 + 3 + 1) both halves run on rows + halo;
 // with halo EXCHANGE (rt64_host.cpp) the inputs are made for the device's own rows only and the halo rows of both images arrive from the neighbours.
-hipError_t launch_svgf_inputs(const ViewImages &I, int cur, int width, int height, int gy0, int gy1, int vy0, int vy1, hipStream_t s) {
+hipError_t launch_svgf_inputs(const ViewImages &I, int cur, int width, int height, int gy0, int gy1, int vy0, int vy1, bool inputByResolve, hipStream_t s) {
     if (gy1 > gy0) {
         dim3 grid((unsigned)(width + 31) / 32, (unsigned)(gy1 - gy0 + 7) / 8);
         hipLaunchKernelGGL(svgf_guide_kernel, grid, dim3(256), 0, s, I.instanceId, I.normal[cur], I.depth[cur], I.svgfGuide, width, height, gy0, gy1);
@@ -304,7 +315,7 @@ hipError_t launch_svgf_inputs(const ViewImages &I, int cur, int width, int heigh
     if (vy1 > vy0) {
         dim3 grid((unsigned)(width + 31) / 32, (unsigned)(vy1 - vy0 + 7) / 8);
         hipLaunchKernelGGL(svgf_variance_kernel, grid, dim3(256), 0, s, reinterpret_cast<const uint2 *>(I.indirectLight[cur]), reinterpret_cast<const float2 *>(I.moments[cur]), I.instanceId, I.svgfGuide,
-                           reinterpret_cast<uint2 *>(I.filteredIndirect[0]), reinterpret_cast<uint2 *>(I.filteredIndirect[1]), width, height, vy0, vy1);
+                           reinterpret_cast<uint2 *>(I.filteredIndirect[0]), reinterpret_cast<uint2 *>(I.filteredIndirect[1]), width, height, vy0, vy1, inputByResolve ? I.svgfYoung : nullptr);
     }
     return hipGetLastError();
 }
@@ -329,6 +340,6 @@ hipError_t launch_svgf_atrous(const ViewImages &I, int width, int height, int y0
 }
 hipError_t launch_svgf(const ViewImages &I, int cur, int width, int height, int y0, int y1, hipStream_t s) {
     if (y1 <= y0) return hipSuccess;
-    hipError_t e = launch_svgf_inputs(I, cur, width, height, y0, y1, y0, y1, s);
+    hipError_t e = launch_svgf_inputs(I, cur, width, height, y0, y1, y0, y1, false, s);
     return e != hipSuccess ? e : launch_svgf_atrous(I, width, height, y0, y1, y0, y1, 0, 5, nullptr, s);
 }

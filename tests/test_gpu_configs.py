@@ -345,13 +345,16 @@ def test_simple_frame_kernels_equal_the_general_kernels(rt64_lib, sample_data, c
 def test_folded_guide_and_compose_equal_their_own_launches(rt64_lib, sample_data, config, bands):
     """Frames with the wavefront GI chain + SVGF: bounce_resolve_kernel writes the filter's guide records (the same bytes as svgf_guide_kernel) and the last
     a-trous iteration composes its pixels itself (the operations of compose_post_kernel on the value it has just rounded).  Device options fold_guide = 0 /
-    fold_compose = 0 bring the two launches back.  The guide fold changes no byte.  The Compose fold is another instantiation of the a-trous kernel, whose
+    fold_compose = 0 bring the two launches back; fold_variance = 0 has svgf_variance_kernel make the filter input of every pixel again instead of only the young ones
+    bounce_resolve_kernel marked.  The guide and variance folds change no byte.  The Compose fold is another instantiation of the a-trous kernel, whose
     arithmetic is compiled with fp-contract(fast) (tolerance-tested filter): the compiler may fuse a multiply-add differently in it, so a handful of filtered
     values may differ by one RGBA16F step -- and nothing else."""
     a, ref, sa = _bench_pair(rt64_lib, sample_data, config, frames=3, bands=bands)
     g, _, _ = _bench_pair(rt64_lib, sample_data, config, frames=3, bands=bands, options={"fold_guide": 0})
+    v, _, _ = _bench_pair(rt64_lib, sample_data, config, frames=3, bands=bands, options={"fold_variance": 0})
     for k in a:
         assert np.array_equal(a[k].view(np.uint8), g[k].view(np.uint8)), k
+        assert np.array_equal(a[k].view(np.uint8), v[k].view(np.uint8)), k
     b, _, sb = _bench_pair(rt64_lib, sample_data, config, frames=3, bands=bands, options={"fold_guide": 0, "fold_compose": 0})
     for k in a:
         if k in ("OUTPUT_RGBA32F", "FINAL_RGBA8", "INDIRECT_LIGHT_FILTERED"):
