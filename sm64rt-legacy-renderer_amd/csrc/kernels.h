@@ -89,7 +89,6 @@ hipError_t launch_raster_draw(const GpuRasterInstance *instances, const void *tr
 // variance estimate + 5 a-trous iterations over the GI buffer; result in filteredIndirect[1]
 #define SVGF_HALO_ROWS 66            // rows of neighbourhood the SVGF result of a row depends on (62 a-trous + 3 variance + 1 gradient)
 #define GAUSSIAN_HALO_ROWS 5         // five 3x3 passes
-hipError_t launch_svgf(const ViewImages &I, int cur, int width, int height, int y0, int y1, hipStream_t s);
 #define SVGF_ATROUS_HALO_ROWS 62     // rows of a-trous INPUT (variance image + guide records) the result of a row depends on: what a halo exchange ships
 #define SVGF_INPUT_HALO_ROWS 4       // rows of G-buffer + GI around the rows whose a-trous input is made (3 variance taps + 1 depth gradient)
 hipError_t launch_svgf_inputs(const ViewImages &I, int cur, int width, int height, int gy0, int gy1, int vy0, int vy1, bool inputByResolve, hipStream_t s);      // inputByResolve: bounce_resolve_kernel wrote the filter input and marked the young pixels (ViewImages::svgfYoung)

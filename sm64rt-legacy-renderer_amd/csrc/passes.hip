@@ -1585,9 +1585,7 @@ __global__ __launch_bounds__(256) void compose_post_kernel(FrameParams Pv, ViewI
 // whatever order the atomics resolve: any permutation renders the same picture.
 __global__ __launch_bounds__(1024) void tile_order_kernel(uint32_t *cost, uint32_t *order, uint32_t n) {
     __shared__ uint32_t bucket[1024];
-    __shared__ uint32_t carry;
     bucket[threadIdx.x] = 0;
-    if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += 1024) atomicAdd(&bucket[1023u - min(cost[i], 1023u)], 1u);
     __syncthreads();
@@ -1609,7 +1607,6 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(uint32_t *cost, uint32
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += 1024) cost[i] = 0;
-    (void)carry;
 }
 
 // Extension primary_spp (rule P3, oracle/oracle_render.c): rtOutput of sub-frame `sub` added to the running sum of the frame's sub-frames, in order; the last

@@ -732,8 +732,8 @@ void View::createImages(int w, int h, int screenW, int screenH) {       // View:
         img.normal[i] = static_cast<uint16_t *>(alloc(n * 8)); img.depth[i] = static_cast<float *>(alloc(n * 4));
         img.moments[i] = static_cast<float *>(alloc(n * 16));
         if (i == 0) img.svgfGuide = static_cast<uint4 *>(alloc(n * 16));
-        if (i == 0) { const size_t young = (size_t)((w + 31) / 32) * (size_t)h * 4; img.svgfYoung = static_cast<uint32_t *>(alloc(young)); HIP_CHECK(hipMemset(img.svgfYoung, 0, young)); }
-        if (i == 0) { img.reflectFlags = static_cast<uint32_t *>(alloc(64)); HIP_CHECK(hipMemset(img.reflectFlags, 0, 64)); }
+        if (i == 0) { const size_t young = (size_t)((w + 31) / 32) * (size_t)h * 4; img.svgfYoung = static_cast<uint32_t *>(alloc(young)); }
+        if (i == 0) { img.reflectFlags = static_cast<uint32_t *>(alloc(64)); }
     }
     img.reflection = static_cast<uint16_t *>(alloc(n * 8)); img.refraction = static_cast<uint16_t *>(alloc(n * 8)); img.transparent = static_cast<uint16_t *>(alloc(n * 8));
     img.flow = static_cast<uint16_t *>(alloc(n * 4));
@@ -1268,7 +1268,7 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         // Image-tile partition with a spatial filter downstream: the GI denoiser reads a neighbourhood of every row this device
         // owns (SVGF: 66 rows, the reference's five 3x3 Gaussians: 5), so the passes that feed it -- primary visibility, G-buffer,
         // GI bounce -- also cover a halo above and below the device's rows.  Pixel-local passes (direct light, reflection,
-        // refraction, compose) stay on the owned rows.  The halo rows are recomputed, not exchanged: no mid-frame collective.
+        // refraction, compose) stay on the owned rows.  By default the halo rows are recomputed -- no mid-frame collective; with a halo exchange set up (below) they arrive from the neighbouring bands.
         const bool denoiseGI = denoiserEnabled && giSamples > 0;
         bool guideByResolve = false, inputByResolve = false;
         FrameParams X = P;                                        // X: owned rows + halo

@@ -338,8 +338,3 @@ hipError_t launch_svgf_atrous(const ViewImages &I, int width, int height, int y0
     }
     return hipGetLastError();
 }
-hipError_t launch_svgf(const ViewImages &I, int cur, int width, int height, int y0, int y1, hipStream_t s) {
-    if (y1 <= y0) return hipSuccess;
-    hipError_t e = launch_svgf_inputs(I, cur, width, height, y0, y1, y0, y1, false, s);
-    return e != hipSuccess ? e : launch_svgf_atrous(I, width, height, y0, y1, y0, y1, 0, 5, nullptr, s);
-}
