@@ -142,3 +142,25 @@ def test_host_side_tree_depth_equals_the_depth_of_the_oracle_lbvh(built, sample_
     check(p, rng.integers(0, 600, size=900), 12)
     big = rng.normal(size=(3 * 4097, 3)).astype(np.float32)                       # above the single-workgroup builder: "deep" without looking
     assert lib.MeshTreeDepth(big.ctypes.data, len(big), 12, np.arange(3 * 4097, dtype=np.uint32).ctypes.data, 3 * 4097) == 255
+
+
+def test_bench_configurations_are_consistent():
+    """sample_scene.BENCH_CONFIGS is what bench.py, tools/band_costs.py and tests/test_gpu_configs.py all read: every configuration bench.py offers exists, the ones
+    that run BASELINE.json's wording through the library's extensions say which, every note belongs to a configuration, and the option keys they set are keys
+    RT64_SetDeviceOption knows (looked up in the host source: the call itself needs a device)."""
+    import os
+    import re
+    from sm64rt_legacy_renderer_amd import sample_scene
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = open(os.path.join(root, "bench.py")).read()
+    choices = re.search(r'"--config", default="C2", choices=\[([^\]]*)\]', bench).group(1)
+    offered = set(re.findall(r'"([^"]+)"', choices))
+    assert offered == set(sample_scene.BENCH_CONFIGS) and "C2" in offered
+    host = open(os.path.join(root, "sm64rt-legacy-renderer_amd", "csrc", "rt64_host.cpp")).read()
+    for name, cfg in sample_scene.BENCH_CONFIGS.items():
+        assert {"width", "height", "gi_samples", "denoiser"} <= set(cfg)
+        for key in set(cfg) - {"width", "height", "gi_samples", "denoiser"}:
+            assert 'k == "%s"' % key in host, key                 # an option RT64_SetDeviceOption knows
+        assert name.endswith("-literal") == bool(set(cfg) & {"primary_spp", "gi_bounces"})
+    assert set(sample_scene.BENCH_DEVIATIONS) <= set(sample_scene.BENCH_CONFIGS)
+    assert all(n in sample_scene.BENCH_DEVIATIONS for n in ("C4", "C5", "C4-literal", "C5-literal"))

@@ -178,3 +178,68 @@ def test_sample_scene_construction(sample_data):
     assert s.bluenoise.shape == (512, 512, 4)
     c = s.meshes[0].vertices["position"][:, :3]
     assert np.allclose(np.linalg.norm(c - np.array([0, 0.5, 0], dtype=np.float32), axis=1), 2.5455842, atol=1e-4)
+
+
+def test_path_tracing_extensions_of_the_oracle(sample_data, oracle_lib):
+    """Rules B1-B3 (giBounces = 2) and P1-P4 (primarySpp = N) of oracle/oracle_render.c, checked on the CPU through properties that do not need a second
+    implementation.  Off = the reference frame, byte for byte.  B: one more indirect ray per GI ray that resolved to a surface and no other ray; pixels whose GI rays
+    all left the scene keep their value; with no ambient-without-GI term the second bounce can only ADD light.  P: N sub-frames trace N times the primary rays; the
+    frame count advances N times; silhouettes and texture detail move; the back buffer is PostProcess of the averaged output; an upscaler or a
+    resolution scale with primarySpp is refused."""
+    import copy
+    import ctypes as C
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    W, H = 96, 54
+
+    def scene(mod=None):
+        d = copy.copy(sample_data)
+        desc = rt64.SCENE_DESC(); C.memmove(C.byref(desc), C.byref(sample_data.desc), C.sizeof(rt64.SCENE_DESC)); d.desc = desc
+        if mod:
+            mod(d)
+        return oracle_py.OracleScene(d)
+
+    # --- off = the reference frame
+    a, b = scene(), scene()
+    try:
+        for _ in range(2):
+            ra = a.render(W, H, giSamples=2)
+            rb = b.render(W, H, giSamples=2, giBounces=1, primarySpp=1)
+        for k in ("output", "final", "indirectLight", "primaryHit"):
+            assert np.array_equal(ra[k].view(np.uint8), rb[k].view(np.uint8)), k
+    finally:
+        a.close(); b.close()
+
+    # --- B: second bounce
+    def no_ambient(d):
+        d.desc.ambientNoGIColor = rt64.VECTOR3(0.0, 0.0, 0.0)
+    one, two = scene(no_ambient), scene(no_ambient)
+    try:
+        r1 = one.render(W, H, giSamples=2)
+        r2 = two.render(W, H, giSamples=2, giBounces=2)
+        c1, c2 = r1["counters"], r2["counters"]
+        assert c1["primaryRays"] == c2["primaryRays"] and c1["indirectRays"] < c2["indirectRays"] <= 2 * c1["indirectRays"]
+        assert np.array_equal(r1["primaryHit"], r2["primaryHit"])
+        d = r2["indirectLight"][..., :3] - r1["indirectLight"][..., :3]
+        assert d.min() >= -2e-3 and d.max() > 1e-3            # only more light (RGBA16F rounding below), and some of it
+        assert (np.abs(d).max(axis=-1) == 0).mean() > 0.3      # sky pixels and pixels whose GI rays all left the scene are untouched
+    finally:
+        one.close(); two.close()
+
+    # --- P: sub-frames
+    s1, s4 = scene(), scene()
+    try:
+        r1 = s1.render(W, H)
+        r4 = s4.render(W, H, primarySpp=4)
+        assert r4["counters"]["primaryRays"] == 4 * r1["counters"]["primaryRays"] == 4 * W * H
+        assert oracle_lib.oracle_scene_frame_count(s4.scene) == 4 and oracle_lib.oracle_scene_frame_count(s1.scene) == 1
+        moved = np.abs(r4["output"][..., :3] - r1["output"][..., :3]).max(axis=-1) > 0.02
+        assert 0.002 < moved.mean() < 0.6                      # silhouettes and texture detail (a 96 x 54 frame has much of it), not the whole picture
+        f = r4["final"].astype(np.int32)
+        off = np.abs(f[..., :3] - np.clip(np.rint(r4["output"][..., :3] * 255.0), 0, 255).astype(np.int32)).max(axis=-1) > 1
+        assert off.mean() < 0.05                               # back buffer = PostProcess of the mean (+ the HUD triangle, drawn once over it)
+        with pytest.raises(AssertionError):
+            s4.render(W, H, primarySpp=2, resolutionScale=0.5)
+        with pytest.raises(AssertionError):
+            s4.render(W, H, primarySpp=2, upscaler=rt64.UPSCALER_FSR)
+    finally:
+        s1.close(); s4.close()
