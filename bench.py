@@ -66,7 +66,7 @@ def parse_args():
     ap.add_argument("--prewarm", type=int, default=100, help="untimed frames before the W warm-up steps (GPU clock ramp; the line reports them)")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE", help="RT64_SetDeviceOption(key, value) before the run (A/B measurements; the line records them under config.options)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU-staged rehearsal of the N>1 path")
-    ap.add_argument("--band-rebalance", type=int, default=2, help="N > 1, GI + denoiser bands: rounds of measured-cost feedback after the modelled cut (each rank times its band, one all-gather, "
+    ap.add_argument("--band-rebalance", type=int, default=3, help="N > 1, GI + denoiser bands: rounds of measured-cost feedback after the modelled cut (each rank times its band, one all-gather, "
                     "RT64_RebalanceGatherBands + RT64_SetGatherBands on every rank); 0 keeps the modelled cut")
     ap.add_argument("--halo", default="exchange", choices=["exchange", "recompute"], help="N > 1, GI + denoiser bands: exchange the denoiser's halo rows between neighbouring bands (RCCL) or re-render them on every band")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a 1-GPU box: every rank renders on device 0")

@@ -438,7 +438,7 @@ typedef struct {
     X(BalanceGatherBands, RT64_BalanceGatherBands, void, (const unsigned int *hitCounts, int width, int height, int count, int *starts)) \
     /* Feedback on the measured cost: the modelled cut does not know which rows are expensive (a band over the sphere costs 1.5 x a band over the floor of the \
        sample scene).  Each rank measures the GPU time of its band, the host shares the figures (one all-gather of `count` floats), every rank computes the \
-       same new boundaries with RT64_RebalanceGatherBands (pure function: equal cost above a fixed part (0.4 of the cheapest band) under an even spread inside each measured band, moves damped to 9/10, 16-row \
+       same new boundaries with RT64_RebalanceGatherBands (pure function: equal cost above a fixed part (0.4 of the cheapest band) under an even spread inside each measured band, moves damped to 0.5 (two bands) ... 0.8 (eight), 16-row \
        minimum; returns 0 on invalid boundaries) and hands them to its gather with RT64_SetGatherBands -- a gather of bands = 1 or 2 (equal bands need no whole \
        frame for the first cut), between the same two frames on every rank; the communicator stays, send buffers grow when a band does.  Two or three rounds level the bands (tools/band_costs.py --rebalance). */ \
     X(RebalanceGatherBands, RT64_RebalanceGatherBands, int, (int height, int count, const int *starts, const float *msPerRank, int *newStarts)) \

@@ -2036,7 +2036,7 @@ static void gather_balanced_bands(const uint32_t *hitCounts, int width, int heig
 
 // Feedback step of the band balance: given the bands a frame was cut into and what each rank's share cost (ms of GPU work per frame, measured), the bands of
 // about equal cost under the assumption that a band's cost is spread evenly over its rows.  A fixed point when all costs are equal; the caller iterates
-// (measure, rebalance) two or three times.  Moves are damped to 9/10 of the way and every band keeps RT64_BAND_MIN_ROWS rows.
+// (measure, rebalance) two or three times.  Moves are damped (below) and every band keeps RT64_BAND_MIN_ROWS rows.
 static void gather_rebalanced_bands(int height, int count, const int *starts, const float *ms, int *out) {
     // what moves with the boundaries is the cost above the part every band pays whatever its height (launches, latency tails: about half of the cheapest
     // band's time on the sample scene); 0.4 of the cheapest band is taken as that part
@@ -2047,13 +2047,16 @@ static void gather_rebalanced_bands(int height, int count, const int *starts, co
     for (int r = 0; r < count; r++) cum[(size_t)r + 1] = cum[(size_t)r] + std::max((double)ms[r] - fixed, 1e-6);
     const double total = cum[(size_t)count];
     const int minRows = height >= count * RT64_BAND_MIN_ROWS ? RT64_BAND_MIN_ROWS : std::max(height / count, 1);
+    // the even spread is a coarse model of a tall band (two ranks: a cut that moves into rows twice as dense as its band's average overshoots and the rounds
+    // oscillate at full step) and a good one of a thin band: half the way for two bands, 0.8 of it for eight
+    const double damp = 0.5 + 0.4 * (1.0 - 2.0 / (double)std::max(count, 2));
     out[0] = 0;
     for (int k = 1; k < count; k++) {
         const double target = total * (double)k / (double)count;
         int r = 0; while (r + 1 < count && cum[(size_t)r + 1] < target) r++;                  // the band the k-th cut falls into
         const double rows = (double)(starts[r + 1] - starts[r]), inside = (target - cum[(size_t)r]) / (cum[(size_t)r + 1] - cum[(size_t)r]);
         const double ideal = (double)starts[r] + rows * std::min(std::max(inside, 0.0), 1.0);
-        int y = (int)std::lround((double)starts[k] + 0.9 * (ideal - (double)starts[k]));
+        int y = (int)std::lround((double)starts[k] + damp * (ideal - (double)starts[k]));
         y = std::max(y, out[k - 1] + minRows);
         y = std::min(y, height - (count - k) * minRows);
         out[k] = std::max(y, out[k - 1]);
