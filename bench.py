@@ -223,6 +223,8 @@ def main():
         except Exception as e:       # keep measuring: synchronous frames + blocking gather (same result, no overlap)
             print("bench.py: renderer stream not usable from torch (%r): synchronous gather" % (e,), file=sys.stderr)
             pipelined = False
+    if ext_stream is not None:
+        scene.option("overlap_frames", 0)    # torch orders its copies behind the frames on ONE stream of the library's: keep every frame on it
     gatherer = tiles.FrameGatherer(H, W, rank, N, comm_device, stream=ext_stream, bands=use_bands) if (G and not native) else None
     staging = torch.zeros(max(tiles.strips_per_rank(H, N) * 16, tiles.band_rows(H, N)) * W * 4, dtype=torch.uint8, device="cuda") if (G and not pipelined) else None
     local = torch.zeros(max(tiles.max_owned_rows(H, N), 1) * W * 4, dtype=torch.uint8, device="cuda")

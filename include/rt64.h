@@ -367,6 +367,8 @@ typedef struct {
     float accumMsTotal, accumMsBuild, accumMsPrimaryTrace, accumMsPrimaryShade, accumMsDirect, accumMsIndirect, accumMsReflectRefract, accumMsDenoise, accumMsComposePost;
     unsigned int fusedFrame;                /* 1: the lean frame ran as ONE kernel (primary visibility + resolve + direct light + compose); 2: a full frame's primary visibility + G-buffer + direct light ran as one kernel; the kernel's time is reported as msPrimaryTrace */
     unsigned int packedFinal;               /* 1: the frame wrote its owned back-buffer rows to the RT64_SetDeviceGatherTarget memory */
+    unsigned int overlappedFrame;           /* 1: the frame was enqueued on the device's second render stream, beside the frame before it (sync_present = 0, option overlap_frames; pixel-local frames on unchanged tables only) */
+    unsigned int traversalOverflow;         /* traversal-stack entries dropped by the frame's rays (count_traversal = 1); anything but 0 is an error RT64_DrawDevice also reports through RT64_GetLastError */
 } RT64_FRAME_STATS;
 
 #define RT64_EXT_API_LIST(X) \

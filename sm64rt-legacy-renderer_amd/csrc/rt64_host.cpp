@@ -155,6 +155,7 @@ struct Options {
     bool foldCompose = true;       // frames with the SVGF denoiser: ComposePS inside the last a-trous iteration (0: compose_post_kernel, its own launch)
     bool foldVariance = true;      // ... and the filter's input (variance from the moments) for every pixel with four frames of history; svgf_variance_kernel then only runs where a younger pixel is marked (0: it makes every pixel's input)
     bool foldGuide = true;         // frames with the wavefront GI chain + SVGF: bounce_resolve_kernel writes the filter's guide records (0: svgf_guide_kernel, its own launch)
+    bool overlapFrames = true;     // enqueued (sync_present = 0) pixel-local frames alternate between two render streams: frame k+1 starts while the last waves of frame k are still walking (Device::draw)
     bool overlapReflection = true; // frames with reflection passes AND the SVGF denoiser: the reflection launches run on a second stream beside the a-trous iterations (they share no image)
     bool haloExchange = false;     // band partitions of GI + SVGF frames: ship the filter input of the halo rows between the devices of the gather (RCCL) instead of re-rendering them
     bool haloDryRun = false;       // timing aid: an exchanging band runs its frame but moves no halo rows (what one rank's GPU work costs, measured on one device; results outside the band's interior are then wrong)
@@ -168,7 +169,25 @@ struct Options {
 
 struct Device {
     int hipDevice = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;         // the render stream of the frame in hand: streams[cur]
+    // Two render streams (option overlap_frames).  A frame that is pixel-local from its primary rays to the back buffer, uploads nothing and has no temporal
+    // consumer ("pure": the one-kernel lean frame on unchanged tables) reads only what earlier frames left untouched and writes only per-slot storage -- back
+    // buffer, gather send buffer, traversal spill slab, tile-cost order, all indexed by `cur` -- so consecutive pure frames may run side by side: with
+    // sync_present = 0 they alternate between the two streams, and frame k+1's first waves fill the wave slots the tail of frame k has left empty.  Everything
+    // else -- an upload, a build, a frame with history, a readback, any API call that touches device memory -- first makes the current stream wait for the other
+    // one (joinStreams), after which streams[cur] is ordered behind everything enqueued so far, exactly as with one stream.
+    hipStream_t streams[2] = { nullptr, nullptr }; int cur = 0;
+    hipEvent_t streamJoin = nullptr;
+    bool otherBusy = false;               // streams[cur ^ 1] may hold work streams[cur] has not waited for
+    bool framePure = false, lastFramePure = false;
+    void joinStreams() {
+        if (!otherBusy) return;
+        HIP_CHECK(hipEventRecord(streamJoin, streams[cur ^ 1]));
+        HIP_CHECK(hipStreamWaitEvent(stream, streamJoin, 0));
+        otherBusy = false;
+    }
+    void impure() { framePure = false; joinStreams(); }                   // this frame enqueues something that is not slot-local: it runs behind every earlier frame
+    void enter() { use(); joinStreams(); lastFramePure = false; }         // API entry that touches device memory outside RT64_DrawDevice / RT64_SubmitGather
     int width = 0, height = 0, pendingWidth = 0, pendingHeight = 0;
     int tileY0 = 0, tileY1 = 0; bool tileSet = false;
     int stripRank = 0, stripCount = 1;
@@ -178,7 +197,7 @@ struct Device {
     bool profNow = false, statsProfiled = false; unsigned profCounter = 0;       // this frame records its pass events (option profile_every)
     double hostUpdateUs = 0.0, hostRenderUs = 0.0, hostStageUs[16] = {}, hostEventUs = 0.0; unsigned long long hostFrames = 0;      // host-side cost of View::update / View::render (RT64_HOST_TIMING=1 prints them)
     void finishStats();
-    DevArray<uint32_t> spillStack;
+    DevArray<uint32_t> spillStack[2];                                     // HBM half of the traversal stacks, one slab per render stream (indexed by the launch's lanes)
     void *gatherTarget = nullptr; size_t gatherTargetBytes = 0;          // RT64_SetDeviceGatherTarget
     hipStream_t auxStream = nullptr; hipEvent_t forkEvent = nullptr, joinEvent = nullptr;      // second stream of a frame whose reflection passes run beside its denoiser (created on first use)
     // Halo exchange of the SVGF filter input between the bands of a partition (RT64_SetDeviceHaloExchange / option halo_exchange): transport and layout
@@ -360,7 +379,8 @@ struct View {
     // extension primary_spp (rules P1-P4, oracle/oracle_render.c): the frame as `subFrames` complete sub-frames; Device::draw drives them
     int subFrame = 0, subFrames = 1; DevArray<float> sppSum;
     // longest-first tile order of the one-kernel frame on scenes that walk from HBM (device option tile_order): last frame's cost per tile and the order made from it
-    DevArray<uint32_t> tileCost, tileOrder; uint32_t tileOrderTiles = 0; bool tileOrderValid = false;
+    DevArray<uint32_t> tileCost[2], tileOrder[2]; uint32_t tileOrderTiles = 0; bool tileOrderValid[2] = { false, false };      // (one set per render stream: Device::streams)
+    uint8_t *finalBuf[2] = { nullptr, nullptr };      // the back buffer, one per render stream; img.final is the one of the frame in hand / last drawn
 
     explicit View(Scene *s);
     ~View();
@@ -398,7 +418,10 @@ Device::Device(int w, int h, int dev) {
     HIP_CHECK(hipGetDeviceProperties(&prop, dev));
     if (w <= 0 || h <= 0) throw std::runtime_error("Invalid device size.");
     width = pendingWidth = w; height = pendingHeight = h; tileY0 = 0; tileY1 = h;
-    HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&streams[0], hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&streams[1], hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&streamJoin, hipEventDisableTiming));
+    stream = streams[0]; cur = 0;
     for (auto &ev : events) HIP_CHECK(hipEventCreate(&ev));
     counters.reserve((size_t)CTR_COUNT * RT_COUNTER_STRIPES);
     HIP_CHECK(hipMemsetAsync(counters.ptr, 0, counters.bytes(), stream));
@@ -418,7 +441,7 @@ Device::Device(int w, int h, int dev) {
 
 Device::~Device() {
     hipSetDevice(hipDevice);
-    hipStreamSynchronize(stream);
+    for (hipStream_t st : streams) if (st) hipStreamSynchronize(st);
     if (getenv("RT64_HOST_TIMING") && hostFrames) fprintf(stderr, "RT64 host timing: %llu frames, View::update %.1f us, View::render %.1f us per frame\n", hostFrames, hostUpdateUs / (double)hostFrames, hostRenderUs / (double)hostFrames);
     if (getenv("RT64_HOST_TIMING") && hostFrames) { fprintf(stderr, "  launch host us by stage (up to each event mark):"); for (int i = 0; i < 16; i++) if (hostStageUs[i] > 0.0) fprintf(stderr, " [%d] %.1f", i, hostStageUs[i] / (double)hostFrames); fprintf(stderr, "  event records %.1f\n", hostEventUs / (double)hostFrames); }
     auto scenesCopy = scenes;
@@ -432,14 +455,15 @@ Device::~Device() {
     if (halo.ready) hipEventDestroy(halo.ready);
     if (halo.done) hipEventDestroy(halo.done);
     if (ring) hipHostFree(ring);
-    if (stream) hipStreamDestroy(stream);
+    if (streamJoin) hipEventDestroy(streamJoin);
+    for (hipStream_t st : streams) if (st) hipStreamDestroy(st);
 }
 
 // ---- Texture ----------------------------------------------------------------------------------------------------------------
 
 void Texture::setRGBA8(const void *bytes, int byteCount, int w, int h, int rowPitch) {
     if (!bytes || w <= 0 || h <= 0 || rowPitch < w * 4 || (long long)rowPitch * h > (long long)byteCount + (rowPitch - w * 4)) throw std::runtime_error("RT64_CreateTexture: invalid RGBA8 description.");
-    device->use();
+    device->enter();
     width = w; height = h; mips = 1; mipOffset[0] = 0;     // mip generation is compiled out in the reference (rt64_device.cpp:758-762)
     texels.reserve((size_t)w * h * 4);
     uint8_t *stage = static_cast<uint8_t *>(device->staging((size_t)w * h * 4));
@@ -472,7 +496,7 @@ void Texture::setDDS(const void *data, int byteCount) {
     else throw std::runtime_error("RT64_CreateTexture: unsupported DDS pixel format.");
     if (mipCount == 0) mipCount = 1;
     if (mipCount > RT64_MAX_MIPS || w == 0 || h == 0) throw std::runtime_error("RT64_CreateTexture: invalid DDS dimensions.");
-    device->use();
+    device->enter();
     width = (int)w; height = (int)h; mips = (int)mipCount;
     size_t totalTexels = 0, totalSrc = 0;
     { uint32_t mw = w, mh = h; for (uint32_t m = 0; m < mipCount; m++) { mipOffset[m] = (uint32_t)totalTexels; totalTexels += (size_t)mw * mh; totalSrc += bc7 ? (size_t)((mw + 3) / 4) * ((mh + 3) / 4) * 16 : (size_t)mw * mh * 4; mw = mw > 1 ? mw / 2 : 1; mh = mh > 1 ? mh / 2 : 1; } }
@@ -570,7 +594,7 @@ void Mesh::set(const void *vertexArray, int vcount, int vstride, const unsigned 
         }
     }
     memcpy(hostBmin, mn, 12); memcpy(hostBmax, mx, 12);
-    device->use();
+    device->enter();
     if (vertices.ptr) device->beforeSceneMutation();       // a kept lean frame may still read this mesh's arrays (a first upload changes nothing a frame has seen)
     // rt64_mesh.cpp:30-39,76-82: a change of counts/stride discards the BLAS even if updatable.
     const bool sameShape = vertices.ptr && vertexCount == vcount && vertexStride == vstride && indexCount == icount;
@@ -613,6 +637,7 @@ Mesh::~Mesh() {
 void Device::flushMeshBuilds() {
     if (dirtyMeshes.empty()) return;
     use();
+    impure();
     std::vector<LbvhArgs> small; uint32_t maxN = 0;
     for (Mesh *m : dirtyMeshes) {
         LbvhArgs a = {};
@@ -712,13 +737,14 @@ View::~View() {
 }
 void View::releaseImages() {
     for (void *p : allocations) hipFree(p);
-    allocations.clear(); img = ViewImages(); bounceSamples = 0; leanFrame = false; fusedFrame = false;
+    allocations.clear(); img = ViewImages(); bounceSamples = 0; leanFrame = false; fusedFrame = false; finalBuf[0] = finalBuf[1] = nullptr;
     for (auto &u : upscaled) { if (u) hipFree(u); u = nullptr; }
     upW = upH = 0; upValid = false;
 }
 
 void View::createImages(int w, int h, int screenW, int screenH) {       // View::createOutputBuffers, rt64_view.cpp:105-298 (same formats)
     scene->device->use();
+    scene->device->impure();
     releaseImages();
     const size_t n = (size_t)w * h;
     auto alloc = [&](size_t bytes) { void *p = nullptr; HIP_CHECK(hipMalloc(&p, bytes)); HIP_CHECK(hipMemsetAsync(p, 0, bytes, scene->device->stream)); allocations.push_back(p); return p; };
@@ -738,7 +764,9 @@ void View::createImages(int w, int h, int screenW, int screenH) {       // View:
     img.reflection = static_cast<uint16_t *>(alloc(n * 8)); img.refraction = static_cast<uint16_t *>(alloc(n * 8)); img.transparent = static_cast<uint16_t *>(alloc(n * 8));
     img.flow = static_cast<uint16_t *>(alloc(n * 4));
     img.reactiveMask = static_cast<uint8_t *>(alloc(n)); img.lockMask = static_cast<uint8_t *>(alloc(n));
-    img.output = static_cast<float *>(alloc(n * 16)); img.final = static_cast<uint8_t *>(alloc((size_t)screenW * screenH * 4));
+    img.output = static_cast<float *>(alloc(n * 16));
+    for (auto &fb : finalBuf) fb = static_cast<uint8_t *>(alloc((size_t)screenW * screenH * 4));
+    img.final = finalBuf[scene->device->cur];
     img.primaryHit = static_cast<uint32_t *>(alloc(n * 16));
     hitInstance.reserve(n);
     HIP_CHECK(hipMemsetAsync(hitInstance.ptr, 0xFF, n * 4, scene->device->stream));
@@ -820,6 +848,7 @@ void View::prepareRasterList(const std::vector<RenderInstance> &list, RasterList
     const bool sameContent = rl.ready && rl.uploaded.size() == bytes && memcmp(rl.uploaded.data(), hst.data(), bytes) == 0 &&
                              rl.w == w && rl.h == h && rl.y0 == y0 && rl.y1 == y1 && rl.apply == apply;
     if (sameContent && !dev->opt.alwaysRebuild) return;
+    dev->impure();
     rl.contentChanged = !sameContent;
     rl.table.reserve(hst.size()); rl.tris.reserve(std::max<size_t>(raster_tri_bytes(triTotal), 16));
     const bool inlineTable = raster_setup_takes_table_inline((uint32_t)hst.size());      // a short list rides in the setup kernel's arguments: no copy on the stream
@@ -1054,6 +1083,7 @@ void View::update() {                          // View::update, rt64_view.cpp:10
     // before new contents overwrite them.  (always_rebuild re-uploads identical bytes to the same places: nothing to save.)
     if (!sameContent && leanFrame) { materialise(); dev->leanHoldoff = RT64_LEAN_HOLDOFF_FRAMES; }
     if (!unchanged) {
+        dev->impure();           // new table bytes: behind every frame that still reads the old ones
         // TLAS: full rebuild (rt64_view.cpp:412-452 rebuilds every frame, updateOnly = false) -- of a few instances on the host, into the same upload
         const uint32_t n = (uint32_t)nInst;
         const bool hostTlas = n >= 1 && n <= RT64_HOST_TLAS_MAX && dev->opt.hostTlas;
@@ -1093,6 +1123,7 @@ void View::update() {                          // View::update, rt64_view.cpp:10
         dev->workSinceMark = true;
     }
     if (cacheWords && !cacheImageValid) {
+        dev->impure();
         cacheImage.reserve((size_t)cacheWords * 16);
         HIP_CHECK(launch_scene_cache_image(dInstances.ptr, tlasIndexAt, tlasNodesAt, (uint32_t)nInst, cacheImage.ptr, dev->stream));
         cacheImageValid = true;
@@ -1107,6 +1138,7 @@ void View::update() {                          // View::update, rt64_view.cpp:10
         if (!rasterBg.empty() && (backgroundW != finalW || backgroundH != finalH)) { background.reserve((size_t)finalW * finalH * 4); backgroundW = finalW; backgroundH = finalH; rasterBgEnv.changed = true; }      // (a resize has dropped every kept frame: View::createImages)
         if (leanFrame && (rasterBgEnv.contentChanged || (!rasterBgEnv.ready && lastParams.background.texels))) { materialise(); dev->leanHoldoff = RT64_LEAN_HOLDOFF_FRAMES; }      // the kept frame's sky pixels read gBackground
         if (rasterBgEnv.ready && rasterBgEnv.changed) {        // gBackground: cleared to 0, drawn without scissors / viewports (rt64_view.cpp:1298-1319)
+            dev->impure();
             HIP_CHECK(hipMemsetAsync(background.ptr, 0, (size_t)finalW * finalH * 4, dev->stream));
             const int sr = dev->stripRank, sc = dev->stripCount; dev->stripRank = 0; dev->stripCount = 1;
             drawRasterList(rasterBgEnv, background.ptr);
@@ -1161,6 +1193,7 @@ void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64
     if (skyPlane && (giSamples > 0 || anyReflection) && skyPlane->width >= 4 && skyPlane->height >= 4 &&
         (skyPlane->width & (skyPlane->width - 1)) == 0 && (skyPlane->height & (skyPlane->height - 1)) == 0) {
         if (skyTiledSerial != skyPlane->serial) {
+            dev->impure();
             skyTiled.reserve((size_t)skyPlane->width * skyPlane->height);
             HIP_CHECK(tile_texture_launch(skyPlane->texels.ptr, skyTiled.ptr, (uint32_t)skyPlane->width, (uint32_t)skyPlane->height, dev->stream));
             skyTiledSerial = skyPlane->serial;
@@ -1206,8 +1239,13 @@ void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64
     P.lightCount = (uint32_t)scene->lights.size(); P.instanceCount = (uint32_t)rtInstances.size();
     P.countTraversal = dev->opt.countTraversal ? 1u : 0u;
     P.instances = dInstances.ptr; P.tlasNodes = tlasNodesAt; P.tlasIndex = tlasIndexAt; P.textures = dTextures.ptr; P.lights = dLights.ptr;
-    if (needSpillSlab) dev->spillStack.reserve(rt_stack_spill_bytes(imgW, imgH) / sizeof(uint32_t));      // grows with the render size (no-op otherwise); never allocated for shallow scenes
-    P.blueNoise = dev->blueNoise.ptr; P.traversalStack = dev->spillStack.ptr; P.counters = dev->counters.ptr;
+    {   // grows with the render size (no-op otherwise); never allocated for shallow scenes; one slab per render stream
+        DevArray<uint32_t> &slab = dev->spillStack[dev->cur];
+        const size_t words = needSpillSlab ? rt_stack_spill_bytes(imgW, imgH) / sizeof(uint32_t) : 0;
+        if (words > slab.count) { dev->impure(); slab.reserve(words); }
+        P.traversalStack = slab.ptr;
+    }
+    P.blueNoise = dev->blueNoise.ptr; P.counters = dev->counters.ptr;
     P.tileTiming = nullptr;
     if (dev->opt.tileTiming) { dev->tileTiming.reserve((size_t)RT_TIMING_WAVES * 3); P.tileTiming = dev->tileTiming.ptr; }      // two records per wave + one more in diagnostic builds
 }
@@ -1218,6 +1256,8 @@ void View::render() {                          // View::render, rt64_view.cpp:11
     Device *dev = scene->device;
     hipStream_t s = dev->stream;
     const bool prof = dev->profNow;
+    const int slot = dev->cur;                   // per-stream storage of this frame: back buffer, tile order (Device::streams)
+    img.final = finalBuf[slot];
     static const bool hostTiming = getenv("RT64_HOST_TIMING") != nullptr;
     auto hostPrev = std::chrono::steady_clock::now();
     auto mark = [&](int ev) {
@@ -1290,6 +1330,9 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         // it then writes the whole G-buffer over the rows with the denoiser halo (X) and DirectRayGen's images over the owned rows.
         const bool fusedFull = !lean && !klist && dev->opt.fusedLean;
         leanFrame = lean; fusedFrame = fused; fusedFullFrame = fusedFull; lastParams = P; lastCur = cur;
+        // Only the one-kernel lean frame that stores nothing but its slot's back buffer may run beside its neighbours (Device::streams); every other kind of
+        // frame reads or writes images that are not per slot and runs behind everything enqueued before it.
+        if (!(fused && !P.separatePost && !rtRect && !dev->opt.leanRecords)) dev->impure();
         // The foreground (HUD) list is pixel-local too: the one-kernel frame blends it over each pixel before the store, no launch of its own.
         if (fused && !P.separatePost && !rtRect && rasterFgScreen.ready && rasterFgScreen.triTotal > 0 && dev->opt.foldForeground) {
             P.rasterFg = rasterFgScreen.table.ptr; P.rasterFgTris = rasterFgScreen.tris.ptr; P.rasterFgCount = rasterFgScreen.triTotal;
@@ -1311,11 +1354,15 @@ void View::render() {                          // View::render, rt64_view.cpp:11
             const unsigned tiles = lean_frame_tiles(F);
             if (tiles == 0u) return 0u;
             if (tileOrderTiles != tiles) {
-                tileCost.reserve(tiles); tileOrder.reserve(tiles);
-                HIP_CHECK(hipMemsetAsync(tileCost.ptr, 0, (size_t)tiles * 4, s));
-                tileOrderTiles = tiles; tileOrderValid = false;
+                dev->impure();
+                for (int k = 0; k < 2; k++) {
+                    tileCost[k].reserve(tiles); tileOrder[k].reserve(tiles);
+                    HIP_CHECK(hipMemsetAsync(tileCost[k].ptr, 0, (size_t)tiles * 4, s));
+                    tileOrderValid[k] = false;
+                }
+                tileOrderTiles = tiles;
             }
-            F.tileCost = tileCost.ptr; F.tileOrder = tileOrderValid ? tileOrder.ptr : nullptr;
+            F.tileCost = tileCost[slot].ptr; F.tileOrder = tileOrderValid[slot] ? tileOrder[slot].ptr : nullptr;
             return tiles;
         };
         if (fused) {
@@ -1323,7 +1370,7 @@ void View::render() {                          // View::render, rt64_view.cpp:11
             if (P.tileTiming) { HIP_CHECK(hipMemsetAsync(dev->tileTiming.ptr, 0, dev->tileTiming.bytes(), s)); }
             const unsigned ordered = orderTiles(P);
             L(launch_lean_frame(P, img, dev->opt.leanRecords ? hitInstance.ptr : nullptr, cur, false, 0, imgH, dev->opt.maxFrameGroups, perWave, s));
-            if (ordered) { L(launch_tile_order(tileCost.ptr, tileOrder.ptr, ordered, s)); tileOrderValid = true; }
+            if (ordered) { L(launch_tile_order(tileCost[slot].ptr, tileOrder[slot].ptr, ordered, s)); tileOrderValid[slot] = true; }
             fusedStoreless = !dev->opt.leanRecords;
             mark(Device::EV_PRIMARY_TRACE); mark(Device::EV_PRIMARY); mark(Device::EV_DIRECT);
         }
@@ -1332,7 +1379,7 @@ void View::render() {                          // View::render, rt64_view.cpp:11
             if (X.tileTiming) { HIP_CHECK(hipMemsetAsync(dev->tileTiming.ptr, 0, dev->tileTiming.bytes(), s)); }
             const unsigned ordered = orderTiles(X);
             L(launch_lean_frame(X, img, hitInstance.ptr, cur, true, P.tileY0, P.tileY1, dev->opt.maxFrameGroups, perWave, s));
-            if (ordered) { L(launch_tile_order(tileCost.ptr, tileOrder.ptr, ordered, s)); tileOrderValid = true; }
+            if (ordered) { L(launch_tile_order(tileCost[slot].ptr, tileOrder[slot].ptr, ordered, s)); tileOrderValid[slot] = true; }
             mark(Device::EV_PRIMARY_TRACE); mark(Device::EV_PRIMARY); mark(Device::EV_DIRECT);
         }
         else {
@@ -1427,6 +1474,7 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         if (P.separatePost) L(launch_post_process(P, img, s));
     }
     else {
+        dev->impure();
         leanFrame = false; fusedFrame = false; fusedFullFrame = false; packedFinal = false;
         mark(Device::EV_PRIMARY_TRACE); mark(Device::EV_PRIMARY); mark(Device::EV_DIRECT); mark(Device::EV_INDIRECT); mark(Device::EV_REFL); mark(Device::EV_DENOISE);
         L(launch_clear_final(P, img, s));
@@ -1442,6 +1490,7 @@ void View::materialise() {
     if (!leanFrame) return;
     Device *dev = scene->device;
     dev->use();
+    dev->joinStreams();
     if (fusedFrame && fusedStoreless) {
         // the frame kept no records: the FULL variant of the frame kernel traces the same rays again and writes the whole G-buffer and DirectRayGen's two images
         FrameParams Q = lastParams;
@@ -1472,6 +1521,14 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
     }
     if (tileY1 > height) tileY1 = height;
     if (tileY0 >= tileY1) { tileY0 = 0; tileY1 = height; }
+    // Two render streams (see Device::streams): an enqueued frame that follows a pure frame starts on the other stream, beside that frame's tail; it is joined
+    // behind it the moment it turns out not to be pure itself (impure(): an upload, a build, a frame with history).  Frame counters, the tile-timing records and
+    // the sub-frame accumulation are one per device: frames that use them stay in order.
+    const bool mayOverlap = opt.overlapFrames && !opt.syncPresent && !opt.countTraversal && !opt.tileTiming && opt.primarySpp <= 1;
+    const bool flipped = mayOverlap && lastFramePure;
+    if (flipped) { cur ^= 1; stream = streams[cur]; otherBusy = true; }
+    framePure = mayOverlap; lastFramePure = false;       // (a frame that ends in an exception leaves "not pure" behind)
+    if (!mayOverlap) joinStreams();
     if (opt.countTraversal) HIP_CHECK(hipMemsetAsync(counters.ptr, 0, counters.bytes(), stream));
     // pass events on every profile_every-th frame only: each event is a barrier packet (~5 us of stream time; six of them are 5 % of a 0.6 ms GI frame)
     profNow = opt.profilePasses && (opt.profileEvery <= 1 || profCounter++ % (unsigned)opt.profileEvery == 0);
@@ -1489,6 +1546,7 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
         v->subFrame = 0;
     }
     if (leanHoldoff) leanHoldoff--;
+    lastFramePure = framePure;
     auto tu2 = std::chrono::steady_clock::now();
     hostUpdateUs += std::chrono::duration<double, std::micro>(tu1 - tu0).count(); hostRenderUs += std::chrono::duration<double, std::micro>(tu2 - tu1).count(); hostFrames++;
     if (profNow) {             // the end mark shares the last mark's event when nothing was launched after it (one barrier packet less per frame)
@@ -1512,6 +1570,7 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
     st.screenWidth = (unsigned)width; st.screenHeight = (unsigned)height;
     st.msHostWall = std::chrono::duration<float, std::milli>(t1 - t0).count();
     st.stripRank = (unsigned)stripRank; st.stripCount = (unsigned)stripCount; st.rowsRendered = (unsigned)ownedRows();
+    st.overlappedFrame = (flipped && framePure) ? 1u : 0u;
     bool haveView = false;
     for (Scene *sc : scenes) for (View *v : sc->views) {
         if (haveView) continue;
@@ -1610,7 +1669,7 @@ static bool image_info(View *v, int image, ImageInfo &info, size_t &dstPixelByte
 static View *first_view(Device *dev) { for (Scene *sc : dev->scenes) for (View *v : sc->views) return v; return nullptr; }
 
 static size_t readback(Device *dev, int image, void *dst, size_t dstBytes, bool toDevice) {
-    dev->use();
+    dev->enter();
     View *v = first_view(dev);
     if (!v) throw std::runtime_error("RT64_ReadbackDevice: the device has no view.");
     if (image == RT64_IMAGE_BACKGROUND) {        // gBackground: whole screen on every device; zeros when the frame had no background instance
@@ -1758,6 +1817,7 @@ RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, doubl
     else if (k == "denoiser_mode") d->opt.denoiserMode = (int)value;
     else if (k == "bounce_refill") d->opt.bounceRefill = (int)value;
     else if (k == "overlap_reflection") d->opt.overlapReflection = value != 0.0;
+    else if (k == "overlap_frames") d->opt.overlapFrames = value != 0.0;       // 0: every frame on one render stream (a host that orders its own work behind frames on RT64_GetDeviceStream)
     else if (k == "tile_order") d->opt.tileOrder = value != 0.0;
     else if (k == "fold_variance") d->opt.foldVariance = value != 0.0;
     else if (k == "fold_guide") d->opt.foldGuide = value != 0.0;
@@ -1792,7 +1852,7 @@ RT64_EXPORT size_t RT64_ReadbackTileTiming(RT64_DEVICE *device, void *dst, size_
     RT64_TRY
     Device *d = reinterpret_cast<Device *>(device);
     if (!d || !dst || !d->tileTiming.ptr) throw std::runtime_error("RT64_ReadbackTileTiming: set the device option tile_timing and draw a frame first.");
-    d->use();
+    d->enter();
     const size_t bytes = std::min(dstBytes, d->tileTiming.bytes());
     HIP_CHECK(hipMemcpyAsync(dst, d->tileTiming.ptr, bytes, hipMemcpyDeviceToHost, d->stream));
     HIP_CHECK(hipStreamSynchronize(d->stream));
@@ -1822,7 +1882,7 @@ RT64_EXPORT void RT64_SetViewSkyPlane(RT64_VIEW *viewPtr, RT64_TEXTURE *textureP
 RT64_EXPORT RT64_INSTANCE *RT64_GetViewRaytracedInstanceAt(RT64_VIEW *viewPtr, int x, int y) {         // rt64_view.cpp:1932-1998
     RT64_TRY
     View *v = reinterpret_cast<View *>(viewPtr); if (!v) return nullptr;
-    Device *dev = v->scene->device; dev->use();
+    Device *dev = v->scene->device; dev->enter();
     const float xs = (float)v->imgW / (float)dev->width, ys = (float)v->imgH / (float)dev->height;
     x = (int)lroundf(x * xs); y = (int)lroundf(y * ys);
     if (x < 0 || x >= v->imgW || y < 0 || y >= v->imgH) return nullptr;
@@ -1867,7 +1927,7 @@ RT64_EXPORT RT64_MESH *RT64_CreateMesh(RT64_DEVICE *devicePtr, int flags) {
 RT64_EXPORT void RT64_SetMesh(RT64_MESH *meshPtr, void *vertexArray, int vertexCount, int vertexStride, unsigned int *indexArray, int indexCount) {
     RT64_TRY if (!meshPtr) throw std::runtime_error("RT64_SetMesh: NULL mesh."); reinterpret_cast<Mesh *>(meshPtr)->set(vertexArray, vertexCount, vertexStride, indexArray, indexCount); RT64_CATCH_VOID
 }
-RT64_EXPORT void RT64_DestroyMesh(RT64_MESH *meshPtr) { RT64_TRY Mesh *m = reinterpret_cast<Mesh *>(meshPtr); if (m) { m->device->use(); m->device->beforeSceneMutation(); hipStreamSynchronize(m->device->stream); } delete m; RT64_CATCH_VOID }
+RT64_EXPORT void RT64_DestroyMesh(RT64_MESH *meshPtr) { RT64_TRY Mesh *m = reinterpret_cast<Mesh *>(meshPtr); if (m) { m->device->enter(); m->device->beforeSceneMutation(); hipStreamSynchronize(m->device->stream); } delete m; RT64_CATCH_VOID }
 
 // ---- shader (rt64_shader.cpp:810-824) ----
 RT64_EXPORT RT64_SHADER *RT64_CreateShader(RT64_DEVICE *devicePtr, unsigned int shaderId, unsigned int filter, unsigned int hAddr, unsigned int vAddr, int flags) {
@@ -1907,12 +1967,12 @@ RT64_EXPORT RT64_TEXTURE *RT64_CreateTexture(RT64_DEVICE *devicePtr, RT64_TEXTUR
     return reinterpret_cast<RT64_TEXTURE *>(t);
     } catch (const std::exception &e) { GlobalLastError = e.what(); fprintf(stderr, "%s\n", e.what()); delete t; return nullptr; }
 }
-RT64_EXPORT void RT64_DestroyTexture(RT64_TEXTURE *texture) { RT64_TRY Texture *t = reinterpret_cast<Texture *>(texture); if (t) { t->device->use(); t->device->beforeSceneMutation(); hipStreamSynchronize(t->device->stream); } delete t; RT64_CATCH_VOID }
+RT64_EXPORT void RT64_DestroyTexture(RT64_TEXTURE *texture) { RT64_TRY Texture *t = reinterpret_cast<Texture *>(texture); if (t) { t->device->enter(); t->device->beforeSceneMutation(); hipStreamSynchronize(t->device->stream); } delete t; RT64_CATCH_VOID }
 
 // ---- debug readback of acceleration structures (additive) ----
 static size_t accel_readback(Device *dev, int what, uint32_t n, const GpuNode *nodes, const GpuTri *tris, const uint32_t *sorted, const uint32_t *morton,
                              const BlasHeader *header, void *dst, size_t dstBytes) {
-    dev->use();
+    dev->enter();
     const void *src = nullptr; size_t bytes = 0;
     switch (what) {
     case RT64_ACCEL_NODES: src = nodes; bytes = (size_t)std::max<uint32_t>(n > 0 ? n - 1 : 0, 1) * sizeof(GpuNode); break;
@@ -2081,7 +2141,7 @@ struct Gather {
 
 Gather::Gather(Device *d, const ncclUniqueId &id, int rank_, int count_, int bands_) : dev(d), rank(rank_), count(count_), bands(bands_) {
     if (count < 1 || rank < 0 || rank >= count) throw std::runtime_error("RT64_CreateGather: rank / count out of range.");
-    dev->use();
+    dev->enter();
     W = dev->pendingWidth; H = dev->pendingHeight;
     if (count > RT64_GATHER_MAX_RANKS) throw std::runtime_error("RT64_CreateGather: more ranks than RT64_GATHER_MAX_RANKS.");
     if (bands < 0 || bands > 2) throw std::runtime_error("RT64_CreateGather: bands must be 0 (interleaved strips), 1 (equal bands) or 2 (cost-balanced bands).");
@@ -2123,7 +2183,8 @@ Gather::Gather(Device *d, const ncclUniqueId &id, int rank_, int count_, int ban
 }
 Gather::~Gather() {
     hipSetDevice(dev->hipDevice);
-    hipStreamSynchronize(dev->stream); if (commStream) hipStreamSynchronize(commStream);
+    for (hipStream_t st : dev->streams) if (st) hipStreamSynchronize(st);
+    if (commStream) hipStreamSynchronize(commStream);
     if (dev->gatherTarget == slots[0].local || dev->gatherTarget == slots[1].local) { dev->gatherTarget = nullptr; dev->gatherTargetBytes = 0; }
     if (dev->halo.gather == this) dev->halo.gather = nullptr;
     if (comm) rccl().CommDestroy(comm);
@@ -2133,7 +2194,8 @@ Gather::~Gather() {
 // The renderer may write slot `slot` again: its previous exchange (two frames ago) is ordered before whatever the render stream does next.
 void Gather::prepare(int slot) {
     Slot &sl = slots[slot];
-    if (sl.pending) { HIP_CHECK(hipStreamWaitEvent(dev->stream, sl.gathered, 0)); sl.pending = false; }
+    // (both render streams: the next frame may start on either, Device::streams)
+    if (sl.pending) { for (hipStream_t st : dev->streams) HIP_CHECK(hipStreamWaitEvent(st, sl.gathered, 0)); sl.pending = false; }
     dev->gatherTarget = sl.local; dev->gatherTargetBytes = slotBytes;
 }
 // After RT64_DrawDevice: exchange the frame just drawn.  Returns the slot it travels in.
@@ -2169,7 +2231,7 @@ int Gather::submit() {
 void Gather::setBands(const int *starts) {
     if (bands == 0) throw std::runtime_error("RT64_SetGatherBands: a gather of interleaved strips (bands = 0) has no boundaries; create it with bands = 1 or bands = 2.");
     if (!halo_starts_valid(H, count, starts)) throw std::runtime_error("RT64_SetGatherBands: starts[0 .. count] must rise from 0 to the frame height.");
-    dev->use();
+    dev->enter();
     HIP_CHECK(hipStreamSynchronize(dev->stream)); HIP_CHECK(hipStreamSynchronize(commStream));        // nothing of the old layout is in flight
     for (Slot &sl : slots) sl.pending = false;
     bands = 2; layout.mode = 2;              // (a gather of equal bands becomes one of given boundaries: no whole frame has to be rendered for the first cut)
@@ -2192,7 +2254,7 @@ void Gather::setBands(const int *starts) {
 void Gather::wait(int slot, bool host) {
     Slot &sl = slots[slot];
     if (host) HIP_CHECK(hipEventSynchronize(sl.gathered));
-    else HIP_CHECK(hipStreamWaitEvent(dev->stream, sl.gathered, 0));
+    else for (hipStream_t st : dev->streams) HIP_CHECK(hipStreamWaitEvent(st, sl.gathered, 0));
 }
 
 // ---- halo exchange of the SVGF filter input ("renders its rows plus a halo ..., or exchanges halos") -------------------------------------

@@ -33,10 +33,10 @@ def test_c_host_builds_and_reads_the_sample_assets_like_the_python_harness(sampl
     by_name = {t.name: t for t in sample_data.textures}
     for name in ("grass_nrm.png", "grass_spc.png", "clouds.png", "tiles_dif.png", "tiles_nrm.png", "tiles_spc.png"):
         t = by_name[name]
-        w, h, s = out[name]
+        w, h, s, _fnv = out[name]
         flat = t.data.reshape(-1, 4).astype(np.uint64)
         assert (w, h) == (t.width, t.height) and s == int((flat * np.array([1, 2, 3, 4], dtype=np.uint64)).sum()), name
-    n, h = out["sphere.obj"]
+    n, h, _pn = out["sphere.obj"]
     v = np.ascontiguousarray(sample_data.meshes[0].vertices)
     assert n == len(v) == 960 and h == fnv1a(v.tobytes())
 

@@ -1,0 +1,124 @@
+"""Two render streams (device option overlap_frames): enqueued pixel-local frames alternate between two HIP streams so that frame
+k + 1 starts beside the tail of frame k.  Every frame must be the frame the one-stream path renders, byte for byte -- whichever stream and
+whichever of the two back buffers it landed in -- and anything that is not pixel-local (an upload, a frame with history, a readback) must
+fall back into order."""
+import copy
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+W, H = 320, 180
+
+
+def _camera(data, k):
+    """Frame k's view matrix: the sample camera, moved a little every frame (so that no two frames are the same image)."""
+    d = copy.copy(data)
+    v = np.array(data.view, dtype=np.float32).copy()
+    v[3][0] += 0.25 * k
+    v[3][1] -= 0.1 * k
+    d.view = v
+    return d
+
+
+def _run(rt64_lib, sample_data, overlap, lds_cache, frames, change_at=None, groups=0, interleave=None):
+    """Draw `frames` enqueued frames with a moving camera; returns the back buffer after every frame listed in `check` plus the per-frame stats flags."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    s = sample_scene.Rt64Scene(rt64_lib, sample_data, W, H, hip_device=0)
+    finals, flags = {}, []
+    try:
+        assert s.option("lds_cache", lds_cache) and s.option("overlap_frames", overlap)
+        if groups:
+            assert s.option("max_frame_groups", groups)
+        if interleave:
+            s.set_interleave(*interleave)
+        s.draw()                       # first frame: uploads + builds (synchronous)
+        s.option("sync_present", 0)
+        for k in range(frames):
+            s.data = _camera(sample_data, k)
+            if change_at is not None and k == change_at:      # a table change in the middle of the run: that frame uploads, so it has to run behind its predecessor
+                d2 = copy.copy(s.data)
+                d2.instances = [copy.copy(i) for i in d2.instances]
+                t = np.array(d2.instances[0].transform, dtype=np.float32).copy(); t[3][1] += 0.5
+                d2.instances[0].transform = t; d2.instances[0].previous_transform = t
+                s.data = d2
+                s.set_instance(0, d2.instances[0])
+                sample_data_moved = d2
+            elif change_at is not None and k > change_at:
+                d2 = _camera(sample_data_moved, k); s.data = d2
+            s.draw()
+            if k in (frames - 1, frames - 2, 1):
+                flags.append(int(s.stats().overlappedFrame))           # (reading the stats waits for the frame)
+                finals[k] = s.readback(rt64.IMAGE_FINAL_RGBA8).copy()
+        # several frames back to back with no host-side wait in between, then only the last one is looked at
+        for k in range(frames, frames + 6):
+            s.data = _camera(sample_data, k) if change_at is None else _camera(sample_data_moved, k)
+            s.draw()
+        st = s.stats()
+        flags.append(int(st.overlappedFrame))
+        finals["burst"] = s.readback(rt64.IMAGE_FINAL_RGBA8).copy()
+        hit = s.readback(rt64.IMAGE_PRIMARY_HIT).copy()               # materialise of an overlapped frame: the FULL variant re-traces the LAST frame
+        return finals, flags, hit
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("lds_cache,groups", [(1, 0), (0, 0), (0, 20)])
+def test_overlapped_frames_are_the_one_stream_frames(rt64_lib, sample_data, lds_cache, groups):
+    """C2-style frames (one-kernel lean frame; lds_cache = 0 puts the sample scene on the per-wave form with the cost-ordered tiles, whose order arrays are per
+    stream) with the camera moving every frame: enqueued on two alternating streams or on one, every back buffer that is read is the same."""
+    a, fa, ha = _run(rt64_lib, sample_data, 1, lds_cache, 7, groups=groups)
+    b, fb, hb = _run(rt64_lib, sample_data, 0, lds_cache, 7, groups=groups)
+    assert fa[-1] == 1 and any(fa), fa          # the overlapped run really alternated streams ...
+    assert not any(fb), fb                      # ... and the reference run never did
+    assert a.keys() == b.keys()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(ha.view(np.uint8), hb.view(np.uint8))
+
+
+def test_a_table_change_between_overlapped_frames_runs_in_order(rt64_lib, sample_data):
+    """An instance moves in the middle of an overlapped run: that frame uploads new tables and a new TLAS, so it is joined behind the frame before it and the one
+    after it does not start before the upload -- the images equal the one-stream run's."""
+    a, fa, ha = _run(rt64_lib, sample_data, 1, 1, 8, change_at=4)
+    b, fb, hb = _run(rt64_lib, sample_data, 0, 1, 8, change_at=4)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(ha.view(np.uint8), hb.view(np.uint8))
+
+
+def test_overlapped_strips_fill_both_gather_slots(rt64_lib, sample_data):
+    """The N > 1 loop on a world of one: RT64_DrawDevice + RT64_SubmitGather with frames enqueued on alternating streams, each frame writing its packed rows into its own
+    slot's send buffer.  The assembled frames of the last two slots are the last two frames."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    out = {}
+    for overlap in (1, 0):
+        s = sample_scene.Rt64Scene(rt64_lib, sample_data, W, H, hip_device=0)
+        try:
+            assert s.option("overlap_frames", overlap)
+            uid = (C.c_uint8 * rt64.GATHER_ID_BYTES)()
+            assert rt64_lib.GetGatherUniqueId(uid, len(uid)) == 1, rt64_lib.last_error()
+            g = rt64_lib.CreateGather(s.device, uid, len(uid), 0, 1, 0)
+            assert g, rt64_lib.last_error()
+            s.option("sync_present", 0)
+            slots = []
+            for k in range(9):
+                s.data = _camera(sample_data, k)
+                s.draw()
+                slots.append(rt64_lib.SubmitGather(g))
+            st = s.stats()
+            assert bool(st.packedFinal) and int(st.overlappedFrame) == overlap
+            frames = []
+            for slot in (slots[-2], slots[-1]):
+                buf = np.zeros((H, W, 4), dtype=np.uint8)
+                assert rt64_lib.ReadbackGather(g, slot, buf.ctypes.data, buf.nbytes, 0) == buf.nbytes, rt64_lib.last_error()
+                frames.append(buf)
+            assert not np.array_equal(frames[0], frames[1])          # the camera moved between them
+            out[overlap] = frames
+            rt64_lib.DestroyGather(g)
+        finally:
+            s.close()
+    for x, y in zip(out[1], out[0]):
+        assert np.array_equal(x, y)

@@ -294,13 +294,18 @@ int main(int argc, char **argv) {
         printf("{");
         for (int k = 0; k < 6; k++) {
             int w, h; unsigned char *rgba = load_png_rgba8(assets, pngs[k], &w, &h);
-            unsigned long long sum = 0; for (size_t i = 0; i < (size_t)w * h * 4; i++) sum += (unsigned long long)rgba[i] * (1 + (i & 3));
-            printf("\"%s\": [%d, %d, %llu], ", pngs[k], w, h, sum); free(rgba);
+            unsigned long long sum = 0, th = 1469598103934665603ull;      /* weighted byte sum + FNV-1a 64 of the texels (the latter is what oracle/ref_inputs_dump.cpp prints for stb_image's bytes) */
+            for (size_t i = 0; i < (size_t)w * h * 4; i++) { sum += (unsigned long long)rgba[i] * (1 + (i & 3)); th = (th ^ rgba[i]) * 1099511628211ull; }
+            printf("\"%s\": [%d, %d, %llu, \"%016llx\"], ", pngs[k], w, h, sum, th); free(rgba);
         }
         int n = 0; VERTEX *v = load_obj_unrolled(assets, "sphere.obj", &n);
-        unsigned long long fnv = 1469598103934665603ull; const unsigned char *b = (const unsigned char *)v;
+        unsigned long long fnv = 1469598103934665603ull, pn = 1469598103934665603ull; const unsigned char *b = (const unsigned char *)v;
         for (size_t i = 0; i < (size_t)n * sizeof(VERTEX); i++) fnv = (fnv ^ b[i]) * 1099511628211ull;
-        printf("\"sphere.obj\": [%d, \"%016llx\"]}\n", n, fnv); free(v);
+        for (int i = 0; i < n; i++) {          /* position.xyz + normal.xyz per vertex: the part tiny_obj_loader decides (oracle/ref_inputs_dump.cpp: sphere.posnrm) */
+            const unsigned char *q = (const unsigned char *)&v[i].position; for (int k = 0; k < 12; k++) pn = (pn ^ q[k]) * 1099511628211ull;
+            q = (const unsigned char *)&v[i].normal; for (int k = 0; k < 12; k++) pn = (pn ^ q[k]) * 1099511628211ull;
+        }
+        printf("\"sphere.obj\": [%d, \"%016llx\", \"%016llx\"]}\n", n, fnv, pn); free(v);
         return 0;
     }
     /* multi-GPU: fork the other ranks now, before the library is loaded or any GPU call is made; ids travel over one pipe per rank */
