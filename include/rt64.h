@@ -404,6 +404,9 @@ typedef struct {
     /* Debug readback of acceleration structures (RT64_ACCEL_*): the mesh's BLAS / the view's TLAS of the last frame. \
        Returns bytes written (0 on error); pass dst = NULL to query the size. */ \
     X(ReadbackMeshAccel, RT64_ReadbackMeshAccel, size_t, (RT64_MESH *mesh, int what, void *dst, size_t dstBytes)) \
+    /* Debug readback of a texture's texels as the kernels sample them: RGBA8 of mip level `mip`, rows top to bottom (a BC7 DDS: what the library's \
+       decoder made of the blocks at RT64_CreateTexture).  Returns bytes written (0 on error); dst = NULL queries the size. */ \
+    X(ReadbackTexture, RT64_ReadbackTexture, size_t, (RT64_TEXTURE *texture, int mip, void *dst, size_t dstBytes)) \
     X(ReadbackViewAccel, RT64_ReadbackViewAccel, size_t, (RT64_VIEW *view, int what, void *dst, size_t dstBytes)) \
     /* Depth of the BLAS RT64_SetMesh will build over these triangles (pure host function, no device; 0 = invalid arguments, 255 = a tree \
        of the multi-kernel builder): the library sizes its traversal stacks by it without waiting for the build. */ \

@@ -214,7 +214,9 @@ class OracleScene:
         d = self._desc(inst)
         self.L.oracle_scene_set_instance(self.scene, k, C.byref(d))
 
-    def render(self, width, height, brute_force=False, cull_behind_opaque=True, threads=0, can_reproject=True, tile=None, **over):
+    def render(self, width, height, brute_force=False, cull_behind_opaque=True, threads=0, can_reproject=True, tile=None, images=True, **over):
+        """One frame.  images=False renders it (history, frame count and counters advance) and returns the counters only -- the intermediate frames of a
+        multi-frame test skip the copies of two dozen images per frame."""
         p = OFrameParams()
         p.width, p.height = width, height
         p.tileY0, p.tileY1 = tile if tile else (0, height)
@@ -228,6 +230,11 @@ class OracleScene:
         r = OFrameResult()
         ok = self.L.oracle_render(self.scene, C.byref(p), C.byref(r))
         assert ok
+        counters = {k: getattr(r, k) for k in ("primaryRays", "shadowRays", "indirectRays", "reflectionRays", "refractionRays",
+                                               "nodesVisited", "trianglesTested", "nodesVisitedPrimary", "trianglesTestedPrimary",
+                                               "nodesVisitedShadow", "trianglesTestedShadow", "secondsBuild", "secondsRender")}
+        if not images:
+            return {"counters": counters}
         screen_w, screen_h = width, height
         width, height = r.width, r.height            # render size (differs from the screen size with resolutionScale)
         n = width * height
@@ -255,9 +262,7 @@ class OracleScene:
         out["upscaled"] = (np.ctypeslib.as_array(r.upscaledRGBA32F, shape=(screen_h * screen_w * 4,)).copy().reshape(screen_h, screen_w, 4)
                            if r.upscaledRGBA32F else None)
         out["pixelJitter"] = (float(r.pixelJitter[0]), float(r.pixelJitter[1]))
-        out["counters"] = {k: getattr(r, k) for k in ("primaryRays", "shadowRays", "indirectRays", "reflectionRays", "refractionRays",
-                                                      "nodesVisited", "trianglesTested", "nodesVisitedPrimary", "trianglesTestedPrimary",
-                                                      "nodesVisitedShadow", "trianglesTestedShadow", "secondsBuild", "secondsRender")}
+        out["counters"] = counters
         return out
 
     def mesh_bvh(self, k):

@@ -135,6 +135,7 @@ static GpuCombiner decode_combiner(uint32_t shaderId) {
 
 // ---- objects ---------------------------------------------------------------------------------------------------------------
 
+#define RT64_RENDER_STREAMS_MAX 4
 #define RT64_LEAN_HOLDOFF_FRAMES 4     // frames that store their whole G-buffer after a scene change had to materialise a lean frame (Device::beforeSceneMutation)
 
 struct Options {
@@ -176,18 +177,35 @@ struct Device {
     // sync_present = 0 they alternate between the two streams, and frame k+1's first waves fill the wave slots the tail of frame k has left empty.  Everything
     // else -- an upload, a build, a frame with history, a readback, any API call that touches device memory -- first makes the current stream wait for the other
     // one (joinStreams), after which streams[cur] is ordered behind everything enqueued so far, exactly as with one stream.
-    hipStream_t streams[2] = { nullptr, nullptr }; int cur = 0;
-    hipEvent_t streamJoin = nullptr;
-    bool otherBusy = false;               // streams[cur ^ 1] may hold work streams[cur] has not waited for
+    hipStream_t streams[RT64_RENDER_STREAMS_MAX] = {}; int cur = 0, streamCount = 2;      // (RT64_RENDER_STREAMS = 1 .. 4 at device creation; default 2)
+    hipEvent_t streamJoin[RT64_RENDER_STREAMS_MAX] = {};
+    bool streamBusy[RT64_RENDER_STREAMS_MAX] = {};      // streams[k] may hold work streams[cur] has not waited for
     bool framePure = false, lastFramePure = false;
     void joinStreams() {
-        if (!otherBusy) return;
-        HIP_CHECK(hipEventRecord(streamJoin, streams[cur ^ 1]));
-        HIP_CHECK(hipStreamWaitEvent(stream, streamJoin, 0));
-        otherBusy = false;
+        for (int k = 0; k < streamCount; k++) {
+            if (k == cur || !streamBusy[k]) continue;
+            HIP_CHECK(hipEventRecord(streamJoin[k], streams[k]));
+            HIP_CHECK(hipStreamWaitEvent(stream, streamJoin[k], 0));
+            streamBusy[k] = false;
+        }
     }
-    void impure() { framePure = false; joinStreams(); }                   // this frame enqueues something that is not slot-local: it runs behind every earlier frame
-    void enter() { use(); joinStreams(); lastFramePure = false; }         // API entry that touches device memory outside RT64_DrawDevice / RT64_SubmitGather
+    // ... and the other direction: work that is not slot-local (always enqueued on the stream that is current at the time, behind a join) has to be seen by every
+    // later frame on ANY stream.  `orderedEpoch` counts such work; a stream that is switched to without having seen the latest epoch first waits for the stream
+    // that is being left (which has, by induction) -- one event at the first switch onto each stream after an upload, nothing in the steady state.
+    unsigned long long orderedEpoch = 1, seenEpoch[RT64_RENDER_STREAMS_MAX] = {};
+    hipEvent_t streamCatchUp = nullptr;
+    void noteOrderedWork() { seenEpoch[cur] = ++orderedEpoch; }
+    void impure() { framePure = false; joinStreams(); noteOrderedWork(); }      // this frame enqueues something that is not slot-local: it runs behind every earlier frame
+    void enter() { use(); joinStreams(); noteOrderedWork(); lastFramePure = false; }   // API entry that touches device memory outside RT64_DrawDevice / RT64_SubmitGather
+    void switchStream() {
+        const int prev = cur;
+        streamBusy[prev] = true; cur = (cur + 1) % streamCount; stream = streams[cur];
+        if (seenEpoch[cur] != orderedEpoch) {
+            HIP_CHECK(hipEventRecord(streamCatchUp, streams[prev]));
+            HIP_CHECK(hipStreamWaitEvent(stream, streamCatchUp, 0));
+            seenEpoch[cur] = orderedEpoch;
+        }
+    }
     int width = 0, height = 0, pendingWidth = 0, pendingHeight = 0;
     int tileY0 = 0, tileY1 = 0; bool tileSet = false;
     int stripRank = 0, stripCount = 1;
@@ -197,7 +215,7 @@ struct Device {
     bool profNow = false, statsProfiled = false; unsigned profCounter = 0;       // this frame records its pass events (option profile_every)
     double hostUpdateUs = 0.0, hostRenderUs = 0.0, hostStageUs[16] = {}, hostEventUs = 0.0; unsigned long long hostFrames = 0;      // host-side cost of View::update / View::render (RT64_HOST_TIMING=1 prints them)
     void finishStats();
-    DevArray<uint32_t> spillStack[2];                                     // HBM half of the traversal stacks, one slab per render stream (indexed by the launch's lanes)
+    DevArray<uint32_t> spillStack[RT64_RENDER_STREAMS_MAX];                                     // HBM half of the traversal stacks, one slab per render stream (indexed by the launch's lanes)
     void *gatherTarget = nullptr; size_t gatherTargetBytes = 0;          // RT64_SetDeviceGatherTarget
     hipStream_t auxStream = nullptr; hipEvent_t forkEvent = nullptr, joinEvent = nullptr;      // second stream of a frame whose reflection passes run beside its denoiser (created on first use)
     // Halo exchange of the SVGF filter input between the bands of a partition (RT64_SetDeviceHaloExchange / option halo_exchange): transport and layout
@@ -379,8 +397,8 @@ struct View {
     // extension primary_spp (rules P1-P4, oracle/oracle_render.c): the frame as `subFrames` complete sub-frames; Device::draw drives them
     int subFrame = 0, subFrames = 1; DevArray<float> sppSum;
     // longest-first tile order of the one-kernel frame on scenes that walk from HBM (device option tile_order): last frame's cost per tile and the order made from it
-    DevArray<uint32_t> tileCost[2], tileOrder[2]; uint32_t tileOrderTiles = 0; bool tileOrderValid[2] = { false, false };      // (one set per render stream: Device::streams)
-    uint8_t *finalBuf[2] = { nullptr, nullptr };      // the back buffer, one per render stream; img.final is the one of the frame in hand / last drawn
+    DevArray<uint32_t> tileCost[RT64_RENDER_STREAMS_MAX], tileOrder[RT64_RENDER_STREAMS_MAX]; uint32_t tileOrderTiles = 0; bool tileOrderValid[RT64_RENDER_STREAMS_MAX] = {};      // (one set per render stream: Device::streams)
+    uint8_t *finalBuf[RT64_RENDER_STREAMS_MAX] = {};      // the back buffer, one per render stream; img.final is the one of the frame in hand / last drawn
 
     explicit View(Scene *s);
     ~View();
@@ -418,10 +436,13 @@ Device::Device(int w, int h, int dev) {
     HIP_CHECK(hipGetDeviceProperties(&prop, dev));
     if (w <= 0 || h <= 0) throw std::runtime_error("Invalid device size.");
     width = pendingWidth = w; height = pendingHeight = h; tileY0 = 0; tileY1 = h;
-    HIP_CHECK(hipStreamCreateWithFlags(&streams[0], hipStreamNonBlocking));
-    HIP_CHECK(hipStreamCreateWithFlags(&streams[1], hipStreamNonBlocking));
-    HIP_CHECK(hipEventCreateWithFlags(&streamJoin, hipEventDisableTiming));
-    stream = streams[0]; cur = 0;
+    if (const char *e = getenv("RT64_RENDER_STREAMS")) streamCount = std::min(std::max(atoi(e), 1), RT64_RENDER_STREAMS_MAX);
+    for (int k = 0; k < streamCount; k++) {
+        HIP_CHECK(hipStreamCreateWithFlags(&streams[k], hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&streamJoin[k], hipEventDisableTiming));
+    }
+    HIP_CHECK(hipEventCreateWithFlags(&streamCatchUp, hipEventDisableTiming));
+    stream = streams[0]; cur = 0; seenEpoch[0] = orderedEpoch;
     for (auto &ev : events) HIP_CHECK(hipEventCreate(&ev));
     counters.reserve((size_t)CTR_COUNT * RT_COUNTER_STRIPES);
     HIP_CHECK(hipMemsetAsync(counters.ptr, 0, counters.bytes(), stream));
@@ -455,7 +476,8 @@ Device::~Device() {
     if (halo.ready) hipEventDestroy(halo.ready);
     if (halo.done) hipEventDestroy(halo.done);
     if (ring) hipHostFree(ring);
-    if (streamJoin) hipEventDestroy(streamJoin);
+    for (hipEvent_t ev : streamJoin) if (ev) hipEventDestroy(ev);
+    if (streamCatchUp) hipEventDestroy(streamCatchUp);
     for (hipStream_t st : streams) if (st) hipStreamDestroy(st);
 }
 
@@ -737,7 +759,7 @@ View::~View() {
 }
 void View::releaseImages() {
     for (void *p : allocations) hipFree(p);
-    allocations.clear(); img = ViewImages(); bounceSamples = 0; leanFrame = false; fusedFrame = false; finalBuf[0] = finalBuf[1] = nullptr;
+    allocations.clear(); img = ViewImages(); bounceSamples = 0; leanFrame = false; fusedFrame = false; for (auto &fb : finalBuf) fb = nullptr;
     for (auto &u : upscaled) { if (u) hipFree(u); u = nullptr; }
     upW = upH = 0; upValid = false;
 }
@@ -765,7 +787,7 @@ void View::createImages(int w, int h, int screenW, int screenH) {       // View:
     img.flow = static_cast<uint16_t *>(alloc(n * 4));
     img.reactiveMask = static_cast<uint8_t *>(alloc(n)); img.lockMask = static_cast<uint8_t *>(alloc(n));
     img.output = static_cast<float *>(alloc(n * 16));
-    for (auto &fb : finalBuf) fb = static_cast<uint8_t *>(alloc((size_t)screenW * screenH * 4));
+    for (int k = 0; k < scene->device->streamCount; k++) finalBuf[k] = static_cast<uint8_t *>(alloc((size_t)screenW * screenH * 4));
     img.final = finalBuf[scene->device->cur];
     img.primaryHit = static_cast<uint32_t *>(alloc(n * 16));
     hitInstance.reserve(n);
@@ -1355,7 +1377,7 @@ void View::render() {                          // View::render, rt64_view.cpp:11
             if (tiles == 0u) return 0u;
             if (tileOrderTiles != tiles) {
                 dev->impure();
-                for (int k = 0; k < 2; k++) {
+                for (int k = 0; k < dev->streamCount; k++) {
                     tileCost[k].reserve(tiles); tileOrder[k].reserve(tiles);
                     HIP_CHECK(hipMemsetAsync(tileCost[k].ptr, 0, (size_t)tiles * 4, s));
                     tileOrderValid[k] = false;
@@ -1524,9 +1546,9 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
     // Two render streams (see Device::streams): an enqueued frame that follows a pure frame starts on the other stream, beside that frame's tail; it is joined
     // behind it the moment it turns out not to be pure itself (impure(): an upload, a build, a frame with history).  Frame counters, the tile-timing records and
     // the sub-frame accumulation are one per device: frames that use them stay in order.
-    const bool mayOverlap = opt.overlapFrames && !opt.syncPresent && !opt.countTraversal && !opt.tileTiming && opt.primarySpp <= 1;
+    const bool mayOverlap = opt.overlapFrames && streamCount > 1 && !opt.syncPresent && !opt.countTraversal && !opt.tileTiming && opt.primarySpp <= 1;
     const bool flipped = mayOverlap && lastFramePure;
-    if (flipped) { cur ^= 1; stream = streams[cur]; otherBusy = true; }
+    if (flipped) switchStream();
     framePure = mayOverlap; lastFramePure = false;       // (a frame that ends in an exception leaves "not pure" behind)
     if (!mayOverlap) joinStreams();
     if (opt.countTraversal) HIP_CHECK(hipMemsetAsync(counters.ptr, 0, counters.bytes(), stream));
@@ -1969,6 +1991,23 @@ RT64_EXPORT RT64_TEXTURE *RT64_CreateTexture(RT64_DEVICE *devicePtr, RT64_TEXTUR
 }
 RT64_EXPORT void RT64_DestroyTexture(RT64_TEXTURE *texture) { RT64_TRY Texture *t = reinterpret_cast<Texture *>(texture); if (t) { t->device->enter(); t->device->beforeSceneMutation(); hipStreamSynchronize(t->device->stream); } delete t; RT64_CATCH_VOID }
 
+// Debug readback of a texture's texels as the kernels sample them (additive): RGBA8, mip `mip`, rows top to bottom -- for a BC7 DDS what bc7_decode_kernel
+// wrote at creation (rt64_texture.cpp:146-187 hands the blocks to the sampler hardware; here they are decoded once).  dst = NULL returns the size.
+RT64_EXPORT size_t RT64_ReadbackTexture(RT64_TEXTURE *texturePtr, int mip, void *dst, size_t dstBytes) {
+    RT64_TRY
+    Texture *t = reinterpret_cast<Texture *>(texturePtr);
+    if (!t || mip < 0 || mip >= t->mips) throw std::runtime_error("RT64_ReadbackTexture: NULL texture or no such mip level.");
+    const int mw = std::max(t->width >> mip, 1), mh = std::max(t->height >> mip, 1);
+    const size_t need = (size_t)mw * mh * 4;
+    if (!dst) return need;
+    if (dstBytes < need) throw std::runtime_error("RT64_ReadbackTexture: destination buffer is too small.");
+    t->device->enter();
+    HIP_CHECK(hipStreamSynchronize(t->device->stream));
+    HIP_CHECK(hipMemcpy(dst, t->texels.ptr + (size_t)t->mipOffset[mip] * 4, need, hipMemcpyDeviceToHost));
+    return need;
+    RT64_CATCH(0)
+}
+
 // ---- debug readback of acceleration structures (additive) ----
 static size_t accel_readback(Device *dev, int what, uint32_t n, const GpuNode *nodes, const GpuTri *tris, const uint32_t *sorted, const uint32_t *morton,
                              const BlasHeader *header, void *dst, size_t dstBytes) {
@@ -2195,7 +2234,7 @@ Gather::~Gather() {
 void Gather::prepare(int slot) {
     Slot &sl = slots[slot];
     // (both render streams: the next frame may start on either, Device::streams)
-    if (sl.pending) { for (hipStream_t st : dev->streams) HIP_CHECK(hipStreamWaitEvent(st, sl.gathered, 0)); sl.pending = false; }
+    if (sl.pending) { for (hipStream_t st : dev->streams) if (st) HIP_CHECK(hipStreamWaitEvent(st, sl.gathered, 0)); sl.pending = false; }
     dev->gatherTarget = sl.local; dev->gatherTargetBytes = slotBytes;
 }
 // After RT64_DrawDevice: exchange the frame just drawn.  Returns the slot it travels in.
@@ -2254,7 +2293,7 @@ void Gather::setBands(const int *starts) {
 void Gather::wait(int slot, bool host) {
     Slot &sl = slots[slot];
     if (host) HIP_CHECK(hipEventSynchronize(sl.gathered));
-    else for (hipStream_t st : dev->streams) HIP_CHECK(hipStreamWaitEvent(st, sl.gathered, 0));
+    else for (hipStream_t st : dev->streams) if (st) HIP_CHECK(hipStreamWaitEvent(st, sl.gathered, 0));
 }
 
 // ---- halo exchange of the SVGF filter input ("renders its rows plus a halo ..., or exchanges halos") -------------------------------------

@@ -194,6 +194,7 @@ EXT_API = [
     ("GetDeviceStream", "RT64_GetDeviceStream", _P, [_P]),
     ("SetDeviceGatherTarget", "RT64_SetDeviceGatherTarget", None, [_P, _P, C.c_size_t]),
     ("ReadbackMeshAccel", "RT64_ReadbackMeshAccel", C.c_size_t, [_P, C.c_int, _P, C.c_size_t]),
+    ("ReadbackTexture", "RT64_ReadbackTexture", C.c_size_t, [_P, C.c_int, _P, C.c_size_t]),
     ("ReadbackViewAccel", "RT64_ReadbackViewAccel", C.c_size_t, [_P, C.c_int, _P, C.c_size_t]),
     ("MeshTreeDepth", "RT64_MeshTreeDepth", C.c_uint, [_P, C.c_int, C.c_int, _P, C.c_int]),
     ("GetGatherUniqueId", "RT64_GetGatherUniqueId", C.c_int, [_P, C.c_size_t]),

@@ -31,15 +31,41 @@ def _rmse(a, b):
     return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
 
 
-def _bench_pair(rt64_lib, sample_data, config, frames, width=W, height=H, bands=None, options=None):
-    """Render `frames` steps of bench.py's `--config` on the HIP library (whole frame, or one device per band) and on the oracle."""
-    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+_ORACLE_FRAMES = {}          # (config, frames, width, height) -> the oracle's last frame: the A/B tests below render the same configuration several times
+
+
+def _oracle_frames(sample_data, config, frames, width, height):
+    """Frame `frames` of bench.py's `--config` on the oracle (the call sequence of _bench_pair); small frames are kept for the session."""
+    from sm64rt_legacy_renderer_amd import sample_scene
     from oracle import oracle_py
+    key = (config, frames, width, height)
+    if key in _ORACLE_FRAMES:
+        return _ORACLE_FRAMES[key]
+    data = _variant(sample_data)
+    cfg = sample_scene.BENCH_CONFIGS[config]
+    anim = sample_scene.apply_bench_config(data, config)
+    o = oracle_py.OracleScene(data)
+    try:
+        kw = dict(giSamples=cfg["gi_samples"], denoiserEnabled=int(cfg["denoiser"]), denoiserMode=1, primarySpp=cfg.get("primary_spp", 1), giBounces=cfg.get("gi_bounces", 1))
+        for f in range(frames):
+            if anim is not None:
+                o.set_mesh(o.meshes[0], anim[(f + 1) % len(anim)], data.meshes[0].indices)
+            ref = o.render(width, height, images=(f == frames - 1), **kw)
+    finally:
+        o.close()
+    if width * height <= W * H:
+        _ORACLE_FRAMES[key] = ref
+    return ref
+
+
+def _bench_pair(rt64_lib, sample_data, config, frames, width=W, height=H, bands=None, options=None, need_ref=True):
+    """Render `frames` steps of bench.py's `--config` on the HIP library (whole frame, or one device per band) and on the oracle (need_ref = False: the
+    caller compares two runs of the library with each other and wants no oracle frame)."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
     data = _variant(sample_data)
     cfg = sample_scene.BENCH_CONFIGS[config]
     anim = sample_scene.apply_bench_config(data, config)
     parts = [sample_scene.Rt64Scene(rt64_lib, data, width, height, hip_device=0) for _ in (bands or [None])]
-    o = oracle_py.OracleScene(data)
     try:
         for s, band in zip(parts, bands or [None]):
             s.set_view_description(gi_samples=cfg["gi_samples"], denoiser=cfg["denoiser"])
@@ -49,23 +75,20 @@ def _bench_pair(rt64_lib, sample_data, config, frames, width=W, height=H, bands=
                 s.set_tile(*band)
             s.option("count_traversal", 1)
             assert s.option("primary_spp", cfg.get("primary_spp", 1)) and s.option("gi_bounces", cfg.get("gi_bounces", 1))
-        kw = dict(giSamples=cfg["gi_samples"], denoiserEnabled=int(cfg["denoiser"]), denoiserMode=1, primarySpp=cfg.get("primary_spp", 1), giBounces=cfg.get("gi_bounces", 1))
         for f in range(frames):
             if anim is not None:          # bench.py step(): frame_no += 1; SetMesh(anim[frame_no % len])
                 v = anim[(f + 1) % len(anim)]
                 for s in parts:
                     s.set_mesh(s.meshes[0], v, data.meshes[0].indices)
-                o.set_mesh(o.meshes[0], v, data.meshes[0].indices)
             for s in parts:
                 s.draw()
-            ref = o.render(width, height, **kw)
         names = ("OUTPUT_RGBA32F", "FINAL_RGBA8", "PRIMARY_HIT", "INDIRECT_LIGHT_RAW", "INDIRECT_LIGHT_FILTERED", "REFLECTION", "DIFFUSE", "INSTANCE_ID")
         got = {k: np.concatenate([s.readback(getattr(rt64, "IMAGE_" + k)) for s in parts], axis=0) for k in names}
-        return got, ref, [s.stats() for s in parts]
+        stats = [s.stats() for s in parts]
     finally:
         for s in parts:
             s.close()
-        o.close()
+    return got, (_oracle_frames(sample_data, config, frames, width, height) if need_ref else None), stats
 
 
 def _check_gi_frame(got, ref):
@@ -233,7 +256,7 @@ def test_several_tiles_per_workgroup_walk_of_the_one_kernel_frame(rt64_lib, samp
     frame above 1080p: C4 and C5).  max_frame_groups = 50 puts a 320 x 180 frame (240 tiles) on that walk (5 tiles per workgroup) for
     the lean kernel (C2, FULL = false) and the full one (C3, FULL = true): same bytes as one workgroup per tile, and parity with the oracle."""
     got, ref, st = _bench_pair(rt64_lib, sample_data, config, frames=3, options={"max_frame_groups": 50})
-    base, _, st0 = _bench_pair(rt64_lib, sample_data, config, frames=3)
+    base, _, st0 = _bench_pair(rt64_lib, sample_data, config, frames=3, need_ref=False)
     assert st[0].fusedFrame == st0[0].fusedFrame == (1 if config == "C2" else 2)
     for k in got:
         assert np.array_equal(got[k].view(np.uint8), base[k].view(np.uint8)), k
@@ -333,8 +356,8 @@ def test_simple_frame_kernels_equal_the_general_kernels(rt64_lib, sample_data, c
     """The sample scene is a "simple" frame (every texture a power of two in both sizes, every instance shadow-opaque): it runs the kernels of
     passes_simple.hip, compiled without non-power-of-two addressing and without the shadow any-hit program.  Device option simple_kernels = 0
     sends the same frames through the general kernels: every image and every counter is identical."""
-    a, _, sa = _bench_pair(rt64_lib, sample_data, config, frames=3)
-    b, _, sb = _bench_pair(rt64_lib, sample_data, config, frames=3, options={"simple_kernels": 0})
+    a, _, sa = _bench_pair(rt64_lib, sample_data, config, frames=3, need_ref=False)
+    b, _, sb = _bench_pair(rt64_lib, sample_data, config, frames=3, options={"simple_kernels": 0}, need_ref=False)
     for k in a:
         assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), k
     assert (sa[0].primaryRays, sa[0].shadowRays, sa[0].indirectRays, sa[0].reflectionRays, sa[0].nodesVisited, sa[0].trianglesTested) == \
@@ -350,12 +373,12 @@ def test_folded_guide_and_compose_equal_their_own_launches(rt64_lib, sample_data
     arithmetic is compiled with fp-contract(fast) (tolerance-tested filter): the compiler may fuse a multiply-add differently in it, so a handful of filtered
     values may differ by one RGBA16F step -- and nothing else."""
     a, ref, sa = _bench_pair(rt64_lib, sample_data, config, frames=3, bands=bands)
-    g, _, _ = _bench_pair(rt64_lib, sample_data, config, frames=3, bands=bands, options={"fold_guide": 0})
-    v, _, _ = _bench_pair(rt64_lib, sample_data, config, frames=3, bands=bands, options={"fold_variance": 0})
+    g, _, _ = _bench_pair(rt64_lib, sample_data, config, frames=3, bands=bands, options={"fold_guide": 0}, need_ref=False)
+    v, _, _ = _bench_pair(rt64_lib, sample_data, config, frames=3, bands=bands, options={"fold_variance": 0}, need_ref=False)
     for k in a:
         assert np.array_equal(a[k].view(np.uint8), g[k].view(np.uint8)), k
         assert np.array_equal(a[k].view(np.uint8), v[k].view(np.uint8)), k
-    b, _, sb = _bench_pair(rt64_lib, sample_data, config, frames=3, bands=bands, options={"fold_guide": 0, "fold_compose": 0})
+    b, _, sb = _bench_pair(rt64_lib, sample_data, config, frames=3, bands=bands, options={"fold_guide": 0, "fold_compose": 0}, need_ref=False)
     for k in a:
         if k in ("OUTPUT_RGBA32F", "FINAL_RGBA8", "INDIRECT_LIGHT_FILTERED"):
             d = np.abs(a[k].astype(np.float64) - b[k].astype(np.float64))

@@ -18,9 +18,9 @@ def _pair(rt64_lib, data, w, h, frames=1, **kw):
     o = oracle_py.OracleScene(data)
     try:
         s.option("count_traversal", 1)
-        for _ in range(frames):
+        for f in range(frames):
             s.draw()
-            ref = o.render(w, h, **kw)
+            ref = o.render(w, h, images=(f == frames - 1), **kw)
         got = {k: s.readback(getattr(rt64, "IMAGE_" + k)) for k in ("OUTPUT_RGBA32F", "FINAL_RGBA8", "PRIMARY_HIT", "INSTANCE_ID")}
         return got, ref, s.stats()
     finally:

@@ -45,7 +45,7 @@ def _render_pair(rt64_lib, data, frames=1, view_desc=None, options=None, per_fra
             if per_frame:
                 per_frame(f, s, o)
             s.draw()
-            ref = o.render(W, H, **kw)
+            ref = o.render(W, H, images=(f == frames - 1), **kw)
         names = images or (("OUTPUT_RGBA32F", "FINAL_RGBA8", "INSTANCE_ID", "PRIMARY_HIT", "DIFFUSE", "DIRECT_LIGHT_RAW", "INDIRECT_LIGHT_RAW",
                             "INDIRECT_LIGHT_FILTERED", "REFLECTION", "REFRACTION", "TRANSPARENT") + tuple(extra_images))
         got = {k: s.readback(getattr(rt64, "IMAGE_" + k)) for k in names}

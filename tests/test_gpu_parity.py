@@ -198,10 +198,13 @@ def test_tlas_host_and_gpu_builders_agree(rt64_lib, oracle_lib, extra):
         s.close(); o.close()
 
 
-@pytest.mark.parametrize("subdiv,grid", [(2, 1), (3, 64)])
+@pytest.mark.parametrize("subdiv,grid", [(2, 1), (3, 64), (5, 1)])
 def test_large_meshes_bit_exact(rt64_lib, oracle_lib, subdiv, grid):
     """Stress variant of the sample scene: 5 120 / 20 480-triangle spheres (multi-block radix path above 4096
-    leaves), 8 192-triangle floor.  BLAS arrays and the rendered hit records must still equal the oracle's bit for bit."""
+    leaves), 8 192-triangle floor; and a 327 680-triangle sphere -- above 131 072 leaves the bottom-up box fit of the large-tree builder
+    takes two group levels (lg_fit_group_kernel, lbvh.hip) and its 37 MB of nodes and triangles no longer sit in one XCD's L2, so the
+    one-step-per-trip walk (trace_ray_stepwise) fetches from the Infinity Cache / HBM.  BLAS arrays, the rendered hit records and the
+    visit counters must still equal the oracle's bit for bit."""
     from sm64rt_legacy_renderer_amd import rt64, sample_scene
     from oracle import oracle_py
     data = sample_scene.make_sample_scene(subdiv=subdiv, floor_grid=grid)
