@@ -66,9 +66,10 @@ def parse_args():
     ap.add_argument("--prewarm", type=int, default=100, help="untimed frames before the W warm-up steps (GPU clock ramp; the line reports them)")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE", help="RT64_SetDeviceOption(key, value) before the run (A/B measurements; the line records them under config.options)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU-staged rehearsal of the N>1 path")
-    ap.add_argument("--band-rebalance", type=int, default=3, help="N > 1, GI + denoiser bands: rounds of measured-cost feedback after the modelled cut (each rank times its band, one all-gather, "
-                    "RT64_RebalanceGatherBands + RT64_SetGatherBands on every rank); 0 keeps the modelled cut")
-    ap.add_argument("--halo", default="exchange", choices=["exchange", "recompute"], help="N > 1, GI + denoiser bands: exchange the denoiser's halo rows between neighbouring bands (RCCL) or re-render them on every band")
+    ap.add_argument("--band-rebalance", type=int, default=0, help="N > 1, GI + denoiser bands: rounds of measured-cost feedback after the modelled cut (each rank times its band, one all-gather, "
+                    "RT64_RebalanceGatherBands + RT64_SetGatherBands on every rank); 0 (default) keeps the modelled cut.  Opt-in until RT64_SetGatherBands has run between two GPUs (an A/B line, not the headline)")
+    ap.add_argument("--halo", default="recompute", choices=["exchange", "recompute"], help="N > 1, GI + denoiser bands: re-render the denoiser's halo rows on every band (default: no mid-frame collective, the path every "
+                    "partition test covers) or exchange them between neighbouring bands (RCCL ncclSend / ncclRecv in the middle of the frame: opt-in until it has run between two GPUs)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a 1-GPU box: every rank renders on device 0")
     ap.add_argument("--force-gather", action="store_true", help="rehearsal: run the N > 1 code path (enqueued frames + pipelined RCCL gather) with a world of 1")
     ap.add_argument("--pretend-ranks", type=int, default=0, help="diagnosis on a 1-GPU box: render only rank 0's share of a P-way partition, frames enqueued, no gather; `value` is then NOT a throughput of the whole frame")

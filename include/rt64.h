@@ -104,6 +104,68 @@ enum { /* ref:70-86 */
     RT64_TEXTURE_FORMAT_RGBA8 = 0x1, RT64_TEXTURE_FORMAT_DDS = 0x2
 };
 
+/* The reference spells every constant above as a preprocessor macro (ref:11-86), so a host may test one with #ifdef / #if.  They are enumerators here
+   (typed, visible to a debugger) AND macros of the same value, defined after the enumerations so that the two never meet in one declaration;
+   tests/test_boundary_cpu.py holds the two spellings -- and the reference's -- together. */
+#define RT64_MATERIAL_FILTER_POINT               0
+#define RT64_MATERIAL_FILTER_LINEAR              1
+#define RT64_MATERIAL_ADDR_WRAP                  0
+#define RT64_MATERIAL_ADDR_MIRROR                1
+#define RT64_MATERIAL_ADDR_CLAMP                 2
+#define RT64_MATERIAL_CC_SHADER_0                0
+#define RT64_MATERIAL_CC_SHADER_INPUT_1          1
+#define RT64_MATERIAL_CC_SHADER_INPUT_2          2
+#define RT64_MATERIAL_CC_SHADER_INPUT_3          3
+#define RT64_MATERIAL_CC_SHADER_INPUT_4          4
+#define RT64_MATERIAL_CC_SHADER_TEXEL0           5
+#define RT64_MATERIAL_CC_SHADER_TEXEL0A          6
+#define RT64_MATERIAL_CC_SHADER_TEXEL1           7
+#define RT64_ATTRIBUTE_NONE                      0x0000
+#define RT64_MESH_RAYTRACE_ENABLED               0x1
+#define RT64_MESH_RAYTRACE_UPDATABLE             0x2
+#define RT64_MESH_RAYTRACE_FAST_TRACE            0x4
+#define RT64_MESH_RAYTRACE_COMPACT               0x8
+#define RT64_SHADER_FILTER_POINT                 0x0
+#define RT64_SHADER_FILTER_LINEAR                0x1
+#define RT64_SHADER_ADDRESSING_WRAP              0x0
+#define RT64_SHADER_ADDRESSING_MIRROR            0x1
+#define RT64_SHADER_ADDRESSING_CLAMP             0x2
+#define RT64_SHADER_RASTER_ENABLED               0x1
+#define RT64_SHADER_RAYTRACE_ENABLED             0x2
+#define RT64_SHADER_NORMAL_MAP_ENABLED           0x4
+#define RT64_SHADER_SPECULAR_MAP_ENABLED         0x8
+#define RT64_INSTANCE_RASTER_BACKGROUND          0x1
+#define RT64_INSTANCE_DISABLE_BACKFACE_CULLING   0x2
+#define RT64_UPSCALER_OFF                        0x0
+#define RT64_UPSCALER_AUTO                       0x1
+#define RT64_UPSCALER_DLSS                       0x2
+#define RT64_UPSCALER_FSR                        0x3
+#define RT64_UPSCALER_XESS                       0x4
+#define RT64_UPSCALER_MODE_AUTO                  0x0
+#define RT64_UPSCALER_MODE_ULTRA_PERFORMANCE     0x1
+#define RT64_UPSCALER_MODE_PERFORMANCE           0x2
+#define RT64_UPSCALER_MODE_BALANCED              0x3
+#define RT64_UPSCALER_MODE_QUALITY               0x4
+#define RT64_UPSCALER_MODE_ULTRA_QUALITY         0x5
+#define RT64_UPSCALER_MODE_NATIVE                0x6
+#define RT64_TEXTURE_FORMAT_RGBA8                0x1
+#define RT64_TEXTURE_FORMAT_DDS                  0x2
+#define RT64_ATTRIBUTE_IGNORE_NORMAL_FACTOR      0x0001
+#define RT64_ATTRIBUTE_UV_DETAIL_SCALE           0x0002
+#define RT64_ATTRIBUTE_REFLECTION_FACTOR         0x0004
+#define RT64_ATTRIBUTE_REFLECTION_FRESNEL_FACTOR 0x0008
+#define RT64_ATTRIBUTE_REFLECTION_SHINE_FACTOR   0x0010
+#define RT64_ATTRIBUTE_REFRACTION_FACTOR         0x0020
+#define RT64_ATTRIBUTE_SPECULAR_COLOR            0x0040
+#define RT64_ATTRIBUTE_SPECULAR_EXPONENT         0x0080
+#define RT64_ATTRIBUTE_SOLID_ALPHA_MULTIPLIER    0x0100
+#define RT64_ATTRIBUTE_SHADOW_ALPHA_MULTIPLIER   0x0200
+#define RT64_ATTRIBUTE_DEPTH_BIAS                0x0400
+#define RT64_ATTRIBUTE_SHADOW_RAY_BIAS           0x0800
+#define RT64_ATTRIBUTE_SELF_LIGHT                0x1000
+#define RT64_ATTRIBUTE_LIGHT_GROUP_MASK_BITS     0x2000
+#define RT64_ATTRIBUTE_DIFFUSE_COLOR_MIX         0x4000
+
 /* ---- opaque handles, ref:88-96 ------------------------------------------------------------- */
 
 typedef struct RT64_DEVICE RT64_DEVICE;
@@ -368,6 +430,7 @@ typedef struct {
     unsigned int fusedFrame;                /* 1: the lean frame ran as ONE kernel (primary visibility + resolve + direct light + compose); 2: a full frame's primary visibility + G-buffer + direct light ran as one kernel; the kernel's time is reported as msPrimaryTrace */
     unsigned int packedFinal;               /* 1: the frame wrote its owned back-buffer rows to the RT64_SetDeviceGatherTarget memory */
     unsigned int overlappedFrame;           /* 1: the frame was enqueued on the device's second render stream, beside the frame before it (sync_present = 0, option overlap_frames; pixel-local frames on unchanged tables only) */
+    unsigned int reflectionBesideDenoiser;  /* 1: the reflection passes ran on a second stream beside the denoiser's iterations; msReflectRefract is their own time there and overlaps msDenoise */
     unsigned int traversalOverflow;         /* traversal-stack entries dropped by the frame's rays (count_traversal = 1); anything but 0 is an error RT64_DrawDevice also reports through RT64_GetLastError */
 } RT64_FRAME_STATS;
 
@@ -445,7 +508,10 @@ typedef struct {
        sample scene).  Each rank measures the GPU time of its band, the host shares the figures (one all-gather of `count` floats), every rank computes the \
        same new boundaries with RT64_RebalanceGatherBands (pure function: equal cost above a fixed part (0.4 of the cheapest band) under an even spread inside each measured band, moves damped to 0.5 (two bands) ... 0.8 (eight), 16-row \
        minimum; returns 0 on invalid boundaries) and hands them to its gather with RT64_SetGatherBands -- a gather of bands = 1 or 2 (equal bands need no whole \
-       frame for the first cut), between the same two frames on every rank; the communicator stays, send buffers grow when a band does.  Two or three rounds level the bands (tools/band_costs.py --rebalance). */ \
+       frame for the first cut), between the same two frames on every rank; the communicator stays, send buffers grow when a band does.  Two or three rounds level the bands (tools/band_costs.py --rebalance). \
+       Boundaries must rise strictly (every rank keeps at least one row).  Temporal state: a band holds GI history only for its rows and the halo it renders them with; the \
+       accumulation of rows a band GAINS beyond that restarts at the next frame (history length 0), so for a few frames after a rebalance those rows are as noisy as in a \
+       freshly cut partition and differ from the single-device frame until their history has grown back. */ \
     X(RebalanceGatherBands, RT64_RebalanceGatherBands, int, (int height, int count, const int *starts, const float *msPerRank, int *newStarts)) \
     X(SetGatherBands, RT64_SetGatherBands, int, (RT64_GATHER *gather, const int *starts)) \
     /* ---- halo EXCHANGE for band partitions of frames with GI + the SVGF denoiser.  The filter result of a row depends on the filter INPUT (noisy GI + \

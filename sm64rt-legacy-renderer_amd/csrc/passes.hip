@@ -1720,7 +1720,7 @@ size_t rt_stack_spill_bytes(int width, int rows) {
     size_t blocks = tiles > (size_t)RT_GRID_BLOCKS ? tiles : (size_t)RT_GRID_BLOCKS;
     if (blocks > RT_MAX_FRAME_GROUPS) blocks = RT_MAX_FRAME_GROUPS;
     blocks += 8;          // the per-wave frame rounds its grid up to whole groups of 8 tiles (32 one-wave workgroups)       // no launch has more workgroups than that (launch_lean_frame, sparse_grid)
-    return blocks * RT_BLOCK * RT_STACK_SPILL * sizeof(uint32_t);
+    return blocks * RT_BLOCK * RT_STACK_SPILL * sizeof(uint32_t) + RT_STACK_SPILL_HEADER * sizeof(uint32_t);      // (+ the header in front of the entries: trace.h)
 }
 #endif
 

@@ -32,6 +32,12 @@ struct alignas(16) GpuTri {
     float v2[3]; uint32_t pad2;
 };
 static_assert(sizeof(GpuTri) == 48, "GpuTri");
+// The one-step-per-trip walk (trace_ray_stepwise, trace.h) -- the walk of every ray kernel that does not hold the LDS scene cache -- fetches a leaf's 48-byte
+// record with the same four 16-byte loads as a 64-byte node: 16 bytes past the record.  EVERY array reached through GpuInstance::tris therefore ends with
+// this much readable slack behind its last record (gpu_tri_array_bytes is the one place that says how much to allocate).
+#define GPU_TRI_FETCH_SLACK_BYTES (sizeof(GpuNode) - sizeof(GpuTri))
+static_assert(GPU_TRI_FETCH_SLACK_BYTES == 16 && GPU_TRI_FETCH_SLACK_BYTES <= sizeof(GpuTri), "a triangle is fetched as one node-sized record");
+inline size_t gpu_tri_array_bytes(size_t triangles) { return triangles * sizeof(GpuTri) + GPU_TRI_FETCH_SLACK_BYTES; }
 
 struct BlasHeader {
     float bmin[3]; uint32_t count;

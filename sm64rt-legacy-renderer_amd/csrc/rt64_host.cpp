@@ -177,7 +177,7 @@ struct Device {
     // sync_present = 0 they alternate between the two streams, and frame k+1's first waves fill the wave slots the tail of frame k has left empty.  Everything
     // else -- an upload, a build, a frame with history, a readback, any API call that touches device memory -- first makes the current stream wait for the other
     // one (joinStreams), after which streams[cur] is ordered behind everything enqueued so far, exactly as with one stream.
-    hipStream_t streams[RT64_RENDER_STREAMS_MAX] = {}; int cur = 0, streamCount = 2;      // (RT64_RENDER_STREAMS = 1 .. 4 at device creation; default 2)
+    hipStream_t streams[RT64_RENDER_STREAMS_MAX] = {}; int cur = 0, streamCount = 3;      // (RT64_RENDER_STREAMS = 1 .. 4 at device creation; default 3: measured)
     hipEvent_t streamJoin[RT64_RENDER_STREAMS_MAX] = {};
     bool streamBusy[RT64_RENDER_STREAMS_MAX] = {};      // streams[k] may hold work streams[cur] has not waited for
     bool framePure = false, lastFramePure = false;
@@ -215,6 +215,8 @@ struct Device {
     bool profNow = false, statsProfiled = false; unsigned profCounter = 0;       // this frame records its pass events (option profile_every)
     double hostUpdateUs = 0.0, hostRenderUs = 0.0, hostStageUs[16] = {}, hostEventUs = 0.0; unsigned long long hostFrames = 0;      // host-side cost of View::update / View::render (RT64_HOST_TIMING=1 prints them)
     void finishStats();
+    uint32_t *traversalOverflow = nullptr;      // pinned host word the traversal stacks report a dropped entry to (TraceStack::report_overflow); read after every frame the host waits for
+    void checkTraversalOverflow();
     DevArray<uint32_t> spillStack[RT64_RENDER_STREAMS_MAX];                                     // HBM half of the traversal stacks, one slab per render stream (indexed by the launch's lanes)
     void *gatherTarget = nullptr; size_t gatherTargetBytes = 0;          // RT64_SetDeviceGatherTarget
     hipStream_t auxStream = nullptr; hipEvent_t forkEvent = nullptr, joinEvent = nullptr;      // second stream of a frame whose reflection passes run beside its denoiser (created on first use)
@@ -231,9 +233,21 @@ struct Device {
     DevArray<uint8_t> blueNoise;
     uint8_t *pinned[2] = { nullptr, nullptr }; size_t pinnedBytes[2] = { 0, 0 };
     enum { EV_BEGIN, EV_BUILD, EV_PRIMARY_TRACE, EV_PRIMARY, EV_DIRECT, EV_INDIRECT, EV_REFL, EV_DENOISE, EV_END, EV_COUNT };
-    hipEvent_t events[EV_COUNT] = {};
+    // One set of pass events per sub-frame of a primary_spp frame (the pass timings of such a frame are the sums over its sub-frames; beyond EV_SETS sub-frames the
+    // last EV_SETS are measured and scaled up), plus a pair around the reflection passes when they run on the second stream beside the denoiser.
+    enum { EV_SETS = 8 };
+    hipEvent_t eventSets[EV_SETS][EV_COUNT] = {}, auxEvents[EV_SETS][2] = {};
     // A mark with no GPU work since the previous mark reuses that mark's event: every hipEventRecord is a barrier packet (~4 us of GPU idle).
-    int eventAlias[EV_COUNT] = {}; int lastMark = EV_BEGIN; bool workSinceMark = false;
+    int eventAliases[EV_SETS][EV_COUNT] = {}; bool auxTimed[EV_SETS] = {}; int evSet = 0, evSetsUsed = 1, evSubFrames = 1; int lastMark = EV_BEGIN; bool workSinceMark = false;
+    hipEvent_t *events = eventSets[0]; int *eventAlias = eventAliases[0];
+    void beginEventSet(int sub) {           // first thing of sub-frame `sub` (0: the frame's start, before the builds)
+        evSet = sub % EV_SETS; events = eventSets[evSet]; eventAlias = eventAliases[evSet]; auxTimed[evSet] = false;
+        HIP_CHECK(hipEventRecord(events[EV_BEGIN], stream)); eventAlias[EV_BEGIN] = EV_BEGIN; lastMark = EV_BEGIN; workSinceMark = false;
+    }
+    void endEventSet() {                    // the end mark shares the last mark's event when nothing was launched after it (one barrier packet less per frame)
+        if (workSinceMark) { HIP_CHECK(hipEventRecord(events[EV_END], stream)); eventAlias[EV_END] = EV_END; }
+        else eventAlias[EV_END] = eventAlias[lastMark];
+    }
 
     Device(int w, int h, int dev);
     ~Device();
@@ -442,8 +456,10 @@ Device::Device(int w, int h, int dev) {
         HIP_CHECK(hipEventCreateWithFlags(&streamJoin[k], hipEventDisableTiming));
     }
     HIP_CHECK(hipEventCreateWithFlags(&streamCatchUp, hipEventDisableTiming));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&traversalOverflow), 64, hipHostMallocMapped)); *traversalOverflow = 0;
     stream = streams[0]; cur = 0; seenEpoch[0] = orderedEpoch;
-    for (auto &ev : events) HIP_CHECK(hipEventCreate(&ev));
+    for (auto &set : eventSets) for (auto &ev : set) HIP_CHECK(hipEventCreate(&ev));
+    for (auto &set : auxEvents) for (auto &ev : set) HIP_CHECK(hipEventCreate(&ev));
     counters.reserve((size_t)CTR_COUNT * RT_COUNTER_STRIPES);
     HIP_CHECK(hipMemsetAsync(counters.ptr, 0, counters.bytes(), stream));
     // Blue-noise table (Device::loadBlueNoise, rt64_device.cpp:794-797): 512x512 RGBA8.
@@ -467,7 +483,8 @@ Device::~Device() {
     if (getenv("RT64_HOST_TIMING") && hostFrames) { fprintf(stderr, "  launch host us by stage (up to each event mark):"); for (int i = 0; i < 16; i++) if (hostStageUs[i] > 0.0) fprintf(stderr, " [%d] %.1f", i, hostStageUs[i] / (double)hostFrames); fprintf(stderr, "  event records %.1f\n", hostEventUs / (double)hostFrames); }
     auto scenesCopy = scenes;
     for (Scene *s : scenesCopy) delete s;                 // rt64_device.cpp:97-100
-    for (auto &ev : events) if (ev) hipEventDestroy(ev);
+    for (auto &set : eventSets) for (auto &ev : set) if (ev) hipEventDestroy(ev);
+    for (auto &set : auxEvents) for (auto &ev : set) if (ev) hipEventDestroy(ev);
     for (auto *p : pinned) if (p) hipHostFree(p);
     if (auxStream) { hipStreamSynchronize(auxStream); hipStreamDestroy(auxStream); }
     if (forkEvent) hipEventDestroy(forkEvent);
@@ -476,6 +493,7 @@ Device::~Device() {
     if (halo.ready) hipEventDestroy(halo.ready);
     if (halo.done) hipEventDestroy(halo.done);
     if (ring) hipHostFree(ring);
+    if (traversalOverflow) hipHostFree(traversalOverflow);
     for (hipEvent_t ev : streamJoin) if (ev) hipEventDestroy(ev);
     if (streamCatchUp) hipEventDestroy(streamCatchUp);
     for (hipStream_t st : streams) if (st) hipStreamDestroy(st);
@@ -642,7 +660,8 @@ void Mesh::set(const void *vertexArray, int vcount, int vstride, const unsigned 
         // A refit keeps the topology of the tree that exists (or is about to exist, if its build is still pending).
         pendingRefit = buildPending ? (pendingRefit && refit) : refit;
         if (!pendingRefit) depth = host_blas_depth(static_cast<const uint8_t *>(vertexArray), (size_t)vstride, indexArray, n);
-        nodes.reserve(std::max<size_t>(n - 1, 1)); tris.reserve((size_t)n + 1); header.reserve(1);      // + 1: the stepwise walk reads a 48-byte triangle as 64 bytes (trace.h)
+        nodes.reserve(std::max<size_t>(n - 1, 1)); tris.reserve((gpu_tri_array_bytes(n) + sizeof(GpuTri) - 1) / sizeof(GpuTri)); header.reserve(1);      // records + the fetch slack behind the last one (rt64_gpu.h: GPU_TRI_FETCH_SLACK_BYTES)
+        if (tris.bytes() < gpu_tri_array_bytes(n)) throw std::runtime_error("RT64_SetMesh: triangle array without its fetch slack.");
         sortedIndex.reserve(n); morton.reserve(n); leafParent.reserve(n);
         if (n > LBVH_SMALL_MAX) buildScratch.reserve(lbvh_large_scratch_bytes(n));
         blasCount = n;
@@ -1264,8 +1283,14 @@ void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64
     {   // grows with the render size (no-op otherwise); never allocated for shallow scenes; one slab per render stream
         DevArray<uint32_t> &slab = dev->spillStack[dev->cur];
         const size_t words = needSpillSlab ? rt_stack_spill_bytes(imgW, imgH) / sizeof(uint32_t) : 0;
-        if (words > slab.count) { dev->impure(); slab.reserve(words); }
-        P.traversalStack = slab.ptr;
+        if (words > slab.count) {
+            dev->impure(); slab.reserve(words);
+            // header in front of the entries: where an overflowing walk reports (trace.h)
+            uint32_t header[RT_STACK_SPILL_HEADER] = {}; void *flagDev = nullptr;
+            HIP_CHECK(hipHostGetDevicePointer(&flagDev, dev->traversalOverflow, 0)); memcpy(header, &flagDev, sizeof(flagDev));
+            HIP_CHECK(hipMemcpy(slab.ptr, header, sizeof(header), hipMemcpyHostToDevice));
+        }
+        P.traversalStack = slab.ptr ? slab.ptr + RT_STACK_SPILL_HEADER : nullptr;
     }
     P.blueNoise = dev->blueNoise.ptr; P.counters = dev->counters.ptr;
     P.tileTiming = nullptr;
@@ -1449,7 +1474,9 @@ void View::render() {                          // View::render, rt64_view.cpp:11
             }
             HIP_CHECK(hipEventRecord(dev->forkEvent, s));
             HIP_CHECK(hipStreamWaitEvent(dev->auxStream, dev->forkEvent, 0));
+            if (prof) { HIP_CHECK(hipEventRecord(dev->auxEvents[dev->evSet][0], dev->auxStream)); dev->auxTimed[dev->evSet] = true; }
             for (int r = 0; r < dev->opt.maxReflections; r++) L(launch_reflection(P, img, klist, r, r == dev->opt.maxReflections - 1, cur, dev->auxStream));
+            if (prof) HIP_CHECK(hipEventRecord(dev->auxEvents[dev->evSet][1], dev->auxStream));
             HIP_CHECK(hipEventRecord(dev->joinEvent, dev->auxStream));
         };
         if (anyReflection && !reflectBeside) for (int r = 0; r < dev->opt.maxReflections; r++) L(launch_reflection(P, img, klist, r, r == dev->opt.maxReflections - 1, cur, s));
@@ -1554,7 +1581,7 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
     if (opt.countTraversal) HIP_CHECK(hipMemsetAsync(counters.ptr, 0, counters.bytes(), stream));
     // pass events on every profile_every-th frame only: each event is a barrier packet (~5 us of stream time; six of them are 5 % of a 0.6 ms GI frame)
     profNow = opt.profilePasses && (opt.profileEvery <= 1 || profCounter++ % (unsigned)opt.profileEvery == 0);
-    if (profNow) { HIP_CHECK(hipEventRecord(events[EV_BEGIN], stream)); eventAlias[EV_BEGIN] = EV_BEGIN; lastMark = EV_BEGIN; workSinceMark = false; }
+    if (profNow) beginEventSet(0);
     auto tu0 = std::chrono::steady_clock::now();
     flushMeshBuilds();
     for (Scene *sc : scenes) for (View *v : sc->views) v->update();
@@ -1564,17 +1591,18 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
         // the mean of their composed outputs is the frame (rules P1-P4 at oracle_render, oracle/oracle_render.c)
         v->subFrames = std::max(1, opt.primarySpp); v->subFrame = 0;
         v->render();
-        for (int sub = 1; sub < v->subFrames; sub++) { v->subFrame = sub; v->update(); v->render(); }
+        for (int sub = 1; sub < v->subFrames; sub++) {
+            if (profNow) { endEventSet(); beginEventSet(sub); }
+            v->subFrame = sub; v->update(); v->render();
+        }
+        evSubFrames = v->subFrames; evSetsUsed = std::min(v->subFrames, (int)EV_SETS);
         v->subFrame = 0;
     }
     if (leanHoldoff) leanHoldoff--;
     lastFramePure = framePure;
     auto tu2 = std::chrono::steady_clock::now();
     hostUpdateUs += std::chrono::duration<double, std::micro>(tu1 - tu0).count(); hostRenderUs += std::chrono::duration<double, std::micro>(tu2 - tu1).count(); hostFrames++;
-    if (profNow) {             // the end mark shares the last mark's event when nothing was launched after it (one barrier packet less per frame)
-        if (workSinceMark) { HIP_CHECK(hipEventRecord(events[EV_END], stream)); eventAlias[EV_END] = EV_END; }
-        else eventAlias[EV_END] = eventAlias[lastMark];
-    }
+    if (profNow) endEventSet();
     // postRender: Present + waitForGPU (:1006-1025).  Option sync_present = 0 turns RT64_DrawDevice into "enqueue the frame": the
     // host returns at once and orders its own work behind the frame on RT64_GetDeviceStream (pipelined multi-GPU gather in bench.py).
     if (opt.syncPresent) {
@@ -1586,6 +1614,7 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
         else HIP_CHECK(hipStreamSynchronize(stream));
     }
     auto t1 = std::chrono::steady_clock::now();
+    const unsigned dropped = traversalOverflow ? *traversalOverflow : 0u;       // (enqueued frames: whatever earlier frames have reported by now; RT64_GetDeviceStats waits for the last one)
 
     RT64_FRAME_STATS st = {};
     st.structSize = sizeof(st); st.width = (unsigned)width; st.height = (unsigned)height; st.tileY0 = (unsigned)tileY0; st.tileY1 = (unsigned)tileY1;
@@ -1605,8 +1634,18 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
         st.triangleCount = tri; st.blasNodeBytes = nodeBytes; st.blasTriangleBytes = triBytes;
         st.tlasNodeBytes = (unsigned)(std::max<size_t>(v->rtInstances.size() ? v->rtInstances.size() - 1 : 0, 1) * sizeof(GpuNode));
     }
+    st.traversalOverflow = dropped;
     stats = st; statsHaveView = haveView; statsPending = true; statsProfiled = profNow;
     if (opt.syncPresent) finishStats();
+    checkTraversalOverflow();
+}
+
+// A walk that had to drop a stack entry has skipped a subtree: the image is wrong and the host must hear of it (RT64_DrawDevice keeps the message for RT64_GetLastError).
+void Device::checkTraversalOverflow() {
+    if (!traversalOverflow || *traversalOverflow == 0u) return;
+    const unsigned n = *traversalOverflow; *traversalOverflow = 0;
+    throw std::runtime_error("RT64_DrawDevice: " + std::to_string(n) + " traversal-stack entries were dropped (TLAS depth + BLAS depth exceed " + std::to_string(RT_STACK_LDS + RT_STACK_SPILL) +
+                             " levels): the frame is missing geometry.");
 }
 
 // Timings and counters of the last frame: they need the frame to have finished on the GPU (lazy when sync_present = 0).
@@ -1618,12 +1657,23 @@ void Device::finishStats() {
     // The timings and counters below belong to the LAST frame handed to RT64_DrawDevice (one event set, re-recorded by every frame):
     // wait for it whatever sync_present says now -- the option may have been switched since the frame was enqueued.
     HIP_CHECK(hipStreamSynchronize(stream));
+    if (traversalOverflow && *traversalOverflow) st.traversalOverflow = *traversalOverflow;
     if (statsProfiled && haveView) {
-        auto ms = [&](int a, int b) { float v = 0.0f; if (eventAlias[a] != eventAlias[b] && hipEventElapsedTime(&v, events[eventAlias[a]], events[eventAlias[b]]) != hipSuccess) { (void)hipGetLastError(); v = 0.0f; } return v; };
-        st.msTotal = ms(EV_BEGIN, EV_END); st.msBuild = ms(EV_BEGIN, EV_BUILD); st.msPrimary = ms(EV_BUILD, EV_PRIMARY);
-        st.msPrimaryTrace = ms(EV_BUILD, EV_PRIMARY_TRACE); st.msPrimaryShade = ms(EV_PRIMARY_TRACE, EV_PRIMARY);
-        st.msDirect = ms(EV_PRIMARY, EV_DIRECT); st.msIndirect = ms(EV_DIRECT, EV_INDIRECT); st.msReflectRefract = ms(EV_INDIRECT, EV_REFL);
-        st.msDenoise = ms(EV_REFL, EV_DENOISE); st.msComposePost = ms(EV_DENOISE, EV_END);
+        // sums over the sub-frames of a primary_spp frame (one event set each; more than EV_SETS sub-frames: the measured ones scaled up)
+        const float scale = (float)evSubFrames / (float)std::max(evSetsUsed, 1);
+        for (int set = 0; set < evSetsUsed; set++) {
+            hipEvent_t *E = eventSets[set]; const int *A = eventAliases[set];
+            auto ms = [&](int a, int b) { float v = 0.0f; if (A[a] != A[b] && hipEventElapsedTime(&v, E[A[a]], E[A[b]]) != hipSuccess) { (void)hipGetLastError(); v = 0.0f; } return v * scale; };
+            st.msTotal += ms(EV_BEGIN, EV_END); st.msBuild += ms(EV_BEGIN, EV_BUILD); st.msPrimary += ms(EV_BUILD, EV_PRIMARY);
+            st.msPrimaryTrace += ms(EV_BUILD, EV_PRIMARY_TRACE); st.msPrimaryShade += ms(EV_PRIMARY_TRACE, EV_PRIMARY);
+            st.msDirect += ms(EV_PRIMARY, EV_DIRECT); st.msIndirect += ms(EV_DIRECT, EV_INDIRECT);
+            st.msDenoise += ms(EV_REFL, EV_DENOISE); st.msComposePost += ms(EV_DENOISE, EV_END);
+            // reflection passes that ran on the second stream beside the a-trous iterations have their own pair of events: the time they took there (it
+            // overlaps msDenoise; the two do not add up to wall time)
+            float aux = 0.0f;
+            if (auxTimed[set]) { if (hipEventElapsedTime(&aux, auxEvents[set][0], auxEvents[set][1]) != hipSuccess) { (void)hipGetLastError(); aux = 0.0f; } st.reflectionBesideDenoiser = 1; }
+            st.msReflectRefract += ms(EV_INDIRECT, EV_REFL) + aux * scale;
+        }
         accum.accumFrames++; accum.accumMsTotal += st.msTotal; accum.accumMsBuild += st.msBuild; accum.accumMsPrimaryTrace += st.msPrimaryTrace;
         accum.accumMsPrimaryShade += st.msPrimaryShade; accum.accumMsDirect += st.msDirect; accum.accumMsIndirect += st.msIndirect;
         accum.accumMsReflectRefract += st.msReflectRefract; accum.accumMsDenoise += st.msDenoise; accum.accumMsComposePost += st.msComposePost;
@@ -2163,7 +2213,7 @@ static void gather_rebalanced_bands(int height, int count, const int *starts, co
     out[count] = height;
 }
 
-static bool halo_starts_valid(int H, int count, const int *starts);
+static bool halo_starts_valid(int H, int count, const int *starts, bool strict = false);
 
 struct Gather {
     Device *dev; int rank, count, bands; int W, H; size_t slotBytes; GatherLayout layout;
@@ -2269,7 +2319,7 @@ int Gather::submit() {
 // New boundaries for a gather of cost-balanced bands (RT64_SetGatherBands): every rank calls it with the same boundaries between the same two frames.
 void Gather::setBands(const int *starts) {
     if (bands == 0) throw std::runtime_error("RT64_SetGatherBands: a gather of interleaved strips (bands = 0) has no boundaries; create it with bands = 1 or bands = 2.");
-    if (!halo_starts_valid(H, count, starts)) throw std::runtime_error("RT64_SetGatherBands: starts[0 .. count] must rise from 0 to the frame height.");
+    if (!halo_starts_valid(H, count, starts, true)) throw std::runtime_error("RT64_SetGatherBands: starts[0 .. count] must rise strictly from 0 to the frame height (every rank keeps at least one row).");
     dev->enter();
     HIP_CHECK(hipStreamSynchronize(dev->stream)); HIP_CHECK(hipStreamSynchronize(commStream));        // nothing of the old layout is in flight
     for (Slot &sl : slots) sl.pending = false;
@@ -2286,6 +2336,23 @@ void Gather::setBands(const int *starts) {
         }
         slotBytes = need;
         HIP_CHECK(hipStreamSynchronize(dev->stream));
+    }
+    // Temporal state of the rows this band gains: a band keeps G-buffer, GI accumulation and luminance moments only for its rows and the halo it renders them with
+    // (66 rows re-rendered, or halo_margin with the exchange); rows further out hold whatever this device rendered there last -- the first whole frame, or an older
+    // cut -- and the next frame would reproject against that.  Their accumulation restarts instead (history length 0: IndirectRayGen.hlsl:43-56 then takes the new
+    // sample alone), so a rebalanced partition converges like a freshly cut one; rows inside the old halo keep their history.
+    if (View *v = first_view(dev)) {
+        const int keep = dev->haloActive() ? std::max(dev->opt.haloMargin, SVGF_INPUT_HALO_ROWS) : (dev->opt.denoiserMode == 1 ? SVGF_HALO_ROWS : GAUSSIAN_HALO_ROWS);
+        const int old0 = std::max(0, dev->tileY0 - keep), old1 = std::min(H, dev->tileY1 + keep);
+        const int new0 = std::max(0, layout.starts[rank] - keep), new1 = std::min(H, layout.starts[rank + 1] + keep);
+        auto restart = [&](int y0, int y1) {
+            if (y1 <= y0 || v->imgW != W || v->imgH != H) return;
+            for (int k = 0; k < 2; k++) {
+                HIP_CHECK(hipMemsetAsync(reinterpret_cast<uint8_t *>(v->img.indirectLight[k]) + (size_t)y0 * W * 8, 0, (size_t)(y1 - y0) * W * 8, dev->stream));
+                HIP_CHECK(hipMemsetAsync(reinterpret_cast<uint8_t *>(v->img.moments[k]) + (size_t)y0 * W * 8, 0, (size_t)(y1 - y0) * W * 8, dev->stream));
+            }
+        };
+        restart(new0, std::min(new1, old0)); restart(std::max(new0, old1), new1);
     }
     dev->tileSet = true; dev->tileY0 = layout.starts[rank]; dev->tileY1 = layout.starts[rank + 1]; dev->stripRank = 0; dev->stripCount = 1;
     prepare(next);
@@ -2317,9 +2384,11 @@ static int halo_plan(int H, int count, const int *starts, int rank, int halo, RT
     }
     return n;
 }
-static bool halo_starts_valid(int H, int count, const int *starts) {
+// strict: every band has at least one row -- what a LIVE partition needs (a device with an empty band would fall back to the whole frame while the layout says
+// it owns nothing, and its neighbours would wait for rows it never sends); the schedule as a pure function (RT64_HaloPlan) also answers for empty bands.
+static bool halo_starts_valid(int H, int count, const int *starts, bool strict) {
     if (!starts || count < 1 || count > RT64_GATHER_MAX_RANKS || starts[0] != 0 || starts[count] != H) return false;
-    for (int r = 0; r < count; r++) if (starts[r + 1] < starts[r]) return false;
+    for (int r = 0; r < count; r++) if (strict ? starts[r + 1] <= starts[r] : starts[r + 1] < starts[r]) return false;
     return true;
 }
 bool Device::haloActive() const {
@@ -2469,7 +2538,7 @@ RT64_EXPORT int RT64_HaloPlan(int height, int count, const int *starts, int rank
 RT64_EXPORT int RT64_SetDeviceHaloExchange(RT64_DEVICE *device, RT64_HALO_EXCHANGE exchange, void *user, const int *starts, int rank, int count) {
     Device *d = reinterpret_cast<Device *>(device); if (!d) return 0;
     if (!exchange) { d->halo.fn = nullptr; d->halo.user = nullptr; d->halo.count = 0; d->halo.starts.clear(); return 1; }
-    if (!halo_starts_valid(d->pendingHeight, count, starts) || rank < 0 || rank >= count) return 0;
+    if (!halo_starts_valid(d->pendingHeight, count, starts, true) || rank < 0 || rank >= count) return 0;       // (strictly rising: every band has a row)
     d->halo.fn = exchange; d->halo.user = user; d->halo.rank = rank; d->halo.count = count; d->halo.starts.assign(starts, starts + count + 1);
     return 1;
 }

@@ -137,7 +137,7 @@ class FRAME_STATS(C.Structure):
                 ("accumMsTotal", C.c_float), ("accumMsBuild", C.c_float), ("accumMsPrimaryTrace", C.c_float), ("accumMsPrimaryShade", C.c_float),
                 ("accumMsDirect", C.c_float), ("accumMsIndirect", C.c_float), ("accumMsReflectRefract", C.c_float), ("accumMsDenoise", C.c_float),
                 ("accumMsComposePost", C.c_float), ("fusedFrame", C.c_uint), ("packedFinal", C.c_uint),
-                ("overlappedFrame", C.c_uint), ("traversalOverflow", C.c_uint)]
+                ("overlappedFrame", C.c_uint), ("reflectionBesideDenoiser", C.c_uint), ("traversalOverflow", C.c_uint)]
 
 
 assert C.sizeof(MATERIAL) == 132 and C.sizeof(LIGHT) == 60 and C.sizeof(SCENE_DESC) == 84

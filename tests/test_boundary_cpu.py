@@ -164,3 +164,35 @@ def test_bench_configurations_are_consistent():
         assert name.endswith("-literal") == bool(set(cfg) & {"primary_spp", "gi_bounces"})
     assert set(sample_scene.BENCH_DEVIATIONS) <= set(sample_scene.BENCH_CONFIGS)
     assert all(n in sample_scene.BENCH_DEVIATIONS for n in ("C4", "C5", "C4-literal", "C5-literal"))
+
+
+def _macro_constants(text):
+    return {m.group(1): int(m.group(2), 0) for m in re.finditer(r"^[ \t]*#[ \t]*define[ \t]+(RT64_[A-Z0-9_]+)[ \t]+(0x[0-9A-Fa-f]+|\d+)u?[ \t]*(?:/\*.*)?$", text, re.M)}
+
+
+def test_constants_are_macros_like_the_references_and_equal_the_enumerators():
+    """public/rt64.h:11-86 defines its constants with #define: a host may test them with #ifdef / #if.  include/rt64.h carries each one as an enumerator and as a
+    macro of the same value; with the reference at hand every numeric macro of its header has to exist here with the reference's value."""
+    header = open(os.path.join(ROOT, "include", "rt64.h")).read()
+    macros = _macro_constants(header)
+    head = header.split("/* ---- opaque handles", 1)[0]
+    enums = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"\b(RT64_[A-Z0-9_]+)\s*=\s*(0x[0-9A-Fa-f]+|\d+)", head)}
+    enums.update({"RT64_ATTRIBUTE_" + m.group(1): int(m.group(2), 0) for m in re.finditer(r"X\((\w+),\s*(0x[0-9A-Fa-f]+),\s*\w+\)", head)})
+    enums.pop("RT64_ATTRIBUTE_ALL_")
+    assert len(enums) >= 55
+    for name, value in enums.items():
+        assert macros.get(name) == value, name
+    ref = "/root/reference/src/rt64lib/public/rt64.h"
+    if os.path.exists(ref):
+        theirs = _macro_constants(open(ref).read())
+        assert len(theirs) >= 55
+        for name, value in theirs.items():
+            assert macros.get(name) == value, (name, value, macros.get(name))
+    # ... and the preprocessor sees them: #ifdef and #if arithmetic on a constant of every group
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "m.c")
+        open(src, "w").write('#include "rt64.h"\n#if !defined(RT64_ATTRIBUTE_DIFFUSE_COLOR_MIX) || RT64_ATTRIBUTE_DIFFUSE_COLOR_MIX != 0x4000 || RT64_MESH_RAYTRACE_UPDATABLE != 2 || '
+                             'RT64_UPSCALER_FSR != 3 || RT64_TEXTURE_FORMAT_DDS != 2 || RT64_MATERIAL_CC_SHADER_TEXEL1 != 7 || RT64_INSTANCE_DISABLE_BACKFACE_CULLING != 2\n#error constants\n#endif\n'
+                             'int main(void) { return RT64_ATTRIBUTE_NONE; }\n')
+        subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), "-fsyntax-only", src], check=True)
