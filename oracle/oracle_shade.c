@@ -591,11 +591,32 @@ static of3 perpendicular_vector(of3 u) {
     return v3cross(u, v3((float)xm, (float)ym, (float)zm));
 }
 
+/* Direction spec D1 (shared with the HIP side, csrc/device_math.h: sincos_turns): sine and cosine of 2 pi u for u in [0, 1] with every operation spelled
+ * out, so that the angle of a bounce direction -- a value that defines a RAY -- has the same bits on both sides (libm's and the device library's sinf / cosf
+ * are different code; the reference's HLSL sin / cos compile to approximate GPU instructions whose bits nothing specifies).
+ *   a = 4 u; k = (int)(a + 0.5f); x = (a - k) * (pi / 2) in [-pi/4, pi/4]; z = x x;
+ *   s = fma(x z, fma(z, fma(z, S3, S2), S1), x);  c = fma(z, fma(z, fma(z, fma(z, C4, C3), C2), -0.5), 1)   (Cephes sinf / cosf kernels)
+ *   quadrant k & 3 rotates: 0 (s, c), 1 (c, -s), 2 (-s, -c), 3 (-c, s). */
+static void sincos_turns(float u, float *sn, float *cs) {
+    const float a = u * 4.0f;
+    const int k = (int)(a + 0.5f);
+    const float x = (a - (float)k) * 1.57079637f, z = x * x;
+    const float s = fmaf(x * z, fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), x);
+    const float c = fmaf(z, fmaf(z, fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f), -0.5f), 1.0f);
+    switch (k & 3) {
+    case 0: *sn = s; *cs = c; break;
+    case 1: *sn = c; *cs = -s; break;
+    case 2: *sn = -s; *cs = -c; break;
+    default: *sn = -c; *cs = s; break;
+    }
+}
+
 of3 oshade_cos_hemisphere_blue_noise(const OShadeCtx *c, uint32_t px, uint32_t py, uint32_t frame, of3 hitNorm) {
     of3 bn = oshade_blue_noise(c, px, py, frame);
     of3 bitangent = perpendicular_vector(hitNorm);
     of3 tangent = v3cross(bitangent, hitNorm);
     float r = sqrtf(bn.x);
-    float phi = 2.0f * 3.14159265f * bn.y;
-    return v3add(v3add(v3scale(tangent, r * cosf(phi)), v3scale(bitangent, r * sinf(phi))), v3scale(hitNorm, sqrtf(fmaxf(0.0f, 1.0f - bn.x))));
+    float sn, cs;                               /* phi = 2 pi bn.y (IndirectRayGen.hlsl:24): by direction spec D1 */
+    sincos_turns(bn.y, &sn, &cs);
+    return v3add(v3add(v3scale(tangent, r * cs), v3scale(bitangent, r * sn)), v3scale(hitNorm, sqrtf(fmaxf(0.0f, 1.0f - bn.x))));
 }

@@ -57,6 +57,24 @@ HD f3 normalize3(f3 a) { float inv = s_rsqrt(dot3(a, a)); return mk3(a.x * inv, 
 // to the scalar reference tracer.
 HD float len3_exact(f3 a) { return sqrtf(dot3(a, a)); }
 HD f3 normalize3_exact(f3 a) { float inv = 1.0f / len3_exact(a); return mk3(a.x * inv, a.y * inv, a.z * inv); }
+// Direction spec D1 (shared with oracle/oracle_shade.c: sincos_turns): sine and cosine of 2 pi u for u in [0, 1], every operation spelled out so that the
+// device and the scalar reference tracer produce the same bits -- the angle of a cosine-weighted bounce direction (IndirectRayGen.hlsl:18-29) defines a RAY,
+// and the library's sinf / cosf are different code on the two sides.  a = 4 u; k = (int)(a + 0.5f); x = (a - k) * (pi / 2) in [-pi/4, pi/4];
+// s = x + x z (S1 + z (S2 + z S3)), c = 1 + z (C1 + z (C2 + z (C3))) with z = x x, as fmaf chains (Cephes' single-precision kernels, |error| < 1e-7);
+// the quadrant k rotates (s, c).  (The reference evaluates sin / cos with the GPU's approximate instructions: no bit pattern is specified there.)
+HD void sincos_turns(float u, float &sn, float &cs) {
+    const float a = u * 4.0f;
+    const int k = (int)(a + 0.5f);
+    const float x = (a - (float)k) * 1.57079637f, z = x * x;
+    const float s = fmaf(x * z, fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), x);
+    const float c = fmaf(z, fmaf(z, fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f), -0.5f), 1.0f);
+    switch (k & 3) {
+    case 0: sn = s; cs = c; break;
+    case 1: sn = c; cs = -s; break;
+    case 2: sn = -s; cs = -c; break;
+    default: sn = -c; cs = s; break;
+    }
+}
 HD float lerpf(float a, float b, float t) { return a + t * (b - a); }        // HLSL lerp
 HD f3 lerp3(f3 a, f3 b, float t) { return a + (b - a) * t; }
 HD float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }

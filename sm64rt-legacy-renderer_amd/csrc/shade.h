@@ -683,8 +683,9 @@ DEV f3 cos_hemisphere_blue_noise(PRef P, uint32_t px, uint32_t py, uint32_t fram
     f3 bitangent = perpendicular_vector(hitNorm);
     f3 tangent = cross3(bitangent, hitNorm);
     float r = sqrtf(bn.x);
-    float phi = 2.0f * 3.14159265f * bn.y;
-    return (tangent * (r * cosf(phi)) + bitangent * (r * sinf(phi))) + hitNorm * sqrtf(fmaxf(0.0f, 1.0f - bn.x));
+    float sn, cs;                               // phi = 2 pi bn.y: sine and cosine by direction spec D1 (device_math.h) -- the same bits as the scalar reference tracer's
+    sincos_turns(bn.y, sn, cs);
+    return (tangent * (r * cs) + bitangent * (r * sn)) + hitNorm * sqrtf(fmaxf(0.0f, 1.0f - bn.x));
 }
 
 DEV f2 world_to_screen(const float *viewProj, f3 p) {                            // PrimaryRayGen.hlsl:19-23
