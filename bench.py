@@ -65,7 +65,9 @@ def parse_args():
                     "(~5 us of stream time each, six per GI frame); 0 = auto: 1 for one-kernel frames (C2: two events, 0.4 us), 8 for frames of several passes")
     ap.add_argument("--prewarm", type=int, default=100, help="untimed frames before the W warm-up steps (GPU clock ramp; the line reports them)")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE", help="RT64_SetDeviceOption(key, value) before the run (A/B measurements; the line records them under config.options)")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU-staged rehearsal of the N>1 path")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="data path of the N > 1 gather: nccl = RCCL over xGMI (the library's own communicator, RT64_CreateGather); gloo: CPU-staged rehearsal of the N>1 path")
+    ap.add_argument("--control", default="gloo", choices=["gloo", "nccl"], help="torch.distributed backend of the CONTROL plane (rendezvous of the gather's unique id, barriers, the MAX over ranks, the band-cost all-gather): "
+                    "gloo (default) keeps ONE RCCL communicator per process -- the library's; nccl gives torch a second one on the same device (what rounds 1-3 ran)")
     ap.add_argument("--band-rebalance", type=int, default=0, help="N > 1, GI + denoiser bands: rounds of measured-cost feedback after the modelled cut (each rank times its band, one all-gather, "
                     "RT64_RebalanceGatherBands + RT64_SetGatherBands on every rank); 0 (default) keeps the modelled cut.  Opt-in until RT64_SetGatherBands has run between two GPUs (an A/B line, not the headline)")
     ap.add_argument("--halo", default="recompute", choices=["exchange", "recompute"], help="N > 1, GI + denoiser bands: re-render the denoiser's halo rows on every band (default: no mid-frame collective, the path every "
@@ -130,15 +132,22 @@ def main():
     if G:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.backend == "nccl":
-            if N == 1:
-                os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
-                dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
-            else:
-                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # The data path (the gather, the halo exchange) is the library's: grouped ncclSend / ncclRecv on its own communicator and stream.  torch.distributed is the
+        # control plane only, and on gloo by default: a process then holds ONE RCCL communicator, and nothing of torch's ever runs on the GPU beside the frames.
+        torch_backend = "nccl" if (args.backend == "nccl" and args.control == "nccl") else "gloo"
+        if N == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+        kw = dict(rank=0, world_size=1) if N == 1 else {}
+        if torch_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), **kw)
         else:
-            dist.init_process_group(backend="gloo")
-    comm_device = "cuda" if args.backend == "nccl" else "cpu" 
+            # one node: every rank is on this host, so gloo's pairs can use the loopback interface (a container's hostname may not resolve)
+            if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            dist.init_process_group(backend="gloo", **kw)
+    else:
+        torch_backend = None
+    comm_device = "cuda" if torch_backend == "nccl" else "cpu"
 
     if args.config != "C2":
         c = sample_scene.BENCH_CONFIGS[args.config]
@@ -193,14 +202,14 @@ def main():
         if rank == 0 and not lib.GetGatherUniqueId(uid.data_ptr(), uid.numel()):
             raise SystemExit("RT64_GetGatherUniqueId: " + lib.last_error())
         if N > 1:
-            uid_dev = uid.cuda()
+            uid_dev = uid.to(comm_device)
             dist.broadcast(uid_dev, 0)
             uid = uid_dev.cpu()
         # frames with GI + denoiser: contiguous bands of about equal modelled cost (cut from the whole frame every rank has just rendered)
         gather = lib.CreateGather(scene.device, uid.data_ptr(), uid.numel(), rank, N, 2 if use_bands else 0)       # also sets this device's share of the frame
         # every rank has to have it, or none uses it: a rank without RCCL behind the library falls back to the torch.distributed gatherer
         # of tiles.py (same layout, same pipelining) -- together with all the others, and the line says which one ran
-        ok = torch.tensor([1 if gather else 0], dtype=torch.int32, device="cuda")
+        ok = torch.tensor([1 if gather else 0], dtype=torch.int32, device=comm_device)
         if N > 1:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if not int(ok.item()):
@@ -217,6 +226,8 @@ def main():
     # stream, and the RCCL gather of frame k runs beside the rendering of frame k+1 (two slots).  Everything is complete at the
     # closing barrier + synchronize, which is inside the timed region.
     pipelined = G and args.backend == "nccl" and os.environ.get("RT64_BENCH_PIPELINE", "1") != "0"
+    if pipelined and not native and torch_backend != "nccl":
+        pipelined = False                    # the torch.distributed gatherer of tiles.py pipelines on torch's RCCL communicator only; on gloo it is the CPU-staged rehearsal
     ext_stream = None
     if pipelined and not native:
         try:
@@ -515,6 +526,8 @@ def main():
                                   "gather": "in-library (RT64_SubmitGather: grouped ncclSend / ncclRecv + reassembly kernel on the library's comm stream)" if native else "torch.distributed gather (tiles.FrameGatherer)",
                               "denoiser_halo": (("exchanged between neighbouring bands (ncclSend / ncclRecv of 24 B per pixel, 62 rows per side)" if halo_mode == "exchange" else "re-rendered by every band (66 rows per side)") if halo_mode else "none (pixel-local frame)"),
                               "send_buffer": ("written by the frame kernel (RT64_SetDeviceGatherTarget)" if (packed[0] or (native and scene.stats().packedFinal)) else "packed after each frame (RT64_CopyDeviceImage layout)"),
+                                  "control_plane": "torch.distributed on %s (%s)" % (torch_backend, "one RCCL communicator per process: the library's" if (native and torch_backend == "gloo") else
+                                                                                     ("a second RCCL communicator beside the library's" if native else "torch's gatherer")),
                                   "host_ms_per_step": round(enqueue_ms, 5)}
         result["accel_build"] = {"first_frame_ms": round(first_frame_build_ms, 4), "triangles": int(st_full.triangleCount), "blas_node_bytes": int(st_full.blasNodeBytes),
                                  "what": "GPU time of all BLAS builds (LBVH: Morton, radix sort, Karras, fit) + the TLAS build, executed at the first frame after the RT64_SetMesh calls"}

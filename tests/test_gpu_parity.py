@@ -231,6 +231,37 @@ def test_large_meshes_bit_exact(rt64_lib, oracle_lib, subdiv, grid):
         s.close(); o.close()
 
 
+@pytest.mark.parametrize("subdiv,grid", [(6, 256), (7, 256)])
+def test_stress_scene_at_1080p_against_the_oracle(rt64_lib, oracle_lib, subdiv, grid):
+    """The stress variant SURVEY 8(d) defines (sphere subdivided to >= 1.3 M triangles + a tessellated floor: a BVH that leaves every cache) and the one
+    bench.py measures (--subdiv 7 --floor-grid 256: 5.4 M triangles, 344 MB of nodes), at 1920 x 1080: the large-tree builder (radix sort over 5.2 M keys, three
+    levels of box fit), the one-wave form of the frame kernel with its cost-ordered tiles and the walk from HBM.  Hit records of all 2 M pixels and the visit
+    counters of all 3 M rays equal the oracle's; three frames, so that the second and third start their tiles in the recorded cost order."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    from oracle import oracle_py
+    data = sample_scene.make_sample_scene(subdiv=subdiv, floor_grid=grid)
+    s = sample_scene.Rt64Scene(rt64_lib, data, 1920, 1080, hip_device=0)
+    o = oracle_py.OracleScene(data)
+    try:
+        s.option("count_traversal", 1)
+        for _ in range(3):
+            s.draw()
+        st = s.stats()
+        assert st.fusedFrame == 1 and st.traversalOverflow == 0
+        ref = o.render(1920, 1080)
+        assert np.array_equal(s.readback(rt64.IMAGE_PRIMARY_HIT), ref["primaryHit"])
+        c = ref["counters"]
+        assert (st.primaryRays, st.shadowRays) == (c["primaryRays"], c["shadowRays"])
+        assert st.nodesVisited == c["nodesVisited"] and st.trianglesTested == c["trianglesTested"]
+        assert st.nodesPrimary == c["nodesVisitedPrimary"] and st.nodesDirect == c["nodesVisitedShadow"]
+        out = s.readback(rt64.IMAGE_OUTPUT_RGBA32F)
+        assert float(np.sqrt(np.mean((out[..., :3].astype(np.float64) - ref["output"][..., :3]) ** 2))) <= 1e-3
+        d = np.abs(s.readback(rt64.IMAGE_FINAL_RGBA8).astype(np.int32) - ref["final"].astype(np.int32))
+        assert d.max() <= 1
+    finally:
+        s.close(); o.close()
+
+
 def test_picking_returns_instance_pointer(scene_256):
     lib = scene_256.lib
     centre = lib.GetViewRaytracedInstanceAt(scene_256.view, 128, 150)
