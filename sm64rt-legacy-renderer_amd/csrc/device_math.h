@@ -135,6 +135,10 @@ DEV void store_rgba16f(uint16_t *img, size_t i, float x, float y, float z, float
     v.y = (uint32_t)f32_to_f16_bits(z) | ((uint32_t)f32_to_f16_bits(w) << 16);
     reinterpret_cast<uint2 *>(img)[i] = v;
 }
+DEV uint32_t pack_rgba16f_lo(float a, float b) { return (uint32_t)f32_to_f16_bits(a) | ((uint32_t)f32_to_f16_bits(b) << 16); }      // two RGBA16F channels as one dword (store_rgba16f's packing)
+DEV f4 unpack_rgba16f_bits(uint32_t xy, uint32_t zw) {
+    return mk4(f16_bits_to_f32((uint16_t)(xy & 0xFFFFu)), f16_bits_to_f32((uint16_t)(xy >> 16)), f16_bits_to_f32((uint16_t)(zw & 0xFFFFu)), f16_bits_to_f32((uint16_t)(zw >> 16)));
+}
 DEV f4 load_rgba16f(const uint16_t *img, size_t i) {
     uint2 v = reinterpret_cast<const uint2 *>(img)[i];
     return mk4(f16_bits_to_f32((uint16_t)(v.x & 0xFFFFu)), f16_bits_to_f32((uint16_t)(v.x >> 16)),

@@ -73,6 +73,7 @@ hipError_t launch_refraction_simple(const FrameParams &P, const ViewImages &I, b
 hipError_t launch_reflection_simple(const FrameParams &P, const ViewImages &I, bool klist, int pass, bool last, int parity, hipStream_t s);
 hipError_t launch_lean_frame_simple(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, int cur, bool full, int ownedY0, int ownedY1, unsigned maxGroups, bool perWave, hipStream_t s);
 hipError_t launch_clear_final(const FrameParams &P, const ViewImages &I, hipStream_t s);
+hipError_t launch_apply_reflection_state(const ViewImages &I, int width, int y0, int y1, uint32_t frameTag, hipStream_t s);      // rows [y0, y1): the continuation state the reflection passes tagged `frameTag` folded back into the G-buffer (readback only)
 unsigned lean_frame_tiles(const FrameParams &P);        // tiles of the one-kernel frame's launch (the device's rows, 16 x 16)
 hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, uint32_t tiles, hipStream_t s);
 hipError_t launch_spp_accumulate(const FrameParams &P, const ViewImages &I, float *sum, int sub, int count, hipStream_t s);

@@ -1422,17 +1422,25 @@ __global__ __launch_bounds__(RT_BLOCK) void refraction_kernel(FrameParams Pv, Vi
 // pass before it left a reflection alpha above EPSILON (a mirror seen in a mirror); that pass says so in I.reflectFlags[parity][pass], and a pass whose flag is
 // clear ends before it reads a pixel (the second pass of the sample scene's reflective floor: 32 us of a C5 frame).  The frame's last pass clears the other
 // parity's flags for the next frame.  A stale set flag only costs the scan it used to cost.
-template <bool KLIST>
-__global__ __launch_bounds__(RT_BLOCK) void reflection_kernel(FrameParams Pv, ViewImages Iv, int pass, int last, int parity) {
+// CACHED (round 4; opaque frames of scenes with the LDS scene cache): the walk of the mirrored ray and of its shadow ray from LDS like the frame kernel's -- scene cache +
+// int16 stacks + light columns sized by the frame's light count: 32 KB of LDS per workgroup on the sample scene where the uncached form holds 46.6 KB (24 KB of
+// stacks, 21.7 KB of columns for 17 lights whatever the frame has), i.e. 5 instead of 3 workgroups per CU, and every node visit a ds_read_b128 instead of an L2
+// round trip.  The cache is filled when the workgroup starts, like everywhere else (a fill that waits for the first tile with a mirror measured slower in round 3:
+// the vote and the fill were serial in workgroups of one tile).
+template <bool KLIST, bool CACHED = false>
+__global__ __launch_bounds__(RT_BLOCK, CACHED ? DIRECT_WAVES : 1) void reflection_kernel(FrameParams Pv, ViewImages Iv, int pass, int last, int parity) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
     if (last && blockIdx.x == 0 && threadIdx.x < 4) I.reflectFlags[(parity ^ 1) * 4 + threadIdx.x] = 0;
     if (pass > 0 && pass < 4 && I.reflectFlags[parity * 4 + pass] == 0u) return;          // (workgroup-uniform: written by the launch before this one; passes beyond the fourth always scan)
-    constexpr uint32_t STACK_WORDS = RT_STACK_LDS;
+    const uint32_t frameTag = P.frameCount + 1u;       // marks the continuation state this frame wrote (never 0: the images start zeroed)
+    constexpr uint32_t STACK_WORDS = CACHED ? RT_STACK_LDS_CACHED / 2 : RT_STACK_LDS;
     __shared__ uint32_t ldsStack[STACK_WORDS * RT_BLOCK];
-    __shared__ float ldsLightIntensity[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
-    __shared__ uint8_t ldsLightIndex[(RT64_MAX_LIGHTS + 1) * RT_BLOCK];
+    __shared__ float ldsLightIntensity[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
+    __shared__ uint8_t ldsLightIndex[CACHED ? 1 : (RT64_MAX_LIGHTS + 1) * RT_BLOCK];
+    extern __shared__ u32x4_lds dynLds[];
     ShadeEnv env; env.stk = make_stack(P, ldsStack, STACK_WORDS); env.cnt = TraceCounts(); env.shadowRays = 0;
     light_columns(env, ldsLightIntensity, ldsLightIndex, RT64_MAX_LIGHTS + 1);
+    if (CACHED) cached_env(P, env, dynLds);
     uint32_t rays = 0;
     const f3 ambient = mk3(P.ambientBaseColor[0], P.ambientBaseColor[1], P.ambientBaseColor[2]) + mk3(P.ambientNoGIColor[0], P.ambientNoGIColor[1], P.ambientNoGIColor[2]);
     const uint32_t tiles = tile_count(P);
@@ -1442,18 +1450,29 @@ __global__ __launch_bounds__(RT_BLOCK) void reflection_kernel(FrameParams Pv, Vi
         if (!p.valid) continue;
         const uint32_t px = p.x, py = p.y;
         const size_t i = (size_t)py * (size_t)P.width + px;
-        const int instanceId = I.instanceId[i];
         f4 refl = load_rgba16f(I.reflection, i);
         const float reflectionAlpha = refl.w;
-        if (instanceId < 0 || reflectionAlpha <= RT_EPSILON) continue;
-        const float4 pos4 = reinterpret_cast<const float4 *>(I.shadingPosition)[i];
-        f3 shadingPosition = mk3(pos4.x, pos4.y, pos4.z), viewDirection = xyz(load_rgba16f(I.viewDirection, i)), shadingNormal = xyz(load_rgba16f(I.shadingNormal, i));
+        // the surface this pass mirrors: the G-buffer's (pass 0), or what the pass before left in the continuation state (ViewImages::reflState0 / 1)
+        int instanceId; f3 shadingPosition, viewDirection, shadingNormal;
+        if (pass == 0) {
+            instanceId = I.instanceId[i];
+            if (instanceId < 0 || reflectionAlpha <= RT_EPSILON) continue;
+            const float4 pos4 = reinterpret_cast<const float4 *>(I.shadingPosition)[i];
+            shadingPosition = mk3(pos4.x, pos4.y, pos4.z); viewDirection = xyz(load_rgba16f(I.viewDirection, i)); shadingNormal = xyz(load_rgba16f(I.shadingNormal, i));
+        }
+        else {
+            if (reflectionAlpha <= RT_EPSILON || I.reflTag[i] != frameTag) continue;        // (an alpha above EPSILON was left by a pass that also wrote the state)
+            const uint4 s0 = I.reflState0[i], s1 = I.reflState1[i];
+            instanceId = (int)s0.w;
+            shadingPosition = mk3(__uint_as_float(s0.x), __uint_as_float(s0.y), __uint_as_float(s0.z));
+            viewDirection = xyz(unpack_rgba16f_bits(s1.x, s1.y)); shadingNormal = xyz(unpack_rgba16f_bits(s1.z, s1.w));
+        }
         f3 rayDirection = reflect3(viewDirection, shadingNormal);
         float newReflectionAlpha = 0.0f;
         const f3 bgColor = sky_over_background_envmap(P, rayDirection);
         RayDiff rd; rd.dOdx = rd.dOdy = rd.dDdx = rd.dDdy = mk3s(0.0f);
         SurfaceHit best;
-        const uint32_t nhits = trace_surface<KLIST>(P, env, I, i, shadingPosition, rayDirection, rd, px, py, best);
+        const uint32_t nhits = trace_surface<KLIST, CACHED>(P, env, I, i, shadingPosition, rayDirection, rd, px, py, best);
         rays++;
         const RT64_MATERIAL &pm = P.instances[instanceId].material;
         f3 resPosition = mk3s(0.0f), resNormal = mk3s(0.0f), resSpecular = mk3s(0.0f), resTransparent = mk3s(0.0f); f4 resColor = mk4(0, 0, 0, 1); int resInstanceId = -1;
@@ -1486,12 +1505,12 @@ __global__ __launch_bounds__(RT_BLOCK) void reflection_kernel(FrameParams Pv, Vi
         }
         f3 rgb = xyz(resColor);
         if (resInstanceId >= 0) {
-            f3 directLight = compute_lights_random(P, env, px, py, rayDirection, (uint32_t)resInstanceId, resPosition, resNormal, resSpecular, 1, false) + ld_v3(P.instances[resInstanceId].material.selfLight);
+            f3 directLight = compute_lights_random<CACHED>(P, env, px, py, rayDirection, (uint32_t)resInstanceId, resPosition, resNormal, resSpecular, 1, false) + ld_v3(P.instances[resInstanceId].material.selfLight);
             rgb = rgb * (ambient + directLight);
-            reinterpret_cast<float4 *>(I.shadingPosition)[i] = make_float4(resPosition.x, resPosition.y, resPosition.z, 0.0f);
-            store_rgba16f(I.viewDirection, i, rayDirection.x, rayDirection.y, rayDirection.z, 0.0f);
-            store_rgba16f(I.shadingNormal, i, resNormal.x, resNormal.y, resNormal.z, 0.0f);
-            I.instanceId[i] = resInstanceId;
+            // ReflectionRayGen.hlsl:117-124: the next pass continues from here (values rounded as the images the reference rewrites round them: RGBA32F / RGBA16F)
+            I.reflState0[i] = make_uint4(__float_as_uint(resPosition.x), __float_as_uint(resPosition.y), __float_as_uint(resPosition.z), (uint32_t)resInstanceId);
+            I.reflState1[i] = make_uint4(pack_rgba16f_lo(rayDirection.x, rayDirection.y), pack_rgba16f_lo(rayDirection.z, 0.0f), pack_rgba16f_lo(resNormal.x, resNormal.y), pack_rgba16f_lo(resNormal.z, 0.0f));
+            I.reflTag[i] = frameTag;
         }
         rgb = rgb + (bgColor * resColor.w + resTransparent);
         const f3 HighlightColor = mk3(1.0f, 1.05f, 1.2f), ShadowColor = mk3(0.1f, 0.05f, 0.0f);
@@ -1697,6 +1716,21 @@ __global__ __launch_bounds__(256) void indirect_constant_kernel(FrameParams Pv, 
     store_rgba16f(I.filteredIndirect[1], i, r, g, b, 0.0f);
 }
 
+// The reflection passes keep their continuation state beside the G-buffer (ViewImages::reflState0 / 1); the reference rewrites the G-buffer itself
+// (ReflectionRayGen.hlsl:117-124).  A reader of gShadingPosition / gViewDirection / gShadingNormal / gInstanceId gets the reference's bytes through this
+// kernel: every pixel the frame's passes tagged takes its last state (View::applyReflectionState, on readback only).
+__global__ __launch_bounds__(256) void apply_reflection_state_kernel(ViewImages I, int width, int y0, int y1, uint32_t frameTag) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = y0 + blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= width || y >= y1) return;
+    const size_t i = (size_t)y * (size_t)width + x;
+    if (I.reflTag[i] != frameTag) return;
+    const uint4 s0 = I.reflState0[i], s1 = I.reflState1[i];
+    reinterpret_cast<float4 *>(I.shadingPosition)[i] = make_float4(__uint_as_float(s0.x), __uint_as_float(s0.y), __uint_as_float(s0.z), 0.0f);
+    reinterpret_cast<uint2 *>(I.viewDirection)[i] = make_uint2(s1.x, s1.y);
+    reinterpret_cast<uint2 *>(I.shadingNormal)[i] = make_uint2(s1.z, s1.w);
+    I.instanceId[i] = (int32_t)s0.w;
+}
+
 __global__ __launch_bounds__(256) void clear_final_kernel(FrameParams Pv, ViewImages Iv) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
     if (P.separatePost) {         // the back buffer has the screen size, the frame is not partitioned
@@ -1860,6 +1894,7 @@ hipError_t RT_LAUNCHER(launch_refraction)(const FrameParams &P, const ViewImages
 hipError_t RT_LAUNCHER(launch_reflection)(const FrameParams &P, const ViewImages &I, bool klist, int pass, bool last, int parity, hipStream_t s) {
     RT_ROUTE_SIMPLE(launch_reflection_simple(P, I, klist, pass, last, parity, s));
     if (klist) hipLaunchKernelGGL(reflection_kernel<true>, dim3(sparse_grid(P)), dim3(RT_BLOCK), 0, s, P, I, pass, last ? 1 : 0, parity);
+    else if (P.cacheWords) hipLaunchKernelGGL((reflection_kernel<false, true>), dim3(sparse_grid(P)), dim3(RT_BLOCK), cached_lds_bytes(P, true), s, P, I, pass, last ? 1 : 0, parity);
     else hipLaunchKernelGGL(reflection_kernel<false>, dim3(sparse_grid(P)), dim3(RT_BLOCK), 0, s, P, I, pass, last ? 1 : 0, parity);
     return hipGetLastError();
 }
@@ -1892,6 +1927,12 @@ hipError_t launch_spp_accumulate(const FrameParams &P, const ViewImages &I, floa
 hipError_t launch_post_process(const FrameParams &P, const ViewImages &I, hipStream_t s) {
     dim3 grid((unsigned)((int)P.resolution[2] + 31) / 32, (unsigned)((int)P.resolution[3] + 7) / 8);
     hipLaunchKernelGGL(post_process_kernel, grid, dim3(256), 0, s, P, I);
+    return hipGetLastError();
+}
+hipError_t launch_apply_reflection_state(const ViewImages &I, int width, int y0, int y1, uint32_t frameTag, hipStream_t s) {
+    if (y1 <= y0) return hipSuccess;
+    dim3 grid((unsigned)(width + 31) / 32, (unsigned)(y1 - y0 + 7) / 8);
+    hipLaunchKernelGGL(apply_reflection_state_kernel, grid, dim3(256), 0, s, I, width, y0, y1, frameTag);
     return hipGetLastError();
 }
 hipError_t launch_clear_final(const FrameParams &P, const ViewImages &I, hipStream_t s) {

@@ -174,6 +174,12 @@ struct ViewImages {
     BounceRadiance *bounceResults;       // radiance of every (GI sample, pixel), 12 bytes (round 3: was a float4 with an unused lane -- 4 x 16 B read by the resolve and written by the walk / hit kernels per pixel of C5)
     uint4 *svgfGuide;                    // SVGF: 16-B guide record per pixel (normal 3 x f16, valid, depth, depth gradient)
     uint32_t *svgfYoung;                 // SVGF: [row][32-pixel segment] != 0: the segment has a pixel with fewer than 4 frames of history (set by bounce_resolve_kernel when it also writes the filter input, read and cleared by svgf_variance_kernel, which then only runs where one is set)
+    // Continuation state of the reflection passes (ReflectionRayGen.hlsl:117-124 rewrites gShadingPosition / gViewDirection / gShadingNormal / gInstanceId in place so that
+    // its next pass continues from the mirrored hit).  Kept beside the G-buffer here -- nobody but the next reflection pass and a debug readback reads the rewritten
+    // values -- so that the passes touch no image another pass of the frame reads and can run on a second stream from the moment the G-buffer exists:
+    // [0] = position.xyz + instance id bits, [1] = view direction RGBA16F | shading normal RGBA16F; reflTag[i] = frame tag of the last write (readback folds the
+    // tagged pixels back into the G-buffer: View::applyReflectionState).  nullptr until a frame has a reflective material.
+    uint4 *reflState0, *reflState1; uint32_t *reflTag;
     uint32_t *reflectFlags;              // [2][4]: does any pixel go on to reflection pass p of the frame of this parity?  (set by pass p - 1, the other parity cleared by the frame's last pass; a later pass with nothing to do ends at once)
     // Per-pixel sorted hit list (k-buffer), [RT64_MAX_HIT_QUERIES + 1][pixels]; allocated only while some instance is not
     // provably opaque.  The reference keeps 17 x 34 B per pixel for every frame (rt64_view.cpp:237-241).

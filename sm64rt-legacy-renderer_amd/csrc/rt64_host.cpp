@@ -157,6 +157,7 @@ struct Options {
     bool foldVariance = true;      // ... and the filter's input (variance from the moments) for every pixel with four frames of history; svgf_variance_kernel then only runs where a younger pixel is marked (0: it makes every pixel's input)
     bool foldGuide = true;         // frames with the wavefront GI chain + SVGF: bounce_resolve_kernel writes the filter's guide records (0: svgf_guide_kernel, its own launch)
     bool overlapFrames = true;     // enqueued (sync_present = 0) pixel-local frames alternate between two render streams: frame k+1 starts while the last waves of frame k are still walking (Device::draw)
+    bool reflectionEarly = true;   // ... and they fork as soon as the G-buffer exists (beside the GI chain too), not only beside the a-trous iterations (0: round 3's placement)
     bool overlapReflection = true; // frames with reflection passes AND the SVGF denoiser: the reflection launches run on a second stream beside the a-trous iterations (they share no image)
     bool haloExchange = false;     // band partitions of GI + SVGF frames: ship the filter input of the halo rows between the devices of the gather (RCCL) instead of re-rendering them
     bool haloDryRun = false;       // timing aid: an exchanging band runs its frame but moves no halo rows (what one rank's GPU work costs, measured on one device; results outside the band's interior are then wrong)
@@ -408,6 +409,9 @@ struct View {
     bool fusedStoreless = false;              // ... and that kernel stored the back buffer only (no hit records, no direct-light image)
     bool fusedFrame = false;                  // ... and ran as lean_frame_kernel: rtOutput was not written either (unless PostProcess ran separately)
     FrameParams lastParams; int lastCur = 0;
+    // the last frame's reflection passes left their continuation state beside the G-buffer: a readback of the four images the reference rewrites folds it back first
+    bool reflStatePending = false; uint32_t reflStateTag = 0; int reflStateY0 = 0, reflStateY1 = 0;
+    void applyReflectionState();
     // extension primary_spp (rules P1-P4, oracle/oracle_render.c): the frame as `subFrames` complete sub-frames; Device::draw drives them
     int subFrame = 0, subFrames = 1; DevArray<float> sppSum;
     // longest-first tile order of the one-kernel frame on scenes that walk from HBM (device option tile_order): last frame's cost per tile and the order made from it
@@ -1352,6 +1356,18 @@ void View::render() {                          // View::render, rt64_view.cpp:11
             img.bounceLists = static_cast<uint32_t *>(l); img.bounceCounts = static_cast<uint32_t *>(c); img.bounceResults = static_cast<BounceRadiance *>(r);
         }
         const bool klist = anyNonOpaque;
+        reflStatePending = false;
+        if (anyReflection && dev->opt.maxReflections > 0) {
+            if (!img.reflState0) {          // continuation state of the reflection passes (ViewImages::reflState0 / 1 / reflTag), 36 B per pixel, from the first frame with a reflective material on
+                void *a = nullptr, *b = nullptr, *c = nullptr;
+                HIP_CHECK(hipMalloc(&a, n * sizeof(uint4))); allocations.push_back(a);
+                HIP_CHECK(hipMalloc(&b, n * sizeof(uint4))); allocations.push_back(b);
+                HIP_CHECK(hipMalloc(&c, n * sizeof(uint32_t))); allocations.push_back(c);
+                HIP_CHECK(hipMemsetAsync(c, 0, n * sizeof(uint32_t), s));
+                img.reflState0 = static_cast<uint4 *>(a); img.reflState1 = static_cast<uint4 *>(b); img.reflTag = static_cast<uint32_t *>(c);
+            }
+            reflStatePending = true; reflStateTag = P.frameCount + 1u; reflStateY0 = P.tileY0; reflStateY1 = P.tileY1;
+        }
         // Image-tile partition with a spatial filter downstream: the GI denoiser reads a neighbourhood of every row this device
         // owns (SVGF: 66 rows, the reference's five 3x3 Gaussians: 5), so the passes that feed it -- primary visibility, G-buffer,
         // GI bounce -- also cover a halo above and below the device's rows.  Pixel-local passes (direct light, reflection,
@@ -1412,6 +1428,22 @@ void View::render() {                          // View::render, rt64_view.cpp:11
             F.tileCost = tileCost[slot].ptr; F.tileOrder = tileOrderValid[slot] ? tileOrder[slot].ptr : nullptr;
             return tiles;
         };
+        const bool reflectBeside = anyReflection && dev->opt.maxReflections > 0 && denoiseGI && dev->opt.denoiserMode == 1 && dev->opt.overlapReflection;
+        auto reflectOnAux = [&]() {
+            if (!dev->auxStream) {
+                HIP_CHECK(hipStreamCreateWithFlags(&dev->auxStream, hipStreamNonBlocking));
+                HIP_CHECK(hipEventCreateWithFlags(&dev->forkEvent, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&dev->joinEvent, hipEventDisableTiming));
+            }
+            HIP_CHECK(hipEventRecord(dev->forkEvent, s));
+            HIP_CHECK(hipStreamWaitEvent(dev->auxStream, dev->forkEvent, 0));
+            if (prof) { HIP_CHECK(hipEventRecord(dev->auxEvents[dev->evSet][0], dev->auxStream)); dev->auxTimed[dev->evSet] = true; }
+            for (int r = 0; r < dev->opt.maxReflections; r++) L(launch_reflection(P, img, klist, r, r == dev->opt.maxReflections - 1, cur, dev->auxStream));
+            if (prof) HIP_CHECK(hipEventRecord(dev->auxEvents[dev->evSet][1], dev->auxStream));
+            HIP_CHECK(hipEventRecord(dev->joinEvent, dev->auxStream));
+        };
+        // ... and from the moment the G-buffer exists when nothing else of the frame shares storage with them: their continuation state is their own (ViewImages::reflState0 / 1),
+        // but the per-pixel hit lists of a k-buffer frame and the HBM half of the traversal stacks are per launch position, one set per frame -- such frames keep the later fork.
+        const bool reflectEarly = reflectBeside && !klist && !needSpillSlab && dev->opt.reflectionEarly;
         if (fused) {
             // nullptr: the frame stores its back buffer only (hit records and the direct-light image come back through materialise); option lean_records = 1 keeps them
             if (P.tileTiming) { HIP_CHECK(hipMemsetAsync(dev->tileTiming.ptr, 0, dev->tileTiming.bytes(), s)); }
@@ -1428,6 +1460,7 @@ void View::render() {                          // View::render, rt64_view.cpp:11
             L(launch_lean_frame(X, img, hitInstance.ptr, cur, true, P.tileY0, P.tileY1, dev->opt.maxFrameGroups, perWave, s));
             if (ordered) { L(launch_tile_order(tileCost[slot].ptr, tileOrder[slot].ptr, ordered, s)); tileOrderValid[slot] = true; }
             mark(Device::EV_PRIMARY_TRACE); mark(Device::EV_PRIMARY); mark(Device::EV_DIRECT);
+            if (reflectEarly) reflectOnAux();              // beside the GI chain and the denoiser: joined before the composing iteration
         }
         else {
             L(launch_primary_trace(X, img, hitInstance.ptr, klist, s));
@@ -1438,6 +1471,7 @@ void View::render() {                          // View::render, rt64_view.cpp:11
             // so rtFilteredDirectLight[1] is always a plain copy of the raw accumulation.
             L(launch_direct(P, img, cur, lean, s));
             mark(Device::EV_DIRECT);
+            if (reflectEarly) reflectOnAux();
         }
         if (lean) {}                                                                  // constant ambient folded into Compose
         else if (giSamples == 0) L(launch_indirect_constant(P, img, cur, s));  // IndirectRayGen.hlsl:135: constant ambient
@@ -1461,31 +1495,18 @@ void View::render() {                          // View::render, rt64_view.cpp:11
         // read and write the filter's ping-pong images and read the guide records: no image in common.  On frames that have both, the reflection launches
         // therefore go to a second stream once the filter's INPUT is made (the variance kernel reads the instance ids the reflection pass rewrites), beside the
         // five iterations, and the frame joins the two before Compose -- two latency-bound launches fill each other's idle issue slots (C5: DESIGN 8).
-        const bool reflectBeside = anyReflection && dev->opt.maxReflections > 0 && denoiseGI && dev->opt.denoiserMode == 1 && dev->opt.overlapReflection;
         // Frames with the SVGF denoiser: ComposePS runs inside the last a-trous iteration (svgf.hip), on the filtered value that iteration has just rounded
         if (subFrames > 1) sppSum.reserve(n * 4);
         SvgfComposeFold foldArgs = { img.diffuse, img.filteredDirect[1], img.reflection, img.refraction, img.transparent, img.output, img.final, P.tileY0, P.tileY1, (!P.separatePost && subFrames == 1) ? 1 : 0,
                                      subFrames > 1 ? sppSum.ptr : nullptr, subFrame, subFrames };
         const SvgfComposeFold *composeFold = (denoiseGI && dev->opt.denoiserMode == 1 && !lean && dev->opt.foldCompose && P.stripCount == 1) ? &foldArgs : nullptr;
-        auto reflectOnAux = [&]() {
-            if (!dev->auxStream) {
-                HIP_CHECK(hipStreamCreateWithFlags(&dev->auxStream, hipStreamNonBlocking));
-                HIP_CHECK(hipEventCreateWithFlags(&dev->forkEvent, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&dev->joinEvent, hipEventDisableTiming));
-            }
-            HIP_CHECK(hipEventRecord(dev->forkEvent, s));
-            HIP_CHECK(hipStreamWaitEvent(dev->auxStream, dev->forkEvent, 0));
-            if (prof) { HIP_CHECK(hipEventRecord(dev->auxEvents[dev->evSet][0], dev->auxStream)); dev->auxTimed[dev->evSet] = true; }
-            for (int r = 0; r < dev->opt.maxReflections; r++) L(launch_reflection(P, img, klist, r, r == dev->opt.maxReflections - 1, cur, dev->auxStream));
-            if (prof) HIP_CHECK(hipEventRecord(dev->auxEvents[dev->evSet][1], dev->auxStream));
-            HIP_CHECK(hipEventRecord(dev->joinEvent, dev->auxStream));
-        };
         if (anyReflection && !reflectBeside) for (int r = 0; r < dev->opt.maxReflections; r++) L(launch_reflection(P, img, klist, r, r == dev->opt.maxReflections - 1, cur, s));
         mark(Device::EV_REFL);
         if (denoiseGI && dev->opt.denoiserMode == 1 && reflectBeside) {
             const int ay0 = haloExchange ? std::max(0, P.tileY0 - SVGF_ATROUS_HALO_ROWS) : X.tileY0, ay1 = haloExchange ? std::min(imgH, P.tileY1 + SVGF_ATROUS_HALO_ROWS) : X.tileY1;
             if (haloExchange) { L(launch_svgf_inputs(img, cur, imgW, imgH, std::max(0, P.tileY0 - 3), guideByResolve ? 0 : std::min(imgH, P.tileY1 + 3), P.tileY0, P.tileY1, inputByResolve, s)); }
             else L(launch_svgf_inputs(img, cur, imgW, imgH, X.tileY0, guideByResolve ? 0 : X.tileY1, X.tileY0, X.tileY1, inputByResolve, s));
-            reflectOnAux();                                      // (before the exchange: the reflection pass also runs beside the wait for the neighbours' rows)
+            if (!reflectEarly) reflectOnAux();                   // (before the exchange: the reflection pass also runs beside the wait for the neighbours' rows)
             if (haloExchange) halo_exchange(dev, img, imgW, imgH, s);
             // (the folded Compose reads the reflection image: the join comes before the last iteration instead of behind it)
             L(launch_svgf_atrous(img, imgW, imgH, ay0, ay1, P.tileY0, P.tileY1, 0, composeFold ? 4 : 5, nullptr, s));
@@ -1532,6 +1553,16 @@ void View::render() {                          // View::render, rt64_view.cpp:11
     if (!fgFolded && subFrame == subFrames - 1) drawRasterList(rasterFgScreen, img.final);   // foreground instances over the finished frame (rt64_view.cpp:1657-1661)
     // End of frame (rt64_view.cpp:1663-1667)
     rtSwap = !rtSwap; skipReprojection = false; frameCount++;
+}
+
+// The G-buffer as the reference leaves it after its reflection passes (ReflectionRayGen.hlsl:117-124 rewrites position / view direction / normal / instance id of
+// every mirrored pixel): the passes here keep that state beside the G-buffer, a reader gets it folded back.
+void View::applyReflectionState() {
+    if (!reflStatePending || !img.reflState0) return;
+    Device *dev = scene->device;
+    dev->use(); dev->joinStreams();
+    HIP_CHECK(launch_apply_reflection_state(img, imgW, reflStateY0, reflStateY1, reflStateTag, dev->stream));
+    reflStatePending = false;
 }
 
 // A lean frame left some images untouched; produce them now from the frame's retained inputs (hit records, parameters).
@@ -1761,6 +1792,7 @@ static size_t readback(Device *dev, int image, void *dst, size_t dstBytes, bool 
         return need;
     }
     if (image != RT64_IMAGE_FINAL_RGBA8 && (image != RT64_IMAGE_OUTPUT_RGBA32F || v->fusedFrame)) v->materialise();
+    if (image == RT64_IMAGE_SHADING_POSITION || image == RT64_IMAGE_VIEW_DIRECTION || image == RT64_IMAGE_SHADING_NORMAL || image == RT64_IMAGE_INSTANCE_ID) v->applyReflectionState();
     ImageInfo info; size_t dstPixelBytes;
     if (!image_info(v, image, info, dstPixelBytes)) throw std::runtime_error("RT64_ReadbackDevice: unknown image id.");
     // Sizes: every image has the render size except the back buffer (screen size); they differ only with resolutionScale != 1,
@@ -1889,6 +1921,7 @@ RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, doubl
     else if (k == "denoiser_mode") d->opt.denoiserMode = (int)value;
     else if (k == "bounce_refill") d->opt.bounceRefill = (int)value;
     else if (k == "overlap_reflection") d->opt.overlapReflection = value != 0.0;
+    else if (k == "reflection_early") d->opt.reflectionEarly = value != 0.0;
     else if (k == "overlap_frames") d->opt.overlapFrames = value != 0.0;       // 0: every frame on one render stream (a host that orders its own work behind frames on RT64_GetDeviceStream)
     else if (k == "tile_order") d->opt.tileOrder = value != 0.0;
     else if (k == "fold_variance") d->opt.foldVariance = value != 0.0;
