@@ -47,7 +47,7 @@ hipError_t bc7_decode_launch(const uint8_t *blocks, uint8_t *rgba, uint32_t widt
 #define RT_MAX_FRAME_GROUPS 8192u     // largest grid of the one-workgroup-per-tile kernels (bigger frames give every workgroup a few tiles)
 size_t rt_stack_spill_bytes(int width, int rows);        // bytes FrameParams::traversalStack needs for a frame of that size
 
-hipError_t launch_scene_cache_image(const GpuInstance *instances, const uint32_t *tlasIndex, const GpuNode *tlasNodes, uint32_t cacheInstances, void *image, hipStream_t s);   // LDS scene cache contents, flat (FrameParams::cacheImage)
+hipError_t launch_scene_cache_image(const GpuInstance *instances, const uint32_t *tlasIndex, const GpuNode *tlasNodes, uint32_t cacheInstances, void *image, bool blasOnly, hipStream_t s);   // LDS scene cache contents, flat (FrameParams::cacheImage)
 hipError_t launch_primary_trace(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, bool klist, hipStream_t s);
 hipError_t launch_primary_shade(const FrameParams &P, const ViewImages &I, const int32_t *hitInstance, int cur, bool transparentLighting, bool lean, hipStream_t s);
 hipError_t launch_direct(const FrameParams &P, const ViewImages &I, int cur, bool lean, hipStream_t s);

@@ -43,6 +43,10 @@ struct Pixel { uint32_t x, y; bool valid; };
 //   ROWS   32x8,  wave = 32x2 pixels  : shading kernels (a wave's image store covers whole 128/256-byte lines)
 // Tile rows owned by this device: strips stripRank, stripRank + stripCount, ... of the 16-row strips in [tileY0, tileY1).
 enum TileShape { TILE_SQUARE = 0, TILE_ROWS = 1 };
+#ifndef RT_WAVE_BLOCK_W
+#define RT_WAVE_BLOCK_W 8        // pixels per row of a wave's block inside a SQUARE tile: 8 (8 x 8, shipped) or 16 (16 x 4: experiment of round 4, tools/exp/r04_wave_block.sh)
+#endif
+#define RT_WAVE_BLOCK_H (64 / RT_WAVE_BLOCK_W)
 template <int SHAPE> struct TileDim { static constexpr int W = SHAPE == TILE_SQUARE ? 16 : 32, H = SHAPE == TILE_SQUARE ? 16 : 8; };
 
 DEV uint32_t owned_strips(PRef P) {
@@ -58,7 +62,13 @@ template <int SHAPE = TILE_SQUARE> DEV Pixel tile_pixel_at(PRef P, uint32_t tile
     const uint32_t tx = tile % tilesX, lt = tile / tilesX;
     const uint32_t strip = (lt / perStrip) * (uint32_t)P.stripCount + (uint32_t)P.stripRank;
     Pixel p;
-    if (SHAPE == TILE_SQUARE) { p.x = tx * TW + (wave & 1) * 8 + (lane & 7); p.y = (wave >> 1) * 8 + (lane >> 3); }
+    if (SHAPE == TILE_SQUARE) {
+#if RT_WAVE_BLOCK_W == 16
+        p.x = tx * TW + (lane & 15); p.y = wave * 4 + (lane >> 4);           // a wave owns 16 x 4 pixels: its stores are whole 64-byte pieces of image rows
+#else
+        p.x = tx * TW + (wave & 1) * 8 + (lane & 7); p.y = (wave >> 1) * 8 + (lane >> 3);
+#endif
+    }
     else { p.x = tx * TW + (lane & 31); p.y = wave * 2 + (lane >> 5); }
     p.y += (uint32_t)P.tileY0 + strip * 16 + (lt % perStrip) * TH;
     p.valid = p.x < (uint32_t)P.width && p.y < (uint32_t)P.tileY1;
@@ -105,11 +115,12 @@ DEV void copy_cache_nodes(const GpuNode *nodes, uint32_t count, u32x4 *dst) {   
         dst[t] = w;
     }
 }
-__global__ __launch_bounds__(RT_BLOCK) void scene_cache_image_kernel(const GpuInstance *instances, const uint32_t *tlasIndex, const GpuNode *tlasNodes, uint32_t m, u32x4 *cache) {
+// blasOnly: the head (instance records + TLAS nodes) arrived with the table upload, written by the host (View::update: hostCache); only the BLAS node arrays are copied
+__global__ __launch_bounds__(RT_BLOCK) void scene_cache_image_kernel(const GpuInstance *instances, const uint32_t *tlasIndex, const GpuNode *tlasNodes, uint32_t m, u32x4 *cache, int blasOnly) {
     typedef u32x4 W4;
     const uint32_t T = blockDim.x, tid = threadIdx.x;
 
-    for (uint32_t k = tid; k < m; k += T) {
+    for (uint32_t k = tid; k < m && !blasOnly; k += T) {
         const uint32_t inst = tlasIndex[k];
         const GpuInstance &in = instances[inst];
         const float *M = in.worldToObject;
@@ -122,7 +133,7 @@ __global__ __launch_bounds__(RT_BLOCK) void scene_cache_image_kernel(const GpuIn
         W4 info; info.x = inst | ((in.flags & 0xFFu) << 8) | (in.cacheNodeOffset << 16); info.y = __float_as_uint(in.material.depthBias); info.z = (uint32_t)tp; info.w = (uint32_t)(tp >> 32);
         cache[4 * k + 3] = info;
     }
-    copy_cache_nodes(tlasNodes, m > 1 ? m - 1 : 1u, cache + 4 * m);
+    if (!blasOnly) copy_cache_nodes(tlasNodes, m > 1 ? m - 1 : 1u, cache + 4 * m);
     for (uint32_t k = 0; k < m; k++) {                       // uniform: every thread walks the same instance list
         const GpuInstance &in = instances[tlasIndex[k]];
         copy_cache_nodes(in.nodes, in.triCount > 1 ? in.triCount - 1 : 1u, cache + in.cacheNodeOffset);
@@ -695,9 +706,9 @@ __global__ __launch_bounds__(BLOCK, WAVES) void lean_frame_kernel(FrameParams Pv
             // in RGBA8 exactly as raster_draw_kernel would blend it over the stored pixel (rt64_view.cpp:1657-1661), without the launch
             uint32_t bits = (uint32_t)to_unorm8(result.x) | ((uint32_t)to_unorm8(result.y) << 8) | ((uint32_t)to_unorm8(result.z) << 16) | ((uint32_t)to_unorm8(1.0f) << 24);
             if (P.rasterFgCount) {
-                const int wx0 = __builtin_amdgcn_readfirstlane((int)(px & ~7u)), wy0 = __builtin_amdgcn_readfirstlane((int)(py & ~7u));      // the wave's 8 x 8 pixel block
+                const int wx0 = __builtin_amdgcn_readfirstlane((int)(px & ~(uint32_t)(RT_WAVE_BLOCK_W - 1))), wy0 = __builtin_amdgcn_readfirstlane((int)(py & ~(uint32_t)(RT_WAVE_BLOCK_H - 1)));      // the wave's pixel block (8 x 8)
                 bool loaded = true, dirty = false;
-                raster_blend_pixel(P.rasterFg, static_cast<const RasterTri *>(P.rasterFgTris), P.rasterFgCount, P.textures, (int)px, (int)py, true, wx0, wx0 + 7, wy0, wy0 + 7, nullptr, bits, loaded, dirty);
+                raster_blend_pixel(P.rasterFg, static_cast<const RasterTri *>(P.rasterFgTris), P.rasterFgCount, P.textures, (int)px, (int)py, true, wx0, wx0 + RT_WAVE_BLOCK_W - 1, wy0, wy0 + RT_WAVE_BLOCK_H - 1, nullptr, bits, loaded, dirty);
             }
             reinterpret_cast<uint32_t *>(I.final)[i] = bits;
             if (P.finalPacked) {        // the gather's send buffer: row r of the owned rows, strips back to back (same order as RT64_CopyDeviceImage)
@@ -1777,8 +1788,8 @@ static size_t cached_lds_bytes(const FrameParams &P, bool lights) {
 #define LAUNCH_RAY_LDS(kernel, bytes, ...) do { hipLaunchKernelGGL(kernel, dim3(rt_grid(P)), dim3(RT_BLOCK), bytes, s, __VA_ARGS__); return hipGetLastError(); } while (0)
 
 #ifndef RT_ASSUME_SIMPLE
-hipError_t launch_scene_cache_image(const GpuInstance *instances, const uint32_t *tlasIndex, const GpuNode *tlasNodes, uint32_t cacheInstances, void *image, hipStream_t s) {
-    hipLaunchKernelGGL(scene_cache_image_kernel, dim3(1), dim3(RT_BLOCK), 0, s, instances, tlasIndex, tlasNodes, cacheInstances, static_cast<u32x4 *>(image));
+hipError_t launch_scene_cache_image(const GpuInstance *instances, const uint32_t *tlasIndex, const GpuNode *tlasNodes, uint32_t cacheInstances, void *image, bool blasOnly, hipStream_t s) {
+    hipLaunchKernelGGL(scene_cache_image_kernel, dim3(1), dim3(RT_BLOCK), 0, s, instances, tlasIndex, tlasNodes, cacheInstances, static_cast<u32x4 *>(image), blasOnly ? 1 : 0);
     return hipGetLastError();
 }
 hipError_t launch_primary_trace(const FrameParams &P, const ViewImages &I, int32_t *hitInstance, bool klist, hipStream_t s) {

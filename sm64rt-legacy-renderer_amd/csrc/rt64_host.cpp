@@ -369,6 +369,9 @@ struct View {
     // rectangle of the ray-traced picture: the first ray-traced instance's scissor / viewport when it has any (rt64_view.cpp:1258-1271)
     float rtViewport[4] = { 0, 0, 0, 0 }; int rtScissor[4] = { 0, 0, 0, 0 }; bool rtRect = false;
     DevArray<uint8_t> cacheImage; bool cacheImageValid = false;      // FrameParams::cacheImage: rebuilt after every table upload that leaves the cache enabled
+    // ... or, with a host-built TLAS, inside the table allocation: its head (instance records + TLAS nodes) is written by the host into the same upload as the tables and
+    // only the BLAS node arrays behind it are copied by a kernel -- when a mesh of the frame was built, refitted or replaced, not when an instance moved
+    const uint8_t *cacheImageAt = nullptr; std::vector<uint64_t> cacheBlasKey;
     bool needSpillSlab = false;                // some walk of this frame can outgrow its LDS stack entries (see View::update)
     uint32_t cacheWords = 0;                   // LDS scene cache size in 16-byte words (0: the scene does not fit / option lds_cache = 0)
     bool separatePost() const { return upscaleActive || rtRect || imgW != finalW || imgH != finalH || (motionBlurStrength > 0.0f && motionBlurSamples > 0); }
@@ -1133,8 +1136,10 @@ void View::update() {                          // View::update, rt64_view.cpp:10
         const uint32_t n = (uint32_t)nInst;
         const bool hostTlas = n >= 1 && n <= RT64_HOST_TLAS_MAX && dev->opt.hostTlas;
         const size_t tlasAt = (tableBytes + 63) & ~(size_t)63, nodeBytes = sizeof(GpuNode) * std::max<size_t>(n ? n - 1 : 0, 1);
-        const size_t uploadBytes = hostTlas ? tlasAt + nodeBytes + sizeof(BlasHeader) + 2 * sizeof(uint32_t) * n : tableBytes;
-        dTables.reserve(std::max<size_t>(uploadBytes, 4096));
+        const bool hostCache = hostTlas && cacheWords != 0;
+        const size_t cacheAt = (tlasAt + nodeBytes + sizeof(BlasHeader) + 2 * sizeof(uint32_t) * n + 63) & ~(size_t)63, headWords = hostCache ? 4 * (size_t)n + 4 * std::max<size_t>(n - 1, 1) : 0;
+        const size_t uploadBytes = hostTlas ? (hostCache ? cacheAt + headWords * 16 : tlasAt + nodeBytes + sizeof(BlasHeader) + 2 * sizeof(uint32_t) * n) : tableBytes;
+        dTables.reserve(std::max<size_t>(hostCache ? cacheAt + (size_t)cacheWords * 16 : uploadBytes, 4096));
         dInstances.ptr = reinterpret_cast<GpuInstance *>(dTables.ptr); dTextures.ptr = reinterpret_cast<GpuTexture *>(dTables.ptr + instBytes);
         dLights.ptr = reinterpret_cast<RT64_LIGHT *>(dTables.ptr + instBytes + texBytes);
         if (uploadBytes) {       // staged in the pinned upload ring: no wait before the region is reused (a wrap-around of the ring drains the stream)
@@ -1148,6 +1153,25 @@ void View::update() {                          // View::update, rt64_view.cpp:10
                 float mn[RT64_HOST_TLAS_MAX][3], mx[RT64_HOST_TLAS_MAX][3];
                 for (uint32_t i = 0; i < n; i++) { memcpy(mn[i], rtInstances[i].instance->mesh->hostBmin, 12); memcpy(mx[i], rtInstances[i].instance->mesh->hostBmax, 12); }
                 host_build_tlas(hInst, mn, mx, n, hn, hi, hm, hh);
+                if (hostCache) {        // head of the LDS scene cache image (layout: fill_scene_cache, passes.hip): one 64-byte record per TLAS leaf slot, then the TLAS nodes with 16-bit child references
+                    memset(pinnedStage + tlasAt + nodeBytes + sizeof(BlasHeader) + 2 * sizeof(uint32_t) * n, 0, cacheAt - (tlasAt + nodeBytes + sizeof(BlasHeader) + 2 * sizeof(uint32_t) * n));
+                    uint32_t *cw = reinterpret_cast<uint32_t *>(pinnedStage + cacheAt);
+                    for (uint32_t k = 0; k < n; k++) {
+                        const uint32_t inst = hi[k]; const GpuInstance &g = hInst[inst]; const float *M = g.worldToObject;
+                        for (int c = 0; c < 3; c++) { const float row[4] = { M[c], M[4 + c], M[8 + c], M[12 + c] }; memcpy(cw + 16 * k + 4 * c, row, 16); }
+                        const uint64_t tp = reinterpret_cast<uint64_t>(g.tris);
+                        uint32_t info[4] = { inst | ((g.flags & 0xFFu) << 8) | (g.cacheNodeOffset << 16), 0u, (uint32_t)tp, (uint32_t)(tp >> 32) };
+                        memcpy(&info[1], &g.material.depthBias, 4);
+                        memcpy(cw + 16 * k + 12, info, 16);
+                    }
+                    auto childRef = [](uint32_t c) { return (c & RT64_LEAF_BIT) ? (c == RT64_NO_CHILD ? c : (0xFFFF8000u | (c & 0x7FFFu))) : c; };
+                    const uint32_t tn = std::max<uint32_t>(n - 1, 1);
+                    for (uint32_t t = 0; t < tn; t++) {
+                        uint32_t *dst = cw + 16 * (size_t)n + 16 * (size_t)t;
+                        memcpy(dst, &hn[t], 64);
+                        dst[12] = childRef(hn[t].left); dst[13] = childRef(hn[t].right);
+                    }
+                }
                 uint8_t *base = dTables.ptr + tlasAt;
                 tlasNodesAt = reinterpret_cast<const GpuNode *>(base); tlasHeaderAt = reinterpret_cast<const BlasHeader *>(base + nodeBytes);
                 tlasIndexAt = reinterpret_cast<const uint32_t *>(tlasHeaderAt + 1); tlasMortonAt = tlasIndexAt + n;
@@ -1164,14 +1188,27 @@ void View::update() {                          // View::update, rt64_view.cpp:10
             tlasNodesAt = tlasNodes.ptr; tlasIndexAt = tlasIndex.ptr; tlasMortonAt = tlasMorton.ptr; tlasHeaderAt = tlasHeader.ptr;
         }
         cacheImageValid = false;
+        if (hostCache) {
+            // the BLAS node arrays behind the head: copied again only when one of them -- or the allocation they are copied into -- changed
+            cacheImageAt = dTables.ptr + cacheAt;
+            std::vector<uint64_t> key; key.reserve(2 + 4 * (size_t)n);
+            key.push_back(reinterpret_cast<uint64_t>(cacheImageAt)); key.push_back(cacheWords);
+            for (uint32_t i = 0; i < n; i++) { key.push_back(reinterpret_cast<uint64_t>(hInst[i].nodes)); key.push_back(hInst[i].meshVersion); key.push_back(hInst[i].cacheNodeOffset); key.push_back(hInst[i].triCount); }
+            if (key != cacheBlasKey) {
+                HIP_CHECK(launch_scene_cache_image(dInstances.ptr, tlasIndexAt, tlasNodesAt, n, const_cast<uint8_t *>(cacheImageAt), true, dev->stream));
+                cacheBlasKey.swap(key);
+            }
+            cacheImageValid = true;
+        }
+        else cacheBlasKey.clear();
         uploadedTables.assign(stage, stage + tableBytes);
         dev->workSinceMark = true;
     }
     if (cacheWords && !cacheImageValid) {
         dev->impure();
         cacheImage.reserve((size_t)cacheWords * 16);
-        HIP_CHECK(launch_scene_cache_image(dInstances.ptr, tlasIndexAt, tlasNodesAt, (uint32_t)nInst, cacheImage.ptr, dev->stream));
-        cacheImageValid = true;
+        HIP_CHECK(launch_scene_cache_image(dInstances.ptr, tlasIndexAt, tlasNodesAt, (uint32_t)nInst, cacheImage.ptr, false, dev->stream));
+        cacheImageAt = cacheImage.ptr; cacheImageValid = true;
     }
     // Raster lists (background first, then foreground; rt64_view.cpp:1138-1147).  They are a handful of HUD instances: uploaded every frame.
     {
@@ -1253,7 +1290,7 @@ void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64
     P.binaryLockMask = upscaleActive ? 0u : 1u;               // rtUpscaleMode != FSR (:1018): the built-in stage stands where FSR does and takes the continuous mask
     P.visualizationMode = 0;
     P.width = imgW; P.height = imgH; P.tileY0 = dev->tileY0; P.tileY1 = dev->tileY1; P.stripRank = dev->stripRank; P.stripCount = dev->stripCount;
-    P.cacheWords = cacheWords; P.cacheInstances = cacheWords ? (uint32_t)rtInstances.size() : 0u; P.cacheImage = cacheWords ? cacheImage.ptr : nullptr;
+    P.cacheWords = cacheWords; P.cacheInstances = cacheWords ? (uint32_t)rtInstances.size() : 0u; P.cacheImage = cacheWords ? cacheImageAt : nullptr;
     P.separatePost = separatePost() ? 1u : 0u;
     P.simpleKernels = simpleFrame ? 1u : 0u;
     P.postSource = img.output; P.postSourceW = imgW; P.postSourceH = imgH;
