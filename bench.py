@@ -76,6 +76,8 @@ def parse_args():
     ap.add_argument("--force-gather", action="store_true", help="rehearsal: run the N > 1 code path (enqueued frames + pipelined RCCL gather) with a world of 1")
     ap.add_argument("--pretend-ranks", type=int, default=0, help="diagnosis on a 1-GPU box: render only rank 0's share of a P-way partition, frames enqueued, no gather; `value` is then NOT a throughput of the whole frame")
     ap.add_argument("--cpu-baseline-height", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = all)")
+    ap.add_argument("--timed-loop-only", action="store_true", help="profiling runs (tools/profile_round.sh): only the timed loop of `value` -- no always_rebuild leg, no enqueued leg (whose frames overlap on the "
+                    "library's render streams: their launches would enter a profiler's per-kernel average with stretched durations), no parity object, no CPU baseline")
     return ap.parse_args()
 
 
@@ -404,7 +406,7 @@ def main():
     # loop above ran with the frame-table cache (identical descriptors are not re-uploaded).  Same K steps again with the cache off,
     # outside the timed region of `value`, so that the line carries both figures.
     rebuild = None
-    if not G and PR <= 1 and not args.always_rebuild:
+    if not G and PR <= 1 and not args.always_rebuild and not args.timed_loop_only:
         scene.option("always_rebuild", 1)
         for _ in range(min(args.warmup, 5)):
             step()
@@ -423,7 +425,7 @@ def main():
     # at the end.  `value` above keeps the reference's frame-by-frame wait (rt64_device.cpp:1006-1025); this is the same work without the
     # launch-to-completion round trip between frames.
     enqueued = None
-    if not G and PR <= 1 and anim is None:
+    if not G and PR <= 1 and anim is None and not args.timed_loop_only:
         scene.option("sync_present", 0)
         for _ in range(min(args.warmup, 5)):
             step()
@@ -537,9 +539,9 @@ def main():
             result["always_rebuild"] = rebuild
         result["frame_tables"] = "rebuilt every frame (always_rebuild)" if args.always_rebuild else "cached while the host re-sends identical descriptors (steady state of the sample host, main.cpp:97-134); `always_rebuild` holds the figure with the cache off"
         oracle_frame = None
-        if N == 1 and not args.no_cpu_baseline:
+        if N == 1 and not args.no_cpu_baseline and not args.timed_loop_only:
             result["cpu_baseline"], oracle_frame = cpu_baseline(data, W, H, args.cpu_baseline_height, keep_frame=(args.config == "C2" and not args.gi_samples))
-        if N == 1 and not G and PR <= 1 and not args.no_parity:
+        if N == 1 and not G and PR <= 1 and not args.no_parity and not args.timed_loop_only:
             # Outside the timed region: the measured configuration at its full size against the oracle (BASELINE.json gate: RMSE <= 1e-3 on the
             # composed RGBA32F image; hit records are bit-exact).  A line whose frame is wrong is not a measurement: exit non-zero.
             result["parity"] = parity_object(lib, scene, data, args, W, H, local_rank, oracle_frame)

@@ -7,20 +7,20 @@
 # tools/collect_counters.py then merges the four into profiles/kernel_counters.json (run it here AND commit the result: bench.py
 # refuses a file whose source hash differs from the kernels it runs).
 set -e
-TAG=${1:-r03}; WL=${2:-C2}; shift 2 || true
+TAG=${1:-r04}; WL=${2:-C2}; shift 2 || true
 REPO=$(pwd)
 OUT=$REPO/gpurun_out
 mkdir -p "$OUT"
 P=$OUT/${TAG}_${WL}
 SQ="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "${P}_stats" -- python3 "$REPO/bench.py" --steps 60 --warmup 8 --no-cpu-baseline "$@" > "${P}_stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "${P}_stats" -- python3 "$REPO/bench.py" --steps 60 --warmup 8 --timed-loop-only "$@" > "${P}_stats.log" 2>&1
 echo "stats pass done"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "${P}_fetch" -- python3 "$REPO/bench.py" --steps 6 --warmup 2 --no-cpu-baseline "$@" > "${P}_pmc_fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "${P}_fetch" -- python3 "$REPO/bench.py" --steps 6 --warmup 2 --timed-loop-only "$@" > "${P}_pmc_fetch.log" 2>&1
 echo "fetch pass done"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "${P}_write" -- python3 "$REPO/bench.py" --steps 6 --warmup 2 --no-cpu-baseline "$@" > "${P}_pmc_write.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "${P}_write" -- python3 "$REPO/bench.py" --steps 6 --warmup 2 --timed-loop-only "$@" > "${P}_pmc_write.log" 2>&1
 echo "write pass done"
-rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d "${P}_sq" -- python3 "$REPO/bench.py" --steps 6 --warmup 2 --no-cpu-baseline "$@" > "${P}_pmc_sq.log" 2>&1
+rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d "${P}_sq" -- python3 "$REPO/bench.py" --steps 6 --warmup 2 --timed-loop-only "$@" > "${P}_pmc_sq.log" 2>&1
 echo "sq pass done"
 find "${P}_stats" -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} "${P}_kernel_stats.csv"
 for k in fetch write sq; do
