@@ -72,6 +72,9 @@ def parse_args():
                     "RT64_RebalanceGatherBands + RT64_SetGatherBands on every rank); 0 (default) keeps the modelled cut.  Opt-in until RT64_SetGatherBands has run between two GPUs (an A/B line, not the headline)")
     ap.add_argument("--halo", default="recompute", choices=["exchange", "recompute"], help="N > 1, GI + denoiser bands: re-render the denoiser's halo rows on every band (default: no mid-frame collective, the path every "
                     "partition test covers) or exchange them between neighbouring bands (RCCL ncclSend / ncclRecv in the middle of the frame: opt-in until it has run between two GPUs)")
+    ap.add_argument("--gather", default="auto", choices=["auto", "rccl", "direct"], help="N > 1, in-library gather: rccl = every rank's rows travel to rank 0 through grouped ncclSend / ncclRecv + a reassembly kernel; "
+                    "direct = the frame kernels store their rows straight into rank 0's frame slots through an IPC mapping (peer stores over xGMI) and only a 4-byte token per rank goes through RCCL "
+                    "(RT64_SetGatherDirect); auto (default) = direct for pixel-local configurations after a self-check -- one frame gathered both ways must give the same bytes on rank 0 -- and rccl otherwise")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a 1-GPU box: every rank renders on device 0")
     ap.add_argument("--force-gather", action="store_true", help="rehearsal: run the N > 1 code path (enqueued frames + pipelined RCCL gather) with a world of 1")
     ap.add_argument("--pretend-ranks", type=int, default=0, help="diagnosis on a 1-GPU box: render only rank 0's share of a P-way partition, frames enqueued, no gather; `value` is then NOT a throughput of the whole frame")
@@ -282,6 +285,45 @@ def main():
     my_bytes = (gatherer.owned_bytes() if gatherer else my_rows * W * 4) if G else H * W * 4
     if PR > 1:
         my_bytes = ((tiles.band_range(H, 0, PR)[1] - tiles.band_range(H, 0, PR)[0]) if (args.gi_samples > 0 and args.denoiser) else tiles.owned_rows(H, 0, PR)) * W * 4
+
+    # Direct gather (RT64_SetGatherDirect): every decision below is taken by all ranks together (MIN over ranks of a flag), so that no rank is left in the other mode.
+    gather_mode = "rccl" if native else None
+    if native and (args.gather == "direct" or (args.gather == "auto" and not use_bands)):
+        def agree(flag):
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=comm_device)
+            if N > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(int(t.item()))
+
+        def gathered_sum():
+            scene.draw()
+            sl = lib.SubmitGather(gather)
+            buf = np.zeros(H * W * 4, dtype=np.uint8)
+            got = lib.ReadbackGather(gather, sl, buf.ctypes.data, buf.nbytes, 0)
+            return (sl >= 0 and (rank != 0 or got == buf.nbytes)), (int(buf.astype(np.int64).sum()) if rank == 0 else 0)
+        handle = torch.zeros(64, dtype=torch.uint8)
+        have = True
+        if rank == 0:
+            have = lib.GetGatherDirectHandle(gather, handle.data_ptr(), handle.numel()) == 64
+        if N > 1:
+            hd = handle.to(comm_device); dist.broadcast(hd, 0); handle = hd.cpu()
+        ok_a, sum_a = gathered_sum()                     # the same static frame through the RCCL exchange first: the reference of the self-check
+        if agree(have and ok_a):
+            switched = lib.SetGatherDirect(gather, handle.data_ptr(), handle.numel(), 1) == 1
+            if agree(switched):
+                ok_b, sum_b = gathered_sum()
+                good = agree(ok_b and (rank != 0 or sum_a == sum_b))
+                if good:
+                    gather_mode = "direct"
+                else:
+                    print("bench.py: rank %d: direct gather self-check failed (%s, %d vs %d): RCCL exchange of the rows instead" % (rank, lib.last_error(), sum_a, sum_b), file=sys.stderr)
+                    lib.SetGatherDirect(gather, None, 0, 0)
+            else:
+                print("bench.py: rank %d: RT64_SetGatherDirect unavailable on some rank (%s): RCCL exchange of the rows instead" % (rank, lib.last_error() if not switched else "ok here"), file=sys.stderr)
+                if switched:
+                    lib.SetGatherDirect(gather, None, 0, 0)
+        if args.gather == "direct" and gather_mode != "direct":
+            raise SystemExit("bench.py: --gather direct was asked for and is not available: " + lib.last_error())
 
     def fetch(dst):
         n = lib.CopyDeviceImage(scene.device, rt64.IMAGE_FINAL_RGBA8, dst.data_ptr(), dst.numel())
@@ -525,9 +567,10 @@ def main():
             result["config"]["options"] = list(args.option)      # non-default library options: an A/B line, not the headline
         if G:
             result["pipeline"] = {"frames": "enqueued (sync_present=0), 2 gather slots" if pipelined else "synchronous, CPU-staged gather (rehearsal)",
-                                  "gather": "in-library (RT64_SubmitGather: grouped ncclSend / ncclRecv + reassembly kernel on the library's comm stream)" if native else "torch.distributed gather (tiles.FrameGatherer)",
+                                  "gather": (("in-library, direct (RT64_SetGatherDirect: the frame kernels store their rows into rank 0's frame slots through an IPC mapping -- peer stores over xGMI --, a 4-byte token per rank through RCCL; self-checked against the RCCL exchange)"
+                                              if gather_mode == "direct" else "in-library (RT64_SubmitGather: grouped ncclSend / ncclRecv + reassembly kernel on the library's comm stream)") if native else "torch.distributed gather (tiles.FrameGatherer)"),
                               "denoiser_halo": (("exchanged between neighbouring bands (ncclSend / ncclRecv of 24 B per pixel, 62 rows per side)" if halo_mode == "exchange" else "re-rendered by every band (66 rows per side)") if halo_mode else "none (pixel-local frame)"),
-                              "send_buffer": ("written by the frame kernel (RT64_SetDeviceGatherTarget)" if (packed[0] or (native and scene.stats().packedFinal)) else "packed after each frame (RT64_CopyDeviceImage layout)"),
+                              "send_buffer": ("none: rows stored once, into the frame slot" if gather_mode == "direct" else ("written by the frame kernel (RT64_SetDeviceGatherTarget)" if (packed[0] or (native and scene.stats().packedFinal)) else "packed after each frame (RT64_CopyDeviceImage layout)")),
                                   "control_plane": "torch.distributed on %s (%s)" % (torch_backend, "one RCCL communicator per process: the library's" if (native and torch_backend == "gloo") else
                                                                                      ("a second RCCL communicator beside the library's" if native else "torch's gatherer")),
                                   "host_ms_per_step": round(enqueue_ms, 5)}

@@ -488,6 +488,15 @@ typedef struct {
     X(ReadbackGather, RT64_ReadbackGather, size_t, (RT64_GATHER *gather, int slot, void *dst, size_t dstBytes, int toDevice)) \
     X(GetGatherFrame, RT64_GetGatherFrame, void *, (RT64_GATHER *gather, int slot)) \
     X(DestroyGather, RT64_DestroyGather, void, (RT64_GATHER *gather)) \
+    /* DIRECT mode of a gather: no rows travel through RCCL.  Rank 0 owns six whole frame slots and exports them (RT64_GetGatherDirectHandle fills an IPC handle of \
+       RT64_GATHER_DIRECT_HANDLE_BYTES; the host hands it to the other ranks like the unique id); after RT64_SetGatherDirect(gather, handle, bytes, 1) on every rank -- between \
+       the same two frames -- each rank's frames store their rows straight into the slot of the frame in hand (on ranks other than 0: peer stores over xGMI into rank 0's \
+       memory, inside the render kernels) and RT64_SubmitGather exchanges a 4-byte token per rank instead of the rows: same ordering, same flow control, no transfer stage \
+       and no reassembly.  RT64_SubmitGather then returns slots 0 .. 5 in turn; on rank 0 the frames of the last three submits are never being overwritten.  enable = 0 \
+       returns to the RCCL exchange; enable = 2 makes EVERY rank, 0 included, map `handle` (the slots live in another process: a presenter).  Returns 1, or 0 with \
+       RT64_GetLastError set (no IPC, no peer access): the gather then stays in the mode it was in. */ \
+    X(GetGatherDirectHandle, RT64_GetGatherDirectHandle, size_t, (RT64_GATHER *gather, void *handle, size_t handleBytes)) \
+    X(SetGatherDirect, RT64_SetGatherDirect, int, (RT64_GATHER *gather, const void *handle, size_t handleBytes, int enable)) \
     /* the partition's layout as pure functions (usable without a device): owner rank of frame row y and the row's place in that rank's \
        packed buffer; rows a rank owns; rows every rank's slot is sized for */ \
     X(GatherRowOwner, RT64_GatherRowOwner, int, (int height, int count, int bands, int y, int *packedRow)) \
@@ -533,6 +542,7 @@ typedef struct {
 
 typedef struct RT64_GATHER RT64_GATHER;
 #define RT64_GATHER_ID_BYTES 128       /* size of the rendezvous id (an ncclUniqueId) */
+#define RT64_GATHER_DIRECT_HANDLE_BYTES 64   /* sizeof(hipIpcMemHandle_t): RT64_GetGatherDirectHandle / RT64_SetGatherDirect */
 #define RT64_HALO_ROWS 62              /* rows of filter input around a row that its SVGF result depends on: 2 x (1 + 2 + 4 + 8 + 16) */
 #define RT64_HALO_BYTES_PER_PIXEL 24   /* filter input of a pixel: RGBA16F colour + variance (8) and the guide record (16) */
 typedef struct { int peer; int send; int y0, y1; void *host; size_t bytes; } RT64_HALO_REGION;     /* rows [y0, y1) of the frame; host buffer = the rows' colour + variance, then their guide records */

@@ -40,7 +40,8 @@ hipError_t bc7_decode_launch(const uint8_t *blocks, uint8_t *rgba, uint32_t widt
 #define RT_STACK_LDS 24               // traversal stack entries per lane in LDS of the kernels without the scene cache; deeper levels go to the HBM spill slab
 #define RT_STACK_LDS_CACHED 16        // traversal stack entries (LDS only, no spill path) of the kernels that hold the LDS scene cache: a power of two
 #define RT_STACK_SPILL 84             // entries per lane in the HBM slab behind the LDS entries
-#define RT_STACK_SPILL_HEADER 16      // uint32 words in front of the slab's entries: [0..1] address of the overflow word (host-pinned), rest unused (keeps the entries 64-byte aligned)
+#define RT_STACK_SPILL_HEADER 2       // uint32 words in front of EVERY lane's entries: the address of the overflow word (host-pinned memory); a lane's slab is RT_STACK_SPILL_HEADER + RT_STACK_SPILL words
+hipError_t launch_stack_slab_init(uint32_t *slab, size_t lanes, const uint32_t *flagDevicePointer, hipStream_t s);      // writes every lane's header
 #define RT_GRID_BLOCKS 2048           // persistent grid of every ray kernel (8 workgroups of 256 per CU)
 #define RT_TIMING_WAVES ((8192u + 8u) * 4u)   // waves the tile-timing buffer has records for (profiling aid)
 #define RT_MAX_BOUNCE_GROUPS 65536u    // largest grid of the bounce kernels (one workgroup per 16 x 16 tile up to 4K and beyond; hit-list segments and counts are sized for it)

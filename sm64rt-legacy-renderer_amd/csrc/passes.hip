@@ -86,7 +86,7 @@ DEV TraceStack make_stack(PRef P, uint32_t *ldsStack, uint32_t wordsPerLane = RT
     uint32_t *block = ldsStack + (threadIdx.x >> 6) * wordsPerLane * RT_LANES;       // this wave's [entry][lane] block
     s.lds = (LdsU32Ptr)(block + (threadIdx.x & 63u));
     s.lds16 = (LdsI16Ptr)block + (threadIdx.x & 63u);
-    s.spill = (GlobalU32Ptr)(P.traversalStack + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * RT_STACK_SPILL);
+    s.spill = (GlobalU32Ptr)(P.traversalStack + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (RT_STACK_SPILL_HEADER + RT_STACK_SPILL) + RT_STACK_SPILL_HEADER);
     s.cache = nullptr; s.ldsEntries = RT_STACK_LDS;
     return s;
 }
@@ -1765,7 +1765,7 @@ size_t rt_stack_spill_bytes(int width, int rows) {
     size_t blocks = tiles > (size_t)RT_GRID_BLOCKS ? tiles : (size_t)RT_GRID_BLOCKS;
     if (blocks > RT_MAX_FRAME_GROUPS) blocks = RT_MAX_FRAME_GROUPS;
     blocks += 8;          // the per-wave frame rounds its grid up to whole groups of 8 tiles (32 one-wave workgroups)       // no launch has more workgroups than that (launch_lean_frame, sparse_grid)
-    return blocks * RT_BLOCK * RT_STACK_SPILL * sizeof(uint32_t) + RT_STACK_SPILL_HEADER * sizeof(uint32_t);      // (+ the header in front of the entries: trace.h)
+    return blocks * RT_BLOCK * (RT_STACK_SPILL_HEADER + RT_STACK_SPILL) * sizeof(uint32_t);      // (a lane's entries + the header in front of them: trace.h)
 }
 #endif
 
@@ -1938,6 +1938,18 @@ hipError_t launch_spp_accumulate(const FrameParams &P, const ViewImages &I, floa
 hipError_t launch_post_process(const FrameParams &P, const ViewImages &I, hipStream_t s) {
     dim3 grid((unsigned)((int)P.resolution[2] + 31) / 32, (unsigned)((int)P.resolution[3] + 7) / 8);
     hipLaunchKernelGGL(post_process_kernel, grid, dim3(256), 0, s, P, I);
+    return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void stack_slab_init_kernel(uint32_t *slab, size_t lanes, const uint32_t *flag) {
+    const size_t lane = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (lane >= lanes) return;
+    const uint64_t p = reinterpret_cast<uint64_t>(flag);
+    uint32_t *h = slab + lane * (RT_STACK_SPILL_HEADER + RT_STACK_SPILL);
+    h[0] = (uint32_t)p; h[1] = (uint32_t)(p >> 32);
+}
+hipError_t launch_stack_slab_init(uint32_t *slab, size_t lanes, const uint32_t *flagDevicePointer, hipStream_t s) {
+    if (!lanes) return hipSuccess;
+    hipLaunchKernelGGL(stack_slab_init_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, slab, lanes, flagDevicePointer);
     return hipGetLastError();
 }
 hipError_t launch_apply_reflection_state(const ViewImages &I, int width, int y0, int y1, uint32_t frameTag, hipStream_t s) {

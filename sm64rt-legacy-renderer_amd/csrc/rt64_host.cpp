@@ -220,6 +220,8 @@ struct Device {
     void checkTraversalOverflow();
     DevArray<uint32_t> spillStack[RT64_RENDER_STREAMS_MAX];                                     // HBM half of the traversal stacks, one slab per render stream (indexed by the launch's lanes)
     void *gatherTarget = nullptr; size_t gatherTargetBytes = 0;          // RT64_SetDeviceGatherTarget
+    hipEvent_t frameWait = nullptr;       // set by the gather: the next frame's stream waits for this event before its first launch (the slot that frame writes is free then); applied by Device::draw once it knows the stream
+    uint8_t *finalOverride = nullptr;     // direct gather (RT64_SetGatherDirect): the back buffer of the frame in hand IS the gather's frame slot -- on rank 0 its own memory, on the others rank 0's through an IPC mapping (peer stores over xGMI)
     hipStream_t auxStream = nullptr; hipEvent_t forkEvent = nullptr, joinEvent = nullptr;      // second stream of a frame whose reflection passes run beside its denoiser (created on first use)
     // Halo exchange of the SVGF filter input between the bands of a partition (RT64_SetDeviceHaloExchange / option halo_exchange): transport and layout
     struct HaloLink {
@@ -1326,12 +1328,12 @@ void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64
         const size_t words = needSpillSlab ? rt_stack_spill_bytes(imgW, imgH) / sizeof(uint32_t) : 0;
         if (words > slab.count) {
             dev->impure(); slab.reserve(words);
-            // header in front of the entries: where an overflowing walk reports (trace.h)
-            uint32_t header[RT_STACK_SPILL_HEADER] = {}; void *flagDev = nullptr;
-            HIP_CHECK(hipHostGetDevicePointer(&flagDev, dev->traversalOverflow, 0)); memcpy(header, &flagDev, sizeof(flagDev));
-            HIP_CHECK(hipMemcpy(slab.ptr, header, sizeof(header), hipMemcpyHostToDevice));
+            // header in front of every lane's entries: where an overflowing walk reports (trace.h)
+            void *flagDev = nullptr;
+            HIP_CHECK(hipHostGetDevicePointer(&flagDev, dev->traversalOverflow, 0));
+            HIP_CHECK(launch_stack_slab_init(slab.ptr, words / (RT_STACK_SPILL_HEADER + RT_STACK_SPILL), static_cast<const uint32_t *>(flagDev), dev->stream));
         }
-        P.traversalStack = slab.ptr ? slab.ptr + RT_STACK_SPILL_HEADER : nullptr;
+        P.traversalStack = slab.ptr;
     }
     P.blueNoise = dev->blueNoise.ptr; P.counters = dev->counters.ptr;
     P.tileTiming = nullptr;
@@ -1345,7 +1347,7 @@ void View::render() {                          // View::render, rt64_view.cpp:11
     hipStream_t s = dev->stream;
     const bool prof = dev->profNow;
     const int slot = dev->cur;                   // per-stream storage of this frame: back buffer, tile order (Device::streams)
-    img.final = finalBuf[slot];
+    img.final = dev->finalOverride ? dev->finalOverride : finalBuf[slot];
     static const bool hostTiming = getenv("RT64_HOST_TIMING") != nullptr;
     auto hostPrev = std::chrono::steady_clock::now();
     auto mark = [&](int ev) {
@@ -1645,6 +1647,7 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
     const bool flipped = mayOverlap && lastFramePure;
     if (flipped) switchStream();
     framePure = mayOverlap; lastFramePure = false;       // (a frame that ends in an exception leaves "not pure" behind)
+    if (frameWait) { HIP_CHECK(hipStreamWaitEvent(stream, frameWait, 0)); frameWait = nullptr; }
     if (!mayOverlap) joinStreams();
     if (opt.countTraversal) HIP_CHECK(hipMemsetAsync(counters.ptr, 0, counters.bytes(), stream));
     // pass events on every profile_every-th frame only: each event is a barrier packet (~5 us of stream time; six of them are 5 % of a 0.6 ms GI frame)
@@ -2290,6 +2293,22 @@ struct Gather {
     ncclComm_t comm = nullptr; hipStream_t commStream = nullptr;
     struct Slot { uint8_t *local = nullptr, *bucket = nullptr, *frame = nullptr; hipEvent_t produced = nullptr, gathered = nullptr; bool pending = false; } slots[2];
     int next = 0, last = -1;
+    // Direct mode (RT64_SetGatherDirect): no rows travel through RCCL.  Rank 0 owns DIRECT_SLOTS whole frames in fine-grained device memory and exports them over IPC;
+    // every rank's frame kernel stores its rows straight into the slot of the frame in hand (Device::finalOverride) -- on the other ranks those are peer stores over
+    // xGMI, 4 bytes per pixel riding inside the render kernel -- and the per-frame exchange shrinks to a 4-byte token per rank on the same communicator and stream
+    // (ordering and flow control exactly as with the rows: a rank's token follows its frame, rank 0's `gathered` event follows every token).  Slot reuse: frame j is
+    // written into slot j % DIRECT_SLOTS once this rank's token of frame j - DIRECT_LAG has been taken, i.e. rank 0 has reached that exchange and finished every
+    // earlier one: the frame six submits back is complete, and on rank 0 the frames of the last three submits are never being overwritten.
+    enum { DIRECT_SLOTS = 6, DIRECT_LAG = 3 };
+    struct Direct {
+        bool on = false, mapped = false; uint8_t *mem = nullptr; uint32_t *tokens = nullptr;
+        hipEvent_t produced[DIRECT_SLOTS] = {}, gathered[DIRECT_SLOTS] = {}; bool pending[DIRECT_SLOTS] = {};
+        long long frames = 0;
+    } direct;
+    size_t directHandle(void *handle, size_t bytes);
+    void setDirect(const void *handle, size_t bytes, int enable);
+    void prepareDirect(int slot);
+    int submitDirect();
     Gather(Device *d, const ncclUniqueId &id, int rank_, int count_, int bands_);
     ~Gather();
     void prepare(int slot);
@@ -2344,6 +2363,11 @@ Gather::~Gather() {
     hipSetDevice(dev->hipDevice);
     for (hipStream_t st : dev->streams) if (st) hipStreamSynchronize(st);
     if (commStream) hipStreamSynchronize(commStream);
+    dev->finalOverride = nullptr; dev->frameWait = nullptr;
+    if (direct.mem) { if (direct.mapped) hipIpcCloseMemHandle(direct.mem); else hipFree(direct.mem); }
+    if (direct.tokens) hipFree(direct.tokens);
+    for (hipEvent_t e : direct.produced) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : direct.gathered) if (e) hipEventDestroy(e);
     if (dev->gatherTarget == slots[0].local || dev->gatherTarget == slots[1].local) { dev->gatherTarget = nullptr; dev->gatherTargetBytes = 0; }
     if (dev->halo.gather == this) dev->halo.gather = nullptr;
     if (comm) rccl().CommDestroy(comm);
@@ -2353,12 +2377,85 @@ Gather::~Gather() {
 // The renderer may write slot `slot` again: its previous exchange (two frames ago) is ordered before whatever the render stream does next.
 void Gather::prepare(int slot) {
     Slot &sl = slots[slot];
-    // (both render streams: the next frame may start on either, Device::streams)
-    if (sl.pending) { for (hipStream_t st : dev->streams) if (st) HIP_CHECK(hipStreamWaitEvent(st, sl.gathered, 0)); sl.pending = false; }
+    // (the next frame may start on any render stream: Device::draw makes the one it picks wait)
+    if (sl.pending) { dev->frameWait = sl.gathered; sl.pending = false; }
     dev->gatherTarget = sl.local; dev->gatherTargetBytes = slotBytes;
 }
+// ---- direct mode ----
+size_t Gather::directHandle(void *handle, size_t bytes) {
+    if (rank != 0) throw std::runtime_error("RT64_GetGatherDirectHandle: rank 0 owns the frame slots.");
+    if (!handle || bytes < sizeof(hipIpcMemHandle_t)) throw std::runtime_error("RT64_GetGatherDirectHandle: the handle buffer needs RT64_GATHER_DIRECT_HANDLE_BYTES bytes.");
+    dev->enter();
+    if (!direct.mem) {
+        const size_t total = (size_t)DIRECT_SLOTS * (size_t)W * H * 4;
+        HIP_CHECK(hipExtMallocWithFlags(reinterpret_cast<void **>(&direct.mem), total, hipDeviceMallocFinegrained));      // peers store into it while this device reads it: coherent at system scope
+        HIP_CHECK(hipMemset(direct.mem, 0, total));
+    }
+    hipIpcMemHandle_t h;
+    HIP_CHECK(hipIpcGetMemHandle(&h, direct.mem));
+    memcpy(handle, &h, sizeof(h));
+    return sizeof(h);
+}
+// enable: 0 back to the RCCL exchange of the rows; 1 the slots are rank 0's own memory (the other ranks map `handle`); 2 the slots belong to someone else -- a
+// presenter process, say -- and EVERY rank, rank 0 included, maps `handle`.
+void Gather::setDirect(const void *handle, size_t bytes, int enable) {
+    dev->enter();
+    for (hipStream_t st : dev->streams) if (st) HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipStreamSynchronize(commStream));          // nothing of the other mode is in flight
+    if (!enable) {
+        direct.on = false; dev->finalOverride = nullptr;
+        for (Slot &sl : slots) sl.pending = false;
+        next = 0; last = -1; prepare(next);
+        return;
+    }
+    if (dev->width != W || dev->height != H) throw std::runtime_error("RT64_SetGatherDirect: the device was resized after RT64_CreateGather.");
+    if (!direct.mem) {
+        if (rank == 0 && enable != 2) { unsigned char tmp[sizeof(hipIpcMemHandle_t)]; directHandle(tmp, sizeof(tmp)); }
+        else {
+            if (!handle || bytes < sizeof(hipIpcMemHandle_t)) throw std::runtime_error("RT64_SetGatherDirect: ranks other than 0 need rank 0's handle (RT64_GetGatherDirectHandle).");
+            hipIpcMemHandle_t h; memcpy(&h, handle, sizeof(h));
+            void *p = nullptr;
+            HIP_CHECK(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+            direct.mem = static_cast<uint8_t *>(p); direct.mapped = true;
+        }
+    }
+    if (!direct.tokens) { HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&direct.tokens), sizeof(uint32_t) * (size_t)std::max(count, 16))); HIP_CHECK(hipMemset(direct.tokens, 0, sizeof(uint32_t) * (size_t)std::max(count, 16))); }
+    for (int k = 0; k < DIRECT_SLOTS; k++) {
+        if (!direct.produced[k]) { HIP_CHECK(hipEventCreateWithFlags(&direct.produced[k], hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&direct.gathered[k], hipEventDisableTiming)); }
+        direct.pending[k] = false;
+    }
+    direct.on = true; direct.frames = 0; next = 0; last = -1;
+    dev->gatherTarget = nullptr; dev->gatherTargetBytes = 0;      // no packed copy of the rows: they are stored once, into the frame itself
+    prepareDirect(0);
+}
+// The renderer may write slot `slot`: this rank's token of the frame DIRECT_LAG submits back has been taken (see Gather::Direct).
+void Gather::prepareDirect(int slot) {
+    const int back = (slot + DIRECT_SLOTS - DIRECT_LAG) % DIRECT_SLOTS;
+    if (direct.pending[back]) { dev->frameWait = direct.gathered[back]; direct.pending[back] = false; }          // (applied by Device::draw to the stream the frame starts on)
+    dev->finalOverride = direct.mem + (size_t)slot * (size_t)W * H * 4;
+}
+int Gather::submitDirect() {
+    dev->use();
+    if (dev->width != W || dev->height != H) throw std::runtime_error("RT64_SubmitGather: the device was resized after RT64_CreateGather.");
+    const int slot = next;
+    HIP_CHECK(hipEventRecord(direct.produced[slot], dev->stream));          // the frame's last store into the slot is behind this
+    HIP_CHECK(hipStreamWaitEvent(commStream, direct.produced[slot], 0));
+    if (count > 1) {
+        RcclApi &R = rccl();
+        RCCL_CHECK(R.GroupStart());
+        if (rank == 0) { for (int r = 1; r < count; r++) RCCL_CHECK(R.Recv(direct.tokens + r, 4, ncclUint8, r, comm, commStream)); }
+        else RCCL_CHECK(R.Send(direct.tokens, 4, ncclUint8, 0, comm, commStream));
+        RCCL_CHECK(R.GroupEnd());
+    }
+    HIP_CHECK(hipEventRecord(direct.gathered[slot], commStream));
+    direct.pending[slot] = true; direct.frames++; last = slot; next = (slot + 1) % DIRECT_SLOTS;
+    prepareDirect(next);
+    return slot;
+}
+
 // After RT64_DrawDevice: exchange the frame just drawn.  Returns the slot it travels in.
 int Gather::submit() {
+    if (direct.on) return submitDirect();
     dev->use();
     if (dev->width != W || dev->height != H) throw std::runtime_error("RT64_SubmitGather: the device was resized after RT64_CreateGather.");
     const int slot = next; Slot &sl = slots[slot];
@@ -2428,6 +2525,11 @@ void Gather::setBands(const int *starts) {
     prepare(next);
 }
 void Gather::wait(int slot, bool host) {
+    if (direct.on) {
+        if (host) HIP_CHECK(hipEventSynchronize(direct.gathered[slot]));
+        else for (hipStream_t st : dev->streams) if (st) HIP_CHECK(hipStreamWaitEvent(st, direct.gathered[slot], 0));
+        return;
+    }
     Slot &sl = slots[slot];
     if (host) HIP_CHECK(hipEventSynchronize(sl.gathered));
     else for (hipStream_t st : dev->streams) if (st) HIP_CHECK(hipStreamWaitEvent(st, sl.gathered, 0));
@@ -2561,14 +2663,16 @@ RT64_EXPORT size_t RT64_ReadbackGather(RT64_GATHER *gather, int slot, void *dst,
     Gather *g = reinterpret_cast<Gather *>(gather);
     if (!g) throw std::runtime_error("RT64_ReadbackGather: NULL gather.");
     if (slot < 0) slot = g->last;
-    if (slot < 0 || slot > 1) throw std::runtime_error("RT64_ReadbackGather: no frame has been submitted.");
+    const int slotCount = g->direct.on ? (int)Gather::DIRECT_SLOTS : 2;
+    if (slot < 0 || slot >= slotCount || (g->direct.on && g->direct.frames == 0)) throw std::runtime_error("RT64_ReadbackGather: no frame has been submitted.");
     g->dev->use();
     g->wait(slot, true);                                         // every rank: its part of the exchange has completed
     if (g->rank != 0) return 0;
     const size_t need = (size_t)g->W * g->H * 4;
     if (!dst) return need;
     if (dstBytes < need) throw std::runtime_error("RT64_ReadbackGather: destination buffer is too small.");
-    HIP_CHECK(hipMemcpy(dst, g->slots[slot].frame, need, toDevice ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    const uint8_t *src = g->direct.on ? g->direct.mem + (size_t)slot * need : g->slots[slot].frame;
+    HIP_CHECK(hipMemcpy(dst, src, need, toDevice ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
     return need;
     RT64_CATCH(0)
 }
@@ -2576,7 +2680,15 @@ RT64_EXPORT void *RT64_GetGatherFrame(RT64_GATHER *gather, int slot) {          
     Gather *g = reinterpret_cast<Gather *>(gather);
     if (!g || g->rank != 0) return nullptr;
     if (slot < 0) slot = g->last;
+    if (g->direct.on) return (slot >= 0 && slot < (int)Gather::DIRECT_SLOTS) ? g->direct.mem + (size_t)slot * (size_t)g->W * g->H * 4 : nullptr;
     return (slot == 0 || slot == 1) ? g->slots[slot].frame : nullptr;
+}
+// Direct mode of a gather (see Gather::Direct): rank 0 exports its frame slots, every rank switches over between the same two frames.
+RT64_EXPORT size_t RT64_GetGatherDirectHandle(RT64_GATHER *gather, void *handle, size_t handleBytes) {
+    RT64_TRY Gather *g = reinterpret_cast<Gather *>(gather); if (!g) throw std::runtime_error("RT64_GetGatherDirectHandle: NULL gather."); return g->directHandle(handle, handleBytes); RT64_CATCH(0)
+}
+RT64_EXPORT int RT64_SetGatherDirect(RT64_GATHER *gather, const void *handle, size_t handleBytes, int enable) {
+    RT64_TRY Gather *g = reinterpret_cast<Gather *>(gather); if (!g) throw std::runtime_error("RT64_SetGatherDirect: NULL gather."); g->setDirect(handle, handleBytes, enable); return 1; RT64_CATCH(0)
 }
 RT64_EXPORT void RT64_DestroyGather(RT64_GATHER *gather) { RT64_TRY delete reinterpret_cast<Gather *>(gather); RT64_CATCH_VOID }
 // Partition layout, as pure functions (no device needed): which rank owns frame row y and where the row sits in that rank's packed buffer.

@@ -43,7 +43,7 @@ DEV PPtr kernel_params_here() { uint32_t z; asm volatile("s_mov_b32 %0, 0" : "=s
 #endif
 #ifndef RT_STACK_SPILL
 #define RT_STACK_SPILL 84               // (kernels.h defines both for the host too) entries per lane in the HBM slab behind the LDS entries
-#define RT_STACK_SPILL_HEADER 16        // uint32 words in front of the slab's entries: [0..1] address of the overflow word (host-pinned memory), rest unused
+#define RT_STACK_SPILL_HEADER 2         // uint32 words in front of EVERY lane's entries: the address of the overflow word (host-pinned memory)
 #endif
 #ifndef RT_STACK_LDS_CACHED
 #define RT_STACK_LDS_CACHED 16           // (kernels.h defines it for the host too) kernels that also hold the LDS scene cache: the host enables the cache only when TLAS depth + the deepest BLAS fit in these
@@ -113,13 +113,12 @@ struct TraceStack {
     const u32x4_lds *cache;   // LDS scene cache (see fill_scene_cache), nullptr when the scene does not fit
     int ldsEntries;       // entries of this lane's stack that live in LDS (RT_STACK_LDS or RT_STACK_LDS_CACHED)
     DEV void use_cache(const u32x4_lds *c) { cache = c; ldsEntries = RT_STACK_LDS_CACHED; }
-    // An entry that fits neither half is dropped -- the walk then misses a subtree -- and the frame says so: the slab's header (RT_STACK_SPILL_HEADER words in
-    // front of lane 0's entries) holds the address of a word in pinned host memory, found from this lane's own slab pointer (make_stack's indexing), so the
-    // report costs nothing where no overflow happens.  The host reads the word after the frame (Device::checkTraversalOverflow).
+    // An entry that fits neither half is dropped -- the walk then misses a subtree -- and the frame says so: the two words in front of every lane's entries
+    // (RT_STACK_SPILL_HEADER; written once when the slab is allocated) hold the address of a word in pinned host memory, so the report needs nothing but the
+    // lane's own slab pointer and costs nothing where no overflow happens.  The host reads the word after the frame (Device::checkTraversalOverflow).
     DEV void report_overflow() const {
-        GlobalU32Ptr base = spill - ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * RT_STACK_SPILL;
         typedef uint32_t *__attribute__((address_space(1))) *FlagSlot;
-        uint32_t *flag = *reinterpret_cast<FlagSlot>(reinterpret_cast<uintptr_t>(base - RT_STACK_SPILL_HEADER));
+        uint32_t *flag = *reinterpret_cast<FlagSlot>(reinterpret_cast<uintptr_t>(spill - RT_STACK_SPILL_HEADER));
         if (flag) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     template <bool LDS_ONLY = false> DEV void push(int &sp, uint32_t v) const {

@@ -203,6 +203,8 @@ EXT_API = [
     ("ReadbackGather", "RT64_ReadbackGather", C.c_size_t, [_P, C.c_int, _P, C.c_size_t, C.c_int]),
     ("GetGatherFrame", "RT64_GetGatherFrame", _P, [_P, C.c_int]),
     ("DestroyGather", "RT64_DestroyGather", None, [_P]),
+    ("GetGatherDirectHandle", "RT64_GetGatherDirectHandle", C.c_size_t, [_P, _P, C.c_size_t]),
+    ("SetGatherDirect", "RT64_SetGatherDirect", C.c_int, [_P, _P, C.c_size_t, C.c_int]),
     ("GatherRowOwner", "RT64_GatherRowOwner", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     ("GatherOwnedRows", "RT64_GatherOwnedRows", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     ("GatherSlotRows", "RT64_GatherSlotRows", C.c_int, [C.c_int, C.c_int, C.c_int]),

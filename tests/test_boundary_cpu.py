@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(built):
     h = C.CDLL(built, mode=C.RTLD_LOCAL)
     header = open(os.path.join(ROOT, "include", "rt64.h")).read()
     declared = sorted(set(re.findall(r"X\(\w+,\s*(RT64_\w+),", header)))
-    assert len(declared) == 33 + 33, declared          # the reference's 33 + the additive exports (15 headless / readback / stats / profiling + 16 multi-GPU gather + 2 halo exchange)
+    assert len(declared) == 33 + 35, declared          # the reference's 33 + the additive exports (15 headless / readback / stats / profiling + 18 multi-GPU gather + 2 halo exchange)
     assert sorted(rt64.exported_symbols()) == declared
     for name in declared:
         assert hasattr(h, name), name

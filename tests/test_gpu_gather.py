@@ -139,3 +139,136 @@ def test_cost_balanced_bands_reassemble_the_whole_frame(rt64_lib, sample_data):
         whole.close()
         for p in parts:
             p.close()
+
+
+def test_direct_gather_on_a_world_of_one(rt64_lib, sample_data):
+    """RT64_SetGatherDirect: the frames store their rows straight into the gather's frame slots (six of them, fine-grained device memory rank 0 exports over IPC) and
+    RT64_SubmitGather exchanges a token instead of the rows.  On the one rank a test box has: slots come round 0 .. 5, every gathered frame is the frame the device
+    drew (moving camera: no two are equal), frames overlap on the render streams as without a gather, no packed copy is made, and the gather goes back to the RCCL
+    exchange of the rows (enable = 0) and on again."""
+    import copy
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    W, H = 320, 180
+
+    def camera(k):
+        d = copy.copy(sample_data); v = np.array(sample_data.view, dtype=np.float32).copy(); v[3][0] += 0.2 * k; d.view = v
+        return d
+    s = sample_scene.Rt64Scene(rt64_lib, sample_data, W, H, hip_device=0)
+    try:
+        uid = (C.c_uint8 * rt64.GATHER_ID_BYTES)()
+        assert rt64_lib.GetGatherUniqueId(uid, len(uid)) == 1, rt64_lib.last_error()
+        g = rt64_lib.CreateGather(s.device, uid, len(uid), 0, 1, 0)
+        assert g, rt64_lib.last_error()
+        handle = (C.c_uint8 * 64)()
+        assert rt64_lib.GetGatherDirectHandle(g, handle, 64) == 64, rt64_lib.last_error()
+        assert rt64_lib.SetGatherDirect(g, handle, 64, 1) == 1, rt64_lib.last_error()
+        s.option("sync_present", 0)
+        slots, own = [], {}
+        for k in range(9):
+            s.data = camera(k)
+            s.draw()
+            slots.append(rt64_lib.SubmitGather(g))
+            if k >= 6:
+                own[k] = s.readback(rt64.IMAGE_FINAL_RGBA8).copy()
+        assert slots == [0, 1, 2, 3, 4, 5, 0, 1, 2]
+        st = s.stats()
+        assert not st.packedFinal                                   # the rows are stored once, into the frame slot itself
+        for k in (6, 7, 8):                                         # on rank 0 the frames of the last three submits are intact
+            buf = np.zeros((H, W, 4), dtype=np.uint8)
+            assert rt64_lib.ReadbackGather(g, slots[k], buf.ctypes.data, buf.nbytes, 0) == buf.nbytes, rt64_lib.last_error()
+            assert np.array_equal(buf, own[k]), k
+        assert not np.array_equal(own[7], own[8])
+        assert rt64_lib.GetGatherFrame(g, slots[-1])
+        for k in range(9, 13):                                      # a burst with no host-side wait in between: the frames alternate over the render streams
+            s.data = camera(k); s.draw(); last = rt64_lib.SubmitGather(g)
+        assert int(s.stats().overlappedFrame) == 1
+        frame = s.readback(rt64.IMAGE_FINAL_RGBA8)
+        buf = np.zeros((H, W, 4), dtype=np.uint8)
+        assert rt64_lib.ReadbackGather(g, last, buf.ctypes.data, buf.nbytes, 0) == buf.nbytes and np.array_equal(buf, frame)
+        # back to the RCCL exchange of the rows: two slots, send buffer written by the frame kernel
+        assert rt64_lib.SetGatherDirect(g, None, 0, 0) == 1, rt64_lib.last_error()
+        got = []
+        for k in range(13, 16):
+            s.data = camera(k); s.draw(); got.append(rt64_lib.SubmitGather(g))
+        assert got == [0, 1, 0] and bool(s.stats().packedFinal)
+        frame = s.readback(rt64.IMAGE_FINAL_RGBA8)
+        assert rt64_lib.ReadbackGather(g, -1, buf.ctypes.data, buf.nbytes, 0) == buf.nbytes and np.array_equal(buf, frame)
+        assert rt64_lib.SetGatherDirect(g, handle, 64, 1) == 1      # ... and on again
+        s.data = camera(16); s.draw(); assert rt64_lib.SubmitGather(g) == 0
+        rt64_lib.DestroyGather(g)
+    finally:
+        s.close()
+
+
+_OWNER = r'''
+import ctypes as C, sys, os
+sys.path.insert(0, os.environ["RT64_REPO"])
+import __graft_entry__ as graft
+graft.load_package()
+import numpy as np
+from sm64rt_legacy_renderer_amd import rt64
+lib = rt64.Library()
+W, H = 320, 180
+dev = lib.CreateDeviceHeadless(W, H, 0)
+uid = (C.c_uint8 * rt64.GATHER_ID_BYTES)(); assert lib.GetGatherUniqueId(uid, len(uid)) == 1
+g = lib.CreateGather(dev, uid, len(uid), 0, 1, 0); assert g, lib.last_error()
+handle = (C.c_uint8 * 64)()
+assert lib.GetGatherDirectHandle(g, handle, 64) == 64, lib.last_error()
+assert lib.SetGatherDirect(g, handle, 64, 1) == 1, lib.last_error()
+print("HANDLE " + bytes(handle).hex(), flush=True)
+slot = int(sys.stdin.readline().split()[1])            # the renderer says which slot its last frame went to
+for _ in range(slot + 1):
+    assert lib.SubmitGather(g) >= 0                     # (a world of one: records this slot's events; nothing is drawn here)
+buf = np.zeros((H, W, 4), dtype=np.uint8)
+assert lib.ReadbackGather(g, slot, buf.ctypes.data, buf.nbytes, 0) == buf.nbytes, lib.last_error()
+print("SUM %d %d" % (int(buf.astype(np.int64).sum()), int(buf[..., :3].max())), flush=True)
+sys.stdin.readline()
+lib.DestroyGather(g); lib.DestroyDevice(dev)
+'''
+
+
+def test_direct_gather_stores_into_another_process_through_ipc(rt64_lib, sample_data):
+    """The peer half of the direct gather on one GPU: the frame slots live in ANOTHER process (an owner that exports them with RT64_GetGatherDirectHandle), this process maps
+    them (RT64_SetGatherDirect(..., 2): hipIpcOpenMemHandle) and its frame kernels store the back buffer there.  The owner reads the slot it was told and reports the frame's byte
+    sum: it is the frame this process drew.  (Between two GPUs the same stores travel over xGMI; that leg needs a multi-GPU node: the driver's scaling run.)"""
+    import copy, sys
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    W, H = 320, 180
+    env = dict(os.environ, RT64_REPO=ROOT, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    owner = subprocess.Popen([sys.executable, "-c", _OWNER], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env)
+    s = None
+    try:
+        line = ""
+        while not line.startswith("HANDLE "):
+            line = owner.stdout.readline()
+            assert line, "the owner process ended: " + str(owner.poll())
+        raw = bytes.fromhex(line.split()[1])
+        handle = (C.c_uint8 * 64)(*raw)
+        s = sample_scene.Rt64Scene(rt64_lib, sample_data, W, H, hip_device=0)
+        uid = (C.c_uint8 * rt64.GATHER_ID_BYTES)()
+        assert rt64_lib.GetGatherUniqueId(uid, len(uid)) == 1
+        g = rt64_lib.CreateGather(s.device, uid, len(uid), 0, 1, 0)
+        assert g, rt64_lib.last_error()
+        assert rt64_lib.SetGatherDirect(g, handle, 64, 2) == 1, rt64_lib.last_error()      # 2: this rank 0 maps the handle too -- the slots are the owner's
+        s.option("sync_present", 0)
+        slot = -1
+        for k in range(4):
+            d = copy.copy(sample_data); v = np.array(sample_data.view, dtype=np.float32).copy(); v[3][0] += 0.3 * k; d.view = v; s.data = d
+            s.draw(); slot = rt64_lib.SubmitGather(g)
+        assert slot == 3
+        mine = np.zeros((H, W, 4), dtype=np.uint8)
+        assert rt64_lib.ReadbackGather(g, slot, mine.ctypes.data, mine.nbytes, 0) == mine.nbytes, rt64_lib.last_error()     # (waits for the frame; reads the mapped slot)
+        assert mine[..., :3].max() > 0
+        owner.stdin.write("SLOT %d\n" % slot); owner.stdin.flush()
+        line = owner.stdout.readline()
+        assert line.startswith("SUM "), line
+        total, peak = int(line.split()[1]), int(line.split()[2])
+        assert total == int(mine.astype(np.int64).sum()) and peak == int(mine[..., :3].max())
+        rt64_lib.DestroyGather(g)
+        owner.stdin.write("BYE\n"); owner.stdin.flush()
+        assert owner.wait(timeout=60) == 0
+    finally:
+        if s:
+            s.close()
+        if owner.poll() is None:
+            owner.kill()

@@ -31,6 +31,16 @@ def timed(fn, label):
 timed(lambda: lib.DrawDevice(scene.device, 1, 16.0), "DrawDevice only")
 timed(scene.draw, "scene.draw (4 ctypes calls)")
 timed(lambda: (scene.draw(), lib.CopyDeviceImage(scene.device, rt64.IMAGE_FINAL_RGBA8, dst.data_ptr(), dst.numel())), "draw + CopyDeviceImage")
+# the N > 1 loop on a world of one: RT64_DrawDevice + RT64_SubmitGather, rows through RCCL / stored directly into the frame slots
+import ctypes as C
+uid = (C.c_uint8 * rt64.GATHER_ID_BYTES)(); lib.GetGatherUniqueId(uid, len(uid))
+g = lib.CreateGather(scene.device, uid, len(uid), 0, 1, 0)
+timed(lambda: (lib.DrawDevice(scene.device, 1, 16.0), lib.SubmitGather(g)), "Draw + SubmitGather (rows)")
+timed(lambda: (scene.draw(), lib.SubmitGather(g)), "scene.draw + SubmitGather")
+h = (C.c_uint8 * 64)(); lib.GetGatherDirectHandle(g, h, 64); lib.SetGatherDirect(g, h, 64, 1)
+timed(lambda: (lib.DrawDevice(scene.device, 1, 16.0), lib.SubmitGather(g)), "Draw + SubmitGather (direct)")
+timed(lambda: (scene.draw(), lib.SubmitGather(g)), "scene.draw + Submit (direct)")
+lib.SetGatherDirect(g, None, 0, 0); lib.DestroyGather(g)
 scene.option("profile_passes", 0)
 timed(lambda: lib.DrawDevice(scene.device, 1, 16.0), "DrawDevice, no pass events")
 scene.option("lean_frames", 0)
