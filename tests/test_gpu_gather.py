@@ -97,6 +97,9 @@ def test_c_host_gathers_through_the_c_abi(rt64_lib):
     a = json.loads(next(l for l in subprocess.run(base, env=env, capture_output=True, text=True, timeout=300, check=True).stdout.splitlines() if l.startswith("{")))
     b = json.loads(next(l for l in subprocess.run(base + ["--ranks", "1"], env=env, capture_output=True, text=True, timeout=300, check=True).stdout.splitlines() if l.startswith("{")))
     assert b["ranks"] == 1 and (a["checksum"], a["fnv1a"]) == (b["checksum"], b["fnv1a"])
+    # ... and with the direct gather (RT64_GetGatherDirectHandle / RT64_SetGatherDirect from C): the same frame again
+    c = json.loads(next(l for l in subprocess.run(base + ["--ranks", "1", "--direct"], env=env, capture_output=True, text=True, timeout=300, check=True).stdout.splitlines() if l.startswith("{")))
+    assert (a["checksum"], a["fnv1a"]) == (c["checksum"], c["fnv1a"])
 
 
 def test_cost_balanced_bands_reassemble_the_whole_frame(rt64_lib, sample_data):

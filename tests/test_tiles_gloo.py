@@ -357,3 +357,37 @@ def test_halo_exchange_schedule_over_gloo(world, h, starts):
         init_file = os.path.join(d, "init"); out_file = os.path.join(d, "out")
         mp.spawn(_halo_worker, args=(world, init_file, h, 40, starts, out_file), nprocs=world, join=True)
         assert open(out_file).read() == "ok"
+
+
+def test_direct_gather_flow_control_never_overwrites_a_frame_rank0_still_holds():
+    """The slot discipline of the direct gather (RT64_SetGatherDirect; Gather::Direct in rt64_host.cpp) as an event simulation: `ranks` renderers of random, changing speeds
+    store frame j into slot j mod 6 of rank 0's memory as soon as their own token of frame j - 3 has been taken; rank 0 takes the tokens of frame m in one group, after its
+    own frame m and in frame order.  Asserted at every store: the slot's previous tenant (frame j - 6) was complete on rank 0 -- every rank's token taken -- and is not one of
+    the three most recent frames rank 0 has gathered (the window the interface promises to leave intact)."""
+    import random
+    SLOTS, LAG = 6, 3
+    for seed in range(20):
+        rng = random.Random(seed)
+        ranks, frames = rng.choice([2, 3, 8]), 60
+        speed = [rng.uniform(0.2, 3.0) for _ in range(ranks)]
+        rendered = [[None] * frames for _ in range(ranks)]      # time rank r finished storing frame j
+        started = [[None] * frames for _ in range(ranks)]
+        taken = [None] * frames                                  # time rank 0's group of frame m completed (every token taken)
+        clock = [0.0] * ranks
+        for j in range(frames):
+            for r in range(ranks):
+                t = clock[r]
+                if j - LAG >= 0:
+                    t = max(t, taken[j - LAG])                   # this rank's token of frame j - LAG has been taken (the group completes for every rank together)
+                started[r][j] = t
+                if rng.random() < 0.1:
+                    speed[r] = rng.uniform(0.2, 3.0)
+                rendered[r][j] = t + speed[r] * rng.uniform(0.8, 1.2)
+                clock[r] = rendered[r][j]
+            prev = taken[j - 1] if j else 0.0
+            taken[j] = max(max(rendered[r][j] for r in range(ranks)), prev) + 0.05      # rank 0's groups run in order, each after every rank's frame
+        for j in range(SLOTS, frames):
+            first_store = min(started[r][j] for r in range(ranks))
+            assert taken[j - SLOTS] <= first_store, (seed, j)                            # the previous tenant was complete before anyone stores over it
+            newest = max((m for m in range(frames) if taken[m] <= first_store), default=-1)      # the newest frame rank 0 has gathered when the first store lands
+            assert j - SLOTS <= newest - 3 or newest < 3, (seed, j, newest)              # ... and it is older than the three most recent gathered frames

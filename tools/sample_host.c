@@ -276,7 +276,7 @@ static double now_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &
 int main(int argc, char **argv) {
     int width = 1280, height = 720, frames = 3, warmup = 0;                      /* main.cpp:435-436: 1280 x 720 window */
     const char *assets = "assets/sample", *dump = NULL;
-    int selftest = 0, ranks = 0, bands = 0;
+    int selftest = 0, ranks = 0, bands = 0, direct = 0;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--width") && i + 1 < argc) width = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--height") && i + 1 < argc) height = atoi(argv[++i]);
@@ -287,7 +287,8 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--selftest")) selftest = 1;
         else if (!strcmp(argv[i], "--ranks") && i + 1 < argc) ranks = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--bands")) bands = 1;
-        else { fprintf(stderr, "usage: %s [--width W] [--height H] [--frames N] [--warmup W] [--assets DIR] [--dump frame.rgba] [--selftest] [--ranks N [--bands]]\n", argv[0]); return 2; }
+        else if (!strcmp(argv[i], "--direct")) direct = 1;                       /* direct gather: rows stored into rank 0's frame slots through an IPC mapping (RT64_SetGatherDirect) */
+        else { fprintf(stderr, "usage: %s [--width W] [--height H] [--frames N] [--warmup W] [--assets DIR] [--dump frame.rgba] [--selftest] [--ranks N [--bands] [--direct]]\n", argv[0]); return 2; }
     }
     if (selftest) {       /* the asset readers alone (no library, no GPU): byte sums the CPU test suite compares with the Python harness's loaders */
         static const char *pngs[6] = { "grass_nrm.png", "grass_spc.png", "clouds.png", "tiles_dif.png", "tiles_nrm.png", "tiles_spc.png" };
@@ -339,6 +340,17 @@ int main(int argc, char **argv) {
         else if (read(idPipe[rank][0], id, sizeof(id)) != (ssize_t)sizeof(id)) die("id pipe");
         RT64_GATHER *gather = RT64.ext.CreateGather(RT64.device, id, sizeof(id), rank, ranks, bands);
         if (!gather) { fprintf(stderr, "sample_host: CreateGather: %s\n", RT64.lib.GetLastError()); return 5; }
+        if (direct) {                                                            /* rank 0 exports its frame slots, the handle travels like the id, every rank switches over */
+            unsigned char handle[RT64_GATHER_DIRECT_HANDLE_BYTES];
+            if (!RT64.ext.GetGatherDirectHandle || !RT64.ext.SetGatherDirect) die("librt64.so lacks the direct-gather exports");
+            if (rank == 0) {
+                if (RT64.ext.GetGatherDirectHandle(gather, handle, sizeof(handle)) != sizeof(handle)) die(RT64.lib.GetLastError());
+                for (int r = 1; r < ranks; r++) if (write(idPipe[r][1], handle, sizeof(handle)) != (ssize_t)sizeof(handle)) die("handle pipe");
+            }
+            else if (read(idPipe[rank][0], handle, sizeof(handle)) != (ssize_t)sizeof(handle)) die("handle pipe");
+            if (!RT64.ext.SetGatherDirect(gather, handle, sizeof(handle), 1)) die(RT64.lib.GetLastError());
+        }
+        if (RT64.ext.SetDeviceOption) RT64.ext.SetDeviceOption(RT64.device, "sync_present", 0);        /* frames are enqueued: the exchange of frame k runs beside the rendering of frame k + 1 (and pixel-local frames beside each other) */
         int slot = -1;
         for (int f = 0; f < warmup; f++) { drawFrame(); slot = RT64.ext.SubmitGather(gather); if (slot < 0) die(RT64.lib.GetLastError()); }
         if (warmup) RT64.ext.ReadbackGather(gather, slot, frame, bytes, 0);
