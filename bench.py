@@ -577,6 +577,12 @@ def main():
         result["accel_build"] = {"first_frame_ms": round(first_frame_build_ms, 4), "triangles": int(st_full.triangleCount), "blas_node_bytes": int(st_full.blasNodeBytes),
                                  "what": "GPU time of all BLAS builds (LBVH: Morton, radix sort, Karras, fit) + the TLAS build, executed at the first frame after the RT64_SetMesh calls"}
         if enqueued is not None:
+            if roofline.get("traffic") and fused:
+                # the same HBM bytes per frame at the rate frames complete when they are only enqueued (consecutive pixel-local frames overlap on the library's render
+                # streams, so a launch no longer ends with an idle chip behind its longest ray): what the memory system sustains per frame, not per launch
+                gbps = roofline["traffic"] / (enqueued["ms_per_step"] * 1e-3) / 1e9
+                enqueued["hbm"] = {"bytes_per_frame": int(roofline["traffic"]), "GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBS, 4),
+                                   "note": "PMC bytes of one launch / enqueued ms per frame / 8 TB/s (launches overlap: per-frame throughput, not a per-launch figure)"}
             result["enqueued_frames"] = enqueued
         if rebuild is not None:
             result["always_rebuild"] = rebuild
