@@ -122,3 +122,68 @@ def test_overlapped_strips_fill_both_gather_slots(rt64_lib, sample_data):
             s.close()
     for x, y in zip(out[1], out[0]):
         assert np.array_equal(x, y)
+
+
+def _random_session(rt64_lib, sample_data, overlap, seed, ops=45):
+    """A random session of the calls a host makes between and around frames -- enqueued and waited-for frames, camera moves, an instance that moves (table upload + TLAS),
+    a mesh that is re-sent (BLAS refit), GI switched on and off (frames with history), readbacks of several images, picking, option changes -- returning everything read."""
+    import random
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    rng = random.Random(seed)
+    data = copy.copy(sample_data)
+    data.instances = [copy.copy(i) for i in sample_data.instances]
+    data.meshes = [copy.copy(m) for m in sample_data.meshes]
+    data.meshes[0] = sample_scene.MeshData(data.meshes[0].name, data.meshes[0].flags | rt64.MESH_RAYTRACE_UPDATABLE, data.meshes[0].vertices.copy(), data.meshes[0].indices)
+    s = sample_scene.Rt64Scene(rt64_lib, data, W, H, hip_device=0)
+    out = []
+    try:
+        assert s.option("overlap_frames", overlap)
+        frame = 0
+        for _ in range(ops):
+            op = rng.choice(["draw", "draw", "draw", "draw", "burst", "camera", "move", "mesh", "gi", "sync", "read", "read_gbuffer", "pick", "lds"])
+            if op == "draw":
+                s.draw(); frame += 1
+            elif op == "burst":
+                for _ in range(rng.randint(2, 5)):
+                    d = copy.copy(s.data); v = np.array(d.view, dtype=np.float32).copy(); v[3][0] += 0.1; d.view = v; s.data = d
+                    s.draw(); frame += 1
+            elif op == "camera":
+                d = copy.copy(s.data); v = np.array(d.view, dtype=np.float32).copy(); v[3][0] += rng.uniform(-0.3, 0.3); v[3][1] += rng.uniform(-0.2, 0.2); d.view = v; s.data = d
+            elif op == "move":
+                d = copy.copy(s.data); d.instances = [copy.copy(i) for i in d.instances]
+                k = rng.choice([i for i, inst in enumerate(d.instances) if inst.name in ("sphere", "floor")])
+                t = np.array(d.instances[k].transform, dtype=np.float32).copy(); t[3][1] += rng.uniform(-0.2, 0.2)
+                d.instances[k].previous_transform = d.instances[k].transform; d.instances[k].transform = t
+                s.data = d; s.set_instance(k, d.instances[k])
+            elif op == "mesh":
+                v = data.meshes[0].vertices.copy(); v["position"][:, :3] *= np.float32(1.0 + rng.uniform(-0.02, 0.02))
+                s.set_mesh(s.meshes[0], v, data.meshes[0].indices)
+            elif op == "gi":
+                gi = rng.choice([0, 1]); s.set_view_description(gi_samples=gi, denoiser=bool(gi))
+            elif op == "sync":
+                s.option("sync_present", rng.choice([0, 1]))
+            elif op == "lds":
+                s.option("lds_cache", rng.choice([0, 1]))
+            elif frame and op == "read":
+                out.append(("final", frame, s.readback(rt64.IMAGE_FINAL_RGBA8).copy()))
+            elif frame and op == "read_gbuffer":
+                out.append(("hit", frame, s.readback(rt64.IMAGE_PRIMARY_HIT).copy())); out.append(("out", frame, s.readback(rt64.IMAGE_OUTPUT_RGBA32F).copy()))
+            elif frame and op == "pick":
+                out.append(("pick", frame, np.array([int(bool(rt64_lib.GetViewRaytracedInstanceAt(s.view, W // 2, H // 2)))])))
+        s.draw()
+        out.append(("final", -1, s.readback(rt64.IMAGE_FINAL_RGBA8).copy())); out.append(("hit", -1, s.readback(rt64.IMAGE_PRIMARY_HIT).copy()))
+        return out
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_call_sequences_render_the_same_on_one_stream_and_on_three(rt64_lib, sample_data, seed):
+    """Whatever a host does between frames, the render streams must not show: a random session of draws, bursts of enqueued frames, camera and instance moves, mesh refits, GI on and
+    off, sync_present flips, readbacks and picking returns byte for byte what the same session returns with overlap_frames = 0."""
+    a = _random_session(rt64_lib, sample_data, 1, seed)
+    b = _random_session(rt64_lib, sample_data, 0, seed)
+    assert len(a) == len(b) > 1
+    for (ka, fa, xa), (kb, fb, xb) in zip(a, b):
+        assert (ka, fa) == (kb, fb)
+        assert np.array_equal(xa.view(np.uint8), xb.view(np.uint8)), (seed, ka, fa)
