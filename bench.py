@@ -288,6 +288,7 @@ def main():
 
     # Direct gather (RT64_SetGatherDirect): every decision below is taken by all ranks together (MIN over ranks of a flag), so that no rank is left in the other mode.
     gather_mode = "rccl" if native else None
+    gather_probe = None
     if native and (args.gather == "direct" or (args.gather == "auto" and not use_bands)):
         def agree(flag):
             t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=comm_device)
@@ -307,13 +308,40 @@ def main():
             have = lib.GetGatherDirectHandle(gather, handle.data_ptr(), handle.numel()) == 64
         if N > 1:
             hd = handle.to(comm_device); dist.broadcast(hd, 0); handle = hd.cpu()
+        def pipelined_ms(frames=60):
+            """ms per frame of the gather loop as the timed region runs it (frames enqueued, one wait at the end), MAX over ranks"""
+            scene.option("sync_present", 0)
+            for _ in range(10):
+                scene.draw(); lib.SubmitGather(gather)
+            torch.cuda.synchronize()
+            if N > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            sl = -1
+            for _ in range(frames):
+                scene.draw(); sl = lib.SubmitGather(gather)
+            buf = np.zeros(H * W * 4, dtype=np.uint8)
+            lib.ReadbackGather(gather, sl, buf.ctypes.data, buf.nbytes, 0)
+            torch.cuda.synchronize()
+            t = torch.tensor([(time.perf_counter() - t0) * 1e3 / frames], dtype=torch.float64, device=comm_device)
+            if N > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            scene.option("sync_present", 1)
+            return float(t.item())
         ok_a, sum_a = gathered_sum()                     # the same static frame through the RCCL exchange first: the reference of the self-check
+        gather_probe = None
         if agree(have and ok_a):
+            ms_rows = pipelined_ms()
             switched = lib.SetGatherDirect(gather, handle.data_ptr(), handle.numel(), 1) == 1
             if agree(switched):
                 ok_b, sum_b = gathered_sum()
                 good = agree(ok_b and (rank != 0 or sum_a == sum_b))
-                if good:
+                ms_direct = pipelined_ms() if good else None
+                gather_probe = {"rows_ms_per_frame": round(ms_rows, 5), "direct_ms_per_frame": (round(ms_direct, 5) if ms_direct is not None else None), "same_bytes": bool(good)}
+                if good and args.gather == "auto" and ms_direct > ms_rows:          # correct, but slower on this machine (every rank holds the same two MAX-over-ranks figures: same decision)
+                    print("bench.py: rank %d: direct gather is correct here but slower (%.4f against %.4f ms per frame): RCCL exchange of the rows" % (rank, ms_direct, ms_rows), file=sys.stderr)
+                    lib.SetGatherDirect(gather, None, 0, 0)
+                elif good:
                     gather_mode = "direct"
                 else:
                     print("bench.py: rank %d: direct gather self-check failed (%s, %d vs %d): RCCL exchange of the rows instead" % (rank, lib.last_error(), sum_a, sum_b), file=sys.stderr)
@@ -571,6 +599,7 @@ def main():
                                               if gather_mode == "direct" else "in-library (RT64_SubmitGather: grouped ncclSend / ncclRecv + reassembly kernel on the library's comm stream)") if native else "torch.distributed gather (tiles.FrameGatherer)"),
                               "denoiser_halo": (("exchanged between neighbouring bands (ncclSend / ncclRecv of 24 B per pixel, 62 rows per side)" if halo_mode == "exchange" else "re-rendered by every band (66 rows per side)") if halo_mode else "none (pixel-local frame)"),
                               "send_buffer": ("none: rows stored once, into the frame slot" if gather_mode == "direct" else ("written by the frame kernel (RT64_SetDeviceGatherTarget)" if (packed[0] or (native and scene.stats().packedFinal)) else "packed after each frame (RT64_CopyDeviceImage layout)")),
+                                  "gather_probe": gather_probe,
                                   "control_plane": "torch.distributed on %s (%s)" % (torch_backend, "one RCCL communicator per process: the library's" if (native and torch_backend == "gloo") else
                                                                                      ("a second RCCL communicator beside the library's" if native else "torch's gatherer")),
                                   "host_ms_per_step": round(enqueue_ms, 5)}
