@@ -98,9 +98,28 @@ def spawn_ranks(args):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    # A rank that dies (no such device, a refused option) must not leave the others waiting in a rendezvous or a collective for the backend's own time-out:
+    # the first failure ends the run -- the other ranks are stopped, the status is the failing rank's.
+    rc, live = 0, list(procs)
+    while live:
+        for p in list(live):
+            st = p.poll()
+            if st is None:
+                continue
+            live.remove(p)
+            if st != 0:
+                rc = max(rc, abs(st))
+                for q in live:
+                    q.terminate()
+                for q in live:
+                    try:
+                        q.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        q.kill(); q.wait()
+                live = []
+                break
+        if live:
+            time.sleep(0.05)
     raise SystemExit(rc)
 
 

@@ -42,9 +42,6 @@ struct Pixel { uint32_t x, y; bool valid; };
 //   SQUARE 16x16, wave = 8x8 pixels   : traversal kernels (coherent rays share BVH nodes)
 //   ROWS   32x8,  wave = 32x2 pixels  : shading kernels (a wave's image store covers whole 128/256-byte lines)
 // Tile rows owned by this device: strips stripRank, stripRank + stripCount, ... of the 16-row strips in [tileY0, tileY1).
-#ifndef RT_STACK_LDS_WAVE
-#define RT_STACK_LDS_WAVE RT_STACK_LDS      // LDS stack entries per lane of the per-wave frame kernel (experiment of round 4: 40 / 48, tools/exp/r04_stack_wave.sh)
-#endif
 enum TileShape { TILE_SQUARE = 0, TILE_ROWS = 1 };
 #ifndef RT_WAVE_BLOCK_W
 #define RT_WAVE_BLOCK_W 8        // pixels per row of a wave's block inside a SQUARE tile: 8 (8 x 8, shipped) or 16 (16 x 4: experiment of round 4, tools/exp/r04_wave_block.sh)
@@ -90,7 +87,7 @@ DEV TraceStack make_stack(PRef P, uint32_t *ldsStack, uint32_t wordsPerLane = RT
     s.lds = (LdsU32Ptr)(block + (threadIdx.x & 63u));
     s.lds16 = (LdsI16Ptr)block + (threadIdx.x & 63u);
     s.spill = (GlobalU32Ptr)(P.traversalStack + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (RT_STACK_SPILL_HEADER + RT_STACK_SPILL) + RT_STACK_SPILL_HEADER);
-    s.cache = nullptr; s.ldsEntries = (int)wordsPerLane;        // (kernels with the scene cache switch to their int16 entries in cached_env: use_cache)
+    s.cache = nullptr; s.ldsEntries = RT_STACK_LDS;
     return s;
 }
 // this lane's columns of the light-candidate arrays, [wave][slots][lane] (floats, then bytes)
@@ -620,9 +617,7 @@ DEV bool wave_tile_of(uint32_t seq, uint32_t tiles, uint32_t &tileSeq, uint32_t 
 template <bool CACHED, bool FULL, int WAVES, int BLOCK = RT_BLOCK>
 __global__ __launch_bounds__(BLOCK, WAVES) void lean_frame_kernel(FrameParams Pv, ViewImages Iv, int32_t *hitInstance, int cur, int ownedY0, int ownedY1) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
-    // the per-wave form (BLOCK = 64: scenes that walk from HBM, i.e. deep trees) keeps RT_STACK_LDS_WAVE entries per lane in LDS: its workgroups hold no scene cache and one
-    // wave each, so twelve of them per CU still fit, and a push / pop between levels 24 and RT_STACK_LDS_WAVE of a walk is a ds access instead of a round trip to the HBM slab
-    constexpr uint32_t STACK_WORDS = CACHED ? RT_STACK_LDS_CACHED / 2 : (BLOCK == RT_BLOCK ? RT_STACK_LDS : RT_STACK_LDS_WAVE);
+    constexpr uint32_t STACK_WORDS = CACHED ? RT_STACK_LDS_CACHED / 2 : RT_STACK_LDS;
     __shared__ uint32_t ldsStack[STACK_WORDS * BLOCK];
     // dynamic LDS: [scene cache (CACHED)][light candidates: intensities, indices -- sized by the frame's light count]
     extern __shared__ u32x4_lds dynLds[];

@@ -1,5 +1,5 @@
 #!/bin/bash
-# LDS stack entries per lane of the per-wave frame kernel: 24 (shipped until round 4) against 40 / 48.   build | run
+# LDS stack entries per lane of the per-wave frame kernel: 24 (shipped) against 40 / 48 -- needs profiles/r04_experiments/stack_lds_wave.patch applied to csrc/passes.hip (the macro RT_STACK_LDS_WAVE is not in the shipped source: no effect was measured).   build | run
 cd "$(dirname "$0")/../.."
 CS=sm64rt-legacy-renderer_amd/csrc
 if [ "$1" = build ]; then
