@@ -528,6 +528,35 @@ def main():
                     "what": "sync_present=0: RT64_DrawDevice enqueues, frames run back to back on the library's stream, one wait after the K-th (cached tables)"}
         scene.option("sync_present", 1)
         step(); barrier()
+    # ... and what a game does: an instance moves in EVERY frame, so the tables, the TLAS and the head of the scene-cache image really change (always_rebuild above re-sends
+    # identical bytes).  Changed tables go into another of the view's table slots, so such frames stay one-kernel lean frames and -- enqueued -- stay side by side.
+    moving = None
+    if not G and PR <= 1 and anim is None and not args.timed_loop_only and not (args.gi_samples or args.denoiser):
+        import copy as _copy
+        k_sphere = next((i for i, inst in enumerate(data.instances) if inst.name == "sphere"), -1)
+        if k_sphere >= 0:
+            descs = []
+            for dx in (0.0, 0.02):
+                inst = _copy.copy(data.instances[k_sphere])
+                t = np.array(inst.transform, dtype=np.float32).copy(); t[3][0] += dx
+                inst.transform = t; inst.previous_transform = t
+                descs.append(scene._instance_desc(inst))
+            handle = scene.instances[k_sphere]
+            moving = {"what": "the sphere's transform changes in every frame (two positions in turn): frame tables + TLAS + scene-cache head uploaded every frame into the next table slot"}
+            for name, sync in (("sync", 1), ("enqueued", 0)):
+                scene.option("sync_present", sync)
+                for f in range(min(args.warmup, 5) + 2):
+                    lib.SetInstanceDescription(handle, descs[f % 2]); lib.DrawDevice(scene.device, 1, 16.0)
+                barrier()
+                tm = time.perf_counter()
+                for f in range(args.steps):
+                    lib.SetInstanceDescription(handle, descs[f % 2]); lib.DrawDevice(scene.device, 1, 16.0)
+                barrier()
+                m_ms = (time.perf_counter() - tm) * 1e3 / args.steps
+                stm = scene.stats()
+                moving[name] = {"ms_per_step": round(m_ms, 5), "value": round(rays_total / (m_ms * 1e-3) / 1e6, 2), "lean_frame": int(stm.leanFrame), "one_kernel": int(stm.fusedFrame == 1), "overlapped": int(stm.overlappedFrame)}
+            scene.option("sync_present", 1)
+            lib.SetInstanceDescription(handle, descs[0]); step(); barrier()
     scene.option("profile_every", 1)
     if G or PR > 1:                  # per-kernel timings of this rank's strips from a few untimed frames (reading them synchronises)
         stat_frames = 10
@@ -634,6 +663,8 @@ def main():
             result["enqueued_frames"] = enqueued
         if rebuild is not None:
             result["always_rebuild"] = rebuild
+        if moving is not None:
+            result["moving_instance"] = moving
         result["frame_tables"] = "rebuilt every frame (always_rebuild)" if args.always_rebuild else "cached while the host re-sends identical descriptors (steady state of the sample host, main.cpp:97-134); `always_rebuild` holds the figure with the cache off"
         oracle_frame = None
         if N == 1 and not args.no_cpu_baseline and not args.timed_loop_only:

@@ -270,13 +270,14 @@ struct Device {
     uint8_t *ring = nullptr; size_t ringBytes = 0, ringHead = 0;
     void *ringAlloc(size_t bytes) {
         bytes = (bytes + 255) & ~(size_t)255;
+        auto drain = [&]() { for (hipStream_t st : streams) if (st) HIP_CHECK(hipStreamSynchronize(st)); };       // (table uploads are queued on whichever render stream their frame runs on)
         if (bytes > ringBytes) {
-            HIP_CHECK(hipStreamSynchronize(stream));
+            drain();
             if (ring) hipHostFree(ring);
             ringBytes = std::max(bytes * 2, (size_t)32 << 20); ringHead = 0;
             HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ring), ringBytes, hipHostMallocDefault));
         }
-        if (ringHead + bytes > ringBytes) { HIP_CHECK(hipStreamSynchronize(stream)); ringHead = 0; }
+        if (ringHead + bytes > ringBytes) { drain(); ringHead = 0; }
         void *p = ring + ringHead; ringHead += bytes;
         return p;
     }
@@ -370,10 +371,6 @@ struct View {
     int finalW = 0, finalH = 0;               // back buffer = screen size
     // rectangle of the ray-traced picture: the first ray-traced instance's scissor / viewport when it has any (rt64_view.cpp:1258-1271)
     float rtViewport[4] = { 0, 0, 0, 0 }; int rtScissor[4] = { 0, 0, 0, 0 }; bool rtRect = false;
-    DevArray<uint8_t> cacheImage; bool cacheImageValid = false;      // FrameParams::cacheImage: rebuilt after every table upload that leaves the cache enabled
-    // ... or, with a host-built TLAS, inside the table allocation: its head (instance records + TLAS nodes) is written by the host into the same upload as the tables and
-    // only the BLAS node arrays behind it are copied by a kernel -- when a mesh of the frame was built, refitted or replaced, not when an instance moved
-    const uint8_t *cacheImageAt = nullptr; std::vector<uint64_t> cacheBlasKey;
     bool needSpillSlab = false;                // some walk of this frame can outgrow its LDS stack entries (see View::update)
     uint32_t cacheWords = 0;                   // LDS scene cache size in 16-byte words (0: the scene does not fit / option lds_cache = 0)
     bool separatePost() const { return upscaleActive || rtRect || imgW != finalW || imgH != finalH || (motionBlurStrength > 0.0f && motionBlurSamples > 0); }
@@ -399,12 +396,25 @@ struct View {
     // The frame tables live in ONE device allocation in their staging order (instances | textures | lights) so that a changed
     // frame costs one host-to-device copy (each copy packet is ~10 us of stream time, whatever its size).
     template <class T> struct TablePtr { T *ptr = nullptr; };
-    DevArray<uint8_t> dTables; TablePtr<GpuInstance> dInstances; TablePtr<GpuTexture> dTextures; TablePtr<RT64_LIGHT> dLights;
+    // ... and there are several such allocations (TABLE_SLOTS, one per render stream): tables that CHANGED are uploaded into the next slot, never over the ones the frame
+    // before was rendered with.  The frame before -- still running on another stream, or kept implicit as a lean frame whose G-buffer a reader may ask for later
+    // (View::materialise) -- keeps its instances, textures, lights, TLAS and scene-cache image, so a host that moves an instance every frame (a game) pays neither a
+    // materialise nor a join for it: its frames stay lean and stay side by side.  Unchanged tables stay in their slot.
+    enum { TABLE_SLOTS = 2 * RT64_RENDER_STREAMS_MAX };
+    struct TableSlot {
+        DevArray<uint8_t> dTables; TablePtr<GpuInstance> dInstances; TablePtr<GpuTexture> dTextures; TablePtr<RT64_LIGHT> dLights;
+        DevArray<GpuNode> tlasNodes; DevArray<uint32_t> tlasIndex, tlasMorton, tlasLeafParent; DevArray<BlasHeader> tlasHeader; DevArray<uint8_t> tlasScratch;
+        // where the slot's TLAS lives: the arrays above (GPU build), or the tail of dTables (a few instances: built on the host, uploaded with the tables)
+        const GpuNode *tlasNodesAt = nullptr; const uint32_t *tlasIndexAt = nullptr, *tlasMortonAt = nullptr; const BlasHeader *tlasHeaderAt = nullptr;
+        std::vector<uint8_t> uploadedTables;      // bytes of the slot's instance/texture/light tables (cache key)
+        DevArray<uint8_t> cacheImage; bool cacheImageValid = false;      // FrameParams::cacheImage of frames without a host-built TLAS: rebuilt after every table upload that leaves the cache enabled
+        // ... or, with a host-built TLAS, inside the table allocation: its head (instance records + TLAS nodes) is written by the host into the same upload as the tables and
+        // only the BLAS node arrays behind it are copied by a kernel -- when a mesh of the frame was built, refitted or replaced, not when an instance moved
+        const uint8_t *cacheImageAt = nullptr; std::vector<uint64_t> cacheBlasKey;
+        unsigned readers = 0;                     // render streams (bit mask) whose frames have read the slot since its last upload
+    } tab[TABLE_SLOTS];
+    int tabCur = 0;
     std::vector<uint8_t> tableScratch;
-    DevArray<GpuNode> tlasNodes; DevArray<uint32_t> tlasIndex, tlasMorton, tlasLeafParent; DevArray<BlasHeader> tlasHeader; DevArray<uint8_t> tlasScratch;
-    // where the current TLAS lives: the arrays above (GPU build), or the tail of dTables (a few instances: built on the host, uploaded with the tables)
-    const GpuNode *tlasNodesAt = nullptr; const uint32_t *tlasIndexAt = nullptr, *tlasMortonAt = nullptr; const BlasHeader *tlasHeaderAt = nullptr;
-    std::vector<uint8_t> uploadedTables;      // bytes of the last uploaded instance/texture/light tables (cache key)
     float maxDepthBias = 0.0f;
     bool anyNonOpaque = false, anyReflection = false, anyRefraction = false, anyFog = false;
     bool simpleFrame = false;                 // every texture of the frame is a power of two in both sizes and every instance is shadow-opaque (passes_simple.hip)
@@ -918,7 +928,7 @@ void View::prepareRasterList(const std::vector<RenderInstance> &list, RasterList
 void View::drawRasterList(RasterList &rl, uint8_t *target) {
     if (!rl.ready || rl.triTotal == 0) return;
     Device *dev = scene->device;
-    HIP_CHECK(launch_raster_draw(rl.table.ptr, rl.tris.ptr, rl.triTotal, dTextures.ptr, target, rl.w, rl.y0, rl.y1, rl.bounds, dev->stripRank, dev->stripCount, dev->stream));
+    HIP_CHECK(launch_raster_draw(rl.table.ptr, rl.tris.ptr, rl.triTotal, tab[tabCur].dTextures.ptr, target, rl.w, rl.y0, rl.y1, rl.bounds, dev->stripRank, dev->stripCount, dev->stream));
     dev->workSinceMark = true;
 }
 
@@ -1127,13 +1137,18 @@ void View::update() {                          // View::update, rt64_view.cpp:10
     // The tables (and with them the TLAS) only change when the host changed an instance, a mesh, a texture binding or a light.
     // Identical bytes => the device copies and the TLAS of the previous frame are still exact: skip upload and rebuild.
     const size_t tableBytes = instBytes + texBytes + lightBytes;
-    const bool sameContent = uploadedTables.size() == tableBytes && tableBytes && memcmp(uploadedTables.data(), stage, tableBytes) == 0;
+    const bool sameContent = tab[tabCur].uploadedTables.size() == tableBytes && tableBytes && memcmp(tab[tabCur].uploadedTables.data(), stage, tableBytes) == 0;
     const bool unchanged = sameContent && !dev->opt.alwaysRebuild;
-    // A kept lean frame re-reads the tables, the TLAS and the cache image it was rendered with (View::materialise): its images are produced
-    // before new contents overwrite them.  (always_rebuild re-uploads identical bytes to the same places: nothing to save.)
-    if (!sameContent && leanFrame) { materialise(); dev->leanHoldoff = RT64_LEAN_HOLDOFF_FRAMES; }
+    // A kept lean frame re-reads the tables, the TLAS and the cache image it was rendered with (View::materialise), and so does a frame that is still running on
+    // another render stream: new contents go into ANOTHER slot and leave the last frame's alone.  Which one: a slot that only frames of THIS stream have read since its
+    // last upload (stream order then protects it; an unused slot qualifies) -- with tables that change every frame each stream settles on a slot of its own, and a host
+    // that waits for every frame alternates between two -- or, if there is none, the next one, behind a wait for the other streams.
     if (!unchanged) {
-        dev->impure();           // new table bytes: behind every frame that still reads the old ones
+        int pick = -1;
+        for (int k = 1; k < TABLE_SLOTS && pick < 0; k++) { const int c = (tabCur + k) % TABLE_SLOTS; if (!(tab[c].readers & ~(1u << dev->cur))) pick = c; }
+        if (pick < 0) { pick = (tabCur + 1) % TABLE_SLOTS; dev->impure(); }
+        tabCur = pick;
+        tab[tabCur].readers = 0;
         // TLAS: full rebuild (rt64_view.cpp:412-452 rebuilds every frame, updateOnly = false) -- of a few instances on the host, into the same upload
         const uint32_t n = (uint32_t)nInst;
         const bool hostTlas = n >= 1 && n <= RT64_HOST_TLAS_MAX && dev->opt.hostTlas;
@@ -1141,9 +1156,13 @@ void View::update() {                          // View::update, rt64_view.cpp:10
         const bool hostCache = hostTlas && cacheWords != 0;
         const size_t cacheAt = (tlasAt + nodeBytes + sizeof(BlasHeader) + 2 * sizeof(uint32_t) * n + 63) & ~(size_t)63, headWords = hostCache ? 4 * (size_t)n + 4 * std::max<size_t>(n - 1, 1) : 0;
         const size_t uploadBytes = hostTlas ? (hostCache ? cacheAt + headWords * 16 : tlasAt + nodeBytes + sizeof(BlasHeader) + 2 * sizeof(uint32_t) * n) : tableBytes;
-        dTables.reserve(std::max<size_t>(hostCache ? cacheAt + (size_t)cacheWords * 16 : uploadBytes, 4096));
-        dInstances.ptr = reinterpret_cast<GpuInstance *>(dTables.ptr); dTextures.ptr = reinterpret_cast<GpuTexture *>(dTables.ptr + instBytes);
-        dLights.ptr = reinterpret_cast<RT64_LIGHT *>(dTables.ptr + instBytes + texBytes);
+        {
+            const size_t need = std::max<size_t>(hostCache ? cacheAt + (size_t)cacheWords * 16 : uploadBytes, 4096);
+            if (need > tab[tabCur].dTables.count || (n && !hostTlas)) dev->impure();       // a slot that has to grow is freed and allocated again; a TLAS of more than 64 instances is built by kernels whose scratch is not per slot
+            tab[tabCur].dTables.reserve(need);
+        }
+        tab[tabCur].dInstances.ptr = reinterpret_cast<GpuInstance *>(tab[tabCur].dTables.ptr); tab[tabCur].dTextures.ptr = reinterpret_cast<GpuTexture *>(tab[tabCur].dTables.ptr + instBytes);
+        tab[tabCur].dLights.ptr = reinterpret_cast<RT64_LIGHT *>(tab[tabCur].dTables.ptr + instBytes + texBytes);
         if (uploadBytes) {       // staged in the pinned upload ring: no wait before the region is reused (a wrap-around of the ring drains the stream)
             uint8_t *pinnedStage = static_cast<uint8_t *>(dev->ringAlloc(uploadBytes));
             memcpy(pinnedStage, stage, tableBytes);
@@ -1174,43 +1193,43 @@ void View::update() {                          // View::update, rt64_view.cpp:10
                         dst[12] = childRef(hn[t].left); dst[13] = childRef(hn[t].right);
                     }
                 }
-                uint8_t *base = dTables.ptr + tlasAt;
-                tlasNodesAt = reinterpret_cast<const GpuNode *>(base); tlasHeaderAt = reinterpret_cast<const BlasHeader *>(base + nodeBytes);
-                tlasIndexAt = reinterpret_cast<const uint32_t *>(tlasHeaderAt + 1); tlasMortonAt = tlasIndexAt + n;
+                uint8_t *base = tab[tabCur].dTables.ptr + tlasAt;
+                tab[tabCur].tlasNodesAt = reinterpret_cast<const GpuNode *>(base); tab[tabCur].tlasHeaderAt = reinterpret_cast<const BlasHeader *>(base + nodeBytes);
+                tab[tabCur].tlasIndexAt = reinterpret_cast<const uint32_t *>(tab[tabCur].tlasHeaderAt + 1); tab[tabCur].tlasMortonAt = tab[tabCur].tlasIndexAt + n;
             }
-            HIP_CHECK(hipMemcpyAsync(dTables.ptr, pinnedStage, uploadBytes, hipMemcpyHostToDevice, dev->stream));
+            HIP_CHECK(hipMemcpyAsync(tab[tabCur].dTables.ptr, pinnedStage, uploadBytes, hipMemcpyHostToDevice, dev->stream));
         }
         if (n && !hostTlas) {
-            tlasNodes.reserve(std::max<size_t>(n - 1, 1)); tlasIndex.reserve(n); tlasMorton.reserve(n); tlasLeafParent.reserve(n); tlasHeader.reserve(1);
+            tab[tabCur].tlasNodes.reserve(std::max<size_t>(n - 1, 1)); tab[tabCur].tlasIndex.reserve(n); tab[tabCur].tlasMorton.reserve(n); tab[tabCur].tlasLeafParent.reserve(n); tab[tabCur].tlasHeader.reserve(1);
             LbvhArgs a = {};
-            a.mode = LBVH_MODE_INSTANCES; a.refit = 0; a.n = n; a.instances = dInstances.ptr;
-            a.nodes = tlasNodes.ptr; a.tris = nullptr; a.header = tlasHeader.ptr; a.sortedIndex = tlasIndex.ptr; a.morton = tlasMorton.ptr; a.leafParent = tlasLeafParent.ptr;
-            if (n > LBVH_SMALL_MAX) { tlasScratch.reserve(lbvh_large_scratch_bytes(n)); a.scratch = tlasScratch.ptr; a.scratchBytes = tlasScratch.bytes(); }
+            a.mode = LBVH_MODE_INSTANCES; a.refit = 0; a.n = n; a.instances = tab[tabCur].dInstances.ptr;
+            a.nodes = tab[tabCur].tlasNodes.ptr; a.tris = nullptr; a.header = tab[tabCur].tlasHeader.ptr; a.sortedIndex = tab[tabCur].tlasIndex.ptr; a.morton = tab[tabCur].tlasMorton.ptr; a.leafParent = tab[tabCur].tlasLeafParent.ptr;
+            if (n > LBVH_SMALL_MAX) { tab[tabCur].tlasScratch.reserve(lbvh_large_scratch_bytes(n)); a.scratch = tab[tabCur].tlasScratch.ptr; a.scratchBytes = tab[tabCur].tlasScratch.bytes(); }
             HIP_CHECK(lbvh_launch(a, dev->stream));
-            tlasNodesAt = tlasNodes.ptr; tlasIndexAt = tlasIndex.ptr; tlasMortonAt = tlasMorton.ptr; tlasHeaderAt = tlasHeader.ptr;
+            tab[tabCur].tlasNodesAt = tab[tabCur].tlasNodes.ptr; tab[tabCur].tlasIndexAt = tab[tabCur].tlasIndex.ptr; tab[tabCur].tlasMortonAt = tab[tabCur].tlasMorton.ptr; tab[tabCur].tlasHeaderAt = tab[tabCur].tlasHeader.ptr;
         }
-        cacheImageValid = false;
+        tab[tabCur].cacheImageValid = false;
         if (hostCache) {
             // the BLAS node arrays behind the head: copied again only when one of them -- or the allocation they are copied into -- changed
-            cacheImageAt = dTables.ptr + cacheAt;
+            tab[tabCur].cacheImageAt = tab[tabCur].dTables.ptr + cacheAt;
             std::vector<uint64_t> key; key.reserve(2 + 4 * (size_t)n);
-            key.push_back(reinterpret_cast<uint64_t>(cacheImageAt)); key.push_back(cacheWords);
+            key.push_back(reinterpret_cast<uint64_t>(tab[tabCur].cacheImageAt)); key.push_back(cacheWords);
             for (uint32_t i = 0; i < n; i++) { key.push_back(reinterpret_cast<uint64_t>(hInst[i].nodes)); key.push_back(hInst[i].meshVersion); key.push_back(hInst[i].cacheNodeOffset); key.push_back(hInst[i].triCount); }
-            if (key != cacheBlasKey) {
-                HIP_CHECK(launch_scene_cache_image(dInstances.ptr, tlasIndexAt, tlasNodesAt, n, const_cast<uint8_t *>(cacheImageAt), true, dev->stream));
-                cacheBlasKey.swap(key);
+            if (key != tab[tabCur].cacheBlasKey) {
+                HIP_CHECK(launch_scene_cache_image(tab[tabCur].dInstances.ptr, tab[tabCur].tlasIndexAt, tab[tabCur].tlasNodesAt, n, const_cast<uint8_t *>(tab[tabCur].cacheImageAt), true, dev->stream));
+                tab[tabCur].cacheBlasKey.swap(key);
             }
-            cacheImageValid = true;
+            tab[tabCur].cacheImageValid = true;
         }
-        else cacheBlasKey.clear();
-        uploadedTables.assign(stage, stage + tableBytes);
+        else tab[tabCur].cacheBlasKey.clear();
+        tab[tabCur].uploadedTables.assign(stage, stage + tableBytes);
         dev->workSinceMark = true;
     }
-    if (cacheWords && !cacheImageValid) {
+    if (cacheWords && !tab[tabCur].cacheImageValid) {
         dev->impure();
-        cacheImage.reserve((size_t)cacheWords * 16);
-        HIP_CHECK(launch_scene_cache_image(dInstances.ptr, tlasIndexAt, tlasNodesAt, (uint32_t)nInst, cacheImage.ptr, false, dev->stream));
-        cacheImageAt = cacheImage.ptr; cacheImageValid = true;
+        tab[tabCur].cacheImage.reserve((size_t)cacheWords * 16);
+        HIP_CHECK(launch_scene_cache_image(tab[tabCur].dInstances.ptr, tab[tabCur].tlasIndexAt, tab[tabCur].tlasNodesAt, (uint32_t)nInst, tab[tabCur].cacheImage.ptr, false, dev->stream));
+        tab[tabCur].cacheImageAt = tab[tabCur].cacheImage.ptr; tab[tabCur].cacheImageValid = true;
     }
     // Raster lists (background first, then foreground; rt64_view.cpp:1138-1147).  They are a handful of HUD instances: uploaded every frame.
     {
@@ -1292,7 +1311,7 @@ void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64
     P.binaryLockMask = upscaleActive ? 0u : 1u;               // rtUpscaleMode != FSR (:1018): the built-in stage stands where FSR does and takes the continuous mask
     P.visualizationMode = 0;
     P.width = imgW; P.height = imgH; P.tileY0 = dev->tileY0; P.tileY1 = dev->tileY1; P.stripRank = dev->stripRank; P.stripCount = dev->stripCount;
-    P.cacheWords = cacheWords; P.cacheInstances = cacheWords ? (uint32_t)rtInstances.size() : 0u; P.cacheImage = cacheWords ? cacheImageAt : nullptr;
+    P.cacheWords = cacheWords; P.cacheInstances = cacheWords ? (uint32_t)rtInstances.size() : 0u; P.cacheImage = cacheWords ? tab[tabCur].cacheImageAt : nullptr;
     P.separatePost = separatePost() ? 1u : 0u;
     P.simpleKernels = simpleFrame ? 1u : 0u;
     P.postSource = img.output; P.postSourceW = imgW; P.postSourceH = imgH;
@@ -1322,7 +1341,7 @@ void View::fillParams(FrameParams &P) {        // updateGlobalParamsBuffer, rt64
     }
     P.lightCount = (uint32_t)scene->lights.size(); P.instanceCount = (uint32_t)rtInstances.size();
     P.countTraversal = dev->opt.countTraversal ? 1u : 0u;
-    P.instances = dInstances.ptr; P.tlasNodes = tlasNodesAt; P.tlasIndex = tlasIndexAt; P.textures = dTextures.ptr; P.lights = dLights.ptr;
+    { TableSlot &T = tab[tabCur]; P.instances = T.dInstances.ptr; P.tlasNodes = T.tlasNodesAt; P.tlasIndex = T.tlasIndexAt; P.textures = T.dTextures.ptr; P.lights = T.dLights.ptr; T.readers |= 1u << dev->cur; }
     {   // grows with the render size (no-op otherwise); never allocated for shallow scenes; one slab per render stream
         DevArray<uint32_t> &slab = dev->spillStack[dev->cur];
         const size_t words = needSpillSlab ? rt_stack_spill_bytes(imgW, imgH) / sizeof(uint32_t) : 0;
@@ -2174,7 +2193,7 @@ RT64_EXPORT size_t RT64_ReadbackViewAccel(RT64_VIEW *viewPtr, int what, void *ds
     RT64_TRY
     View *v = reinterpret_cast<View *>(viewPtr); if (!v) throw std::runtime_error("RT64_ReadbackViewAccel: NULL view.");
     if (what == RT64_ACCEL_TRIANGLES) throw std::runtime_error("RT64_ReadbackViewAccel: a TLAS has no triangle array.");
-    return accel_readback(v->scene->device, what, (uint32_t)v->rtInstances.size(), v->tlasNodesAt, nullptr, v->tlasIndexAt, v->tlasMortonAt, v->tlasHeaderAt, dst, dstBytes);
+    return accel_readback(v->scene->device, what, (uint32_t)v->rtInstances.size(), v->tab[v->tabCur].tlasNodesAt, nullptr, v->tab[v->tabCur].tlasIndexAt, v->tab[v->tabCur].tlasMortonAt, v->tab[v->tabCur].tlasHeaderAt, dst, dstBytes);
     RT64_CATCH(0)
 }
 

@@ -187,3 +187,51 @@ def test_random_call_sequences_render_the_same_on_one_stream_and_on_three(rt64_l
     for (ka, fa, xa), (kb, fb, xb) in zip(a, b):
         assert (ka, fa) == (kb, fb)
         assert np.array_equal(xa.view(np.uint8), xb.view(np.uint8)), (seed, ka, fa)
+
+
+def test_an_instance_that_moves_every_frame_keeps_the_frames_lean_and_side_by_side(rt64_lib, sample_data):
+    """What a game does: some instance moves in every frame, so the frame tables (and the TLAS, and the head of the scene-cache image) change in every frame.  Changed tables
+    go into the next of the view's table slots (one per render stream) instead of over the ones the frame before was rendered with: that frame -- possibly still running on
+    another stream, and kept implicit as a lean frame -- needs neither a wait nor a materialise, the frames stay one-kernel lean frames and stay overlapped.  Byte for byte the
+    frames of the same session drawn synchronously on one stream; a G-buffer image of the LAST frame read afterwards is that frame's (its slot was not overwritten)."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    out = {}
+    for overlap, sync in ((1, 0), (0, 1)):
+        data = copy.copy(sample_data)
+        data.instances = [copy.copy(i) for i in sample_data.instances]
+        s = sample_scene.Rt64Scene(rt64_lib, data, W, H, hip_device=0)
+        try:
+            assert s.option("overlap_frames", overlap)
+            s.draw()
+            s.option("sync_present", sync)
+            k = next(i for i, inst in enumerate(data.instances) if inst.name == "sphere")
+            finals, flags = [], []
+            for f in range(9):
+                d = copy.copy(s.data); d.instances = [copy.copy(i) for i in d.instances]
+                t = np.array(d.instances[k].transform, dtype=np.float32).copy(); t[3][0] = 0.15 * f; t[3][1] = 0.05 * f
+                d.instances[k].previous_transform = d.instances[k].transform; d.instances[k].transform = t
+                s.data = d                                   # (Rt64Scene.draw re-sends the sphere's descriptor from s.data like the sample host, main.cpp:129)
+                s.draw()
+                if f >= 6:
+                    st = s.stats()
+                    flags.append((int(st.leanFrame), int(st.fusedFrame), int(st.overlappedFrame)))
+                    finals.append(s.readback(rt64.IMAGE_FINAL_RGBA8).copy())
+            for f in range(9, 14):                           # a burst with no wait in between
+                d = copy.copy(s.data); d.instances = [copy.copy(i) for i in d.instances]
+                t = np.array(d.instances[k].transform, dtype=np.float32).copy(); t[3][0] = 0.15 * f
+                d.instances[k].previous_transform = d.instances[k].transform; d.instances[k].transform = t
+                s.data = d; s.draw()
+            st = s.stats()
+            flags.append((int(st.leanFrame), int(st.fusedFrame), int(st.overlappedFrame)))
+            finals.append(s.readback(rt64.IMAGE_FINAL_RGBA8).copy())
+            hit = s.readback(rt64.IMAGE_PRIMARY_HIT).copy(); pos = s.readback(rt64.IMAGE_SHADING_POSITION).copy()
+            out[overlap] = (finals, flags, hit, pos)
+        finally:
+            s.close()
+    a, b = out[1], out[0]
+    assert all(f[0] == 1 and f[1] == 1 for f in a[1] + b[1]), (a[1], b[1])        # every frame a one-kernel lean frame although its tables changed
+    assert a[1][-1][2] == 1 and not any(f[2] for f in b[1])                        # ... and the enqueued ones ran side by side
+    for x, y in zip(a[0], b[0]):
+        assert np.array_equal(x, y)
+    assert not np.array_equal(a[0][0], a[0][1])
+    assert np.array_equal(a[2].view(np.uint8), b[2].view(np.uint8)) and np.array_equal(a[3].view(np.uint8), b[3].view(np.uint8))
