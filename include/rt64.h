@@ -462,7 +462,8 @@ typedef struct {
     /* Profiling aid (RT64_SetDeviceOption("tile_timing", 1)): two 16-byte records per wave of the last one-kernel frame, in workgroup order: at its \
        start { chip-wide 100 MHz clock, shader clock (low 32 bits each), HW_ID, 1 }, at its end { clock, shader clock, 0, 1 }; zeros for waves that did not run. */ \
     X(ReadbackTileTiming, RT64_ReadbackTileTiming, size_t, (RT64_DEVICE *device, void *dst, size_t dstBytes)) \
-    /* hipStream_t the device submits on, as void*. */ \
+    /* hipStream_t the device submitted its LAST frame on, as void*.  The device has several render streams and enqueued pixel-local frames alternate over them \
+       (option overlap_frames): a host that orders work of its own behind frames on ONE stream sets overlap_frames = 0 first. */ \
     X(GetDeviceStream, RT64_GetDeviceStream, void *, (RT64_DEVICE *device)) \
     /* Debug readback of acceleration structures (RT64_ACCEL_*): the mesh's BLAS / the view's TLAS of the last frame. \
        Returns bytes written (0 on error); pass dst = NULL to query the size. */ \

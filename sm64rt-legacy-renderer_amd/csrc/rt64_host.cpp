@@ -2541,7 +2541,8 @@ void Gather::setBands(const int *starts) {
         restart(new0, std::min(new1, old0)); restart(std::max(new0, old1), new1);
     }
     dev->tileSet = true; dev->tileY0 = layout.starts[rank]; dev->tileY1 = layout.starts[rank + 1]; dev->stripRank = 0; dev->stripCount = 1;
-    prepare(next);
+    if (direct.on) { for (bool &p : direct.pending) p = false; prepareDirect(next); }       // (the frame slots are whole frames: new boundaries change nothing about them)
+    else prepare(next);
 }
 void Gather::wait(int slot, bool host) {
     if (direct.on) {

@@ -196,3 +196,49 @@ def test_constants_are_macros_like_the_references_and_equal_the_enumerators():
                              'RT64_UPSCALER_FSR != 3 || RT64_TEXTURE_FORMAT_DDS != 2 || RT64_MATERIAL_CC_SHADER_TEXEL1 != 7 || RT64_INSTANCE_DISABLE_BACKFACE_CULLING != 2\n#error constants\n#endif\n'
                              'int main(void) { return RT64_ATTRIBUTE_NONE; }\n')
         subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), "-fsyntax-only", src], check=True)
+
+
+def _struct_members(text):
+    """{struct name: [(type, member), ...]} of every `typedef struct { ... } RT64_X;` in a C header: comments dropped, `a, b` declarators split, arrays kept on the name."""
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    out = {}
+    for body, name in re.findall(r"typedef\s+struct\s*\{([^{}]*)\}\s*(RT64_\w+)\s*;", text):
+        members = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            m = re.match(r"(.+?)\s*(\**\w+(?:\[\d+\])*(?:\s*,\s*\**\w+(?:\[\d+\])*)*)$", decl)
+            assert m, decl
+            ctype = " ".join(m.group(1).split())
+            for d in m.group(2).split(","):
+                d = d.strip()
+                stars = len(d) - len(d.lstrip("*"))
+                members.append((ctype + " *" * stars, d.lstrip("*")))
+        out[name] = members
+    return out
+
+
+def test_pod_structs_have_the_references_members_in_the_references_order():
+    """The descriptors a host fills and passes by value (public/rt64.h:98-205): member for member the reference's types, names and order -- compared with the reference's header
+    itself where it is at hand (the build container), and compiled to the sizes / offsets SURVEY 8(b) lists everywhere (test_header_compiles_as_c_and_cpp_and_layouts_match)."""
+    ours = _struct_members(open(os.path.join(ROOT, "include", "rt64.h")).read())
+    pods = ["RT64_VECTOR2", "RT64_VECTOR3", "RT64_VECTOR4", "RT64_MATRIX4", "RT64_RECT", "RT64_MATERIAL", "RT64_LIGHT", "RT64_SCENE_DESC", "RT64_VIEW_DESC", "RT64_INSTANCE_DESC", "RT64_TEXTURE_DESC"]
+    for name in pods:
+        assert name in ours and ours[name], name
+    assert [m for _, m in ours["RT64_MATERIAL"]][:4] == ["diffuseTexIndex", "normalTexIndex", "specularTexIndex", "ignoreNormalFactor"] and ours["RT64_MATERIAL"][-1] == ("int", "enabledAttributes")
+    assert ours["RT64_VIEW_DESC"][-1][1] == "denoiserEnabled" and ours["RT64_INSTANCE_DESC"][0] == ("RT64_MESH *", "mesh")
+    ref = "/root/reference/src/rt64lib/public/rt64.h"
+    if os.path.exists(ref):
+        theirs = _struct_members(open(ref).read())
+        for name in pods:
+            assert ours[name] == theirs[name], (name, ours[name], theirs[name])
+        # ... and the function table: the same member names in the same order behind the module handle (public/rt64.h:305-342)
+        table = re.search(r"typedef\s+struct\s*\{([^{}]*)\}\s*RT64_LIBRARY\s*;", re.sub(r"//[^\n]*", " ", open(ref).read()))
+        their_members = re.findall(r"(\w+)\s*;", re.sub(r"#\w+[^\n]*", " ", table.group(1)))          # (the #ifndef RT64_MINIMAL around the full table dropped)
+        header = open(os.path.join(ROOT, "include", "rt64.h")).read()
+        core = re.search(r"#define RT64_API_LIST_CORE\(X\)(.*?)\n\n", header, re.S).group(1)
+        full = re.search(r"#define RT64_API_LIST_FULL\(X\)(.*?)\n\n", header, re.S).group(1)
+        our_members = ["handle"] + re.findall(r"X\((\w+),\s*RT64_\w+,", core) + re.findall(r"X\((\w+),\s*RT64_\w+,", full)
+        assert our_members == their_members, (our_members, their_members)

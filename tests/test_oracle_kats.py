@@ -119,3 +119,37 @@ def test_hsl_roundtrip_and_envmap(oracle_lib):
     assert abs(uv[0] - 0.5) < 1e-6 and abs(uv[1] - 0.5) < 1e-6
     oracle_lib.oracle_fake_envmap_uv((C.c_float * 3)(0.0, 1.0, 0.0), 0.0, uv)       # straight up: pitch = -pi/2 + pi
     assert abs(uv[1] - 0.25) < 1e-6
+
+
+def test_shader_constants_of_oracle_and_kernels_are_the_references():
+    """The handful of constants the reference's shaders are written around (Constants.hlsli, Ray.hlsli, Lights.hlsli, GlobalHitBuffers.hlsli, BgSky.hlsli,
+    GaussianFilterRGB3x3CS.hlsl), read out of the reference's own files where they are at hand (the build container) and out of the oracle's and the kernels' headers:
+    the same numbers on all three sides.  (A value, not a behaviour -- but every one of them is a place where a restatement can silently drift.)"""
+    import os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def macros(path):
+        out = {}
+        for m in re.finditer(r"^[ \t]*#[ \t]*define[ \t]+(\w+)[ \t]+\(?(-?[0-9][0-9.eE+-]*)f?\)?", open(path).read(), re.M):
+            out[m.group(1)] = float(m.group(2))
+        return out
+    want = {"EPSILON": 1e-6, "M_PI": 3.14159265, "APPLY_LIGHTS_MINIMUM_ALPHA": 0.5, "MAX_HIT_QUERIES": 16, "MAX_LIGHTS": 16, "RAY_MIN_DISTANCE": 0.1, "RAY_MAX_DISTANCE": 100000.0,
+            "SCREEN_WIDTH": 320, "SCREEN_HEIGHT": 240}
+    shaders = "/root/reference/src/rt64lib/shaders"
+    if os.path.isdir(shaders):
+        ref = {}
+        for f in ("Constants.hlsli", "Ray.hlsli", "Lights.hlsli", "GlobalHitBuffers.hlsli", "BgSky.hlsli"):
+            ref.update(macros(os.path.join(shaders, f)))
+        for k, v in want.items():
+            assert ref[k] == pytest.approx(v, rel=0, abs=0), (k, ref[k])
+        # the 3 x 3 Gaussian's weights (GaussianFilterRGB3x3CS.hlsl) as both sides spell them
+        g = open(os.path.join(shaders, "GaussianFilterRGB3x3CS.hlsl")).read()
+        for lit in ("0.077847", "0.123317", "0.195346"):
+            assert lit in g and lit in open(os.path.join(root, "sm64rt-legacy-renderer_amd", "csrc", "passes.hip")).read() and lit in open(os.path.join(root, "oracle", "oracle_render.c")).read(), lit
+    om = macros(os.path.join(root, "oracle", "oracle_math.h")); om.update(macros(os.path.join(root, "oracle", "oracle_internal.h")))
+    dm = macros(os.path.join(root, "sm64rt-legacy-renderer_amd", "csrc", "device_math.h")); dm.update(macros(os.path.join(root, "sm64rt-legacy-renderer_amd", "csrc", "rt64_gpu.h")))
+    pairs = [("EPSILON", "O_EPSILON", "RT_EPSILON"), ("M_PI", "O_PI", "RT_PI"), ("APPLY_LIGHTS_MINIMUM_ALPHA", "O_APPLY_LIGHTS_MINIMUM_ALPHA", "RT_APPLY_LIGHTS_MINIMUM_ALPHA"),
+             ("MAX_HIT_QUERIES", "O_MAX_HIT_QUERIES", "RT64_MAX_HIT_QUERIES"), ("MAX_LIGHTS", "O_MAX_LIGHTS", "RT64_MAX_LIGHTS"),
+             ("RAY_MIN_DISTANCE", "O_RAY_MIN_DISTANCE", "RT_RAY_MIN_DISTANCE"), ("RAY_MAX_DISTANCE", "O_RAY_MAX_DISTANCE", "RT_RAY_MAX_DISTANCE")]
+    for r, o, d in pairs:
+        assert om[o] == want[r] and dm[d] == want[r], (r, om.get(o), dm.get(d))
