@@ -81,6 +81,8 @@ def parse_args():
     ap.add_argument("--cpu-baseline-height", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = all)")
     ap.add_argument("--timed-loop-only", action="store_true", help="profiling runs (tools/profile_round.sh): only the timed loop of `value` -- no always_rebuild leg, no enqueued leg (whose frames overlap on the "
                     "library's render streams: their launches would enter a profiler's per-kernel average with stretched durations), no parity object, no CPU baseline")
+    ap.add_argument("--watchdog", type=float, default=900.0, help="N > 1: seconds after which a rank that is still running dumps every thread's Python stack to stderr and exits with status 1 "
+                    "(a collective whose peer never arrives cannot be left from inside the process; the launcher then stops the other ranks); 0 = off")
     return ap.parse_args()
 
 
@@ -142,6 +144,9 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world > 1 and args.watchdog > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog, exit=True)       # a hung rendezvous / collective ends as a failed run with its stacks in the log, not as the driver's timeout
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launcher's world size and --gpus must agree" % (args.gpus, world))

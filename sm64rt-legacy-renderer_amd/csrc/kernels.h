@@ -87,7 +87,16 @@ hipError_t launch_raster_setup_inline(const GpuRasterInstance *hostTable, GpuRas
 hipError_t launch_raster_setup(const GpuRasterInstance *instances, uint32_t instanceCount, uint32_t triTotal, void *tris, int w, int h, int y0, int y1, bool apply, hipStream_t s);
 // Shade + blend the list, in order, into the RGBA8 target; `bounds` = pixel rectangle [x0, y0, x1, y1) the list can touch.
 hipError_t launch_raster_draw(const GpuRasterInstance *instances, const void *tris, uint32_t triTotal, const GpuTexture *textures, uint8_t *target,
-                              int w, int y0, int y1, const int bounds[4], int stripRank, int stripCount, hipStream_t s);
+                              int w, int y0, int y1, const int bounds[4], int stripRank, int stripCount, bool clear, hipStream_t s);       // clear: the whole target starts as 0 (no memset in front)
+// One launch for what a frame with changed tables queues before its first pass: the frame-table upload (read from the pinned upload ring) + the setup of short draw lists.
+#define RASTER_PROLOGUE_LISTS 3
+#define RASTER_PROLOGUE_INSTANCES 8
+#define RASTER_PROLOGUE_COPY_WORDS (4096u)          // 64 KB of frame tables: beyond that the copy engine's launch is the smaller part
+struct RasterPrologueList { GpuRasterInstance inst[RASTER_PROLOGUE_INSTANCES]; GpuRasterInstance *deviceTable; void *tris; uint32_t instanceCount, triTotal; int32_t w, h, y0, y1, apply; uint32_t firstBlock; };
+struct RasterPrologue { RasterPrologueList list[RASTER_PROLOGUE_LISTS]; const void *copySrc; void *copyDst; uint32_t copyWords, copyBlocks, listCount, pad; };
+static_assert(sizeof(RasterPrologue) <= 3584, "frame_prologue_kernel's arguments");
+bool frame_prologue_takes(const RasterPrologue &a);
+hipError_t launch_frame_prologue(RasterPrologue &a, hipStream_t s);
 
 // ---- svgf.hip ------------------------------------------------------------------------------------------------------
 // variance estimate + 5 a-trous iterations over the GI buffer; result in filteredIndirect[1]

@@ -86,8 +86,7 @@ DEV bool raster_setup_record(RasterTri &r, const ClipVertex v[3], const uint32_t
 struct RasterInlineTable { GpuRasterInstance inst[RASTER_INLINE_MAX]; };
 
 template <class Table>
-DEV void raster_setup_triangle(const Table &instances, uint32_t instanceCount, uint32_t triTotal, RasterTri *tris, int w, int h, int y0, int y1, int apply) {
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+DEV void raster_setup_triangle(const Table &instances, uint32_t instanceCount, uint32_t triTotal, RasterTri *tris, int w, int h, int y0, int y1, int apply, uint32_t t) {
     if (t >= triTotal) return;
     uint32_t lo = 0, hi = instanceCount - 1;                                  // last instance with firstTri <= t
     while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (instances[mid].firstTri <= t) lo = mid; else hi = mid - 1; }
@@ -157,7 +156,7 @@ DEV void raster_setup_triangle(const Table &instances, uint32_t instanceCount, u
 }
 __global__ __launch_bounds__(256) void raster_setup_kernel(const GpuRasterInstance *instances, uint32_t instanceCount, uint32_t triTotal,
                                                            RasterTri *tris, int w, int h, int y0, int y1, int apply) {
-    raster_setup_triangle(instances, instanceCount, triTotal, tris, w, h, y0, y1, apply);
+    raster_setup_triangle(instances, instanceCount, triTotal, tris, w, h, y0, y1, apply, blockIdx.x * 256 + threadIdx.x);
 }
 __global__ __launch_bounds__(256) void raster_setup_inline_kernel(RasterInlineTable table, GpuRasterInstance *deviceTable, uint32_t instanceCount, uint32_t triTotal,
                                                                   RasterTri *tris, int w, int h, int y0, int y1, int apply) {
@@ -166,17 +165,44 @@ __global__ __launch_bounds__(256) void raster_setup_inline_kernel(RasterInlineTa
         const uint32_t *src = reinterpret_cast<const uint32_t *>(&table);
         for (uint32_t k = threadIdx.x; k < words; k += 256) reinterpret_cast<uint32_t *>(deviceTable)[k] = src[k];
     }
-    raster_setup_triangle(table.inst, instanceCount, triTotal, tris, w, h, y0, y1, apply);
+    raster_setup_triangle(table.inst, instanceCount, triTotal, tris, w, h, y0, y1, apply, blockIdx.x * 256 + threadIdx.x);
+}
+
+// Everything a frame with changed tables queues in front of its first pass, as ONE launch: the frame-table upload (workgroups [0, copyBlocks): 16-byte words
+// from the pinned upload ring, which the device reads across the host link) and the setup of up to RASTER_PROLOGUE_LISTS short draw lists, tables by value
+// (workgroups from list.firstBlock on).  A host that re-sends its scene every frame -- the reference's own per-frame behaviour, `always_rebuild` -- queued a copy
+// and two setup launches here, each 3-4 us long and 5 us behind the one before it.
+__global__ __launch_bounds__(256) void frame_prologue_kernel(RasterPrologue a) {
+    const uint32_t b = blockIdx.x;
+    if (b < a.copyBlocks) {
+        const uint32_t k = b * 256 + threadIdx.x;
+        if (k < a.copyWords) static_cast<uint4 *>(a.copyDst)[k] = static_cast<const uint4 *>(a.copySrc)[k];
+        return;
+    }
+#pragma unroll 1
+    for (uint32_t l = 0; l < a.listCount; l++) {
+        const RasterPrologueList &L = a.list[l];
+        const uint32_t blocks = L.triTotal ? (L.triTotal + 255) / 256 : 1u;
+        if (b < L.firstBlock || b >= L.firstBlock + blocks) continue;
+        if (b == L.firstBlock) {
+            const uint32_t words = L.instanceCount * (uint32_t)(sizeof(GpuRasterInstance) / 4);
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(L.inst);
+            for (uint32_t k = threadIdx.x; k < words; k += 256) reinterpret_cast<uint32_t *>(L.deviceTable)[k] = src[k];
+        }
+        raster_setup_triangle(L.inst, L.instanceCount, L.triTotal, static_cast<RasterTri *>(L.tris), L.w, L.h, L.y0, L.y1, L.apply, (b - L.firstBlock) * 256 + threadIdx.x);
+        return;
+    }
 }
 
 __global__ __launch_bounds__(256) void raster_draw_kernel(const GpuRasterInstance *__restrict__ instances, const RasterTri *__restrict__ tris, uint32_t triTotal,
-                                                          const GpuTexture *__restrict__ textures, uint8_t *target, int w, int y0, int y1, int gx0, int gy0, int stripRank, int stripCount) {
+                                                          const GpuTexture *__restrict__ textures, uint8_t *target, int w, int y0, int y1, int gx0, int gy0, int stripRank, int stripCount, int clear) {
     const int bx = (int)blockIdx.x + gx0, by = (int)blockIdx.y + gy0;
     const int x = bx * 32 + (threadIdx.x & 31), y = y0 + by * 8 + (threadIdx.x >> 5);
     const bool inside = x < w && y < y1 && (((y - y0) / 16) % stripCount) == stripRank;
     // wave-uniform pixel rectangle of this wave: 32 x 2
     const int wx0 = bx * 32, wx1 = wx0 + 31, wy0 = __builtin_amdgcn_readfirstlane(y0 + by * 8 + (int)((threadIdx.x >> 6) * 2)), wy1 = wy0 + 1;
-    uint32_t dstBits = 0; bool loaded = false, dirty = false;
+    // clear: the target starts as 0 (gBackground, rt64_view.cpp:1298-1319) -- the launch then covers the whole target and every pixel is stored, covered or not
+    uint32_t dstBits = 0; bool loaded = clear != 0, dirty = clear != 0 && inside;
     const size_t i = (size_t)y * (size_t)w + (size_t)x;
     raster_blend_pixel(instances, tris, triTotal, textures, x, y, inside, wx0, wx1, wy0, wy1, reinterpret_cast<const uint32_t *>(target) + i, dstBits, loaded, dirty);
     if (dirty) reinterpret_cast<uint32_t *>(target)[i] = dstBits;
@@ -203,11 +229,28 @@ hipError_t launch_raster_setup_inline(const GpuRasterInstance *hostTable, GpuRas
 }
 
 hipError_t launch_raster_draw(const GpuRasterInstance *instances, const void *tris, uint32_t triTotal, const GpuTexture *textures, uint8_t *target,
-                              int w, int y0, int y1, const int bounds[4], int stripRank, int stripCount, hipStream_t s) {
-    // grid over the list's bounding rectangle, aligned to the 32 x 8 block shape (rows relative to y0 keep the strip arithmetic)
+                              int w, int y0, int y1, const int bounds[4], int stripRank, int stripCount, bool clear, hipStream_t s) {
+    // grid over the list's bounding rectangle, aligned to the 32 x 8 block shape (rows relative to y0 keep the strip arithmetic); the whole target when it is cleared as well
+    const int whole[4] = { 0, y0, w, y1 };
+    if (clear) bounds = whole;
     const int gx0 = bounds[0] / 32, gx1 = (bounds[2] + 31) / 32, gy0 = (std::max(bounds[1], y0) - y0) / 8, gy1 = (std::min(bounds[3], y1) - y0 + 7) / 8;
-    if (triTotal == 0 || gx1 <= gx0 || gy1 <= gy0) return hipSuccess;
+    if ((triTotal == 0 && !clear) || gx1 <= gx0 || gy1 <= gy0) return hipSuccess;
     hipLaunchKernelGGL(raster_draw_kernel, dim3((unsigned)(gx1 - gx0), (unsigned)(gy1 - gy0)), dim3(256), 0, s, instances, static_cast<const RasterTri *>(tris), triTotal, textures,
-                       target, w, y0, y1, gx0, gy0, stripRank, stripCount);
+                       target, w, y0, y1, gx0, gy0, stripRank, stripCount, clear ? 1 : 0);
+    return hipGetLastError();
+}
+
+bool frame_prologue_takes(const RasterPrologue &a) {
+    if (a.listCount > RASTER_PROLOGUE_LISTS || a.copyWords > RASTER_PROLOGUE_COPY_WORDS) return false;
+    for (uint32_t l = 0; l < a.listCount; l++) if (a.list[l].instanceCount < 1 || a.list[l].instanceCount > RASTER_PROLOGUE_INSTANCES) return false;
+    return a.listCount != 0 || a.copyWords != 0;
+}
+// `a`: copySrc / copyDst / copyWords and the lists filled in by the caller; the workgroup ranges are assigned here
+hipError_t launch_frame_prologue(RasterPrologue &a, hipStream_t s) {
+    if (!frame_prologue_takes(a)) return hipErrorInvalidValue;
+    a.copyBlocks = (a.copyWords + 255) / 256;
+    uint32_t blocks = a.copyBlocks;
+    for (uint32_t l = 0; l < a.listCount; l++) { a.list[l].firstBlock = blocks; blocks += a.list[l].triTotal ? (a.list[l].triTotal + 255) / 256 : 1u; }
+    hipLaunchKernelGGL(frame_prologue_kernel, dim3(blocks), dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -142,6 +142,7 @@ struct Options {
     bool countTraversal = false, profilePasses = true, syncPresent = true, alwaysRebuild = false, leanFrames = true, fusedLean = true, foldForeground = true;
     int profileEvery = 1;         // with profile_passes: record the pass events on every n-th frame only (sampled timings; accumFrames counts the sampled frames)
     bool leanRecords = false;     // 1: the one-kernel lean frame also stores the hit records and the direct-light image (otherwise View::materialise re-traces them on demand)
+    bool framePrologue = true;    // a frame with changed tables queues its table upload and the setup of its short raster lists as ONE launch (frame_prologue_kernel), and clears gBackground inside the draw that fills it
     bool hostTlas = true;         // the TLAS of up to RT64_HOST_TLAS_MAX instances is built on the host and travels in the table upload (0: always the GPU builder)
     bool simpleKernels = true;    // frames whose textures are all power-of-two sized and whose instances are all shadow-opaque run the kernels of passes_simple.hip
     bool ldsCache = true;         // small scenes: BVH nodes + instance records cached in LDS by the ray kernels (0: always walk from HBM/L2)
@@ -391,7 +392,12 @@ struct View {
     RasterList rasterBgEnv, rasterBgScreen, rasterFgScreen;             // bg -> gBackground (no scissors), bg -> back buffer, fg -> back buffer
     DevArray<uint8_t> background; int backgroundW = 0, backgroundH = 0;
     void prepareRasterList(const std::vector<RenderInstance> &list, RasterList &rl, int w, int h, int y0, int y1, bool apply);
-    void drawRasterList(RasterList &rl, uint8_t *target);
+    void drawRasterList(RasterList &rl, uint8_t *target, bool clear = false);
+    // What View::update has decided to put on the stream but not queued yet: the table upload and the setup of short lists leave as one launch (flushPrologue);
+    // whatever else needs the uploaded tables first (a TLAS built by kernels, the scene-cache image, a materialise) calls flushTableCopy and gets the plain copy.
+    RasterPrologue prologue = {}; size_t prologueCopyBytes = 0;
+    void flushTableCopy();
+    void flushPrologue();
     std::vector<Texture *> usedTextures;
     // The frame tables live in ONE device allocation in their staging order (instances | textures | lights) so that a changed
     // frame costs one host-to-device copy (each copy packet is ~10 us of stream time, whatever its size).
@@ -921,14 +927,36 @@ void View::prepareRasterList(const std::vector<RenderInstance> &list, RasterList
     rl.triTotal = triTotal; rl.w = w; rl.h = h; rl.y0 = y0; rl.y1 = y1; rl.apply = apply; rl.ready = true; rl.changed = true;
     rl.bounds[0] = std::max(0, (int)std::floor(std::min(bx0, 1e9f)) - 1); rl.bounds[1] = std::max(y0, (int)std::floor(std::min(by0, 1e9f)) - 1);
     rl.bounds[2] = std::min(w, (int)std::ceil(std::max(bx1, -1e9f)) + 2); rl.bounds[3] = std::min(y1, (int)std::ceil(std::max(by1, -1e9f)) + 2);
-    if (inlineTable) HIP_CHECK(launch_raster_setup_inline(hst.data(), rl.table.ptr, (uint32_t)hst.size(), triTotal, rl.tris.ptr, w, h, y0, y1, apply, dev->stream));
+    if (inlineTable && dev->opt.framePrologue && hst.size() <= RASTER_PROLOGUE_INSTANCES && prologue.listCount < RASTER_PROLOGUE_LISTS) {       // leaves with the frame's other uploads (flushPrologue)
+        RasterPrologueList &L = prologue.list[prologue.listCount++];
+        memset(&L, 0, sizeof(L));
+        memcpy(L.inst, hst.data(), bytes);
+        L.deviceTable = rl.table.ptr; L.tris = rl.tris.ptr; L.instanceCount = (uint32_t)hst.size(); L.triTotal = triTotal; L.w = w; L.h = h; L.y0 = y0; L.y1 = y1; L.apply = apply ? 1 : 0;
+    }
+    else if (inlineTable) HIP_CHECK(launch_raster_setup_inline(hst.data(), rl.table.ptr, (uint32_t)hst.size(), triTotal, rl.tris.ptr, w, h, y0, y1, apply, dev->stream));
     else HIP_CHECK(launch_raster_setup(rl.table.ptr, (uint32_t)hst.size(), triTotal, rl.tris.ptr, w, h, y0, y1, apply, dev->stream));
 }
 
-void View::drawRasterList(RasterList &rl, uint8_t *target) {
+void View::flushTableCopy() {
+    if (!prologueCopyBytes) return;
+    HIP_CHECK(hipMemcpyAsync(prologue.copyDst, prologue.copySrc, prologueCopyBytes, hipMemcpyHostToDevice, scene->device->stream));
+    prologueCopyBytes = 0; prologue.copySrc = nullptr; prologue.copyDst = nullptr;
+}
+void View::flushPrologue() {
+    Device *dev = scene->device;
+    if (prologue.listCount == 0) { flushTableCopy(); return; }        // tables alone: the runtime's own copy (measured equal: moving_instance 0.1685 ms either way)
+    prologue.copyWords = (uint32_t)((prologueCopyBytes + 15) / 16);
+    if (prologueCopyBytes > (size_t)RASTER_PROLOGUE_COPY_WORDS * 16) { flushTableCopy(); prologue.copyWords = 0; }
+    HIP_CHECK(launch_frame_prologue(prologue, dev->stream));
+    prologueCopyBytes = 0;
+    memset(&prologue, 0, sizeof(prologue));
+    dev->workSinceMark = true;
+}
+
+void View::drawRasterList(RasterList &rl, uint8_t *target, bool clear) {
     if (!rl.ready || rl.triTotal == 0) return;
     Device *dev = scene->device;
-    HIP_CHECK(launch_raster_draw(rl.table.ptr, rl.tris.ptr, rl.triTotal, tab[tabCur].dTextures.ptr, target, rl.w, rl.y0, rl.y1, rl.bounds, dev->stripRank, dev->stripCount, dev->stream));
+    HIP_CHECK(launch_raster_draw(rl.table.ptr, rl.tris.ptr, rl.triTotal, tab[tabCur].dTextures.ptr, target, rl.w, rl.y0, rl.y1, rl.bounds, dev->stripRank, dev->stripCount, clear, dev->stream));
     dev->workSinceMark = true;
 }
 
@@ -1014,6 +1042,7 @@ static void host_build_tlas(const GpuInstance *inst, const float (*meshMin)[3], 
 
 void View::update() {                          // View::update, rt64_view.cpp:1053-1178
     Device *dev = scene->device;
+    memset(&prologue, 0, sizeof(prologue)); prologueCopyBytes = 0;       // (nothing is left from a frame that threw half-way)
     {   // View::createOutputBuffers: render size = lround(screen * resolutionScale) (rt64_view.cpp:138-139)
         const float scale = resolutionScale > 0.0f ? resolutionScale : 1.0f;
         int rw = std::max(1, (int)lroundf((float)dev->width * scale)), rh = std::max(1, (int)lroundf((float)dev->height * scale));
@@ -1158,7 +1187,8 @@ void View::update() {                          // View::update, rt64_view.cpp:10
         const size_t uploadBytes = hostTlas ? (hostCache ? cacheAt + headWords * 16 : tlasAt + nodeBytes + sizeof(BlasHeader) + 2 * sizeof(uint32_t) * n) : tableBytes;
         {
             const size_t need = std::max<size_t>(hostCache ? cacheAt + (size_t)cacheWords * 16 : uploadBytes, 4096);
-            if (need > tab[tabCur].dTables.count || (n && !hostTlas)) dev->impure();       // a slot that has to grow is freed and allocated again; a TLAS of more than 64 instances is built by kernels whose scratch is not per slot
+            if (need > tab[tabCur].dTables.count || (n && !hostTlas)) dev->impure();
+            // (the prologue kernel copies whole 16-byte words: the ring rounds its regions to 256 bytes, and `need` is a multiple of 16 or 4096)       // a slot that has to grow is freed and allocated again; a TLAS of more than 64 instances is built by kernels whose scratch is not per slot
             tab[tabCur].dTables.reserve(need);
         }
         tab[tabCur].dInstances.ptr = reinterpret_cast<GpuInstance *>(tab[tabCur].dTables.ptr); tab[tabCur].dTextures.ptr = reinterpret_cast<GpuTexture *>(tab[tabCur].dTables.ptr + instBytes);
@@ -1197,9 +1227,10 @@ void View::update() {                          // View::update, rt64_view.cpp:10
                 tab[tabCur].tlasNodesAt = reinterpret_cast<const GpuNode *>(base); tab[tabCur].tlasHeaderAt = reinterpret_cast<const BlasHeader *>(base + nodeBytes);
                 tab[tabCur].tlasIndexAt = reinterpret_cast<const uint32_t *>(tab[tabCur].tlasHeaderAt + 1); tab[tabCur].tlasMortonAt = tab[tabCur].tlasIndexAt + n;
             }
-            HIP_CHECK(hipMemcpyAsync(tab[tabCur].dTables.ptr, pinnedStage, uploadBytes, hipMemcpyHostToDevice, dev->stream));
+            prologue.copySrc = pinnedStage; prologue.copyDst = tab[tabCur].dTables.ptr; prologueCopyBytes = uploadBytes;       // queued by flushPrologue / flushTableCopy
         }
         if (n && !hostTlas) {
+            flushTableCopy();
             tab[tabCur].tlasNodes.reserve(std::max<size_t>(n - 1, 1)); tab[tabCur].tlasIndex.reserve(n); tab[tabCur].tlasMorton.reserve(n); tab[tabCur].tlasLeafParent.reserve(n); tab[tabCur].tlasHeader.reserve(1);
             LbvhArgs a = {};
             a.mode = LBVH_MODE_INSTANCES; a.refit = 0; a.n = n; a.instances = tab[tabCur].dInstances.ptr;
@@ -1216,6 +1247,7 @@ void View::update() {                          // View::update, rt64_view.cpp:10
             key.push_back(reinterpret_cast<uint64_t>(tab[tabCur].cacheImageAt)); key.push_back(cacheWords);
             for (uint32_t i = 0; i < n; i++) { key.push_back(reinterpret_cast<uint64_t>(hInst[i].nodes)); key.push_back(hInst[i].meshVersion); key.push_back(hInst[i].cacheNodeOffset); key.push_back(hInst[i].triCount); }
             if (key != tab[tabCur].cacheBlasKey) {
+                flushTableCopy();
                 HIP_CHECK(launch_scene_cache_image(tab[tabCur].dInstances.ptr, tab[tabCur].tlasIndexAt, tab[tabCur].tlasNodesAt, n, const_cast<uint8_t *>(tab[tabCur].cacheImageAt), true, dev->stream));
                 tab[tabCur].cacheBlasKey.swap(key);
             }
@@ -1227,6 +1259,7 @@ void View::update() {                          // View::update, rt64_view.cpp:10
     }
     if (cacheWords && !tab[tabCur].cacheImageValid) {
         dev->impure();
+        flushTableCopy();
         tab[tabCur].cacheImage.reserve((size_t)cacheWords * 16);
         HIP_CHECK(launch_scene_cache_image(tab[tabCur].dInstances.ptr, tab[tabCur].tlasIndexAt, tab[tabCur].tlasNodesAt, (uint32_t)nInst, tab[tabCur].cacheImage.ptr, false, dev->stream));
         tab[tabCur].cacheImageAt = tab[tabCur].cacheImage.ptr; tab[tabCur].cacheImageValid = true;
@@ -1238,13 +1271,15 @@ void View::update() {                          // View::update, rt64_view.cpp:10
         prepareRasterList(rasterBg, rasterBgEnv, finalW, finalH, 0, finalH, false);               // gBackground: every rank needs all of it (env-map lookups)
         prepareRasterList((rtInstances.empty() || rtRect) ? rasterBg : std::vector<RenderInstance>(), rasterBgScreen, finalW, finalH, sy0, sy1, true);
         prepareRasterList(rasterFg, rasterFgScreen, finalW, finalH, sy0, sy1, true);
+        flushPrologue();
         if (!rasterBg.empty() && (backgroundW != finalW || backgroundH != finalH)) { background.reserve((size_t)finalW * finalH * 4); backgroundW = finalW; backgroundH = finalH; rasterBgEnv.changed = true; }      // (a resize has dropped every kept frame: View::createImages)
         if (leanFrame && (rasterBgEnv.contentChanged || (!rasterBgEnv.ready && lastParams.background.texels))) { materialise(); dev->leanHoldoff = RT64_LEAN_HOLDOFF_FRAMES; }      // the kept frame's sky pixels read gBackground
         if (rasterBgEnv.ready && rasterBgEnv.changed) {        // gBackground: cleared to 0, drawn without scissors / viewports (rt64_view.cpp:1298-1319)
             dev->impure();
-            HIP_CHECK(hipMemsetAsync(background.ptr, 0, (size_t)finalW * finalH * 4, dev->stream));
+            const bool clearInDraw = dev->opt.framePrologue && rasterBgEnv.triTotal != 0;
+            if (!clearInDraw) HIP_CHECK(hipMemsetAsync(background.ptr, 0, (size_t)finalW * finalH * 4, dev->stream));
             const int sr = dev->stripRank, sc = dev->stripCount; dev->stripRank = 0; dev->stripCount = 1;
-            drawRasterList(rasterBgEnv, background.ptr);
+            drawRasterList(rasterBgEnv, background.ptr, clearInDraw);
             dev->stripRank = sr; dev->stripCount = sc;
         }
     }
@@ -1997,6 +2032,7 @@ RT64_EXPORT int RT64_SetDeviceOption(RT64_DEVICE *device, const char *key, doubl
     else if (k == "lds_cache") d->opt.ldsCache = value != 0.0;
     else if (k == "lean_records") d->opt.leanRecords = value != 0.0;
     else if (k == "host_tlas") d->opt.hostTlas = value != 0.0;
+    else if (k == "frame_prologue") d->opt.framePrologue = value != 0.0;
     else if (k == "simple_kernels") d->opt.simpleKernels = value != 0.0;       // 0: every frame runs the general kernels (A/B tests)
     else if (k == "reset_accum") { d->finishStats(); d->accum = RT64_FRAME_STATS(); }
     else if (k == "fold_foreground") d->opt.foldForeground = value != 0.0;        // 0: the foreground (HUD) list keeps its own raster_draw launch after a one-kernel frame

@@ -199,3 +199,42 @@ def test_homogeneous_clipping_of_triangles_that_cross_w_zero_the_depth_range_and
         assert d.max() <= 2 and (d > 1).mean() < 1e-3, (int(d.max()), float((d > 1).mean()))
         finals.append(got["FINAL_RGBA8"])
     assert np.array_equal(finals[0], finals[1])
+
+
+@pytest.mark.parametrize("many", [0, 1])
+def test_frame_prologue_in_one_launch_equals_the_separate_copy_setups_and_clear(rt64_lib, sample_data, many):
+    """frame_prologue (default 1): the table upload and the setup of the short raster lists leave as one launch, and gBackground is cleared by the draw
+    that fills it.  The same host calls with frame_prologue = 0 (copy, one setup launch per list, memset, draw) give the same back buffer and the
+    same gBackground byte for byte -- with the lists re-staged every frame (always_rebuild, the reference's behaviour), with a background list, a
+    foreground list that is clipped, and (many = 1) a foreground list too long for the launch's arguments, which keeps its own setup launch."""
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+
+    def mod(d):
+        d.meshes.append(_hud_mesh(sample_scene, rt64, [[(-1.0, -0.2), (1.0, -0.1), (0.0, 1.0)], [(-1.0, 1.0), (-1.0, 0.2), (0.2, 1.0)]], alpha=0.9))
+        i = copy.copy(d.instances[0]); i.mesh = len(d.meshes) - 1; i.material = sample_scene.copy_material(d.instances[0].material); i.name = "bg2"
+        i.flags = rt64.INSTANCE_RASTER_BACKGROUND
+        d.instances.append(i)
+        m = _hud_mesh(sample_scene, rt64, [[(0, 0)] * 3] * 2, alpha=0.7)
+        for k, p in enumerate([(-0.8, -0.6, 0.2, 1.0), (0.9, -0.7, 0.2, 1.0), (0.1, 0.4, 0.5, -0.5), (-0.2, -0.2, 0.5, 1.0), (0.3, -0.2, 0.5, 1.0), (0.0, 0.3, 0.5, 1.0)]):
+            m.vertices["position"][k] = p
+        d.meshes.append(m)
+        for n in range(10 if many else 1):
+            i = copy.copy(d.instances[0]); i.mesh = len(d.meshes) - 1; i.material = sample_scene.copy_material(d.instances[0].material); i.name = "fg%d" % n
+            d.instances.append(i)
+    data = _variant(sample_data, mod)
+    out = {}
+    for pro in (1, 0):
+        s = sample_scene.Rt64Scene(rt64_lib, data, 272, 150, hip_device=0)
+        try:
+            assert s.option("frame_prologue", pro)
+            s.option("always_rebuild", 1)
+            frames = []
+            for f in range(4):
+                s.draw()
+                frames.append((s.readback(rt64.IMAGE_FINAL_RGBA8).copy(), s.readback(rt64.IMAGE_BACKGROUND).copy()))
+            out[pro] = frames
+        finally:
+            s.close()
+    for (fa, ba), (fb, bb) in zip(out[1], out[0]):
+        assert np.array_equal(fa, fb) and np.array_equal(ba, bb)
+    assert (out[1][-1][1][..., 3] > 0).sum() > 100 and (out[1][-1][1][..., 3] == 0).sum() > 100        # gBackground: drawn where the list covers it, cleared elsewhere
