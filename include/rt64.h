@@ -366,7 +366,10 @@ RT64_INLINE void RT64_UnloadLibrary(RT64_LIBRARY lib) {   /* ref:404-406 */
  * ============================================================================================ */
 
 /* Images that RT64_ReadbackDevice / RT64_CopyDeviceImage can return.  Element type in brackets.
- * 0 is the presented frame; 1..16 follow the reference's debug view order (GlobalParams.hlsli:45-61). */
+ * 0 is the presented frame; 1..16 follow the reference's debug view order (GlobalParams.hlsli:45-61).
+ * Both calls return the rows of the LAST RENDERED frame -- the tile / strip partition that frame was drawn with (RT64_FRAME_STATS
+ * tileY0 / tileY1 / stripRank / stripCount / rowsRendered), packed in ascending row order -- whatever RT64_SetDeviceTile /
+ * RT64_SetDeviceInterleave / RT64_SetGatherBands have set for the next one. */
 enum {
     RT64_IMAGE_FINAL_RGBA8 = 0,        /* [u8 x4]  back buffer after PostProcessPS                  */
     RT64_IMAGE_SHADING_POSITION = 1,   /* [f32 x4] */

@@ -211,6 +211,8 @@ struct Device {
     int width = 0, height = 0, pendingWidth = 0, pendingHeight = 0;
     int tileY0 = 0, tileY1 = 0; bool tileSet = false;
     int stripRank = 0, stripCount = 1;
+    // The partition the LAST frame was rendered with: what a readback describes (a host may set another partition and read the frame it already has before it draws the next).
+    struct DrawnPartition { int tileY0 = 0, tileY1 = 0, stripRank = 0, stripCount = 1; bool valid = false; } drawn;
     std::vector<Scene *> scenes;
     Options opt;
     RT64_FRAME_STATS stats = {}, accum = {}; bool statsPending = false, statsHaveView = false;
@@ -1699,6 +1701,7 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
     // the sub-frame accumulation are one per device: frames that use them stay in order.
     const bool mayOverlap = opt.overlapFrames && streamCount > 1 && !opt.syncPresent && !opt.countTraversal && !opt.tileTiming && opt.primarySpp <= 1;
     const bool flipped = mayOverlap && lastFramePure;
+    const int curBefore = cur;
     if (flipped) switchStream();
     framePure = mayOverlap; lastFramePure = false;       // (a frame that ends in an exception leaves "not pure" behind)
     if (frameWait) { HIP_CHECK(hipStreamWaitEvent(stream, frameWait, 0)); frameWait = nullptr; }
@@ -1707,10 +1710,11 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
     // pass events on every profile_every-th frame only: each event is a barrier packet (~5 us of stream time; six of them are 5 % of a 0.6 ms GI frame)
     profNow = opt.profilePasses && (opt.profileEvery <= 1 || profCounter++ % (unsigned)opt.profileEvery == 0);
     if (profNow) beginEventSet(0);
-    auto tu0 = std::chrono::steady_clock::now();
+    auto tu0 = std::chrono::steady_clock::now(), tu1 = tu0;
+    try {
     flushMeshBuilds();
     for (Scene *sc : scenes) for (View *v : sc->views) v->update();
-    auto tu1 = std::chrono::steady_clock::now();
+    tu1 = std::chrono::steady_clock::now();
     for (Scene *sc : scenes) for (View *v : sc->views) {
         // extension primary_spp = N: N complete sub-frames -- every pass up to Compose, history and frame count advancing after each -- with jittered primary rays;
         // the mean of their composed outputs is the frame (rules P1-P4 at oracle_render, oracle/oracle_render.c)
@@ -1722,6 +1726,16 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
         }
         evSubFrames = v->subFrames; evSetsUsed = std::min(v->subFrames, (int)EV_SETS);
         v->subFrame = 0;
+    }
+    }
+    catch (...) {
+        // A frame the library refuses (or that fails half-way): the device keeps showing the last complete frame -- its stream and its back-buffer slot are current
+        // again -- and whatever the failed frame has enqueued stays in order in front of everything that follows.
+        if (cur != curBefore) { streamBusy[cur] = true; cur = curBefore; stream = streams[cur]; }
+        try { joinStreams(); noteOrderedWork(); } catch (...) {}
+        lastFramePure = false;
+        for (Scene *sc : scenes) for (View *v : sc->views) v->img.final = finalOverride ? finalOverride : v->finalBuf[cur];
+        throw;
     }
     if (leanHoldoff) leanHoldoff--;
     lastFramePure = framePure;
@@ -1746,6 +1760,7 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
     st.screenWidth = (unsigned)width; st.screenHeight = (unsigned)height;
     st.msHostWall = std::chrono::duration<float, std::milli>(t1 - t0).count();
     st.stripRank = (unsigned)stripRank; st.stripCount = (unsigned)stripCount; st.rowsRendered = (unsigned)ownedRows();
+    drawn.tileY0 = tileY0; drawn.tileY1 = tileY1; drawn.stripRank = stripRank; drawn.stripCount = stripCount; drawn.valid = true;
     st.overlappedFrame = (flipped && framePure) ? 1u : 0u;
     bool haveView = false;
     for (Scene *sc : scenes) for (View *v : sc->views) {
@@ -1867,6 +1882,14 @@ static View *first_view(Device *dev) { for (Scene *sc : dev->scenes) for (View *
 
 static size_t readback(Device *dev, int image, void *dst, size_t dstBytes, bool toDevice) {
     dev->enter();
+    // rows and layout are those of the frame that was rendered, whatever partition has been set since (restored on every way out)
+    struct PartitionOfTheFrame {
+        Device *d; int y0, y1, sr, sc;
+        explicit PartitionOfTheFrame(Device *dev_) : d(dev_), y0(dev_->tileY0), y1(dev_->tileY1), sr(dev_->stripRank), sc(dev_->stripCount) {
+            if (d->drawn.valid) { d->tileY0 = d->drawn.tileY0; d->tileY1 = d->drawn.tileY1; d->stripRank = d->drawn.stripRank; d->stripCount = d->drawn.stripCount; }
+        }
+        ~PartitionOfTheFrame() { d->tileY0 = y0; d->tileY1 = y1; d->stripRank = sr; d->stripCount = sc; }
+    } frameRows(dev);
     View *v = first_view(dev);
     if (!v) throw std::runtime_error("RT64_ReadbackDevice: the device has no view.");
     if (image == RT64_IMAGE_BACKGROUND) {        // gBackground: whole screen on every device; zeros when the frame had no background instance
