@@ -275,3 +275,71 @@ def test_direct_gather_stores_into_another_process_through_ipc(rt64_lib, sample_
             s.close()
         if owner.poll() is None:
             owner.kill()
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_random_gather_sessions_return_the_frames_the_device_drew(rt64_lib, sample_data, seed):
+    """A random session of what a rank does around the gather -- enqueued frames + submits, bursts, camera and instance moves, switching between the exchange of the rows
+    and the direct gather, sync_present flips, tables re-staged every frame -- on the one rank a test box has: every gathered frame that is read back (the latest slot, and in
+    direct mode one of the last three) is byte for byte the frame the device drew for that submit."""
+    import copy, random
+    from sm64rt_legacy_renderer_amd import rt64, sample_scene
+    W, H = 320, 180
+    rng = random.Random(seed)
+    s = sample_scene.Rt64Scene(rt64_lib, sample_data, W, H, hip_device=0)
+    try:
+        uid = (C.c_uint8 * rt64.GATHER_ID_BYTES)()
+        assert rt64_lib.GetGatherUniqueId(uid, len(uid)) == 1, rt64_lib.last_error()
+        g = rt64_lib.CreateGather(s.device, uid, len(uid), 0, 1, 0)
+        assert g, rt64_lib.last_error()
+        handle = (C.c_uint8 * 64)()
+        assert rt64_lib.GetGatherDirectHandle(g, handle, 64) == 64, rt64_lib.last_error()
+        direct = False
+        history = []                                   # (slot, frame the device drew) of the submits, newest last
+        checked = 0
+
+        def submit():
+            s.draw()
+            slot = rt64_lib.SubmitGather(g)
+            assert slot >= 0, rt64_lib.last_error()
+            history.append((slot, s.readback(rt64.IMAGE_FINAL_RGBA8).copy()))
+            del history[:-3]
+        for _ in range(60):
+            op = rng.choice(["submit", "submit", "submit", "burst", "camera", "move", "direct", "sync", "rebuild", "check", "check"])
+            if op == "submit":
+                submit()
+            elif op == "burst":
+                for _ in range(rng.randint(2, 7)):
+                    d = copy.copy(s.data); v = np.array(d.view, dtype=np.float32).copy(); v[3][0] += 0.07; d.view = v; s.data = d
+                    s.draw(); slot = rt64_lib.SubmitGather(g); assert slot >= 0
+                history.clear(); history.append((slot, s.readback(rt64.IMAGE_FINAL_RGBA8).copy()))
+            elif op == "camera":
+                d = copy.copy(s.data); v = np.array(d.view, dtype=np.float32).copy(); v[3][0] += rng.uniform(-0.3, 0.3); v[3][1] += rng.uniform(-0.2, 0.2); d.view = v; s.data = d
+            elif op == "move":
+                d = copy.copy(s.data); d.instances = [copy.copy(i) for i in d.instances]
+                k = rng.choice([i for i, inst in enumerate(d.instances) if inst.name in ("sphere", "floor")])
+                t = np.array(d.instances[k].transform, dtype=np.float32).copy(); t[3][1] += rng.uniform(-0.2, 0.2)
+                d.instances[k].previous_transform = d.instances[k].transform; d.instances[k].transform = t
+                s.data = d; s.set_instance(k, d.instances[k])
+            elif op == "direct":
+                direct = not direct
+                assert rt64_lib.SetGatherDirect(g, handle if direct else None, 64 if direct else 0, 1 if direct else 0) == 1, rt64_lib.last_error()
+                history.clear()                        # (the slots of the other mode are gone)
+            elif op == "sync":
+                s.option("sync_present", rng.choice([0, 1]))
+            elif op == "rebuild":
+                s.option("always_rebuild", rng.choice([0, 1]))
+            elif op == "check" and history:
+                slot, frame = history[-1] if not direct else rng.choice(history)
+                buf = np.zeros((H, W, 4), dtype=np.uint8)
+                assert rt64_lib.ReadbackGather(g, slot, buf.ctypes.data, buf.nbytes, 0) == buf.nbytes, rt64_lib.last_error()
+                assert np.array_equal(buf, frame), (seed, slot, direct)
+                checked += 1
+        submit()
+        slot, frame = history[-1]
+        buf = np.zeros((H, W, 4), dtype=np.uint8)
+        assert rt64_lib.ReadbackGather(g, slot, buf.ctypes.data, buf.nbytes, 0) == buf.nbytes and np.array_equal(buf, frame)
+        assert checked >= 1
+        rt64_lib.DestroyGather(g)
+    finally:
+        s.close()
