@@ -139,9 +139,9 @@ def _random_session(rt64_lib, sample_data, overlap, seed, ops=45, log=None):
     out = []
     try:
         assert s.option("overlap_frames", overlap)
-        frame = 0; gi = 0
+        frame = 0; gi = 0; scale = 1.0
         for _ in range(ops):
-            op = rng.choice(["draw", "draw", "draw", "draw", "burst", "camera", "move", "mesh", "gi", "sync", "read", "read_gbuffer", "pick", "lds", "rebuild", "hud", "strips", "prologue"])
+            op = rng.choice(["draw", "draw", "draw", "draw", "burst", "camera", "move", "mesh", "gi", "sync", "read", "read_gbuffer", "pick", "lds", "rebuild", "hud", "strips", "prologue", "light", "resize", "scale", "texture"])
             if log is not None:
                 log.append((op, frame))
             if op == "draw":
@@ -162,7 +162,7 @@ def _random_session(rt64_lib, sample_data, overlap, seed, ops=45, log=None):
                 v = data.meshes[0].vertices.copy(); v["position"][:, :3] *= np.float32(1.0 + rng.uniform(-0.02, 0.02))
                 s.set_mesh(s.meshes[0], v, data.meshes[0].indices)
             elif op == "gi":
-                gi = rng.choice([0, 1]); s.set_view_description(gi_samples=gi, denoiser=bool(gi))
+                gi = rng.choice([0, 1]); s.set_view_description(gi_samples=gi, denoiser=bool(gi), resolution_scale=scale)
                 if gi: s.set_interleave(0, 1)                                  # (a frame that filters across rows is not cut into strips: the library refuses it)
             elif op == "sync":
                 s.option("sync_present", rng.choice([0, 1]))
@@ -177,7 +177,19 @@ def _random_session(rt64_lib, sample_data, overlap, seed, ops=45, log=None):
                 k = rng.choice([i for i, inst in enumerate(d.instances) if inst.name.startswith("hud")])
                 d.instances[k].scissor = rng.choice([None, (rng.randint(0, W // 2), rng.randint(0, H // 2), rng.randint(8, W // 2), rng.randint(8, H // 2))])
                 s.data = d; s.set_instance(k, d.instances[k])
-            elif op == "strips" and not gi:
+            elif op == "light":                                                # the light table changes (same bytes for both sessions)
+                s._lights[0].position.y = s._lights[0].position.y + rng.uniform(-0.3, 0.3); s._lights[0].diffuseColor.x = rng.uniform(0.4, 1.0)
+            elif op == "resize":                                               # RT64_SetDeviceSize: takes effect at the next frame, every image is created again
+                w, h = rng.choice([(W, H), (272, 150), (200, 112)]); rt64_lib.SetDeviceSize(s.device, w, h); s.set_interleave(0, 1)
+            elif op == "scale":
+                scale = rng.choice([1.0, 1.0, 0.5]); s.set_view_description(gi_samples=gi, denoiser=bool(gi), resolution_scale=scale)
+                if scale != 1.0: s.set_interleave(0, 1)
+            elif op == "texture":                                              # the sphere / floor takes another diffuse texture of the scene: the texture slots of the frame change
+                d = copy.copy(s.data); d.instances = [copy.copy(i) for i in d.instances]
+                k = rng.choice([i for i, inst in enumerate(d.instances) if inst.name in ("sphere", "floor")])
+                d.instances[k].diffuse = rng.choice([t for t in range(len(d.textures)) if t != d.sky])
+                s.data = d; s.set_instance(k, d.instances[k])
+            elif op == "strips" and not gi and scale == 1.0:
                 n = rng.choice([1, 2, 3]); s.set_interleave(rng.randrange(n), n)
             elif frame and op == "read":
                 out.append(("final", frame, s.readback(rt64.IMAGE_FINAL_RGBA8).copy()))
