@@ -24,7 +24,7 @@ def _rot_y(a):
 
 
 def random_scene(sample_data, seed, without=()):
-    """-> (scene data, view description kwargs, what the generator chose); `without`: features left at their defaults (diagnosis: "groups", "depth_bias")"""
+    """-> (scene data, view description kwargs, what the generator chose, per-frame callback for _render_pair); `without`: features left at their defaults (diagnosis: "groups", "depth_bias", "shapes", "motion")"""
     from sm64rt_legacy_renderer_amd import rt64, sample_scene
     rng = random.Random(seed)
     chosen = {}
@@ -118,7 +118,25 @@ def random_scene(sample_data, seed, without=()):
     gi = rng.choice([0, 0, 1])
     view = dict(gi_samples=gi, denoiser=bool(gi and rng.random() < 0.7), max_lights=rng.choice([12, 2]))
     chosen.update(gi=gi, denoiser=view["denoiser"], lights=len(data.lights), instances=len(data.instances), max_lights=view["max_lights"])
-    return data, view, chosen
+    # Motion (frames with history only): the camera drifts and one instance moves between the frames, so the temporal reprojection (IndirectRayGen.hlsl:43-56), the
+    # flow image and the history lengths have something to do; RT64_SetInstanceDescription carries the previous transform like a host's would.
+    chosen["motion"] = bool(gi and "motion" not in without and rng.random() < 0.6)
+    steps = [(rng.uniform(-0.25, 0.25), rng.uniform(-0.1, 0.1), rng.uniform(-0.2, 0.2), rng.uniform(-0.3, 0.3)) for _ in range(3)]
+    mover = rng.choice([k for k, inst in enumerate(data.instances) if not inst.name.startswith("hud")])
+    base_view = np.array(data.view, dtype=np.float32).copy()
+
+    def per_frame(f, s, o):
+        if not chosen["motion"] or f == 0:
+            return
+        v = np.array(data.view, dtype=np.float32).copy(); v[3, 0] += np.float32(steps[f % 3][0]); v[3, 1] += np.float32(steps[f % 3][1])
+        data.view = v
+        inst = copy.copy(data.instances[mover])
+        t = np.array(inst.transform, dtype=np.float32).copy(); t[3, 0] += np.float32(steps[f % 3][2]); t[3, 2] += np.float32(steps[f % 3][3])
+        inst.previous_transform = inst.transform; inst.transform = t
+        data.instances[mover] = inst
+        s.set_instance(mover, inst); o.set_instance(mover, inst)
+    chosen["frames"] = 3 if chosen["motion"] else (2 if gi else 1)
+    return data, view, chosen, per_frame
 
 
 def compare(got, ref, st, chosen):
@@ -149,8 +167,7 @@ def compare(got, ref, st, chosen):
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8, 35, 51])
 def test_random_scenes_against_the_oracle(rt64_lib, sample_data, seed):
-    data, view, chosen = random_scene(sample_data, seed)
-    frames = 2 if view["gi_samples"] else 1
-    got, ref, st = _render_pair(rt64_lib, data, frames=frames, view_desc=view, options={"denoiser_mode": 1})
+    data, view, chosen, per_frame = random_scene(sample_data, seed)
+    got, ref, st = _render_pair(rt64_lib, data, frames=chosen["frames"], view_desc=view, options={"denoiser_mode": 1}, per_frame=per_frame)
     bad = compare(got, ref, st, chosen)
     assert not bad, (seed, chosen, bad)

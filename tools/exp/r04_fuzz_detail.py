@@ -11,9 +11,9 @@ import test_gpu_fuzz as T
 from test_gpu_features import _render_pair
 seed = int(sys.argv[1])
 lib = rt64.Library(); data = sample_scene.make_sample_scene()
-d, view, chosen = T.random_scene(data, seed)
+d, view, chosen, per_frame = T.random_scene(data, seed)
 print(chosen)
-got, ref, st = _render_pair(lib, d, frames=2 if view["gi_samples"] else 1, view_desc=view, options={"denoiser_mode": 1})
+got, ref, st = _render_pair(lib, d, frames=chosen["frames"], view_desc=view, options={"denoiser_mode": 1}, per_frame=per_frame)
 print(T.compare(got, ref, st, chosen))
 pairs = [("OUTPUT_RGBA32F", "output"), ("DIFFUSE", "diffuse"), ("DIRECT_LIGHT_RAW", "directLight"), ("INDIRECT_LIGHT_RAW", "indirectLight"), ("REFLECTION", "reflection"), ("REFRACTION", "refraction"), ("TRANSPARENT", "transparent")]
 out = np.abs(got["OUTPUT_RGBA32F"][..., :3] - ref["output"][..., :3]).max(axis=-1)

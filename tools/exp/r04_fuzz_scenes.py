@@ -13,9 +13,9 @@ without = tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 else ()
 lib = rt64.Library(); data = sample_scene.make_sample_scene()
 nbad = 0; t0 = time.time()
 for seed in range(first, first + count):
-    d, view, chosen = T.random_scene(data, seed, without)
+    d, view, chosen, per_frame = T.random_scene(data, seed, without)
     try:
-        got, ref, st = _render_pair(lib, d, frames=2 if view["gi_samples"] else 1, view_desc=view, options={"denoiser_mode": 1})
+        got, ref, st = _render_pair(lib, d, frames=chosen["frames"], view_desc=view, options={"denoiser_mode": 1}, per_frame=per_frame)
         bad = T.compare(got, ref, st, chosen)
     except Exception as e:
         bad = ["exception %r, last error %r" % (e, lib.last_error())]
