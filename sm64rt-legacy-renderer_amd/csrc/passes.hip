@@ -297,6 +297,14 @@ __global__ __launch_bounds__(RT_BLOCK, KLIST ? 2 : TRACE_WAVES) void primary_tra
 #ifndef DIRECT_WAVES
 #define DIRECT_WAVES 3
 #endif
+// Without SLP pairs (csrc/Makefile) these two sit at 150 / 138 VGPRs: compiled for 4 waves per SIMD (128 VGPRs, 68 / 16 bytes of scratch per lane) they measure C5 2.89 -> 2.81 ms,
+// C3 / C4 unchanged (tools/exp/r04_waves_noslp.sh; the frame kernel at 4 waves: C2 0.154 -> 0.164, the two-phase bounce walk at 6: no change).
+#ifndef HIT_WAVES
+#define HIT_WAVES 4                   // bounce_hit_kernel
+#endif
+#ifndef REFLECT_WAVES
+#define REFLECT_WAVES 4               // reflection_kernel walking from the LDS scene cache
+#endif
 // FULL = false ("lean" frame): no pass of this frame consumes the view direction, reflection / refraction / transparent
 // accumulators, motion vectors or upscaler masks, so they are not written (42 of 94 bytes per pixel); RT64_ReadbackDevice
 // re-runs the FULL variant on demand (View::materialise in rt64_host.cpp).
@@ -1223,7 +1231,7 @@ DEV f3 bounce_sky_term(PRef P, f3 rayDirection) {
 }
 
 template <bool CACHED, bool SECOND = false>    // SECOND: extension gi_bounces = 2 (its own instantiation: the reference's one-bounce kernel stays as it was)
-__global__ __launch_bounds__(RT_BLOCK, DIRECT_WAVES) void bounce_hit_kernel(FrameParams Pv, ViewImages Iv) {
+__global__ __launch_bounds__(RT_BLOCK, HIT_WAVES) void bounce_hit_kernel(FrameParams Pv, ViewImages Iv) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
     constexpr uint32_t STACK_WORDS = CACHED ? RT_STACK_LDS_CACHED / 2 : RT_STACK_LDS;
     __shared__ uint32_t ldsStack[STACK_WORDS * RT_BLOCK];
@@ -1439,7 +1447,7 @@ __global__ __launch_bounds__(RT_BLOCK) void refraction_kernel(FrameParams Pv, Vi
 // round trip.  The cache is filled when the workgroup starts, like everywhere else (a fill that waits for the first tile with a mirror measured slower in round 3:
 // the vote and the fill were serial in workgroups of one tile).
 template <bool KLIST, bool CACHED = false>
-__global__ __launch_bounds__(RT_BLOCK, CACHED ? DIRECT_WAVES : 1) void reflection_kernel(FrameParams Pv, ViewImages Iv, int pass, int last, int parity) {
+__global__ __launch_bounds__(RT_BLOCK, CACHED ? REFLECT_WAVES : 1) void reflection_kernel(FrameParams Pv, ViewImages Iv, int pass, int last, int parity) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
     if (last && blockIdx.x == 0 && threadIdx.x < 4) I.reflectFlags[(parity ^ 1) * 4 + threadIdx.x] = 0;
     if (pass > 0 && pass < 4 && I.reflectFlags[parity * 4 + pass] == 0u) return;          // (workgroup-uniform: written by the launch before this one; passes beyond the fourth always scan)
