@@ -145,8 +145,11 @@ def compare(got, ref, st, chosen):
     if not np.array_equal(got["PRIMARY_HIT"], ref["primaryHit"]):
         bad.append("primary hit records differ on %d pixels" % int((got["PRIMARY_HIT"] != ref["primaryHit"]).any(axis=-1).sum()))
     c = ref["counters"]
+    # Ray counts: exact -- but for the rays that FOLLOW a bounce.  A bounce ray starts in the frame of the stored RGBA16F normal, which a few pixels in a million round to the
+    # neighbouring half on the two sides; such a ray may hit where the other misses, and then one shadow ray more or less is cast (seed 1113: 105 505 against 105 504).
     for k in ("primaryRays", "shadowRays", "reflectionRays", "refractionRays", "indirectRays"):
-        if int(getattr(st, k)) != int(c[k]):
+        slack = max(2, int(2e-5 * int(c[k]))) if (chosen["gi"] and k == "shadowRays") else 0
+        if abs(int(getattr(st, k)) - int(c[k])) > slack:
             bad.append("%s %d against %d" % (k, int(getattr(st, k)), int(c[k])))
     # Rays towards a light pick the light and its sample point through pow / rsqrt (1-ulp device operations, Lights.hlsli:115-168): with several lights a few
     # shadow rays differ in their last bits, so the visit counts agree to a few parts in 10^5 and a handful of pixels on a selection / shadow threshold differ outright
