@@ -300,7 +300,7 @@ __global__ __launch_bounds__(RT_BLOCK, KLIST ? 2 : TRACE_WAVES) void primary_tra
 // Without SLP pairs (csrc/Makefile) these two sit at 150 / 138 VGPRs: compiled for 4 waves per SIMD (128 VGPRs, 68 / 16 bytes of scratch per lane) they measure C5 2.89 -> 2.81 ms,
 // C3 / C4 unchanged (tools/exp/r04_waves_noslp.sh; the frame kernel at 4 waves: C2 0.154 -> 0.164, the two-phase bounce walk at 6: no change).
 #ifndef HIT_WAVES
-#define HIT_WAVES 4                   // bounce_hit_kernel
+#define HIT_WAVES 4                   // bounce_hit_kernel walking from the LDS scene cache (the uncached form keeps DIRECT_WAVES: its 46 KB of LDS bound it to 3 anyway, and asked for 4 the compiler settles on 2)
 #endif
 #ifndef REFLECT_WAVES
 #define REFLECT_WAVES 4               // reflection_kernel walking from the LDS scene cache
@@ -1231,7 +1231,7 @@ DEV f3 bounce_sky_term(PRef P, f3 rayDirection) {
 }
 
 template <bool CACHED, bool SECOND = false>    // SECOND: extension gi_bounces = 2 (its own instantiation: the reference's one-bounce kernel stays as it was)
-__global__ __launch_bounds__(RT_BLOCK, HIT_WAVES) void bounce_hit_kernel(FrameParams Pv, ViewImages Iv) {
+__global__ __launch_bounds__(RT_BLOCK, CACHED ? HIT_WAVES : DIRECT_WAVES) void bounce_hit_kernel(FrameParams Pv, ViewImages Iv) {
     PRef P = *kernel_params(); IRef I = *kernel_images(); (void)Pv; (void)Iv; (void)I;
     constexpr uint32_t STACK_WORDS = CACHED ? RT_STACK_LDS_CACHED / 2 : RT_STACK_LDS;
     __shared__ uint32_t ldsStack[STACK_WORDS * RT_BLOCK];
