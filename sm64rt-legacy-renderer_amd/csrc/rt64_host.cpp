@@ -157,7 +157,7 @@ struct Options {
     bool foldCompose = true;       // frames with the SVGF denoiser: ComposePS inside the last a-trous iteration (0: compose_post_kernel, its own launch)
     bool foldVariance = true;      // ... and the filter's input (variance from the moments) for every pixel with four frames of history; svgf_variance_kernel then only runs where a younger pixel is marked (0: it makes every pixel's input)
     bool foldGuide = true;         // frames with the wavefront GI chain + SVGF: bounce_resolve_kernel writes the filter's guide records (0: svgf_guide_kernel, its own launch)
-    bool overlapFrames = true;     // enqueued (sync_present = 0) pixel-local frames alternate between two render streams: frame k+1 starts while the last waves of frame k are still walking (Device::draw)
+    bool overlapFrames = true;     // enqueued (sync_present = 0) pixel-local frames alternate over the render streams (three by default): frame k+1 starts while the last waves of frame k are still walking (Device::draw)
     bool reflectionEarly = true;   // ... and they fork as soon as the G-buffer exists (beside the GI chain too), not only beside the a-trous iterations (0: round 3's placement)
     bool overlapReflection = true; // frames with reflection passes AND the SVGF denoiser: the reflection launches run on a second stream beside the a-trous iterations (they share no image)
     bool haloExchange = false;     // band partitions of GI + SVGF frames: ship the filter input of the halo rows between the devices of the gather (RCCL) instead of re-rendering them
@@ -173,7 +173,7 @@ struct Options {
 struct Device {
     int hipDevice = 0;
     hipStream_t stream = nullptr;         // the render stream of the frame in hand: streams[cur]
-    // Two render streams (option overlap_frames).  A frame that is pixel-local from its primary rays to the back buffer, uploads nothing and has no temporal
+    // Render streams (option overlap_frames; RT64_RENDER_STREAMS = 1 .. 4, default 3).  A frame that is pixel-local from its primary rays to the back buffer, uploads nothing and has no temporal
     // consumer ("pure": the one-kernel lean frame on unchanged tables) reads only what earlier frames left untouched and writes only per-slot storage -- back
     // buffer, gather send buffer, traversal spill slab, tile-cost order, all indexed by `cur` -- so consecutive pure frames may run side by side: with
     // sync_present = 0 they alternate between the two streams, and frame k+1's first waves fill the wave slots the tail of frame k has left empty.  Everything
@@ -1188,9 +1188,9 @@ void View::update() {                          // View::update, rt64_view.cpp:10
         const size_t cacheAt = (tlasAt + nodeBytes + sizeof(BlasHeader) + 2 * sizeof(uint32_t) * n + 63) & ~(size_t)63, headWords = hostCache ? 4 * (size_t)n + 4 * std::max<size_t>(n - 1, 1) : 0;
         const size_t uploadBytes = hostTlas ? (hostCache ? cacheAt + headWords * 16 : tlasAt + nodeBytes + sizeof(BlasHeader) + 2 * sizeof(uint32_t) * n) : tableBytes;
         {
-            const size_t need = std::max<size_t>(hostCache ? cacheAt + (size_t)cacheWords * 16 : uploadBytes, 4096);
-            if (need > tab[tabCur].dTables.count || (n && !hostTlas)) dev->impure();
-            // (the prologue kernel copies whole 16-byte words: the ring rounds its regions to 256 bytes, and `need` is a multiple of 16 or 4096)       // a slot that has to grow is freed and allocated again; a TLAS of more than 64 instances is built by kernels whose scratch is not per slot
+            // (16-byte granules: the prologue kernel copies the upload as whole 16-byte words, and the ring rounds the region it reads them from to 256 bytes)
+            const size_t need = (std::max<size_t>(hostCache ? cacheAt + (size_t)cacheWords * 16 : uploadBytes, 4096) + 15) & ~(size_t)15;
+            if (need > tab[tabCur].dTables.count || (n && !hostTlas)) dev->impure();       // a slot that has to grow is freed and allocated again; a TLAS of more than 64 instances is built by kernels whose scratch is not per slot
             tab[tabCur].dTables.reserve(need);
         }
         tab[tabCur].dInstances.ptr = reinterpret_cast<GpuInstance *>(tab[tabCur].dTables.ptr); tab[tabCur].dTextures.ptr = reinterpret_cast<GpuTexture *>(tab[tabCur].dTables.ptr + instBytes);
@@ -1696,7 +1696,7 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
     }
     if (tileY1 > height) tileY1 = height;
     if (tileY0 >= tileY1) { tileY0 = 0; tileY1 = height; }
-    // Two render streams (see Device::streams): an enqueued frame that follows a pure frame starts on the other stream, beside that frame's tail; it is joined
+    // Render streams (see Device::streams): an enqueued frame that follows a pure frame starts on the next stream, beside that frame's tail; it is joined
     // behind it the moment it turns out not to be pure itself (impure(): an upload, a build, a frame with history).  Frame counters, the tile-timing records and
     // the sub-frame accumulation are one per device: frames that use them stay in order.
     const bool mayOverlap = opt.overlapFrames && streamCount > 1 && !opt.syncPresent && !opt.countTraversal && !opt.tileTiming && opt.primarySpp <= 1;
@@ -1712,21 +1712,21 @@ void Device::draw(int, float) {                // Device::draw, rt64_device.cpp:
     if (profNow) beginEventSet(0);
     auto tu0 = std::chrono::steady_clock::now(), tu1 = tu0;
     try {
-    flushMeshBuilds();
-    for (Scene *sc : scenes) for (View *v : sc->views) v->update();
-    tu1 = std::chrono::steady_clock::now();
-    for (Scene *sc : scenes) for (View *v : sc->views) {
-        // extension primary_spp = N: N complete sub-frames -- every pass up to Compose, history and frame count advancing after each -- with jittered primary rays;
-        // the mean of their composed outputs is the frame (rules P1-P4 at oracle_render, oracle/oracle_render.c)
-        v->subFrames = std::max(1, opt.primarySpp); v->subFrame = 0;
-        v->render();
-        for (int sub = 1; sub < v->subFrames; sub++) {
-            if (profNow) { endEventSet(); beginEventSet(sub); }
-            v->subFrame = sub; v->update(); v->render();
+        flushMeshBuilds();
+        for (Scene *sc : scenes) for (View *v : sc->views) v->update();
+        tu1 = std::chrono::steady_clock::now();
+        for (Scene *sc : scenes) for (View *v : sc->views) {
+            // extension primary_spp = N: N complete sub-frames -- every pass up to Compose, history and frame count advancing after each -- with jittered primary rays;
+            // the mean of their composed outputs is the frame (rules P1-P4 at oracle_render, oracle/oracle_render.c)
+            v->subFrames = std::max(1, opt.primarySpp); v->subFrame = 0;
+            v->render();
+            for (int sub = 1; sub < v->subFrames; sub++) {
+                if (profNow) { endEventSet(); beginEventSet(sub); }
+                v->subFrame = sub; v->update(); v->render();
+            }
+            evSubFrames = v->subFrames; evSetsUsed = std::min(v->subFrames, (int)EV_SETS);
+            v->subFrame = 0;
         }
-        evSubFrames = v->subFrames; evSetsUsed = std::min(v->subFrames, (int)EV_SETS);
-        v->subFrame = 0;
-    }
     }
     catch (...) {
         // A frame the library refuses (or that fails half-way): the device keeps showing the last complete frame -- its stream and its back-buffer slot are current
