@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off soak of the render streams: many long random host sessions (tests/test_gpu_overlap.py::_random_session), three streams against one, byte for byte.
-   python tools/exp/r04_soak_sessions.py [first_seed] [count] [ops]"""
+   python tools/exp/r04_soak_sessions.py [first_seed] [count] [ops] [width height]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -10,6 +10,8 @@ graft.load_package()
 from sm64rt_legacy_renderer_amd import rt64, sample_scene
 import test_gpu_overlap as T
 first, count, ops = (int(sys.argv[1]) if len(sys.argv) > 1 else 100), (int(sys.argv[2]) if len(sys.argv) > 2 else 40), (int(sys.argv[3]) if len(sys.argv) > 3 else 150)
+if len(sys.argv) > 5:            # frame size of the sessions (default: the tests' 320 x 180; at 1920 x 1080 a frame is long enough for three of them to really run side by side)
+    T.W, T.H = int(sys.argv[4]), int(sys.argv[5])
 lib = rt64.Library()
 data = sample_scene.make_sample_scene()
 bad = 0; t0 = time.time()
