@@ -81,7 +81,7 @@ def parse_args():
     ap.add_argument("--cpu-baseline-height", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = all)")
     ap.add_argument("--timed-loop-only", action="store_true", help="profiling runs (tools/profile_round.sh): only the timed loop of `value` -- no always_rebuild leg, no enqueued leg (whose frames overlap on the "
                     "library's render streams: their launches would enter a profiler's per-kernel average with stretched durations), no parity object, no CPU baseline")
-    ap.add_argument("--watchdog", type=float, default=900.0, help="N > 1: seconds after which a rank that is still running dumps every thread's Python stack to stderr and exits with status 1 "
+    ap.add_argument("--watchdog", type=float, default=600.0, help="N > 1: seconds after which a rank that is still running dumps every thread's Python stack to stderr and exits with status 1 "
                     "(a collective whose peer never arrives cannot be left from inside the process; the launcher then stops the other ranks); 0 = off")
     return ap.parse_args()
 
