@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One-off soak: random scenes (tests/test_gpu_fuzz.py::random_scene) against the oracle.  python tools/exp/r04_fuzz_scenes.py [first] [count]"""
+"""One-off soak: random scenes (tests/test_gpu_fuzz.py::random_scene) against the oracle.  python tools/exp/r04_fuzz_scenes.py [first] [count] [without,features] [option=value ...]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -9,13 +9,16 @@ from sm64rt_legacy_renderer_amd import rt64, sample_scene
 import test_gpu_fuzz as T
 from test_gpu_features import _render_pair
 first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 100), (int(sys.argv[2]) if len(sys.argv) > 2 else 60)
-without = tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 else ()
+without = tuple(w for w in sys.argv[3].split(",") if w) if len(sys.argv) > 3 else ()
+options = {"denoiser_mode": 1}
+for kv in sys.argv[4:]:                      # further device options, e.g. lds_cache=0 (every walk fetches its nodes from HBM / L2: trace_ray_stepwise), simple_kernels=0 (the general kernels)
+    k, _, v = kv.partition("="); options[k] = float(v)
 lib = rt64.Library(); data = sample_scene.make_sample_scene()
 nbad = 0; t0 = time.time()
 for seed in range(first, first + count):
     d, view, chosen, per_frame = T.random_scene(data, seed, without)
     try:
-        got, ref, st = _render_pair(lib, d, frames=chosen["frames"], view_desc=view, options={"denoiser_mode": 1}, per_frame=per_frame)
+        got, ref, st = _render_pair(lib, d, frames=chosen["frames"], view_desc=view, options=options, per_frame=per_frame)
         bad = T.compare(got, ref, st, chosen)
     except Exception as e:
         bad = ["exception %r, last error %r" % (e, lib.last_error())]
