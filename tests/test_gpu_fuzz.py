@@ -24,7 +24,7 @@ def _rot_y(a):
 
 
 def random_scene(sample_data, seed, without=()):
-    """-> (scene data, view description kwargs, what the generator chose, per-frame callback for _render_pair); `without`: features left at their defaults (diagnosis: "groups", "depth_bias", "shapes", "motion")"""
+    """-> (scene data, view description kwargs, what the generator chose, per-frame callback for _render_pair); `without`: features left at their defaults (diagnosis: "groups", "depth_bias", "shapes", "motion", "view")"""
     from sm64rt_legacy_renderer_amd import rt64, sample_scene
     rng = random.Random(seed)
     chosen = {}
@@ -118,6 +118,9 @@ def random_scene(sample_data, seed, without=()):
     gi = rng.choice([0, 0, 1])
     view = dict(gi_samples=gi, denoiser=bool(gi and rng.random() < 0.7), max_lights=rng.choice([12, 2]))
     chosen.update(gi=gi, denoiser=view["denoiser"], lights=len(data.lights), instances=len(data.instances), max_lights=view["max_lights"])
+    if "view" not in without and rng.random() < 0.3:                   # the render size differs from the screen's: PostProcessPS resamples (rt64_view.cpp:138-139, PostProcessPS.hlsl)
+        view["resolution_scale"] = rng.choice([0.5, 0.75, 1.5])
+    chosen["scale"] = view.get("resolution_scale", 1.0)
     # Motion (frames with history only): the camera drifts and one instance moves between the frames, so the temporal reprojection (IndirectRayGen.hlsl:43-56), the
     # flow image and the history lengths have something to do; RT64_SetInstanceDescription carries the previous transform like a host's would.
     chosen["motion"] = bool(gi and "motion" not in without and rng.random() < 0.6)
@@ -155,12 +158,15 @@ def compare(got, ref, st, chosen):
     # shadow rays differ in their last bits, so the visit counts agree to a few parts in 10^5 and a handful of pixels on a selection / shadow threshold differ outright
     # (seed 51, four lights inside a large sphere: 72 scattered pixels of 57 600, every one of them in the direct-light image only: tools/exp/r04_fuzz_detail.py).
     loose = chosen["lights"] > 1
-    if not bad and abs(int(st.nodesVisited) - int(c["nodesVisited"])) > (2e-4 * c["nodesVisited"] if loose else max(16, 2e-7 * c["nodesVisited"])):
+    # ... and a mirror or refraction ray starts from the shading normal, a tolerance-level value: a few such rays in a million take another
+    # path through the tree (seed 5039, three mirror / translucent spheres around the eye: 41 of 8.8 M visits, 7 pixels of 57 600 beyond 0.02)
+    secondary = any(k in ("mirror", "glass") for k in chosen["kinds"])
+    if not bad and abs(int(st.nodesVisited) - int(c["nodesVisited"])) > (2e-4 * c["nodesVisited"] if loose else max(64, 2e-5 * c["nodesVisited"]) if secondary else max(16, 2e-7 * c["nodesVisited"])):
         bad.append("nodesVisited %d against %d" % (int(st.nodesVisited), int(c["nodesVisited"])))
     d = np.abs(got["OUTPUT_RGBA32F"][..., :3] - ref["output"][..., :3]).max(axis=-1)
     off = d > 2e-2
     r = float(np.sqrt(np.mean((got["OUTPUT_RGBA32F"][..., :3][~off].astype(np.float64) - ref["output"][..., :3][~off].astype(np.float64)) ** 2)))
-    if r > 2e-3 or off.mean() > (1e-3 * (chosen["lights"] - 1) if loose else 1e-4):
+    if r > 2e-3 or off.mean() > (1e-3 * (chosen["lights"] - 1) if loose else 5e-4 if secondary else 1e-4):
         bad.append("composed image: RMSE %.2e over the pixels within 0.02, %.5f of the pixels beyond (max %.3f)" % (r, float(off.mean()), float(d.max())))
     f = np.abs(got["FINAL_RGBA8"].astype(np.int32) - ref["final"].astype(np.int32))
     if (f > 1).mean() > 2e-3:
