@@ -71,6 +71,13 @@ def test_committed_profile_belongs_to_the_committed_kernels(bench):
     doc = json.load(open(path))
     assert doc["source_hash"] == bench.source_hash(), "re-run tools/profile_round.sh on the GPU box and commit profiles/kernel_counters.json"
     assert "lean_frame" in doc["workloads"]["C2"]["kernels"]
+    # ... every workload the documents quote was profiled on these sources, and the documents name this profile (not an earlier one)
+    assert {"C2", "C3", "C4", "C5", "C4-literal", "C5-literal", "stress_7_256"} <= set(doc["workloads"])
+    for name in ("DESIGN.md", os.path.join("profiles", "README.md")):
+        assert doc["source_hash"] in open(os.path.join(ROOT, name)).read(), name + " quotes another source hash"
+    # the ray kernels keep the flag their measured figures were taken with (csrc/Makefile: 4-5 % on the frame kernel)
+    mk = open(os.path.join(ROOT, "sm64rt-legacy-renderer_amd", "csrc", "Makefile")).read()
+    assert "build/passes.o build/passes_simple.o: CXXFLAGS += -fno-slp-vectorize" in mk
 
 
 def test_gpus_flag_spawns_ranks_and_fails_loudly():
