@@ -11,7 +11,10 @@ from test_gpu_features import _render_pair
 first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 100), (int(sys.argv[2]) if len(sys.argv) > 2 else 60)
 without = tuple(w for w in sys.argv[3].split(",") if w) if len(sys.argv) > 3 else ()
 options = {"denoiser_mode": 1}
-for kv in sys.argv[4:]:                      # further device options, e.g. lds_cache=0 (every walk fetches its nodes from HBM / L2: trace_ray_stepwise), simple_kernels=0 (the general kernels)
+import test_gpu_features as F
+for kv in [a for a in sys.argv[4:] if a.startswith("size=")]:       # size=WxH: frame size of the comparison (default: the tests' 320 x 180)
+    F.W, F.H = (int(v) for v in kv[5:].split("x"))
+for kv in [a for a in sys.argv[4:] if not a.startswith("size=")]:                      # further device options, e.g. lds_cache=0 (every walk fetches its nodes from HBM / L2: trace_ray_stepwise), simple_kernels=0 (the general kernels)
     k, _, v = kv.partition("="); options[k] = float(v)
 lib = rt64.Library(); data = sample_scene.make_sample_scene()
 nbad = 0; t0 = time.time()
