@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One-off soak: random / pathological meshes through the BLAS builders against the oracle (tests/test_gpu_mesh_fuzz.py).  python tools/exp/r04_fuzz_meshes.py [first] [count]"""
+"""One-off soak: random / pathological meshes through the BLAS builders against the oracle (tests/test_gpu_mesh_fuzz.py).  python tools/exp/r04_fuzz_meshes.py [first] [count] [sizes]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -8,6 +8,8 @@ graft.load_package()
 from sm64rt_legacy_renderer_amd import rt64, sample_scene
 import test_gpu_mesh_fuzz as T
 first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 100), (int(sys.argv[2]) if len(sys.argv) > 2 else 100)
+if len(sys.argv) > 3:            # triangle counts to draw from instead of the tests' (e.g. 131072,131073,200000: the large-tree builder's second group level)
+    T.SIZES = [int(v) for v in sys.argv[3].split(",")]
 lib = rt64.Library(); data = sample_scene.make_sample_scene()
 nbad = 0; t0 = time.time(); seen = {}
 for seed in range(first, first + count):
