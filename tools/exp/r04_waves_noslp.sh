@@ -8,6 +8,8 @@ V[lw4]="-DLEAN_WAVES=4"
 V[dw4]="-DDIRECT_WAVES=4"
 V[sw6]="-DSPLIT_WAVES=6"
 V[sw6dw4]="-DSPLIT_WAVES=6 -DDIRECT_WAVES=4"
+V[tw5]="-DTRACE_WAVES=5"
+V[tw6]="-DTRACE_WAVES=6"
 V[hw4]="-DHIT_WAVES=4"
 V[rw4]="-DREFLECT_WAVES=4"
 V[hw4rw4]="-DHIT_WAVES=4 -DREFLECT_WAVES=4"
